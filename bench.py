@@ -1,0 +1,173 @@
+"""bench.py — BASELINE.json metric: training images/sec, DDPM UNet 32x32, global batch 128.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = the full optimiser step of the reference loop on a synthetic
+batch already resident in HBM: DDPM.training_step (t ~ randint, noise ~ randn on device,
+q_sample, UNet fwd, weighted MSE) -> loss.backward() (hand-written HIP backward) -> gradient
+all-reduce over RCCL when N > 1 -> fused Adam -> EMA update (every 10th step).  The periodic
+in-training sampling (reference F11, every 1000 steps) is outside the window.  Strong scaling:
+the global batch stays 128 (reference DataModule divides the config batch by the GPU count).
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (convolution kernel family, fp32 MFMA
+peak 157.3 TFLOP/s; per-launch durations from HIP events on the launch stream in one extra
+instrumented step right after the timed region) and "cpu_baseline" (the CPU oracle, same
+workload at a bounded batch, on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "lightning-generative-models_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
+GLOBAL_BATCH = 128
+IMG = 32
+DIM = 64
+
+
+def cpu_baseline(batch=16, warmup=1, steps=3):
+    """The CPU oracle (validated against the reference by tests/golden) on this host's cores."""
+    from oracle import diffusion as OD
+    torch.manual_seed(10)
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    P = {k: v.requires_grad_(True) for k, v in OD.unet_init(dim=DIM, channels=3, seed=0).items()}
+    bufs = OD.diffusion_buffers(1000)
+    opt = torch.optim.Adam(list(P.values()), lr=2e-5, betas=(0.9, 0.99))
+    x = torch.rand(batch, 3, IMG, IMG) * 2 - 1
+    times = []
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        t = torch.randint(0, 1000, (batch,))
+        noise = torch.randn_like(x)
+        loss = OD.diffusion_forward(P, bufs, x, t, noise, dim=DIM)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(batch / med, 2), "unit": "images/s", "cores": nthreads, "kind": "port",
+            "sample": f"oracle fwd+bwd+Adam, B={batch}, 3x{IMG}x{IMG}, median of {steps} steps after {warmup} warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=GLOBAL_BATCH, help="global batch (default 128 = the metric)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "--gpus must equal WORLD_SIZE under torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from lgm_hip import ops
+    from lgm_hip.lightning import MiniTrainer
+    from models.generative.diffusion.ddpm import DDPM
+
+    torch.manual_seed(10)                         # reference train.py:20 seeds every rank identically
+    assert args.batch % world == 0
+    per_gpu = args.batch // world
+    model = DDPM(img_channels=3, img_size=IMG, dim=DIM, diffusion_timesteps=1000, sampling_timesteps=None,
+                 lr=2e-5, betas=(0.9, 0.99), ema_update_every=10, ema_decay=0.995)   # configs/diffusion/ddpm.json
+    model.sample_every = 0
+    model.to(dev)
+    model.prepare_hip(dev)
+    model.train()
+    opt = model.configure_optimizers()
+    trainer = MiniTrainer()
+    g = torch.Generator(device="cpu").manual_seed(10 + rank)
+    x = (torch.rand(per_gpu, 3, IMG, IMG, generator=g) * 2 - 1).to(dev)
+    y = torch.zeros(per_gpu, dtype=torch.long, device=dev)
+    batch = (x, y)
+
+    def step(i):
+        loss = model.training_step(batch)
+        loss.backward()
+        trainer.allreduce_grads(model)
+        opt.step()
+        opt.zero_grad()
+        model.on_train_batch_end(None, batch, i)
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item())
+
+    # ---- roofline leg: one extra instrumented step, per-launch HIP events on the launch stream
+    ops.TIMER = ops.KernelTimer()
+    step(args.warmup + args.steps)
+    summ = ops.TIMER.summary()
+    ops.TIMER = None
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.batch * args.steps / elapsed
+        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        name, d = dom
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        conv_ms = sum(v["ms"] for v in summ.values())
+        conv_fl = sum(v["flops"] for v in summ.values())
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                "family": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()},
+                "conv_family_ms_per_step": round(conv_ms, 3),
+                "conv_family_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                "step_flop_frac_of_peak": round(value * 10.95e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4)}
+        line = {"metric": "training images/sec (DDPM UNet 32x32, bs=128)", "value": round(value, 2),
+                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs/diffusion/ddpm.json UNet dim=64, 3x32x32 synthetic NCHW fp32, "
+                                       "training_step+backward+Adam+EMA", "global_batch": args.batch,
+                           "per_gpu_batch": per_gpu, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5)},
+                "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

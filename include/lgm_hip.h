@@ -1,0 +1,205 @@
+/* liblgm_hip.so — C-ABI of the MI355X (gfx950) hot path for lightning-generative-models.
+ *
+ * The reference (pure Python, /root/reference) has no FFI: every entry point below replaces
+ * a group of ATen calls that the reference's nn.Modules issue on the hot path.  Each entry
+ * cites the reference lines whose arithmetic it implements.  SURVEY.md §8(b) defines the
+ * conventions:
+ *   - plain pointers + sizes, no torch types; all device pointers are caller-owned;
+ *   - the library never allocates, frees, retains or synchronises; all work is enqueued on
+ *     the `stream` argument (a hipStream_t passed as void*);
+ *   - return 0 = OK, <0 = invalid argument / unsupported shape, >0 = hipError_t;
+ *     lgm_last_error() returns a thread-local description;
+ *   - stateless and re-entrant (safe from the autograd thread).
+ *
+ * Activation layout: NHWC fp32, addressed as (pointer, pitch) where pitch is the distance
+ * in floats between consecutive pixels (>= channels; lets a tensor be a channel-slice of a
+ * wider concat buffer).  Pointers and pitches of tensors read through the implicit-GEMM
+ * convolutions must be 16-byte aligned / multiples of 4 floats.
+ *
+ * Convolution weights: physical layout [Nw][KH*KW][Cw] (= torch channels_last memory format
+ * of the logical OIHW Conv2d weight; for ConvTranspose2d Nw = in_channels, Cw = out_channels).
+ */
+#ifndef LGM_HIP_H
+#define LGM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGM_ABI_VERSION 1
+#define LGM_OK 0
+#define LGM_ERR_INVALID (-1)
+#define LGM_ERR_UNSUPPORTED (-2)
+
+int lgm_abi_version(void);
+const char* lgm_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Convolution family (implicit GEMM on v_mfma_f32_32x32x2_f32, exact fp32).
+ * Geometry is always that of the equivalent *forward convolution* X -> Y:
+ *   X side: [B, H, W, Cw]   Y side: [B, Ho, Wo, Nw]   weight [Nw][KH*KW][Cw]
+ *   Y[b,oh,ow,n] = sum_{kh,kw,c} X[b, oh*stride-pad+kh, ow*stride-pad+kw, c] * Wt[n][kh*KW+kw][c]
+ * Replaces: nn.Conv2d / nn.ConvTranspose2d forward+backward at
+ *   ddpm.py:96,103,160,187,213,215,252,253,304,377,413,422 (UNet),
+ *   dcgan.py:79-87,150-158 (DCGAN G/D), vqvae.py:36-51,74-85, residual.py:14-18.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t B, H, W, Cw;    /* X side */
+  int32_t Ho, Wo, Nw;     /* Y side */
+  int32_t KH, KW, stride, pad;
+} LgmConvGeom;
+
+/* X -> Y  (Conv2d.forward; ConvTranspose2d input-gradient).
+ * y = conv(x, w) + bias[n] + res   (bias, res optional = NULL; res may alias y). */
+int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w,
+                const float* bias, const float* res, int64_t res_pitch,
+                float* y, int64_t y_pitch, void* stream);
+
+/* Y -> X  (Conv2d input-gradient; ConvTranspose2d.forward).
+ * x = conv_transpose(y, w) + bias[c] + res   (bias, res optional; res may alias x). */
+int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
+                const float* bias, const float* res, int64_t res_pitch,
+                float* x, int64_t x_pitch, void* stream);
+
+/* Weight gradient: gw[n][tap][c] = beta*gw + sum_{b,oh,ow} Y[b,oh,ow,n] * X[b,ih,iw,c].
+ * (Conv2d: Y = grad_output, X = input;  ConvTranspose2d: Y = input, X = grad_output.)
+ * Deterministic: split-K partials go to `workspace` and are reduced in a fixed order.
+ * lgm_conv_wgrad_workspace() returns the bytes needed for the given geometry. */
+int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g);
+int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
+                   int64_t x_pitch, float* gw, float beta, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
+/* Column sums of a [rows, cols] matrix with row pitch: out[c] = beta*out[c] + sum_r a[r,c].
+ * Used for conv/linear bias gradients.  Deterministic two-stage; workspace >=
+ * lgm_colsum_workspace(rows, cols) bytes. */
+int64_t lgm_colsum_workspace(int64_t rows, int64_t cols);
+int lgm_colsum(const float* a, int64_t pitch, int64_t rows, int64_t cols, float* out, float beta,
+               void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * GroupNorm(+FiLM scale/shift)(+SiLU)(+residual)   — Block.forward ddpm.py:164-173
+ *   z = GN(x; gamma, beta, G, eps) * (scale + 1) + shift ;  y = act ? silu(z) : z ;  y += res
+ * x, y, res: [B, HW, C] NHWC with pitches.  ss (optional): [B, >=2C] rows, scale = ss[b, c],
+ * shift = ss[b, C + c] (the chunk(2) of the time-MLP output, ddpm.py:192-194).
+ * Outputs saved for backward: mean, rstd [B, G]; coefA, coefB [B, C]  (z = x*coefA + coefB).
+ * ------------------------------------------------------------------------------------- */
+int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C, int G, float eps,
+               const float* gamma, const float* beta, const float* ss, int64_t ss_pitch, int act,
+               const float* res, int64_t res_pitch, float* y, int64_t y_pitch, float* mean,
+               float* rstd, float* coefA, float* coefB, void* stream);
+/* Backward.  gx (optionally accumulated), ggamma/gbeta (= affine_beta*old + new), gss [B, >=2C]
+ * (optional; = gss_beta*old + new).  workspace: 5*B*C floats. */
+int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
+               int C, int G, const float* gamma, const float* beta, const float* ss,
+               int64_t ss_pitch, int act, const float* mean, const float* rstd, const float* coefA,
+               const float* coefB, float* gx, int64_t gx_pitch, int accumulate_gx, float* ggamma,
+               float* gbeta, float affine_beta, float* gss, int64_t gss_pitch, float gss_beta,
+               float* workspace, void* stream);
+
+/* RMSNorm over channels — ddpm.py:107-113: y = x / max(||x||_2, 1e-12) * g * sqrt(C) (+ res). */
+int lgm_rmsnorm_fwd(const float* x, int64_t x_pitch, const float* g, const float* res,
+                    int64_t res_pitch, float* y, int64_t y_pitch, int64_t npix, int C, void* stream);
+int64_t lgm_rmsnorm_bwd_workspace(int64_t npix, int C);
+int lgm_rmsnorm_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch,
+                    const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, float* gg,
+                    float gg_beta, int64_t npix, int C, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Attention cores on qkv [B, n, 3*heads*32] (channel = which*hidden + head*32 + d).
+ * LinearAttention ddpm.py:217-239 (mem_kv [2, heads, 32, M]); Attention ddpm.py:255-271 +
+ * modules/attend.py:97-126 (mem_kv [2, heads, M, 32]).  out: [B, n, heads*32].
+ * ------------------------------------------------------------------------------------- */
+int lgm_linattn_fwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, int B, int n,
+                    int heads, int dim_head, int M, float* out, int64_t out_pitch, float* ctx,
+                    float* kmax, float* ksum, void* stream);
+int64_t lgm_linattn_bwd_workspace(int B, int heads, int dim_head, int M);
+int lgm_linattn_bwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* gout,
+                    int64_t gout_pitch, const float* ctx, const float* kmax, const float* ksum,
+                    int B, int n, int heads, int dim_head, int M, float* gqkv, int64_t gqkv_pitch,
+                    float* gmem_kv, float gmem_beta, void* workspace, void* stream);
+int lgm_attn_fwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, int B, int n, int heads,
+                 int dim_head, int M, float* out, int64_t out_pitch, float* lse, void* stream);
+int64_t lgm_attn_bwd_workspace(int B, int heads, int dim_head, int M);
+int lgm_attn_bwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* out,
+                 int64_t out_pitch, const float* gout, int64_t gout_pitch, const float* lse, int B,
+                 int n, int heads, int dim_head, int M, float* gqkv, int64_t gqkv_pitch,
+                 float* gmem_kv, float gmem_beta, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Elementwise / data-movement kernels.
+ * ------------------------------------------------------------------------------------- */
+/* SinusoidalPosEmb ddpm.py:125-132: out[b] = cat(sin(t_b f), cos(t_b f)), f_i = exp(-i ln(theta)/(dim/2-1)) */
+int lgm_posemb(const int64_t* t, int B, int dim, float theta, float* out, int64_t pitch, void* stream);
+
+#define LGM_ACT_NONE 0
+#define LGM_ACT_SILU 1  /* nn.SiLU  ddpm.py:162,180 */
+#define LGM_ACT_GELU 2  /* nn.GELU (erf) ddpm.py:331 */
+#define LGM_ACT_RELU 3  /* residual.py:13-16, vqvae.py:38-42, dcgan.py:90 */
+#define LGM_ACT_LRELU 4 /* dcgan.py:161 (slope 0.2) */
+#define LGM_ACT_TANH 5  /* dcgan.py:90, vqvae.py:85 */
+/* y = act(x + bias) (+ res);  gx (+)= gy * act'(x + bias).  [rows, cols] matrices with pitches. */
+int lgm_act_fwd(const float* x, int64_t x_pitch, const float* bias, const float* res,
+                int64_t res_pitch, float* y, int64_t y_pitch, int64_t rows, int cols, int act,
+                float slope, void* stream);
+int lgm_act_bwd(const float* x, int64_t x_pitch, const float* bias, const float* gy,
+                int64_t gy_pitch, float* gx, int64_t gx_pitch, int accumulate, int64_t rows,
+                int cols, int act, float slope, void* stream);
+/* y = alpha*a + beta*b (b optional) */
+int lgm_axpby(const float* a, int64_t a_pitch, float alpha, const float* b, int64_t b_pitch,
+              float beta, float* y, int64_t y_pitch, int64_t rows, int cols, void* stream);
+/* nn.Upsample(scale_factor=2, mode="nearest") ddpm.py:95; x [B,H,W,C] -> y [B,2H,2W,C] */
+int lgm_upsample2x_fwd(const float* x, int64_t x_pitch, float* y, int64_t y_pitch, int B, int H,
+                       int W, int C, void* stream);
+int lgm_upsample2x_bwd(const float* gy, int64_t gy_pitch, float* gx, int64_t gx_pitch, int B, int H,
+                       int W, int C, int accumulate, void* stream);
+/* Rearrange("b c (h p1) (w p2) -> b (c p1 p2) h w") ddpm.py:102 in NHWC.  Hlo/Wlo: low-res size,
+ * C: high-res channels.  inverse=0: src hi-res [B,2H,2W,C] -> dst lo-res [B,H,W,4C];
+ * inverse=1: src lo-res -> dst hi-res (the gradient), optionally accumulated. */
+int lgm_pixel_unshuffle(const float* src, int64_t src_pitch, float* dst, int64_t dst_pitch, int B,
+                        int Hlo, int Wlo, int C, int inverse, int accumulate, void* stream);
+int lgm_nchw_to_nhwc(const float* src, float* dst, int64_t dst_pitch, int B, int C, int HW, int Cpad,
+                     void* stream);
+int lgm_nhwc_to_nchw(const float* src, int64_t src_pitch, float* dst, int B, int C, int HW,
+                     void* stream);
+
+/* Diffusion training elementwise: GaussianDiffusion.forward/q_sample/predict_v
+ * ddpm.py:945, 869-876, 684-688.  img, noise: NCHW dense; xt, target: NHWC pitch (pad zeroed). */
+int lgm_qsample_target(const float* img, const float* noise, const int64_t* t, const float* sqrt_ac,
+                       const float* sqrt_1mac, int normalize, float* xt, float* target,
+                       int64_t pitch, int B, int C, int HW, int Cpad, void* stream);
+/* loss = mean_b( w[t_b] * mean_{chw} (out - target)^2 )  ddpm.py:921-925 (loss_weight NULL => 1) */
+int lgm_weighted_mse_fwd(const float* out, const float* target, int64_t pitch, const int64_t* t,
+                         const float* loss_weight, int B, int C, int HW, int Cpad, float* per_sample,
+                         float* loss, void* stream);
+int lgm_weighted_mse_bwd(const float* out, const float* target, int64_t pitch, const int64_t* t,
+                         const float* loss_weight, const float* gloss, int B, int C, int HW, int Cpad,
+                         float* gout, void* stream);
+
+/* One reverse-diffusion update at a shared timestep (model_predictions ddpm.py:707-734 pred_v branch,
+ * p_sample :748-757, ddim_sample loop body :805-829):
+ *   x0 = clamp(A*x + Bv*v) ; eps = (R*x - x0)/Rm1 ; out = C0*x0 + C1*x + C2*eps + C3*noise
+ * x, v, out, x0_out: dense NHWC with Cpad channels; noise: NCHW dense or NULL. */
+int lgm_sample_step(const float* x, const float* v, const float* noise, float* out, float* x0_out,
+                    int B, int C, int HW, int Cpad, float A, float Bv, int clip, float R, float Rm1,
+                    float C0, float C1, float C2, float C3, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimiser kernels on flat storage.
+ * torch.optim.Adam (coupled L2; decoupled=1 gives AdamW) — ddpm.py:1053-1059, vqvae.py:207-214,
+ * wgan.py:183-195.  step: 1-based count (host value, or read from step_dev when non-NULL).
+ * ------------------------------------------------------------------------------------- */
+int lgm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                  float b2, float eps, float weight_decay, float step, const float* step_dev,
+                  float grad_scale, int decoupled, void* stream);
+/* ema_pytorch.EMA.update (ddpm.py:1047-1048): shadow += (online - shadow) * w   (w = 1 copies) */
+int lgm_ema_lerp(float* shadow, const float* online, int64_t n, float w, void* stream);
+int lgm_add_scalar(float* x, float a, void* stream);
+int lgm_fill(float* x, int64_t n, float val, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGM_HIP_H */

@@ -1,0 +1,539 @@
+// Implicit-GEMM convolution family for gfx950 on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD = the fp32 roof of the chip).
+//
+//   lgm_conv_xy    : Y = conv(X, W)             GEMM  M = B*Ho*Wo, N = Nw, K = T*Cw
+//   lgm_conv_yx    : X = conv_transpose(Y, W)   GEMM  M = B*H*W,   N = Cw, K = T*Nw
+//   lgm_conv_wgrad : gW = Y^T * gather(X)       GEMM  M = Nw, N = T*Cw, K = B*Ho*Wo (split-K)
+//
+// Tiling (xy / yx): 256 threads = 4 waves in a 2x2 grid; each wave owns TM x TN MFMA tiles of
+// 32x32; BK = 32.  Global -> register prefetch of chunk k+1 overlaps the MFMAs of chunk k; LDS is
+// double buffered so one barrier per chunk suffices.  A (gathered activations) and B (weights,
+// k-contiguous) are staged [row][BK+4] so every fragment read is one conflict-free ds_read_b128:
+// lane (r = l&31, h = l>>5) reads k = 8*kc + 4*h .. +3 of its row, and MFMA step s consumes
+// element s of that float4 from both operands (the k -> (half, step) assignment is arbitrary as
+// long as A and B agree; fp32 accumulation order inside a chunk is fixed => deterministic).
+#include "lgm_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDA = BK + 4;  // floats; 16B-aligned rows, conflict-free b128 reads (see header)
+
+enum { MODE_XY = 0, MODE_YX = 1 };
+
+struct IgemmArgs {
+  const float* a;     // gathered activations (X for XY, Y for YX)
+  const float* w;     // [Nw][T][Cw]
+  const float* bias;  // [N] or null
+  const float* res;   // [M, N] pitch res_pitch or null
+  float* out;         // [M, N] pitch out_pitch
+  long a_pitch, res_pitch, out_pitch;
+  int B, H, W, Cw, Ho, Wo, Nw, KH, KW, stride, pad;
+  int M, N, K;        // GEMM sizes
+  int Cg;             // channels of the gathered tensor (Cw for XY, Nw for YX)
+  int tiles_m, tiles_n;
+};
+
+template <int MODE, int BM, int BN, int TM, int TN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+  static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 wave grid");
+  constexpr int A_PER = BM / 32;  // float4 per thread per chunk
+  constexpr int B_PER = BN / 32;
+  // B tile: XY -> [BN][LDA] (k contiguous), YX -> [BK][BN] (n contiguous)
+  constexpr int A_TILE = BM * LDA;
+  constexpr int B_TILE = (MODE == MODE_XY) ? BN * LDA : BK * BN;
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;                 // 2 * A_TILE
+  float* Bs = smem + 2 * A_TILE;    // 2 * B_TILE
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // tile mapping: consecutive blocks walk N first (share the A tile through L2)
+  const int tile = blockIdx.x;
+  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-thread A-row decode (fixed over the K loop) ---------------------------
+  const int acol = tid & 7;    // float4 column inside the 32-wide chunk
+  const int arow = tid >> 3;   // 0..31
+  int r_pix[A_PER], r_h[A_PER], r_w[A_PER];
+  bool r_ok[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int m = m0 + arow + 32 * i;
+    r_ok[i] = m < p.M;
+    const int mm = r_ok[i] ? m : 0;
+    if (MODE == MODE_XY) {
+      const int ow = mm % p.Wo, t = mm / p.Wo;
+      const int oh = t % p.Ho, b = t / p.Ho;
+      r_pix[i] = b * p.H * p.W;
+      r_h[i] = oh * p.stride - p.pad;
+      r_w[i] = ow * p.stride - p.pad;
+    } else {
+      const int iw = mm % p.W, t = mm / p.W;
+      const int ih = t % p.H, b = t / p.H;
+      r_pix[i] = b * p.Ho * p.Wo;
+      r_h[i] = ih + p.pad;
+      r_w[i] = iw + p.pad;
+    }
+  }
+
+  f32x4 ra[A_PER], rb[B_PER];
+
+  auto load_chunk = [&](int k0) {
+    // ---- A: one tap/channel decode per thread per chunk ----
+    const int k = k0 + acol * 4;
+    const bool kok = k < p.K;
+    const int tap = kok ? k / p.Cg : 0;
+    const int c = k - tap * p.Cg;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      bool ok = kok && r_ok[i];
+      long off = 0;
+      if (MODE == MODE_XY) {
+        const int ih = r_h[i] + kh, iw = r_w[i] + kw;
+        ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        off = (long)(r_pix[i] + ih * p.W + iw) * p.a_pitch + c;
+      } else {
+        int th = r_h[i] - kh, tw = r_w[i] - kw;
+        ok = ok && th >= 0 && tw >= 0;
+        if (p.stride != 1) {
+          ok = ok && (th % p.stride == 0) && (tw % p.stride == 0);
+          th /= p.stride;
+          tw /= p.stride;
+        }
+        ok = ok && th < p.Ho && tw < p.Wo;
+        off = (long)(r_pix[i] + th * p.Wo + tw) * p.a_pitch + c;
+      }
+      ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.a + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- B ----
+    if (MODE == MODE_XY) {
+      const int kb = k0 + acol * 4;
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int n = n0 + arow + 32 * i;
+        const bool ok = (n < p.N) && (kb < p.K);
+        rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.w + (long)n * p.K + kb)
+                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      constexpr int TPR = BN / 4;          // threads per k-row
+      constexpr int RPP = 256 / TPR;       // k-rows per pass
+      const int ncol = (tid % TPR) * 4;
+      const int krow = tid / TPR;
+      const int T = p.KH * p.KW;
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int kk = k0 + krow + RPP * i;
+        const bool ok = (kk < p.K) && (n0 + ncol < p.N);
+        const int tp = ok ? kk / p.Cg : 0;
+        const int nn = kk - tp * p.Cg;
+        rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.w + ((long)nn * T + tp) * p.Cw + n0 + ncol)
+                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+    float* as = As + buf * A_TILE;
+    float* bs = Bs + buf * B_TILE;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i)
+      *reinterpret_cast<f32x4*>(as + (arow + 32 * i) * LDA + acol * 4) = ra[i];
+    if (MODE == MODE_XY) {
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i)
+        *reinterpret_cast<f32x4*>(bs + (arow + 32 * i) * LDA + acol * 4) = rb[i];
+    } else {
+      constexpr int TPR = BN / 4;
+      constexpr int RPP = 256 / TPR;
+      const int ncol = (tid % TPR) * 4;
+      const int krow = tid / TPR;
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i)
+        *reinterpret_cast<f32x4*>(bs + (krow + RPP * i) * BN + ncol) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_chunk((kt + 1) * BK);
+
+    const float* as = As + cur * A_TILE + (wm * 32 * TM + lr) * LDA + lh * 4;
+    const float* bs;
+    if (MODE == MODE_XY)
+      bs = Bs + cur * B_TILE + (wn * 32 * TN + lr) * LDA + lh * 4;
+    else
+      bs = Bs + cur * B_TILE + (lh * 4) * BN + wn * 32 * TN + lr;
+
+#pragma unroll
+    for (int kc = 0; kc < BK / 8; ++kc) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDA + kc * 8);
+      if (MODE == MODE_XY) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDA + kc * 8);
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) fb[j][s] = bs[(kc * 8 + s) * BN + j * 32];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    }
+
+    if (kt + 1 < nk) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * 32 * TN + j * 32 + lr;
+    if (n >= p.N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M) {
+          float v = acc[i][j][r] + bv;
+          if (p.res) v += p.res[(long)m * p.res_pitch + n];
+          p.out[(long)m * p.out_pitch + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int MODE, int BM, int BN, int TM, int TN>
+int launch_igemm(IgemmArgs& a, hipStream_t s) {
+  a.tiles_m = lgm_cdiv(a.M, BM);
+  a.tiles_n = lgm_cdiv(a.N, BN);
+  constexpr int A_TILE = BM * LDA;
+  constexpr int B_TILE = (MODE == MODE_XY) ? BN * LDA : BK * BN;
+  const size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
+  auto kern = igemm_kernel<MODE, BM, BN, TM, TN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), smem, s, a);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+template <int MODE>
+int dispatch_igemm(IgemmArgs& a, hipStream_t s) {
+  const long t128 = (long)lgm_cdiv(a.M, 128);
+  const long t64 = (long)lgm_cdiv(a.M, 64);
+  if (a.N > 64 && t128 * lgm_cdiv(a.N, 128) >= 384) return launch_igemm<MODE, 128, 128, 2, 2>(a, s);
+  if (t128 * lgm_cdiv(a.N, 64) >= 384) return launch_igemm<MODE, 128, 64, 2, 1>(a, s);
+  (void)t64;
+  return launch_igemm<MODE, 64, 64, 1, 1>(a, s);
+}
+
+int check_geom(const LgmConvGeom* g) {
+  LGM_REQUIRE(g != nullptr, "conv: null geometry");
+  LGM_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->Cw > 0 && g->Ho > 0 && g->Wo > 0 && g->Nw > 0,
+              "conv: non-positive dimension");
+  LGM_REQUIRE(g->KH > 0 && g->KW > 0 && g->stride > 0 && g->pad >= 0, "conv: bad kernel/stride/pad");
+  LGM_REQUIRE((g->H + 2 * g->pad - g->KH) / g->stride + 1 == g->Ho &&
+                  (g->W + 2 * g->pad - g->KW) / g->stride + 1 == g->Wo,
+              "conv: Ho/Wo inconsistent with H/W, kernel, stride, pad");
+  LGM_REQUIRE((long)g->B * g->H * g->W < (1L << 31) && (long)g->B * g->Ho * g->Wo < (1L << 31),
+              "conv: pixel count overflows int32");
+  return LGM_OK;
+}
+
+}  // namespace
+
+extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w,
+                           const float* bias, const float* res, int64_t res_pitch, float* y,
+                           int64_t y_pitch, void* stream) {
+  if (int rc = check_geom(g)) return rc;
+  LGM_REQUIRE(x && w && y, "conv_xy: null pointer");
+  LGM_REQUIRE(g->Cw % 4 == 0, "conv_xy: Cw=%d must be a multiple of 4 (pad channels)", g->Cw);
+  LGM_REQUIRE(x_pitch % 4 == 0 && x_pitch >= g->Cw && lgm_aligned16(x) && lgm_aligned16(w),
+              "conv_xy: x/w must be 16B aligned with pitch %% 4 == 0");
+  LGM_REQUIRE(y_pitch >= g->Nw && (!res || res_pitch >= g->Nw), "conv_xy: output pitch < Nw");
+  IgemmArgs a{};
+  a.a = x; a.w = w; a.bias = bias; a.res = res; a.out = y;
+  a.a_pitch = x_pitch; a.res_pitch = res_pitch; a.out_pitch = y_pitch;
+  a.B = g->B; a.H = g->H; a.W = g->W; a.Cw = g->Cw; a.Ho = g->Ho; a.Wo = g->Wo; a.Nw = g->Nw;
+  a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
+  a.M = g->B * g->Ho * g->Wo; a.N = g->Nw; a.K = g->KH * g->KW * g->Cw; a.Cg = g->Cw;
+  return dispatch_igemm<MODE_XY>(a, (hipStream_t)stream);
+}
+
+extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
+                           const float* bias, const float* res, int64_t res_pitch, float* x,
+                           int64_t x_pitch, void* stream) {
+  if (int rc = check_geom(g)) return rc;
+  LGM_REQUIRE(x && w && y, "conv_yx: null pointer");
+  LGM_REQUIRE(g->Nw % 4 == 0 && g->Cw % 4 == 0, "conv_yx: Nw=%d, Cw=%d must be multiples of 4", g->Nw, g->Cw);
+  LGM_REQUIRE(y_pitch % 4 == 0 && y_pitch >= g->Nw && lgm_aligned16(y) && lgm_aligned16(w),
+              "conv_yx: y/w must be 16B aligned with pitch %% 4 == 0");
+  LGM_REQUIRE(x_pitch >= g->Cw && (!res || res_pitch >= g->Cw), "conv_yx: output pitch < Cw");
+  IgemmArgs a{};
+  a.a = y; a.w = w; a.bias = bias; a.res = res; a.out = x;
+  a.a_pitch = y_pitch; a.res_pitch = res_pitch; a.out_pitch = x_pitch;
+  a.B = g->B; a.H = g->H; a.W = g->W; a.Cw = g->Cw; a.Ho = g->Ho; a.Wo = g->Wo; a.Nw = g->Nw;
+  a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
+  a.M = g->B * g->H * g->W; a.N = g->Cw; a.K = g->KH * g->KW * g->Nw; a.Cg = g->Nw;
+  return dispatch_igemm<MODE_YX>(a, (hipStream_t)stream);
+}
+
+// =====================================================================================
+// Weight gradient.  GEMM  M = Nw (rows n), N = T*Cw (cols q = tap*Cw + c), K = P = B*Ho*Wo.
+// Both operands are pixel-major in memory, so the LDS tiles are [pixel][row] and every MFMA
+// fragment is a conflict-free ds_read_b32 of 32 consecutive floats.
+// =====================================================================================
+namespace {
+
+constexpr int WBK = 16;  // pixels per chunk
+
+struct WgradArgs {
+  const float* y;  // [P, Nw] rows
+  const float* x;  // X-side NHWC
+  float* out;      // gw (splits == 1) or workspace [splits][Nw][Q]
+  float beta;      // only for splits == 1
+  long y_pitch, x_pitch;
+  int B, H, W, Cw, Ho, Wo, Nw, KH, KW, stride, pad;
+  int P, Q;        // pixels, T*Cw
+  int tiles_m, tiles_n, splits, chunk;  // chunk = pixels per split (multiple of WBK)
+};
+
+template <int BM, int BN, int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+  static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 wave grid");
+  constexpr int A_TPR = BM / 4, A_RPP = 256 / A_TPR, A_PER = WBK / A_RPP > 0 ? WBK / A_RPP : 1;
+  constexpr int B_TPR = BN / 4, B_RPP = 256 / B_TPR, B_PER = WBK / B_RPP > 0 ? WBK / B_RPP : 1;
+  static_assert(A_RPP <= WBK && B_RPP <= WBK, "tile too narrow for 256 threads");
+  __shared__ __align__(16) float As[2][WBK * BM];
+  __shared__ __align__(16) float Bs[2][WBK * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int split = bid % p.splits;
+  bid /= p.splits;
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int m0 = tm * BM, q0 = tn * BN;
+  const int p_begin = split * p.chunk;
+  const int p_end = min(p.P, p_begin + p.chunk);
+
+  // A (Y rows): thread -> (pixel row a_prow + A_RPP*i, float4 column a_ncol)
+  const int a_ncol = (tid % A_TPR) * 4, a_prow = tid / A_TPR;
+  const bool a_nok = (m0 + a_ncol) < p.Nw;
+  // B (X gather): column q fixed per thread -> tap / channel decode once
+  const int b_qcol = (tid % B_TPR) * 4, b_prow = tid / B_TPR;
+  const int q = q0 + b_qcol;
+  const bool b_qok = q < p.Q;
+  const int tap = b_qok ? q / p.Cw : 0;
+  const int cch = q - tap * p.Cw;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+
+  f32x4 ra[A_PER], rb[B_PER];
+  auto load_chunk = [&](int pp0) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int pix = pp0 + a_prow + A_RPP * i;
+      const bool ok = a_nok && pix < p_end;
+      ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.y + (long)pix * p.y_pitch + m0 + a_ncol)
+                 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int pix = pp0 + b_prow + B_RPP * i;
+      bool ok = b_qok && pix < p_end;
+      const int pc = ok ? pix : 0;
+      const int ow = pc % p.Wo, t = pc / p.Wo;
+      const int oh = t % p.Ho, b = t / p.Ho;
+      const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+      ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.x + ((long)(b * p.H + ih) * p.W + iw) * p.x_pitch + cch)
+                 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i)
+      *reinterpret_cast<f32x4*>(&As[buf][(a_prow + A_RPP * i) * BM + a_ncol]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      *reinterpret_cast<f32x4*>(&Bs[buf][(b_prow + B_RPP * i) * BN + b_qcol]) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (p_end - p_begin + WBK - 1) / WBK;
+  if (nk > 0) {
+    load_chunk(p_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_chunk(p_begin + (kt + 1) * WBK);
+    const float* as = &As[cur][lh * BM + wm * 32 * TM + lr];
+    const float* bs = &Bs[cur][lh * BN + wn * 32 * TN + lr];
+#pragma unroll
+    for (int s = 0; s < WBK / 2; ++s) {
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = as[(2 * s) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = bs[(2 * s) * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* out = p.out + (p.splits > 1 ? (long)split * p.Nw * p.Q : 0L);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int qq = q0 + wn * 32 * TN + j * 32 + lr;
+    if (qq >= p.Q) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < p.Nw) {
+          const long o = (long)n * p.Q + qq;
+          float v = acc[i][j][r];
+          if (p.splits == 1 && p.beta != 0.f) v += p.beta * out[o];
+          out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, long n,
+                                    int splits, float beta) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(ws + i);
+    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(ws + (long)k * n + i);
+    if (beta != 0.f) {
+      f32x4 o = *reinterpret_cast<const f32x4*>(gw + i);
+      s += o * beta;
+    }
+    *reinterpret_cast<f32x4*>(gw + i) = s;
+  } else {
+    for (long j = i; j < n; ++j) {
+      float s = ws[j];
+      for (int k = 1; k < splits; ++k) s += ws[(long)k * n + j];
+      if (beta != 0.f) s += beta * gw[j];
+      gw[j] = s;
+    }
+  }
+}
+
+void wgrad_plan(const LgmConvGeom* g, int* splits, int* chunk) {
+  const long P = (long)g->B * g->Ho * g->Wo;
+  const long Q = (long)g->KH * g->KW * g->Cw;
+  const long tiles = (long)lgm_cdiv(g->Nw, 64) * lgm_cdiv(Q, 64);
+  long s = (1024 + tiles - 1) / tiles;           // aim for ~1024 workgroups
+  const long max_s = (P + 255) / 256;            // at least 256 pixels per split
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  long c = (P + s - 1) / s;
+  c = (c + WBK - 1) / WBK * WBK;
+  s = (P + c - 1) / c;
+  *splits = (int)s;
+  *chunk = (int)c;
+}
+
+}  // namespace
+
+extern "C" int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g) {
+  if (check_geom(g) != LGM_OK) return -1;
+  int splits, chunk;
+  wgrad_plan(g, &splits, &chunk);
+  if (splits == 1) return 16;
+  return (int64_t)splits * g->Nw * g->KH * g->KW * g->Cw * (int64_t)sizeof(float);
+}
+
+extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
+                              int64_t x_pitch, float* gw, float beta, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+  if (int rc = check_geom(g)) return rc;
+  LGM_REQUIRE(y && x && gw, "conv_wgrad: null pointer");
+  LGM_REQUIRE(g->Cw % 4 == 0 && g->Nw % 4 == 0, "conv_wgrad: Cw=%d, Nw=%d must be multiples of 4", g->Cw, g->Nw);
+  LGM_REQUIRE(y_pitch % 4 == 0 && x_pitch % 4 == 0 && lgm_aligned16(y) && lgm_aligned16(x) && lgm_aligned16(gw),
+              "conv_wgrad: tensors must be 16B aligned with pitch %% 4 == 0");
+  WgradArgs a{};
+  a.y = y; a.x = x; a.beta = beta; a.y_pitch = y_pitch; a.x_pitch = x_pitch;
+  a.B = g->B; a.H = g->H; a.W = g->W; a.Cw = g->Cw; a.Ho = g->Ho; a.Wo = g->Wo; a.Nw = g->Nw;
+  a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
+  a.P = g->B * g->Ho * g->Wo; a.Q = g->KH * g->KW * g->Cw;
+  wgrad_plan(g, &a.splits, &a.chunk);
+  const long n = (long)a.Nw * a.Q;
+  if (a.splits > 1) {
+    LGM_REQUIRE(workspace && workspace_bytes >= (int64_t)a.splits * n * (int64_t)sizeof(float) && lgm_aligned16(workspace),
+                "conv_wgrad: workspace too small (%lld bytes needed)", (long long)a.splits * n * 4);
+    a.out = (float*)workspace;
+  } else {
+    a.out = gw;
+  }
+  a.tiles_m = lgm_cdiv(a.Nw, 64);
+  a.tiles_n = lgm_cdiv(a.Q, 64);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
+  LGM_LAUNCH_CHECK();
+  if (a.splits > 1) {
+    const long nthreads = (n + 3) / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lgm_cdiv(nthreads, 256)), dim3(256), 0, s,
+                       (const float*)workspace, gw, n, a.splits, beta);
+    LGM_LAUNCH_CHECK();
+  }
+  return LGM_OK;
+}

@@ -1,0 +1,537 @@
+// Small HBM-bound kernels: column sums, time embedding, activations, resampling copies,
+// NCHW<->NHWC conversion, diffusion q_sample / v-target / weighted-MSE loss.
+#include <stdarg.h>
+
+#include "lgm_common.h"
+
+// ---------------------------------------------------------------------------------------
+// error string + ABI version
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void lgm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* lgm_last_error(void) { return g_err; }
+extern "C" int lgm_abi_version(void) { return LGM_ABI_VERSION; }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// colsum: out[c] = beta*out[c] + sum_r a[r, c]
+// ---------------------------------------------------------------------------------------
+constexpr int CS_ROWS = 256;  // rows per stage-1 block
+
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ a, long pitch, long rows, long cols,
+                                                     float* __restrict__ partial) {
+  // block = 64 columns x 4 row lanes
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long c = (long)blockIdx.x * 64 + cl;
+  const long r0 = (long)blockIdx.y * CS_ROWS;
+  const long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+  float s = 0.f;
+  if (c < cols)
+    for (long r = r0 + rl; r < r1; r += 4) s += a[r * pitch + c];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) partial[(long)blockIdx.y * cols + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+
+__global__ void colsum_stage2(const float* __restrict__ partial, long nsplit, long cols, float* __restrict__ out,
+                              float beta) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (long k = 0; k < nsplit; ++k) s += partial[k * cols + c];
+  if (beta != 0.f) s += beta * out[c];
+  out[c] = s;
+}
+
+}  // namespace
+
+extern "C" int64_t lgm_colsum_workspace(int64_t rows, int64_t cols) {
+  return (int64_t)lgm_cdiv(rows, CS_ROWS) * cols * (int64_t)sizeof(float) + 16;
+}
+
+extern "C" int lgm_colsum(const float* a, int64_t pitch, int64_t rows, int64_t cols, float* out, float beta,
+                          void* workspace, void* stream) {
+  LGM_REQUIRE(a && out && workspace && rows > 0 && cols > 0, "colsum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int ns = lgm_cdiv(rows, CS_ROWS);
+  LGM_REQUIRE(ns <= 65535, "colsum: too many rows");
+  hipLaunchKernelGGL(colsum_stage1, dim3(lgm_cdiv(cols, 64), ns), dim3(256), 0, s, a, (long)pitch, (long)rows,
+                     (long)cols, (float*)workspace);
+  hipLaunchKernelGGL(colsum_stage2, dim3(lgm_cdiv(cols, 256)), dim3(256), 0, s, (const float*)workspace, (long)ns,
+                     (long)cols, out, beta);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Sinusoidal position embedding  (ddpm.py:125-132): emb[b] = cat(sin(t*f), cos(t*f)),
+// f[i] = exp(i * -(ln(theta)/(half-1)))
+// ---------------------------------------------------------------------------------------
+namespace {
+__global__ void posemb_kernel(const int64_t* __restrict__ t, int B, int dim, float theta, float* __restrict__ out,
+                              long pitch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * half) return;
+  const int b = i / half, j = i % half;
+  const float step = logf(theta) / (float)(half - 1);
+  const float f = expf((float)j * -step);
+  const float arg = (float)t[b] * f;
+  out[(long)b * pitch + j] = sinf(arg);
+  out[(long)b * pitch + half + j] = cosf(arg);
+}
+
+enum { ACT_SILU = 1, ACT_GELU = 2, ACT_RELU = 3, ACT_LRELU = 4, ACT_TANH = 5 };
+
+__device__ __forceinline__ float act_fwd(float x, int act, float slope) {
+  switch (act) {
+    case ACT_SILU: return x / (1.f + expf(-x));
+    case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    case ACT_RELU: return x > 0.f ? x : 0.f;
+    case ACT_LRELU: return x > 0.f ? x : x * slope;
+    case ACT_TANH: return tanhf(x);
+  }
+  return x;
+}
+// derivative w.r.t. the pre-activation x
+__device__ __forceinline__ float act_bwd(float x, int act, float slope) {
+  switch (act) {
+    case ACT_SILU: {
+      const float s = 1.f / (1.f + expf(-x));
+      return s * (1.f + x * (1.f - s));
+    }
+    case ACT_GELU: {
+      const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+      const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case ACT_LRELU: return x > 0.f ? 1.f : slope;
+    case ACT_TANH: {
+      const float t = tanhf(x);
+      return 1.f - t * t;
+    }
+  }
+  return 1.f;
+}
+
+// y[r, c] = act(x[r, c] + bias[c]) (+ res[r,c])   rows x cols with pitches; cols % 4 == 0
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, long x_pitch,
+                                                      const float* __restrict__ bias, const float* __restrict__ res,
+                                                      long res_pitch, float* __restrict__ y, long y_pitch, long rows,
+                                                      int cols, int act, float slope) {
+  const int c4n = cols / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c4n) return;
+  const long r = i / c4n;
+  const int c = (int)(i % c4n) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(x + r * x_pitch + c);
+  if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = act_fwd(v[k], act, slope);
+  if (res) v += *reinterpret_cast<const f32x4*>(res + r * res_pitch + c);
+  *reinterpret_cast<f32x4*>(y + r * y_pitch + c) = v;
+}
+
+// gx = gy * act'(x + bias)  (optionally accumulated)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, long x_pitch,
+                                                      const float* __restrict__ bias, const float* __restrict__ gy,
+                                                      long gy_pitch, float* __restrict__ gx, long gx_pitch,
+                                                      int accumulate, long rows, int cols, int act, float slope) {
+  const int c4n = cols / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c4n) return;
+  const long r = i / c4n;
+  const int c = (int)(i % c4n) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(x + r * x_pitch + c);
+  if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+  f32x4 g = *reinterpret_cast<const f32x4*>(gy + r * gy_pitch + c);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) g[k] *= act_bwd(v[k], act, slope);
+  float* o = gx + r * gx_pitch + c;
+  if (accumulate) g += *reinterpret_cast<const f32x4*>(o);
+  *reinterpret_cast<f32x4*>(o) = g;
+}
+
+// y = alpha*a + beta*b  on strided [rows, cols] matrices (b optional)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, long a_pitch, float alpha,
+                                                    const float* __restrict__ b, long b_pitch, float beta,
+                                                    float* __restrict__ y, long y_pitch, long rows, int cols) {
+  const int c4n = cols / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c4n) return;
+  const long r = i / c4n;
+  const int c = (int)(i % c4n) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(a + r * a_pitch + c) * alpha;
+  if (b) v += *reinterpret_cast<const f32x4*>(b + r * b_pitch + c) * beta;
+  *reinterpret_cast<f32x4*>(y + r * y_pitch + c) = v;
+}
+
+// nearest-neighbour x2 upsample, NHWC: y[b, 2h+i, 2w+j, :] = x[b, h, w, :]
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, long x_pitch,
+                                                             float* __restrict__ y, long y_pitch, int B, int H, int W,
+                                                             int C) {
+  const int c4n = C / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * 2 * H * 2 * W * c4n;
+  if (i >= total) return;
+  const int c = (int)(i % c4n) * 4;
+  long pix = i / c4n;
+  const int ow = (int)(pix % (2 * W));
+  pix /= 2 * W;
+  const int oh = (int)(pix % (2 * H));
+  const int b = (int)(pix / (2 * H));
+  const long src = ((long)(b * H + (oh >> 1)) * W + (ow >> 1)) * x_pitch + c;
+  const long dst = ((long)(b * 2 * H + oh) * 2 * W + ow) * y_pitch + c;
+  *reinterpret_cast<f32x4*>(y + dst) = *reinterpret_cast<const f32x4*>(x + src);
+}
+// gx[b,h,w,:] = sum of the 4 gy children (fixed order)
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ gy, long gy_pitch,
+                                                             float* __restrict__ gx, long gx_pitch, int B, int H, int W,
+                                                             int C, int accumulate) {
+  const int c4n = C / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W * c4n;
+  if (i >= total) return;
+  const int c = (int)(i % c4n) * 4;
+  long pix = i / c4n;
+  const int w = (int)(pix % W);
+  pix /= W;
+  const int h = (int)(pix % H);
+  const int b = (int)(pix / H);
+  const long base = ((long)(b * 2 * H + 2 * h) * 2 * W + 2 * w) * gy_pitch + c;
+  const long rowp = (long)2 * W * gy_pitch;
+  f32x4 s = (*reinterpret_cast<const f32x4*>(gy + base) + *reinterpret_cast<const f32x4*>(gy + base + gy_pitch)) +
+            (*reinterpret_cast<const f32x4*>(gy + base + rowp) +
+             *reinterpret_cast<const f32x4*>(gy + base + rowp + gy_pitch));
+  float* o = gx + ((long)(b * H + h) * W + w) * gx_pitch + c;
+  if (accumulate) s += *reinterpret_cast<const f32x4*>(o);
+  *reinterpret_cast<f32x4*>(o) = s;
+}
+
+// pixel-unshuffle "b c (h p1) (w p2) -> b (c p1 p2) h w" (ddpm.py:102) in NHWC:
+// y[b, h, w, c*4 + p1*2 + p2] = x[b, 2h+p1, 2w+p2, c].  dir = 0 forward, 1 = inverse (gradient).
+__global__ __launch_bounds__(256) void unshuffle_kernel(const float* __restrict__ src, long src_pitch,
+                                                        float* __restrict__ dst, long dst_pitch, int B, int H, int W,
+                                                        int C, int dir, int accumulate) {
+  // H, W are the LOW-resolution sizes; C the high-resolution channel count.
+  // one thread per (low-res pixel, channel c): moves the 4 (p1,p2) values -> float4 on the 4C side.
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  long pix = i / C;
+  const int w = (int)(pix % W);
+  pix /= W;
+  const int h = (int)(pix % H);
+  const int b = (int)(pix / H);
+  const long hi00 = ((long)(b * 2 * H + 2 * h) * 2 * W + 2 * w);
+  const long lo = ((long)(b * H + h) * W + w);
+  if (dir == 0) {
+    f32x4 v;
+    v[0] = src[(hi00)*src_pitch + c];
+    v[1] = src[(hi00 + 1) * src_pitch + c];
+    v[2] = src[(hi00 + 2 * W) * src_pitch + c];
+    v[3] = src[(hi00 + 2 * W + 1) * src_pitch + c];
+    *reinterpret_cast<f32x4*>(dst + lo * dst_pitch + c * 4) = v;
+  } else {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + lo * src_pitch + c * 4);
+    float* d = dst;
+    if (accumulate) {
+      d[(hi00)*dst_pitch + c] += v[0];
+      d[(hi00 + 1) * dst_pitch + c] += v[1];
+      d[(hi00 + 2 * W) * dst_pitch + c] += v[2];
+      d[(hi00 + 2 * W + 1) * dst_pitch + c] += v[3];
+    } else {
+      d[(hi00)*dst_pitch + c] = v[0];
+      d[(hi00 + 1) * dst_pitch + c] = v[1];
+      d[(hi00 + 2 * W) * dst_pitch + c] = v[2];
+      d[(hi00 + 2 * W + 1) * dst_pitch + c] = v[3];
+    }
+  }
+}
+
+// NCHW [B,C,H,W] dense  <->  NHWC with pitch (pad channels written as zero on the way in)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           long dst_pitch, int B, int C, int HW, int Cpad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * HW * Cpad;
+  if (i >= total) return;
+  const int c = (int)(i % Cpad);
+  const long pix = i / Cpad;
+  const int b = (int)(pix / HW);
+  const int p = (int)(pix % HW);
+  dst[pix * dst_pitch + c] = c < C ? src[((long)b * C + c) * HW + p] : 0.f;
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, long src_pitch,
+                                                           float* __restrict__ dst, int B, int C, int HW) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * C * HW;
+  if (i >= total) return;
+  const int p = (int)(i % HW);
+  const long bc = i / HW;
+  const int c = (int)(bc % C);
+  const int b = (int)(bc / C);
+  dst[i] = src[((long)b * HW + p) * src_pitch + c];
+}
+
+// ---------------------------------------------------------------------------------------
+// Diffusion training elementwise (ddpm.py:869-876, 684-688, 945):
+//   x0 = img*2-1 (auto_normalize) ; x_t = sa[t]*x0 + sb[t]*noise ; v = sa[t]*noise - sb[t]*x0
+// img/noise NCHW dense [B,C,HW]; outputs NHWC with pitch (pad channels zeroed).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qsample_kernel(const float* __restrict__ img, const float* __restrict__ noise,
+                                                      const int64_t* __restrict__ t, const float* __restrict__ sa,
+                                                      const float* __restrict__ sb, int normalize,
+                                                      float* __restrict__ xt, float* __restrict__ target, long pitch,
+                                                      int B, int C, int HW, int Cpad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * HW * Cpad;
+  if (i >= total) return;
+  const int c = (int)(i % Cpad);
+  const long pix = i / Cpad;
+  const int b = (int)(pix / HW);
+  const int p = (int)(pix % HW);
+  float xv = 0.f, tv = 0.f;
+  if (c < C) {
+    const long s = ((long)b * C + c) * HW + p;
+    float x0 = img[s];
+    if (normalize) x0 = x0 * 2.f - 1.f;
+    const float n = noise[s];
+    const float a = sa[t[b]], bb = sb[t[b]];
+    xv = a * x0 + bb * n;
+    tv = a * n - bb * x0;
+  }
+  xt[pix * pitch + c] = xv;
+  if (target) target[pix * pitch + c] = tv;
+}
+
+// per-sample weighted MSE (ddpm.py:921-925): loss = mean_b( w[t_b] * mean_{chw} (out-target)^2 )
+// stage 1: one block per sample -> per-sample value; stage 2: one block -> scalar.  Also emits
+// gout = gscale * 2 * w[t_b] * (out - target) / (C*HW*B) when gout != null (gscale read from device).
+__global__ __launch_bounds__(256) void mse_sample_kernel(const float* __restrict__ out, const float* __restrict__ target,
+                                                         long pitch, const int64_t* __restrict__ t,
+                                                         const float* __restrict__ lw, int C, int HW, int Cpad,
+                                                         float* __restrict__ per_sample) {
+  __shared__ float sh[16];
+  const int b = blockIdx.x;
+  const long n = (long)HW * Cpad;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const long pix = (long)b * HW + i / Cpad;
+    if (c < C) {
+      const float d = out[pix * pitch + c] - target[pix * pitch + c];
+      s += d * d;
+    }
+  }
+  s = lgm_block_sum(s, sh);
+  if (threadIdx.x == 0) per_sample[b] = s / ((float)C * (float)HW) * (lw ? lw[t[b]] : 1.f);
+}
+__global__ void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+  s = lgm_block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ out, const float* __restrict__ target,
+                                                      long pitch, const int64_t* __restrict__ t,
+                                                      const float* __restrict__ lw, const float* __restrict__ gloss,
+                                                      int B, int C, int HW, int Cpad, float* __restrict__ gout) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * HW * Cpad;
+  if (i >= total) return;
+  const int c = (int)(i % Cpad);
+  const long pix = i / Cpad;
+  const int b = (int)(pix / HW);
+  float g = 0.f;
+  if (c < C) {
+    const float w = lw ? lw[t[b]] : 1.f;
+    const float scale = gloss[0] * 2.f * w / ((float)C * (float)HW * (float)B);
+    g = scale * (out[pix * pitch + c] - target[pix * pitch + c]);
+  }
+  gout[pix * pitch + c] = g;
+}
+
+
+// One reverse-diffusion update for a whole batch at a shared timestep (ddpm.py:707-757, 805-829):
+//   x0  = clamp(A*x + Bv*v, -1, 1)            (predict_start_from_v + clip)
+//   eps = (R*x - x0) / Rm1                    (predict_noise_from_start)
+//   out = C0*x0 + C1*x + C2*eps + C3*noise
+// x, v: NHWC pitch Cpad; noise: NCHW dense (or null); out: NHWC pitch Cpad; x0_out optional.
+__global__ __launch_bounds__(256) void sample_step_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                          const float* __restrict__ noise, float* __restrict__ out,
+                                                          float* __restrict__ x0_out, int B, int C, int HW, int Cpad,
+                                                          float A, float Bv, int clip, float R, float Rm1, float C0,
+                                                          float C1, float C2, float C3) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * HW * Cpad;
+  if (i >= total) return;
+  const int c = (int)(i % Cpad);
+  const long pix = i / Cpad;
+  float o = 0.f, x0 = 0.f;
+  if (c < C) {
+    const float xv = x[i];
+    x0 = A * xv + Bv * v[i];
+    if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    const float eps = (R * xv - x0) / Rm1;
+    o = C0 * x0 + C1 * xv + C2 * eps;
+    if (noise && C3 != 0.f) {
+      const int b = (int)(pix / HW), p = (int)(pix % HW);
+      o += C3 * noise[((long)b * C + c) * HW + p];
+    }
+  }
+  out[i] = o;
+  if (x0_out) x0_out[i] = x0;
+}
+
+}  // namespace
+
+extern "C" int lgm_posemb(const int64_t* t, int B, int dim, float theta, float* out, int64_t pitch, void* stream) {
+  LGM_REQUIRE(t && out && B > 0 && dim >= 4 && dim % 2 == 0 && pitch >= dim, "posemb: bad arguments");
+  hipLaunchKernelGGL(posemb_kernel, dim3(lgm_cdiv((long)B * dim / 2, 256)), dim3(256), 0, (hipStream_t)stream, t, B,
+                     dim, theta, out, (long)pitch);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+static int check_mat(const void* a, int64_t pitch, int64_t rows, int cols, const char* who) {
+  LGM_REQUIRE(a && rows > 0 && cols > 0 && cols % 4 == 0 && pitch % 4 == 0 && pitch >= cols && lgm_aligned16(a),
+              "%s: matrix must be non-null, 16B aligned, cols/pitch multiples of 4", who);
+  return LGM_OK;
+}
+
+extern "C" int lgm_act_fwd(const float* x, int64_t x_pitch, const float* bias, const float* res, int64_t res_pitch,
+                           float* y, int64_t y_pitch, int64_t rows, int cols, int act, float slope, void* stream) {
+  if (int rc = check_mat(x, x_pitch, rows, cols, "act_fwd(x)")) return rc;
+  if (int rc = check_mat(y, y_pitch, rows, cols, "act_fwd(y)")) return rc;
+  if (res) if (int rc = check_mat(res, res_pitch, rows, cols, "act_fwd(res)")) return rc;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(lgm_cdiv(rows * (cols / 4), 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)x_pitch, bias, res, (long)res_pitch, y, (long)y_pitch, (long)rows, cols, act, slope);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_act_bwd(const float* x, int64_t x_pitch, const float* bias, const float* gy, int64_t gy_pitch,
+                           float* gx, int64_t gx_pitch, int accumulate, int64_t rows, int cols, int act, float slope,
+                           void* stream) {
+  if (int rc = check_mat(x, x_pitch, rows, cols, "act_bwd(x)")) return rc;
+  if (int rc = check_mat(gy, gy_pitch, rows, cols, "act_bwd(gy)")) return rc;
+  if (int rc = check_mat(gx, gx_pitch, rows, cols, "act_bwd(gx)")) return rc;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(lgm_cdiv(rows * (cols / 4), 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)x_pitch, bias, gy, (long)gy_pitch, gx, (long)gx_pitch, accumulate, (long)rows, cols, act, slope);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_axpby(const float* a, int64_t a_pitch, float alpha, const float* b, int64_t b_pitch, float beta,
+                         float* y, int64_t y_pitch, int64_t rows, int cols, void* stream) {
+  if (int rc = check_mat(a, a_pitch, rows, cols, "axpby(a)")) return rc;
+  if (int rc = check_mat(y, y_pitch, rows, cols, "axpby(y)")) return rc;
+  if (b) if (int rc = check_mat(b, b_pitch, rows, cols, "axpby(b)")) return rc;
+  hipLaunchKernelGGL(axpby_kernel, dim3(lgm_cdiv(rows * (cols / 4), 256)), dim3(256), 0, (hipStream_t)stream, a,
+                     (long)a_pitch, alpha, b, (long)b_pitch, beta, y, (long)y_pitch, (long)rows, cols);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_upsample2x_fwd(const float* x, int64_t x_pitch, float* y, int64_t y_pitch, int B, int H, int W,
+                                  int C, void* stream) {
+  if (int rc = check_mat(x, x_pitch, (long)B * H * W, C, "upsample2x_fwd(x)")) return rc;
+  if (int rc = check_mat(y, y_pitch, (long)B * H * W * 4, C, "upsample2x_fwd(y)")) return rc;
+  const long total = (long)B * 4 * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(lgm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)x_pitch, y, (long)y_pitch, B, H, W, C);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_upsample2x_bwd(const float* gy, int64_t gy_pitch, float* gx, int64_t gx_pitch, int B, int H, int W,
+                                  int C, int accumulate, void* stream) {
+  if (int rc = check_mat(gx, gx_pitch, (long)B * H * W, C, "upsample2x_bwd(gx)")) return rc;
+  if (int rc = check_mat(gy, gy_pitch, (long)B * H * W * 4, C, "upsample2x_bwd(gy)")) return rc;
+  const long total = (long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(lgm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gy,
+                     (long)gy_pitch, gx, (long)gx_pitch, B, H, W, C, accumulate);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_pixel_unshuffle(const float* src, int64_t src_pitch, float* dst, int64_t dst_pitch, int B,
+                                   int Hlo, int Wlo, int C, int inverse, int accumulate, void* stream) {
+  LGM_REQUIRE(src && dst && B > 0 && Hlo > 0 && Wlo > 0 && C > 0, "pixel_unshuffle: bad arguments");
+  LGM_REQUIRE((inverse ? src_pitch : dst_pitch) % 4 == 0, "pixel_unshuffle: 4C-side pitch %% 4 != 0");
+  const long total = (long)B * Hlo * Wlo * C;
+  hipLaunchKernelGGL(unshuffle_kernel, dim3(lgm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (long)src_pitch, dst, (long)dst_pitch, B, Hlo, Wlo, C, inverse, accumulate);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_nchw_to_nhwc(const float* src, float* dst, int64_t dst_pitch, int B, int C, int HW, int Cpad,
+                                void* stream) {
+  LGM_REQUIRE(src && dst && B > 0 && C > 0 && HW > 0 && Cpad >= C && dst_pitch >= Cpad, "nchw_to_nhwc: bad arguments");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(lgm_cdiv((long)B * HW * Cpad, 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, dst, (long)dst_pitch, B, C, HW, Cpad);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_nhwc_to_nchw(const float* src, int64_t src_pitch, float* dst, int B, int C, int HW, void* stream) {
+  LGM_REQUIRE(src && dst && B > 0 && C > 0 && HW > 0 && src_pitch >= C, "nhwc_to_nchw: bad arguments");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(lgm_cdiv((long)B * C * HW, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (long)src_pitch, dst, B, C, HW);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_qsample_target(const float* img, const float* noise, const int64_t* t, const float* sqrt_ac,
+                                  const float* sqrt_1mac, int normalize, float* xt, float* target, int64_t pitch,
+                                  int B, int C, int HW, int Cpad, void* stream) {
+  LGM_REQUIRE(img && noise && t && sqrt_ac && sqrt_1mac && xt && B > 0 && C > 0 && HW > 0 && Cpad >= C && pitch >= Cpad,
+              "qsample_target: bad arguments");
+  hipLaunchKernelGGL(qsample_kernel, dim3(lgm_cdiv((long)B * HW * Cpad, 256)), dim3(256), 0, (hipStream_t)stream, img,
+                     noise, t, sqrt_ac, sqrt_1mac, normalize, xt, target, (long)pitch, B, C, HW, Cpad);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_weighted_mse_fwd(const float* out, const float* target, int64_t pitch, const int64_t* t,
+                                    const float* loss_weight, int B, int C, int HW, int Cpad, float* per_sample,
+                                    float* loss, void* stream) {
+  LGM_REQUIRE(out && target && per_sample && loss && B > 0 && (!loss_weight || t), "weighted_mse_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(mse_sample_kernel, dim3(B), dim3(256), 0, s, out, target, (long)pitch, t, loss_weight, C, HW, Cpad,
+                     per_sample);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, (const float*)per_sample, B, loss);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_weighted_mse_bwd(const float* out, const float* target, int64_t pitch, const int64_t* t,
+                                    const float* loss_weight, const float* gloss, int B, int C, int HW, int Cpad,
+                                    float* gout, void* stream) {
+  LGM_REQUIRE(out && target && gloss && gout && B > 0 && (!loss_weight || t), "weighted_mse_bwd: bad arguments");
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(lgm_cdiv((long)B * HW * Cpad, 256)), dim3(256), 0, (hipStream_t)stream, out,
+                     target, (long)pitch, t, loss_weight, gloss, B, C, HW, Cpad, gout);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_sample_step(const float* x, const float* v, const float* noise, float* out, float* x0_out, int B,
+                               int C, int HW, int Cpad, float A, float Bv, int clip, float R, float Rm1, float C0,
+                               float C1, float C2, float C3, void* stream) {
+  LGM_REQUIRE(x && v && out && B > 0 && C > 0 && HW > 0 && Cpad >= C, "sample_step: bad arguments");
+  hipLaunchKernelGGL(sample_step_kernel, dim3(lgm_cdiv((long)B * HW * Cpad, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     v, noise, out, x0_out, B, C, HW, Cpad, A, Bv, clip, R, Rm1, C0, C1, C2, C3);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}

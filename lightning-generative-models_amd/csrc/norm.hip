@@ -1,0 +1,495 @@
+// GroupNorm (+FiLM scale/shift, +SiLU, +residual) and RMSNorm for NHWC fp32 activations.
+// HBM-bound kernels: float4 accesses, coalesced along channels, deterministic reductions
+// (fixed-order LDS combines, no float atomics).
+//
+// Reference arithmetic: Block.forward ddpm.py:164-173 (GroupNorm(8, C, eps=1e-5) -> x*(scale+1)+shift
+// -> SiLU), RMSNorm ddpm.py:107-113 (F.normalize(x, dim=1) * g * sqrt(C)).
+#include "lgm_common.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float silu_grad(float z) {
+  const float s = 1.f / (1.f + __expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
+
+// ---------------------------------------------------------------------------------------
+// GN statistics: one block per (image, channel block of CB channels); two in-kernel passes
+// (mean, then centred second moment) so the variance does not suffer cancellation.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long pitch, int HW,
+                                                       int C, int G, int CB, float eps,
+                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ float sh[256 * 4];
+  __shared__ float gmean[64];
+  const int nb = C / CB;
+  const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
+  const int c0 = cb * CB;
+  const int Cg = C / G;
+  const int tq = CB / 4;              // threads per pixel
+  const int ppb = 256 / tq;           // pixel lanes
+  const int tid = threadIdx.x;
+  const int q = tid % tq, pl = tid / tq;
+  const bool active = pl < ppb;
+  const float* xb = x + (long)b * HW * pitch + c0 + q * 4;
+  const int ngl = CB / Cg;            // groups in this block
+  const float inv_n = 1.f / ((float)Cg * (float)HW);
+
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (active)
+    for (int p = pl; p < HW; p += ppb) s += *reinterpret_cast<const f32x4*>(xb + (long)p * pitch);
+  *reinterpret_cast<f32x4*>(&sh[tid * 4]) = s;
+  __syncthreads();
+  if (tid < ngl) {
+    float acc = 0.f;
+    for (int pp = 0; pp < ppb; ++pp)
+      for (int c = 0; c < Cg; ++c) acc += sh[(pp * tq) * 4 + tid * Cg + c];
+    gmean[tid] = acc * inv_n;
+  }
+  __syncthreads();
+  f32x4 mu;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) mu[k] = gmean[(q * 4 + k) / Cg];
+  f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
+  if (active)
+    for (int p = pl; p < HW; p += ppb) {
+      f32x4 d = *reinterpret_cast<const f32x4*>(xb + (long)p * pitch) - mu;
+      s2 += d * d;
+    }
+  __syncthreads();
+  *reinterpret_cast<f32x4*>(&sh[tid * 4]) = s2;
+  __syncthreads();
+  if (tid < ngl) {
+    float acc = 0.f;
+    for (int pp = 0; pp < ppb; ++pp)
+      for (int c = 0; c < Cg; ++c) acc += sh[(pp * tq) * 4 + tid * Cg + c];
+    const int g = c0 / Cg + tid;
+    mean[b * G + g] = gmean[tid];
+    rstd[b * G + g] = rsqrtf(acc * inv_n + eps);
+  }
+}
+
+// coefficients: z = x * A[b,c] + Bc[b,c]
+__global__ void gn_coef_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ ss, long ss_pitch, int B, int C, int G,
+                               float* __restrict__ A, float* __restrict__ Bc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  const int g = c / (C / G);
+  const float mu = mean[b * G + g], rs = rstd[b * G + g];
+  float a = rs * gamma[c];
+  float bb = beta[c] - mu * a;
+  if (ss) {
+    const float sc = ss[(long)b * ss_pitch + c] + 1.f;
+    const float sh = ss[(long)b * ss_pitch + C + c];
+    a *= sc;
+    bb = bb * sc + sh;
+  }
+  A[i] = a;
+  Bc[i] = bb;
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, long x_pitch,
+                                                       const float* __restrict__ A, const float* __restrict__ Bc,
+                                                       const float* __restrict__ res, long res_pitch,
+                                                       float* __restrict__ y, long y_pitch, long npix, int HW,
+                                                       int C, int act) {
+  const int c4n = C / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * c4n) return;
+  const long pix = i / c4n;
+  const int c = (int)(i % c4n) * 4;
+  const int b = (int)(pix / HW);
+  const f32x4 xv = *reinterpret_cast<const f32x4*>(x + pix * x_pitch + c);
+  const f32x4 a = *reinterpret_cast<const f32x4*>(A + (long)b * C + c);
+  const f32x4 bc = *reinterpret_cast<const f32x4*>(Bc + (long)b * C + c);
+  f32x4 z = xv * a + bc;
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = silu_f(z[k]);
+  }
+  if (res) z += *reinterpret_cast<const f32x4*>(res + pix * res_pitch + c);
+  *reinterpret_cast<f32x4*>(y + pix * y_pitch + c) = z;
+}
+
+// backward pass 1: S1[b,c] = sum_hw gz, S2[b,c] = sum_hw gz * xhat
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, long x_pitch,
+                                                            const float* __restrict__ gy, long gy_pitch,
+                                                            const float* __restrict__ A, const float* __restrict__ Bc,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            int HW, int C, int G, int CB, int act,
+                                                            float* __restrict__ S1, float* __restrict__ S2) {
+  __shared__ float sh[256 * 8];
+  const int nb = C / CB;
+  const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
+  const int c0 = cb * CB;
+  const int Cg = C / G;
+  const int tq = CB / 4, ppb = 256 / tq;
+  const int tid = threadIdx.x;
+  const int q = tid % tq, pl = tid / tq;
+  const bool active = pl < ppb;
+  const int c = c0 + q * 4;
+  const float* xb = x + (long)b * HW * x_pitch + c;
+  const float* gb = gy + (long)b * HW * gy_pitch + c;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(A + (long)b * C + c);
+  const f32x4 bc = *reinterpret_cast<const f32x4*>(Bc + (long)b * C + c);
+  f32x4 mu, rs;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    mu[k] = mean[b * G + (c + k) / Cg];
+    rs[k] = rstd[b * G + (c + k) / Cg];
+  }
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (active)
+    for (int p = pl; p < HW; p += ppb) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)p * x_pitch);
+      f32x4 g = *reinterpret_cast<const f32x4*>(gb + (long)p * gy_pitch);
+      if (act) {
+        const f32x4 z = xv * a + bc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] *= silu_grad(z[k]);
+      }
+      s1 += g;
+      s2 += g * ((xv - mu) * rs);
+    }
+  *reinterpret_cast<f32x4*>(&sh[tid * 8]) = s1;
+  *reinterpret_cast<f32x4*>(&sh[tid * 8 + 4]) = s2;
+  __syncthreads();
+  if (tid < CB) {  // one thread per channel, fixed-order sum over pixel lanes
+    const int qq = tid / 4, k = tid % 4;
+    float a1 = 0.f, a2 = 0.f;
+    for (int pp = 0; pp < ppb; ++pp) {
+      a1 += sh[(pp * tq + qq) * 8 + k];
+      a2 += sh[(pp * tq + qq) * 8 + 4 + k];
+    }
+    S1[(long)b * C + c0 + tid] = a1;
+    S2[(long)b * C + c0 + tid] = a2;
+  }
+}
+
+// backward pass 2 (tiny): per-(b,c) coefficients P,Qc,Rc for gx = P*gz + Qc + x*Rc, and g_scale/g_shift.
+__global__ void gn_bwd_coef_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ ss, long ss_pitch, float* __restrict__ gss,
+                                   long gss_pitch, float gss_beta, int B, int C, int G, int HW,
+                                   float* __restrict__ P, float* __restrict__ Qc, float* __restrict__ Rc) {
+  // one block per image; blockDim = 256; loops over channels
+  __shared__ float m1s[64], m2s[64];
+  const int b = blockIdx.x;
+  const int Cg = C / G;
+  const float inv_n = 1.f / ((float)Cg * (float)HW);
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
+      const float sc = ss ? ss[(long)b * ss_pitch + c] + 1.f : 1.f;
+      const float w = gamma[c] * sc;
+      a1 += w * S1[(long)b * C + c];
+      a2 += w * S2[(long)b * C + c];
+    }
+    m1s[g] = a1 * inv_n;
+    m2s[g] = a2 * inv_n;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / Cg;
+    const float mu = mean[b * G + g], rs = rstd[b * G + g];
+    const float sc = ss ? ss[(long)b * ss_pitch + c] + 1.f : 1.f;
+    const long i = (long)b * C + c;
+    P[i] = rs * gamma[c] * sc;
+    const float R = -rs * m2s[g];          // multiplies xhat
+    Rc[i] = R * rs;                        // multiplies x
+    Qc[i] = -rs * m1s[g] - mu * rs * R;
+    if (gss) {
+      const float s1 = S1[i], s2 = S2[i];
+      float gsc = gamma[c] * s2 + beta[c] * s1;
+      float gsh = s1;
+      if (gss_beta != 0.f) {
+        gsc += gss_beta * gss[(long)b * gss_pitch + c];
+        gsh += gss_beta * gss[(long)b * gss_pitch + C + c];
+      }
+      gss[(long)b * gss_pitch + c] = gsc;
+      gss[(long)b * gss_pitch + C + c] = gsh;
+    }
+  }
+}
+
+// gamma/beta gradients: reduce over the batch in a fixed order
+__global__ void gn_bwd_affine_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+                                     const float* __restrict__ ss, long ss_pitch, int B, int C,
+                                     float* __restrict__ ggamma, float* __restrict__ gbeta, float beta_acc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float gg = 0.f, gb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float sc = ss ? ss[(long)b * ss_pitch + c] + 1.f : 1.f;
+    gg += sc * S2[(long)b * C + c];
+    gb += sc * S1[(long)b * C + c];
+  }
+  if (beta_acc != 0.f) {
+    gg += beta_acc * ggamma[c];
+    gb += beta_acc * gbeta[c];
+  }
+  ggamma[c] = gg;
+  gbeta[c] = gb;
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, long x_pitch,
+                                                           const float* __restrict__ gy, long gy_pitch,
+                                                           const float* __restrict__ A, const float* __restrict__ Bc,
+                                                           const float* __restrict__ P, const float* __restrict__ Qc,
+                                                           const float* __restrict__ Rc, float* __restrict__ gx,
+                                                           long gx_pitch, long npix, int HW, int C, int act,
+                                                           int accumulate) {
+  const int c4n = C / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * c4n) return;
+  const long pix = i / c4n;
+  const int c = (int)(i % c4n) * 4;
+  const long bc_off = (pix / HW) * C + c;
+  const f32x4 xv = *reinterpret_cast<const f32x4*>(x + pix * x_pitch + c);
+  f32x4 g = *reinterpret_cast<const f32x4*>(gy + pix * gy_pitch + c);
+  if (act) {
+    const f32x4 z = xv * *reinterpret_cast<const f32x4*>(A + bc_off) + *reinterpret_cast<const f32x4*>(Bc + bc_off);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] *= silu_grad(z[k]);
+  }
+  f32x4 r = g * *reinterpret_cast<const f32x4*>(P + bc_off) + *reinterpret_cast<const f32x4*>(Qc + bc_off) +
+            xv * *reinterpret_cast<const f32x4*>(Rc + bc_off);
+  float* o = gx + pix * gx_pitch + c;
+  if (accumulate) r += *reinterpret_cast<const f32x4*>(o);
+  *reinterpret_cast<f32x4*>(o) = r;
+}
+
+int gn_cb(int C, int G) {
+  const int Cg = C / G;
+  int cb = Cg * ((32 + Cg - 1) / Cg);
+  if (cb > C) cb = C;
+  return cb;
+}
+
+int gn_check(int B, int HW, int C, int G) {
+  LGM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm: bad sizes B=%d HW=%d C=%d G=%d", B, HW, C, G);
+  LGM_REQUIRE(C % 4 == 0 && G <= 64, "groupnorm: C %% 4 != 0 or G > 64");
+  const int cb = gn_cb(C, G);
+  LGM_REQUIRE(cb % 4 == 0 && C % cb == 0 && cb / 4 <= 256 && cb <= 256, "groupnorm: unsupported C=%d G=%d", C, G);
+  return LGM_OK;
+}
+
+}  // namespace
+
+extern "C" int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C, int G, float eps,
+                          const float* gamma, const float* beta, const float* ss, int64_t ss_pitch,
+                          int act, const float* res, int64_t res_pitch, float* y, int64_t y_pitch,
+                          float* mean, float* rstd, float* coefA, float* coefB, void* stream) {
+  if (int rc = gn_check(B, HW, C, G)) return rc;
+  LGM_REQUIRE(x && gamma && beta && y && mean && rstd && coefA && coefB, "gn_fwd: null pointer");
+  LGM_REQUIRE(x_pitch % 4 == 0 && y_pitch % 4 == 0 && (!res || res_pitch % 4 == 0), "gn_fwd: pitch %% 4 != 0");
+  hipStream_t s = (hipStream_t)stream;
+  const int cb = gn_cb(C, G);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(B * (C / cb)), dim3(256), 0, s, x, (long)x_pitch, HW, C, G, cb, eps, mean, rstd);
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(lgm_cdiv((long)B * C, 256)), dim3(256), 0, s, mean, rstd, gamma, beta, ss,
+                     (long)ss_pitch, B, C, G, coefA, coefB);
+  const long npix = (long)B * HW;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(lgm_cdiv(npix * (C / 4), 256)), dim3(256), 0, s, x, (long)x_pitch, coefA,
+                     coefB, res, (long)res_pitch, y, (long)y_pitch, npix, HW, C, act);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
+                          int C, int G, const float* gamma, const float* beta, const float* ss,
+                          int64_t ss_pitch, int act, const float* mean, const float* rstd,
+                          const float* coefA, const float* coefB, float* gx, int64_t gx_pitch,
+                          int accumulate_gx, float* ggamma, float* gbeta, float affine_beta, float* gss,
+                          int64_t gss_pitch, float gss_beta, float* workspace, void* stream) {
+  if (int rc = gn_check(B, HW, C, G)) return rc;
+  LGM_REQUIRE(x && gy && gamma && beta && mean && rstd && coefA && coefB && gx && ggamma && gbeta && workspace,
+              "gn_bwd: null pointer");
+  LGM_REQUIRE(x_pitch % 4 == 0 && gy_pitch % 4 == 0 && gx_pitch % 4 == 0, "gn_bwd: pitch %% 4 != 0");
+  hipStream_t s = (hipStream_t)stream;
+  const long bc = (long)B * C;
+  float* S1 = workspace;
+  float* S2 = S1 + bc;
+  float* P = S2 + bc;
+  float* Qc = P + bc;
+  float* Rc = Qc + bc;
+  const int cb = gn_cb(C, G);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * (C / cb)), dim3(256), 0, s, x, (long)x_pitch, gy, (long)gy_pitch,
+                     coefA, coefB, mean, rstd, HW, C, G, cb, act, S1, S2);
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(B), dim3(256), 0, s, S1, S2, mean, rstd, gamma, beta, ss, (long)ss_pitch,
+                     gss, (long)gss_pitch, gss_beta, B, C, G, HW, P, Qc, Rc);
+  hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(lgm_cdiv(C, 64)), dim3(64), 0, s, S1, S2, ss, (long)ss_pitch, B, C,
+                     ggamma, gbeta, affine_beta);
+  const long npix = (long)B * HW;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(lgm_cdiv(npix * (C / 4), 256)), dim3(256), 0, s, x, (long)x_pitch, gy,
+                     (long)gy_pitch, coefA, coefB, P, Qc, Rc, gx, (long)gx_pitch, npix, HW, C, act, accumulate_gx);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// =====================================================================================
+// RMSNorm over channels, one sub-wave group of L = min(64, C/4) lanes per pixel.
+// y = x / max(||x||, 1e-12) * g * sqrt(C)  (+ res)
+// =====================================================================================
+namespace {
+
+constexpr int RMS_MAXQ = 4;  // quads per lane (C <= 1024)
+
+template <int Q>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, long x_pitch,
+                                                          const float* __restrict__ g, const float* __restrict__ res,
+                                                          long res_pitch, float* __restrict__ y, long y_pitch,
+                                                          long npix, int C, int L) {
+  const int ppb = 256 / L;  // pixels per block pass
+  const int tid = threadIdx.x;
+  const int l = tid % L, pg = tid / L;
+  const float sqrtc = sqrtf((float)C);
+  f32x4 gv[Q];
+#pragma unroll
+  for (int k = 0; k < Q; ++k) gv[k] = *reinterpret_cast<const f32x4*>(g + (l + k * L) * 4);
+  for (long pix = (long)blockIdx.x * ppb + pg; pix < npix; pix += (long)gridDim.x * ppb) {
+    f32x4 xv[Q];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      xv[k] = *reinterpret_cast<const f32x4*>(x + pix * x_pitch + (l + k * L) * 4);
+      ss += xv[k][0] * xv[k][0] + xv[k][1] * xv[k][1] + xv[k][2] * xv[k][2] + xv[k][3] * xv[k][3];
+    }
+    for (int off = L >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float inv = sqrtc / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      f32x4 o = xv[k] * gv[k] * inv;
+      if (res) o += *reinterpret_cast<const f32x4*>(res + pix * res_pitch + (l + k * L) * 4);
+      *reinterpret_cast<f32x4*>(y + pix * y_pitch + (l + k * L) * 4) = o;
+    }
+  }
+}
+
+// backward: gx = (gxh - xh * dot(xh, gxh)) / n,  gxh = gy * g * sqrt(C);  gg partial per block.
+template <int Q>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, long x_pitch,
+                                                          const float* __restrict__ gy, long gy_pitch,
+                                                          const float* __restrict__ g, float* __restrict__ gx,
+                                                          long gx_pitch, int accumulate, long npix, int C, int L,
+                                                          float* __restrict__ gg_partial) {
+  __shared__ float sh[256 * 4 * Q];
+  const int ppb = 256 / L;
+  const int tid = threadIdx.x;
+  const int l = tid % L, pg = tid / L;
+  const float sqrtc = sqrtf((float)C);
+  f32x4 gv[Q], gacc[Q];
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    gv[k] = *reinterpret_cast<const f32x4*>(g + (l + k * L) * 4);
+    gacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long pix = (long)blockIdx.x * ppb + pg; pix < npix; pix += (long)gridDim.x * ppb) {
+    f32x4 xv[Q], gv_y[Q];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      xv[k] = *reinterpret_cast<const f32x4*>(x + pix * x_pitch + (l + k * L) * 4);
+      gv_y[k] = *reinterpret_cast<const f32x4*>(gy + pix * gy_pitch + (l + k * L) * 4);
+      ss += xv[k][0] * xv[k][0] + xv[k][1] * xv[k][1] + xv[k][2] * xv[k][2] + xv[k][3] * xv[k][3];
+    }
+    for (int off = L >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float nrm = sqrtf(ss);
+    const bool clamped = nrm < 1e-12f;
+    const float invn = 1.f / fmaxf(nrm, 1e-12f);
+    float dot = 0.f;
+    f32x4 gxh[Q], xh[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      xh[k] = xv[k] * invn;
+      gxh[k] = gv_y[k] * gv[k] * sqrtc;
+      gacc[k] += gv_y[k] * xh[k] * sqrtc;
+      dot += xh[k][0] * gxh[k][0] + xh[k][1] * gxh[k][1] + xh[k][2] * gxh[k][2] + xh[k][3] * gxh[k][3];
+    }
+    for (int off = L >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    if (clamped) dot = 0.f;  // x / eps is linear in x below the clamp
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      f32x4 o = (gxh[k] - xh[k] * dot) * invn;
+      float* dst = gx + pix * gx_pitch + (l + k * L) * 4;
+      if (accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+      *reinterpret_cast<f32x4*>(dst) = o;
+    }
+  }
+  // combine the per-thread g-gradients over the pixel groups of this block (fixed order)
+#pragma unroll
+  for (int k = 0; k < Q; ++k) *reinterpret_cast<f32x4*>(&sh[(tid * Q + k) * 4]) = gacc[k];
+  __syncthreads();
+  if (tid < L) {
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int p = 0; p < ppb; ++p) a += *reinterpret_cast<const f32x4*>(&sh[((p * L + tid) * Q + k) * 4]);
+      *reinterpret_cast<f32x4*>(gg_partial + (long)blockIdx.x * C + (tid + k * L) * 4) = a;
+    }
+  }
+}
+
+int rms_plan(int C, int* L, int* Q) {
+  LGM_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "rmsnorm: unsupported C=%d", C);
+  const int c4 = C / 4;
+  LGM_REQUIRE((c4 & (c4 - 1)) == 0, "rmsnorm: C/4 must be a power of two (C=%d)", C);
+  *L = c4 < 64 ? c4 : 64;
+  *Q = c4 / *L;
+  return LGM_OK;
+}
+
+int rms_blocks(long npix, int L) {
+  const int ppb = 256 / L;
+  long nb = (npix + ppb - 1) / ppb;
+  if (nb > 1024) nb = 1024;
+  return (int)nb;
+}
+
+}  // namespace
+
+extern "C" int lgm_rmsnorm_fwd(const float* x, int64_t x_pitch, const float* g, const float* res,
+                               int64_t res_pitch, float* y, int64_t y_pitch, int64_t npix, int C, void* stream) {
+  int L, Q;
+  if (int rc = rms_plan(C, &L, &Q)) return rc;
+  LGM_REQUIRE(x && g && y && npix > 0, "rmsnorm_fwd: null pointer / empty");
+  LGM_REQUIRE(x_pitch % 4 == 0 && y_pitch % 4 == 0 && (!res || res_pitch % 4 == 0), "rmsnorm_fwd: pitch %% 4 != 0");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = rms_blocks(npix, L);
+#define RMS_FWD(QQ)                                                                                             \
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel<QQ>, dim3(nb), dim3(256), 0, s, x, (long)x_pitch, g, res, (long)res_pitch, y, \
+                     (long)y_pitch, (long)npix, C, L)
+  if (Q == 1) RMS_FWD(1); else if (Q == 2) RMS_FWD(2); else RMS_FWD(4);
+#undef RMS_FWD
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int64_t lgm_rmsnorm_bwd_workspace(int64_t npix, int C) {
+  int L, Q;
+  if (rms_plan(C, &L, &Q)) return -1;
+  return (int64_t)rms_blocks(npix, L) * C * (int64_t)sizeof(float) + lgm_colsum_workspace(rms_blocks(npix, L), C);
+}
+
+extern "C" int lgm_rmsnorm_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch,
+                               const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, float* gg,
+                               float gg_beta, int64_t npix, int C, void* workspace, void* stream) {
+  int L, Q;
+  if (int rc = rms_plan(C, &L, &Q)) return rc;
+  LGM_REQUIRE(x && gy && g && gx && gg && workspace && npix > 0, "rmsnorm_bwd: null pointer / empty");
+  LGM_REQUIRE(x_pitch % 4 == 0 && gy_pitch % 4 == 0 && gx_pitch % 4 == 0, "rmsnorm_bwd: pitch %% 4 != 0");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = rms_blocks(npix, L);
+  float* partial = (float*)workspace;
+#define RMS_BWD(QQ)                                                                                              \
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel<QQ>, dim3(nb), dim3(256), 0, s, x, (long)x_pitch, gy, (long)gy_pitch, g, gx, \
+                     (long)gx_pitch, accumulate_gx, (long)npix, C, L, partial)
+  if (Q == 1) RMS_BWD(1); else if (Q == 2) RMS_BWD(2); else RMS_BWD(4);
+#undef RMS_BWD
+  LGM_LAUNCH_CHECK();
+  return lgm_colsum(partial, C, nb, C, gg, gg_beta, partial + (long)nb * C, stream);
+}

@@ -1,0 +1,118 @@
+// Fused optimiser kernels over FLAT parameter storage (one launch per optimiser step).
+//   lgm_adam_step : torch.optim.Adam semantics (coupled L2 weight decay, no amsgrad), replaces the
+//                   per-tensor foreach kernels of ddpm.py:1053-1059, vqvae.py:207-214, wgan.py:183-195.
+//   lgm_ema_lerp  : ema_pytorch-style shadow update  shadow += (online - shadow) * w  (ddpm.py:1047-1048).
+// Pure HBM streaming: 16 B/lane accesses, 28 B/param (Adam) and 12 B/param (EMA).
+#include "lgm_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                   float b1, float b2, float eps, float wd, float step_host,
+                                                   const float* __restrict__ step_dev, float grad_scale,
+                                                   int decoupled) {
+  const float step = step_dev ? step_dev[0] : step_host;
+  const float bc1 = 1.f - powf(b1, step);
+  const float bc2 = 1.f - powf(b2, step);
+  const float step_size = lr / bc1;
+  const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n) {
+    f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
+    f32x4 gv = *reinterpret_cast<const f32x4*>(g + i) * grad_scale;
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + i);
+    f32x4 vv = *reinterpret_cast<const f32x4*>(v + i);
+    if (decoupled)
+      pv *= (1.f - lr * wd);
+    else if (wd != 0.f)
+      gv += pv * wd;
+    mv += (gv - mv) * (1.f - b1);
+    vv = vv * b2 + gv * gv * (1.f - b2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pv[k] -= step_size * (mv[k] / (sqrtf(vv[k]) * inv_sqrt_bc2 + eps));
+    *reinterpret_cast<f32x4*>(p + i) = pv;
+    *reinterpret_cast<f32x4*>(m + i) = mv;
+    *reinterpret_cast<f32x4*>(v + i) = vv;
+  } else {
+    for (long j = i; j < n; ++j) {
+      float pv = p[j], gv = g[j] * grad_scale, mv = m[j], vv = v[j];
+      if (decoupled)
+        pv *= (1.f - lr * wd);
+      else if (wd != 0.f)
+        gv += pv * wd;
+      mv += (gv - mv) * (1.f - b1);
+      vv = vv * b2 + gv * gv * (1.f - b2);
+      pv -= step_size * (mv / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+      p[j] = pv;
+      m[j] = mv;
+      v[j] = vv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ shadow, const float* __restrict__ online, long n,
+                                                  float w) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(shadow + i);
+    const f32x4 o = *reinterpret_cast<const f32x4*>(online + i);
+    s += (o - s) * w;
+    *reinterpret_cast<f32x4*>(shadow + i) = s;
+  } else {
+    for (long j = i; j < n; ++j) shadow[j] += (online[j] - shadow[j]) * w;
+  }
+}
+
+__global__ void add_scalar_kernel(float* x, float a) { x[0] += a; }
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, long n, float val) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n)
+    *reinterpret_cast<f32x4*>(x + i) = f32x4{val, val, val, val};
+  else
+    for (long j = i; j < n; ++j) x[j] = val;
+}
+
+}  // namespace
+
+extern "C" int lgm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                             float eps, float weight_decay, float step, const float* step_dev, float grad_scale,
+                             int decoupled, void* stream) {
+  LGM_REQUIRE(p && g && m && v && n > 0, "adam_step: bad arguments");
+  LGM_REQUIRE(lgm_aligned16(p) && lgm_aligned16(g) && lgm_aligned16(m) && lgm_aligned16(v),
+              "adam_step: buffers must be 16B aligned");
+  LGM_REQUIRE(step_dev || step >= 1.f, "adam_step: step must be >= 1");
+  const long nthreads = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_kernel, dim3(lgm_cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
+                     lr, b1, b2, eps, weight_decay, step, step_dev, grad_scale, decoupled);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_ema_lerp(float* shadow, const float* online, int64_t n, float w, void* stream) {
+  LGM_REQUIRE(shadow && online && n > 0 && lgm_aligned16(shadow) && lgm_aligned16(online), "ema_lerp: bad arguments");
+  const long nthreads = (n + 3) / 4;
+  hipLaunchKernelGGL(ema_kernel, dim3(lgm_cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, shadow, online,
+                     (long)n, w);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_add_scalar(float* x, float a, void* stream) {
+  LGM_REQUIRE(x, "add_scalar: null pointer");
+  hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, x, a);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_fill(float* x, int64_t n, float val, void* stream) {
+  LGM_REQUIRE(x && n > 0 && lgm_aligned16(x), "fill: bad arguments");
+  const long nthreads = (n + 3) / 4;
+  hipLaunchKernelGGL(fill_kernel, dim3(lgm_cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)n, val);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}

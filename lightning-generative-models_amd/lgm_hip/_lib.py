@@ -1,0 +1,99 @@
+"""ctypes binding of liblgm_hip.so.  Signatures are parsed from include/lgm_hip.h so the Python
+side can never drift from the C-ABI; loading fails loudly when the library is missing (there
+is NO fallback path: the product is the HIP library)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_PKG, "csrc", "liblgm_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "lgm_hip.h")
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("B", "H", "W", "Cw", "Ho", "Wo", "Nw", "KH", "KW", "stride", "pad")]
+
+
+_CTYPES = {
+    "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+    "void": None,
+}
+
+
+def _ctype(decl: str):
+    decl = decl.replace("const", "").strip()
+    if "*" in decl:
+        base = decl.replace("*", "").strip()
+        if base == "char":
+            return ctypes.c_char_p
+        return ctypes.c_void_p  # every pointer crosses as a raw address
+    return _CTYPES[decl]
+
+
+def parse_header(path: str = HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every lgm_* prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"^\s*#[^\n]*", "", text, flags=re.M)      # preprocessor lines
+    text = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", text, flags=re.S)
+    text = text.replace('extern "C" {', "")
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(lgm_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                # drop the parameter name (last identifier)
+                tdecl = re.sub(r"\b\w+$", "", a).strip() if not a.endswith("*") else a
+                argtypes.append(_ctype(tdecl))
+        protos[name] = (_ctype(ret), argtypes)
+    return protos
+
+
+class LgmError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        self._dll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        self._dll.lgm_last_error.restype = ctypes.c_char_p
+        for name, (res, args) in self.protos.items():
+            fn = getattr(self._dll, name)  # AttributeError if the .so misses a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+            if res is ctypes.c_int and name != "lgm_abi_version":
+                setattr(self, name, self._checked(fn, name))
+            else:
+                setattr(self, name, fn)
+
+    def _checked(self, fn, name):
+        last_error = self._dll.lgm_last_error
+
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise LgmError(f"{name} failed (rc={rc}): {last_error().decode()}")
+        call.__name__ = name
+        return call
+
+
+_lib = None
+
+
+def lib() -> _Lib:
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib

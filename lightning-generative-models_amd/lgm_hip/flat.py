@@ -1,0 +1,132 @@
+"""Flat parameter / gradient storage for one network.
+
+All parameters of a network live in ONE fp32 device buffer (and their gradients in a second
+one) so that the optimiser is a single streaming kernel, DDP all-reduces one contiguous
+tensor over RCCL, and the EMA shadow update is one lerp.  Each ``nn.Parameter`` keeps its
+reference shape (state_dict compatible) but is re-pointed at a strided *view* of the flat
+buffer whose physical layout is what the HIP kernels read directly:
+
+  conv / linear weight  logical [N, C, KH, KW]   physical [Np][KH*KW][Cp]  (Np, Cp = N, C rounded up to 4;
+                                                  = torch channels_last with zero padding lanes)
+  vectors (bias, norm)  padded to a multiple of 4 floats
+
+Padding lanes are zero and stay zero under Adam (zero grad -> zero update).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+
+def _r4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class ParamSlot:
+    __slots__ = ("param", "name", "kind", "offset", "numel", "phys_shape")
+
+    def __init__(self, param, name, kind, offset, numel, phys_shape):
+        self.param, self.name, self.kind = param, name, kind
+        self.offset, self.numel, self.phys_shape = offset, numel, phys_shape
+
+
+def phys_numel(p: torch.Tensor, kind: str) -> Tuple[int, Tuple[int, ...]]:
+    if kind == "weight":           # conv [N,C,KH,KW] / convT [Cin,Cout,KH,KW] / linear [N,C]
+        if p.dim() == 4:
+            N, C, KH, KW = p.shape
+        else:
+            (N, C), KH, KW = p.shape, 1, 1
+        shp = (_r4(N), KH * KW, _r4(C))
+        return shp[0] * shp[1] * shp[2], shp
+    n = _r4(p.numel())
+    return n, (n,)
+
+
+def logical_view(buf: torch.Tensor, p_shape: Sequence[int], kind: str, phys_shape) -> torch.Tensor:
+    if kind == "weight":
+        Np, T, Cp = phys_shape
+        if len(p_shape) == 4:
+            N, C, KH, KW = p_shape
+            return buf.view(Np, KH, KW, Cp)[:N, :, :, :C].permute(0, 3, 1, 2)
+        N, C = p_shape
+        return buf.view(Np, Cp)[:N, :C]
+    n = 1
+    for s in p_shape:
+        n *= s
+    return buf[:n].view(*p_shape)
+
+
+class FlatParams:
+    """Owns flat fp32 storage for ``named`` = [(name, param, kind)].  ``order`` is preserved, so
+    callers can make groups of parameters adjacent (e.g. the 19 time-MLP weights of the UNet,
+    which are then one [sum(2C), 256] GEMM operand)."""
+
+    def __init__(self, named: List[Tuple[str, nn.Parameter, str]], device):
+        self.device = torch.device(device)
+        self.slots: List[ParamSlot] = []
+        off = 0
+        for name, p, kind in named:
+            n, shp = phys_numel(p, kind)
+            self.slots.append(ParamSlot(p, name, kind, off, n, shp))
+            off += n
+        self.total = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.by_param: Dict[int, ParamSlot] = {}
+        self.fresh = True        # next backward overwrites (beta = 0) instead of accumulating
+        for s in self.slots:
+            view = logical_view(self.data[s.offset:s.offset + s.numel], s.param.shape, s.kind, s.phys_shape)
+            with torch.no_grad():
+                view.copy_(s.param.data.to(self.device, torch.float32))
+            s.param.data = view
+            s.param.grad = None
+            s.param._lgm_flat = self           # noqa: back-reference used by FusedAdam / EMA
+            self.by_param[id(s.param)] = s
+        self._grad_views_bound = False
+
+    # -- pointers --------------------------------------------------------------------------
+    def ptr(self, p: nn.Parameter) -> int:
+        return self.data.data_ptr() + 4 * self.by_param[id(p)].offset
+
+    def gptr(self, p: nn.Parameter) -> int:
+        return self.grad.data_ptr() + 4 * self.by_param[id(p)].offset
+
+    def slot(self, p: nn.Parameter) -> ParamSlot:
+        return self.by_param[id(p)]
+
+    def still_bound(self) -> bool:
+        """False when something (e.g. module.to()) replaced the parameter storage."""
+        s = self.slots[0]
+        return s.param.data.data_ptr() == self.data.data_ptr() + 4 * s.offset and s.param.device == self.device
+
+    # -- gradients -------------------------------------------------------------------------
+    def begin_backward(self) -> float:
+        """Returns beta for gradient writes of this backward pass (0 = overwrite, 1 = accumulate)."""
+        if self.slots[0].param.grad is None and self._grad_views_bound:
+            # an external optimizer called zero_grad(set_to_none=True)
+            self.fresh = True
+            self._grad_views_bound = False
+        beta = 0.0 if self.fresh else 1.0
+        self.fresh = False
+        return beta
+
+    def bind_grad_views(self):
+        if self._grad_views_bound:
+            return
+        for s in self.slots:
+            s.param.grad = logical_view(self.grad[s.offset:s.offset + s.numel], s.param.shape, s.kind, s.phys_shape)
+        self._grad_views_bound = True
+
+    def zero_grad(self):
+        self.fresh = True
+
+    def clone_storage(self) -> torch.Tensor:
+        return self.data.clone()
+
+
+def module_flat(module: nn.Module) -> Optional[FlatParams]:
+    for p in module.parameters():
+        return getattr(p, "_lgm_flat", None)
+    return None

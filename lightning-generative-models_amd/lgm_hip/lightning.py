@@ -1,0 +1,207 @@
+"""LightningModule / Trainer surface used by the hot path.
+
+If ``pytorch_lightning`` is importable it is used unchanged (the models are ordinary
+LightningModules).  It is not installed in the build image, so this file also provides a
+minimal stand-in with the subset of behaviour the reference relies on
+(train.py:124-141, ddpm.py:983,1017-1027,1047, wgan.py:58-82, vqvae.py:184-194):
+
+  save_hyperparameters / hparams, log / log_dict (kept in ``logged``), global_step (counts
+  optimizer.step() calls, which is what makes WGAN's n_critic schedule work — wgan.py:64),
+  optimizers(), manual_backward(), automatic vs manual optimisation, on_train_batch_end,
+  one process per GPU with gradient averaging over torch.distributed (RCCL on ROCm).
+"""
+from __future__ import annotations
+
+import inspect
+import os
+import time
+from typing import Any, Dict, Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+try:  # pragma: no cover - not available in the build image
+    import pytorch_lightning as _pl  # type: ignore
+    HAVE_PL = True
+except Exception:  # noqa
+    _pl = None
+    HAVE_PL = False
+
+
+class _AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    __setattr__ = dict.__setitem__
+
+
+class _CountingOptimizer:
+    """Proxy that advances the module's global_step on every step() (Lightning semantics)."""
+
+    def __init__(self, opt, owner):
+        self._opt, self._owner = opt, owner
+
+    def step(self, *a, **k):
+        r = self._opt.step(*a, **k)
+        self._owner._global_step += 1
+        return r
+
+    def __getattr__(self, n):
+        return getattr(self._opt, n)
+
+
+class MiniLightningModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._hparams = _AttrDict()
+        self._global_step = 0
+        self.automatic_optimization = True
+        self.logged: Dict[str, Any] = {}
+        self._optimizers: List[Any] = []
+        self.trainer = None
+        self.logger = None
+
+    # -- hyper-parameters ---------------------------------------------------------------
+    def save_hyperparameters(self):
+        frame = inspect.currentframe().f_back
+        args = inspect.getargvalues(frame)
+        for name in args.args:
+            if name != "self":
+                self._hparams[name] = args.locals[name]
+        if args.keywords and args.keywords in args.locals:
+            self._hparams.update(args.locals[args.keywords])
+
+    @property
+    def hparams(self):
+        return self._hparams
+
+    # -- state --------------------------------------------------------------------------
+    @property
+    def global_step(self) -> int:
+        return self._global_step
+
+    @property
+    def device(self):
+        for p in self.parameters():
+            return p.device
+        for b in self.buffers():
+            return b.device
+        return torch.device("cpu")
+
+    def log(self, name, value, **kw):
+        self.logged[name] = value
+
+    def log_dict(self, d, **kw):
+        self.logged.update(d)
+
+    def optimizers(self):
+        if len(self._optimizers) == 1:
+            return self._optimizers[0]
+        return self._optimizers
+
+    def manual_backward(self, loss, *a, **k):
+        loss.backward(*a, **k)
+
+    # hooks (no-ops by default)
+    def on_train_batch_end(self, outputs, batch, batch_idx):
+        pass
+
+    def configure_optimizers(self):
+        raise NotImplementedError
+
+
+LightningModule = _pl.LightningModule if HAVE_PL else MiniLightningModule
+
+
+def _flat_grads_of(module: nn.Module):
+    """Distinct FlatParams objects reachable from the module's parameters."""
+    seen, out = set(), []
+    for p in module.parameters():
+        fp = getattr(p, "_lgm_flat", None)
+        if fp is not None and id(fp) not in seen:
+            seen.add(id(fp))
+            out.append(fp)
+    return out
+
+
+class MiniTrainer:
+    """Single-node trainer: one process per GPU, optional DDP-style gradient averaging with a
+    single all-reduce per flat gradient buffer (RCCL over xGMI when backend is nccl)."""
+
+    def __init__(self, max_steps=-1, max_epochs=-1, accumulate_grad_batches=1, device=None,
+                 default_root_dir=None, log_every=50, **_ignored):
+        self.max_steps, self.max_epochs = max_steps, max_epochs
+        self.accumulate = max(1, int(accumulate_grad_batches))
+        self.device = device
+        self.root = default_root_dir
+        self.log_every = log_every
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+
+    def allreduce_grads(self, module):
+        if self.world == 1:
+            return
+        for fp in _flat_grads_of(module):
+            dist.all_reduce(fp.grad)
+            fp.grad.div_(self.world)
+        # parameters that are not flat-bound (CPU plumbing models)
+        for p in module.parameters():
+            if getattr(p, "_lgm_flat", None) is None and p.grad is not None:
+                dist.all_reduce(p.grad)
+                p.grad.div_(self.world)
+
+    def fit(self, model, datamodule=None, train_dataloader=None, ckpt_path=None):
+        device = torch.device(self.device) if self.device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+        model.to(device)
+        model.trainer = self
+        if ckpt_path:
+            sd = torch.load(ckpt_path, map_location=device)
+            model.load_state_dict(sd["state_dict"])
+            model._global_step = sd.get("global_step", 0)
+        if hasattr(model, "prepare_hip"):
+            model.prepare_hip(device)
+        cfg = model.configure_optimizers()
+        opts = cfg[0] if isinstance(cfg, tuple) else cfg
+        if not isinstance(opts, (list, tuple)):
+            opts = [opts]
+        model._optimizers = [_CountingOptimizer(o, model) for o in opts]
+        loader = train_dataloader if train_dataloader is not None else datamodule.train_dataloader()
+        model.train()
+        epoch, done = 0, False
+        t0 = time.time()
+        takes_idx = "batch_idx" in inspect.signature(model.training_step).parameters
+        while not done:
+            for batch_idx, batch in enumerate(loader):
+                batch = tuple(b.to(device, non_blocking=True) if torch.is_tensor(b) else b for b in batch)
+                if model.automatic_optimization:
+                    opt = model._optimizers[0]
+                    loss = model.training_step(batch, batch_idx) if takes_idx else model.training_step(batch)
+                    if self.accumulate > 1:
+                        loss = loss / self.accumulate
+                    loss.backward()
+                    if (batch_idx + 1) % self.accumulate == 0:
+                        self.allreduce_grads(model)
+                        opt.step()
+                        opt.zero_grad()
+                else:
+                    model.training_step(batch, batch_idx) if takes_idx else model.training_step(batch)
+                model.on_train_batch_end(None, batch, batch_idx)
+                if self.rank == 0 and self.log_every and model.global_step % self.log_every == 0:
+                    msg = {k: (float(v) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
+                    print(f"[step {model.global_step}] {msg} ({time.time() - t0:.1f}s)", flush=True)
+                if 0 < self.max_steps <= model.global_step:
+                    done = True
+                    break
+            epoch += 1
+            if 0 < self.max_epochs <= epoch:
+                done = True
+        if self.root and self.rank == 0:
+            os.makedirs(self.root, exist_ok=True)
+            torch.save({"state_dict": model.state_dict(), "global_step": model.global_step,
+                        "hyper_parameters": dict(model.hparams)}, os.path.join(self.root, "last.ckpt"))
+        return model

@@ -1,0 +1,232 @@
+"""Leaf layers of the HIP engine: nn.Modules that own reference-shaped parameters (so
+state_dicts interchange with the reference) and expose explicit ``fwd`` / ``bwd`` methods over
+NHWC tensors.  Gradients of parameters are written straight into the flat gradient buffer
+(see flat.py); no autograd graph is built inside the engine.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .flat import FlatParams, _r4
+
+
+def _flat(p: nn.Parameter) -> FlatParams:
+    fp = getattr(p, "_lgm_flat", None)
+    if fp is None:
+        raise RuntimeError("parameter is not bound to flat HIP storage; call prepare() on the network first")
+    return fp
+
+
+class GradCtx:
+    """Per-backward bookkeeping: beta for the first gradient write of every parameter
+    (0 = overwrite, 1 = accumulate), 1 afterwards (a parameter used twice in one pass)."""
+
+    def __init__(self, flat: FlatParams):
+        self.flat = flat
+        self.beta0 = flat.begin_backward()
+        self.written = set()
+
+    def beta(self, p: nn.Parameter) -> float:
+        k = id(p)
+        if k in self.written:
+            return 1.0
+        self.written.add(k)
+        return self.beta0
+
+
+class Conv2d(nn.Module):
+    """nn.Conv2d replacement (NHWC, implicit-GEMM MFMA kernels).  Parameter shapes as torch."""
+
+    transposed = False
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.padding = cin, cout, k, stride, padding
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(cin * k * k)
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        self._geoms = {}
+
+    # X side = input (cin), Y side = output (cout)
+    def geom(self, B, H, W):
+        key = (B, H, W)
+        g = self._geoms.get(key)
+        if g is None:
+            g = ops.make_geom(B, H, W, _r4(self.cin), _r4(self.cout), self.k, self.k, self.stride, self.padding)
+            self._geoms[key] = g
+        return g
+
+    def out_shape(self, x):
+        B, H, W, _ = x.shape
+        g = self.geom(B, H, W)
+        return (B, g.Ho, g.Wo, _r4(self.cout))
+
+    def fwd(self, x, out=None, res=None):
+        B, H, W, C = x.shape
+        assert C == _r4(self.cin), f"conv expects {_r4(self.cin)} (padded) channels, got {C}"
+        g = self.geom(B, H, W)
+        fp = _flat(self.weight)
+        y = out if out is not None else ops.new((B, g.Ho, g.Wo, _r4(self.cout)), x)
+        ops.conv_xy(g, x, fp.ptr(self.weight), fp.ptr(self.bias) if self.bias is not None else None, res, y)
+        return y
+
+    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None):
+        """gW, gb into flat grads; returns gx = dgrad(gy) (+ res) (+ existing gx when accumulate)."""
+        B, H, W, _ = x.shape
+        g = self.geom(B, H, W)
+        fp = gc.flat
+        ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), gc.beta(self.weight))
+        if self.bias is not None:
+            ops.colsum(gy, fp.gptr(self.bias), gc.beta(self.bias))
+        if not need_gx:
+            return None
+        if gx is None:
+            gx = ops.new(x.shape, x)
+            accumulate = False
+        if accumulate:
+            assert res is None
+            res = gx
+        ops.conv_yx(g, gy, fp.ptr(self.weight), None, res, gx)
+        return gx
+
+
+class ConvTranspose2d(nn.Module):
+    """nn.ConvTranspose2d replacement: forward is the Y->X pass of the equivalent convolution."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.padding = cin, cout, k, stride, padding
+        self.weight = nn.Parameter(torch.empty(cin, cout, k, k))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(cout * k * k)  # torch: fan_in of the transposed weight = size(1)*k*k
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        self._geoms = {}
+
+    # equivalent conv: X side = convT OUTPUT (cout channels), Y side = convT INPUT (cin channels)
+    def geom(self, B, Hin, Win):
+        key = (B, Hin, Win)
+        g = self._geoms.get(key)
+        if g is None:
+            H = (Hin - 1) * self.stride - 2 * self.padding + self.k
+            W = (Win - 1) * self.stride - 2 * self.padding + self.k
+            g = ops.make_geom(B, H, W, _r4(self.cout), _r4(self.cin), self.k, self.k, self.stride, self.padding)
+            assert g.Ho == Hin and g.Wo == Win
+            self._geoms[key] = g
+        return g
+
+    def fwd(self, x, out=None, res=None):
+        B, H, W, C = x.shape
+        assert C == _r4(self.cin)
+        g = self.geom(B, H, W)
+        fp = _flat(self.weight)
+        y = out if out is not None else ops.new((B, g.H, g.W, _r4(self.cout)), x)
+        ops.conv_yx(g, x, fp.ptr(self.weight), fp.ptr(self.bias) if self.bias is not None else None, res, y)
+        return y
+
+    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None):
+        B, H, W, _ = x.shape
+        g = self.geom(B, H, W)
+        fp = gc.flat
+        ops.conv_wgrad(g, x, gy, fp.gptr(self.weight), gc.beta(self.weight))  # Y side = input, X side = grad
+        if self.bias is not None:
+            ops.colsum(gy, fp.gptr(self.bias), gc.beta(self.bias))
+        if not need_gx:
+            return None
+        if gx is None:
+            gx = ops.new(x.shape, x)
+            accumulate = False
+        if accumulate:
+            assert res is None
+            res = gx
+        ops.conv_xy(g, gy, fp.ptr(self.weight), None, res, gx)
+        return gx
+
+
+class Linear(nn.Module):
+    """nn.Linear replacement = 1x1 convolution over a [B, 1, 1, C] "image"."""
+
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(cin)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        self._geoms = {}
+
+    def geom(self, B):
+        g = self._geoms.get(B)
+        if g is None:
+            g = ops.make_geom(B, 1, 1, _r4(self.cin), _r4(self.cout), 1, 1, 1, 0)
+            self._geoms[B] = g
+        return g
+
+
+def linear_fwd(g, x2d, w_ptr, b_ptr, y2d):
+    ops.conv_xy(g, x2d, w_ptr, b_ptr, None, y2d)
+
+
+class GroupNorm(nn.Module):
+    """Parameters of nn.GroupNorm (weight, bias); the fused GN+FiLM+SiLU kernels are driven by
+    the owning block."""
+
+    def __init__(self, groups, channels, eps=1e-5):
+        super().__init__()
+        self.groups, self.channels, self.eps = groups, channels, eps
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+
+    def fwd(self, x, ss, act, res, out=None):
+        fp = _flat(self.weight)
+        y = out if out is not None else ops.new(x.shape, x)
+        sv = ops.gn_fwd(x, self.groups, self.eps, fp.ptr(self.weight), fp.ptr(self.bias), ss, act, res, y)
+        return y, sv
+
+    def bwd(self, gc: GradCtx, x, gy, ss, act, sv, gss, gx=None, accumulate=False):
+        fp = gc.flat
+        if gx is None:
+            gx = ops.new(x.shape, x)
+            accumulate = False
+        ops.gn_bwd(x, gy, self.groups, fp.ptr(self.weight), fp.ptr(self.bias), ss, act, sv, gx, accumulate,
+                   fp.gptr(self.weight), fp.gptr(self.bias), gc.beta(self.weight), gss, 0.0)
+        gc.beta(self.bias)
+        return gx
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(1, dim, 1, 1))
+
+    def fwd(self, x, res=None, out=None):
+        y = out if out is not None else ops.new(x.shape, x)
+        ops.rmsnorm_fwd(x, _flat(self.g).ptr(self.g), res, y)
+        return y
+
+    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False):
+        if gx is None:
+            gx = ops.new(x.shape, x)
+            accumulate = False
+        ops.rmsnorm_bwd(x, gy, gc.flat.ptr(self.g), gx, accumulate, gc.flat.gptr(self.g), gc.beta(self.g))
+        return gx
+
+
+def param_kind(name: str, p: nn.Parameter) -> str:
+    if name.endswith("weight") and p.dim() in (2, 4):
+        return "weight"
+    return "vector"

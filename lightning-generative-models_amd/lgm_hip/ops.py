@@ -1,0 +1,297 @@
+"""Thin tensor-level wrappers over the C-ABI (liblgm_hip.so).
+
+torch is used for device memory and streams only.  Activations are NHWC fp32 tensors
+``[B, H, W, C]`` (or ``[rows, C]`` matrices) whose last dimension is dense; they may be channel
+slices of a wider buffer (pitch = stride of the pixel dimension).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from ._lib import ConvGeom, lib
+
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3, 4, 5
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def pitch(t: torch.Tensor) -> int:
+    """Distance in floats between consecutive pixels / rows."""
+    assert t.stride(-1) == 1 or t.shape[-1] == 1, "last dim must be dense"
+    if t.dim() == 1:
+        return t.shape[0]
+    pt = t.stride(-2)
+    if t.dim() == 4:
+        B, H, W, _ = t.shape
+        assert (W == 1 or True) and (H == 1 or t.stride(1) == W * pt) and (B == 1 or t.stride(0) == H * W * pt), \
+            f"not a pitched NHWC tensor: shape {tuple(t.shape)} strides {t.stride()}"
+    elif t.dim() == 3:
+        assert t.shape[0] == 1 or t.stride(0) == t.shape[1] * pt
+    return pt
+
+
+def rows(t: torch.Tensor) -> int:
+    n = 1
+    for s in t.shape[:-1]:
+        n *= s
+    return n
+
+
+# ----------------------------------------------------------------------------------------
+# workspace (one growing buffer per device; ops run in stream order so sharing is safe)
+# ----------------------------------------------------------------------------------------
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    key = torch.device(device).index or 0
+    ws = _WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        n = max(int(nbytes * 1.25) // 4 + 64, 1 << 20)
+        ws = torch.empty(n, dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def new(shape, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# ----------------------------------------------------------------------------------------
+# convolution family
+# ----------------------------------------------------------------------------------------
+def make_geom(B, H, W, Cw, Nw, KH, KW, stride, pad) -> ConvGeom:
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    return ConvGeom(B, H, W, Cw, Ho, Wo, Nw, KH, KW, stride, pad)
+
+
+class KernelTimer:
+    """Optional per-launch timing of the convolution family with HIP events recorded on the
+    launch stream (bench.py's roofline leg).  Disabled (None) on the normal path."""
+
+    def __init__(self):
+        self.records = []   # (name, flops, start_event, end_event)
+
+    def begin(self, name, flops):
+        s = torch.cuda.Event(enable_timing=True)
+        s.record()
+        self._cur = (name, flops, s)
+
+    def end(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((*self._cur, e))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, s, e in self.records:
+            d = out.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += s.elapsed_time(e)
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _conv_flops(g: ConvGeom) -> float:
+    return 2.0 * g.B * g.Ho * g.Wo * g.Nw * g.KH * g.KW * g.Cw
+
+
+def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
+    if TIMER is not None:
+        TIMER.begin("igemm_xy", _conv_flops(g))
+    lib().lgm_conv_xy(ctypes.byref(g), x.data_ptr(), pitch(x), w_ptr, bias_ptr, _p(res),
+                      pitch(res) if res is not None else 0, y.data_ptr(), pitch(y), stream())
+    if TIMER is not None:
+        TIMER.end()
+
+
+def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x):
+    if TIMER is not None:
+        TIMER.begin("igemm_yx", _conv_flops(g))
+    lib().lgm_conv_yx(ctypes.byref(g), y.data_ptr(), pitch(y), w_ptr, bias_ptr, _p(res),
+                      pitch(res) if res is not None else 0, x.data_ptr(), pitch(x), stream())
+    if TIMER is not None:
+        TIMER.end()
+
+
+def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float):
+    L = lib()
+    nbytes = L.lgm_conv_wgrad_workspace(ctypes.byref(g))
+    ws = workspace(nbytes, y.device)
+    if TIMER is not None:
+        TIMER.begin("wgrad", _conv_flops(g))
+    L.lgm_conv_wgrad(ctypes.byref(g), y.data_ptr(), pitch(y), x.data_ptr(), pitch(x), gw_ptr, beta,
+                     ws.data_ptr(), ws.numel() * 4, stream())
+    if TIMER is not None:
+        TIMER.end()
+
+
+def colsum(a, out_ptr: int, beta: float):
+    """out[c] = beta*out[c] + sum over all leading dims of a[..., c]."""
+    L = lib()
+    r, c = rows(a), a.shape[-1]
+    ws = workspace(L.lgm_colsum_workspace(r, c), a.device)
+    L.lgm_colsum(a.data_ptr(), pitch(a), r, c, out_ptr, beta, ws.data_ptr(), stream())
+
+
+# ----------------------------------------------------------------------------------------
+# norms
+# ----------------------------------------------------------------------------------------
+class GNSaved:
+    __slots__ = ("mean", "rstd", "A", "Bc")
+
+
+def gn_fwd(x, G, eps, gamma_ptr, beta_ptr, ss, act: bool, res, y) -> GNSaved:
+    B, H, W, C = x.shape
+    sv = GNSaved()
+    stats = new((2, B, G), x)
+    coef = new((2, B, C), x)
+    sv.mean, sv.rstd, sv.A, sv.Bc = stats[0], stats[1], coef[0], coef[1]
+    lib().lgm_gn_fwd(x.data_ptr(), pitch(x), B, H * W, C, G, eps, gamma_ptr, beta_ptr, _p(ss),
+                     pitch(ss) if ss is not None else 0, 1 if act else 0, _p(res),
+                     pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
+                     sv.mean.data_ptr(), sv.rstd.data_ptr(), sv.A.data_ptr(), sv.Bc.data_ptr(), stream())
+    return sv
+
+
+def gn_bwd(x, gy, G, gamma_ptr, beta_ptr, ss, act: bool, sv: GNSaved, gx, accumulate: bool,
+           ggamma_ptr, gbeta_ptr, affine_beta: float, gss, gss_beta: float):
+    B, H, W, C = x.shape
+    ws = workspace(5 * B * C * 4, x.device)
+    lib().lgm_gn_bwd(x.data_ptr(), pitch(x), gy.data_ptr(), pitch(gy), B, H * W, C, G, gamma_ptr, beta_ptr,
+                     _p(ss), pitch(ss) if ss is not None else 0, 1 if act else 0, sv.mean.data_ptr(),
+                     sv.rstd.data_ptr(), sv.A.data_ptr(), sv.Bc.data_ptr(), gx.data_ptr(), pitch(gx),
+                     1 if accumulate else 0, ggamma_ptr, gbeta_ptr, affine_beta, _p(gss),
+                     pitch(gss) if gss is not None else 0, gss_beta, ws.data_ptr(), stream())
+
+
+def rmsnorm_fwd(x, g_ptr, res, y):
+    lib().lgm_rmsnorm_fwd(x.data_ptr(), pitch(x), g_ptr, _p(res), pitch(res) if res is not None else 0,
+                          y.data_ptr(), pitch(y), rows(x), x.shape[-1], stream())
+
+
+def rmsnorm_bwd(x, gy, g_ptr, gx, accumulate: bool, gg_ptr, gg_beta: float):
+    L = lib()
+    n, C = rows(x), x.shape[-1]
+    ws = workspace(L.lgm_rmsnorm_bwd_workspace(n, C), x.device)
+    L.lgm_rmsnorm_bwd(x.data_ptr(), pitch(x), gy.data_ptr(), pitch(gy), g_ptr, gx.data_ptr(), pitch(gx),
+                      1 if accumulate else 0, gg_ptr, gg_beta, n, C, ws.data_ptr(), stream())
+
+
+# ----------------------------------------------------------------------------------------
+# attention cores
+# ----------------------------------------------------------------------------------------
+def linattn_fwd(qkv, mem_ptr, heads, dim_head, M, out):
+    B, H, W, _ = qkv.shape
+    n = H * W
+    ctx = new((B, heads, dim_head, dim_head), qkv)
+    kstat = new((2, B, heads, dim_head), qkv)
+    lib().lgm_linattn_fwd(qkv.data_ptr(), pitch(qkv), mem_ptr, B, n, heads, dim_head, M, out.data_ptr(),
+                          pitch(out), ctx.data_ptr(), kstat[0].data_ptr(), kstat[1].data_ptr(), stream())
+    return ctx, kstat
+
+
+def linattn_bwd(qkv, mem_ptr, gout, ctx, kstat, heads, dim_head, M, gqkv, gmem_ptr, gmem_beta):
+    L = lib()
+    B, H, W, _ = qkv.shape
+    ws = workspace(L.lgm_linattn_bwd_workspace(B, heads, dim_head, M), qkv.device)
+    L.lgm_linattn_bwd(qkv.data_ptr(), pitch(qkv), mem_ptr, gout.data_ptr(), pitch(gout), ctx.data_ptr(),
+                      kstat[0].data_ptr(), kstat[1].data_ptr(), B, H * W, heads, dim_head, M, gqkv.data_ptr(),
+                      pitch(gqkv), gmem_ptr, gmem_beta, ws.data_ptr(), stream())
+
+
+def attn_fwd(qkv, mem_ptr, heads, dim_head, M, out):
+    B, H, W, _ = qkv.shape
+    lse = new((B, heads, H * W), qkv)
+    lib().lgm_attn_fwd(qkv.data_ptr(), pitch(qkv), mem_ptr, B, H * W, heads, dim_head, M, out.data_ptr(),
+                       pitch(out), lse.data_ptr(), stream())
+    return lse
+
+
+def attn_bwd(qkv, mem_ptr, out, gout, lse, heads, dim_head, M, gqkv, gmem_ptr, gmem_beta):
+    L = lib()
+    B, H, W, _ = qkv.shape
+    ws = workspace(L.lgm_attn_bwd_workspace(B, heads, dim_head, M), qkv.device)
+    L.lgm_attn_bwd(qkv.data_ptr(), pitch(qkv), mem_ptr, out.data_ptr(), pitch(out), gout.data_ptr(),
+                   pitch(gout), lse.data_ptr(), B, H * W, heads, dim_head, M, gqkv.data_ptr(), pitch(gqkv),
+                   gmem_ptr, gmem_beta, ws.data_ptr(), stream())
+
+
+# ----------------------------------------------------------------------------------------
+# elementwise
+# ----------------------------------------------------------------------------------------
+def posemb(t, dim, theta, out):
+    lib().lgm_posemb(t.data_ptr(), t.shape[0], dim, theta, out.data_ptr(), pitch(out), stream())
+
+
+def act_fwd(x, bias_ptr, res, y, act, slope=0.0):
+    lib().lgm_act_fwd(x.data_ptr(), pitch(x), bias_ptr, _p(res), pitch(res) if res is not None else 0,
+                      y.data_ptr(), pitch(y), rows(x), x.shape[-1], act, slope, stream())
+
+
+def act_bwd(x, bias_ptr, gy, gx, accumulate, act, slope=0.0):
+    lib().lgm_act_bwd(x.data_ptr(), pitch(x), bias_ptr, gy.data_ptr(), pitch(gy), gx.data_ptr(), pitch(gx),
+                      1 if accumulate else 0, rows(x), x.shape[-1], act, slope, stream())
+
+
+def axpby(a, alpha, b, beta, y):
+    lib().lgm_axpby(a.data_ptr(), pitch(a), alpha, _p(b), pitch(b) if b is not None else 0, beta,
+                    y.data_ptr(), pitch(y), rows(a), a.shape[-1], stream())
+
+
+def upsample2x_fwd(x, y):
+    B, H, W, C = x.shape
+    lib().lgm_upsample2x_fwd(x.data_ptr(), pitch(x), y.data_ptr(), pitch(y), B, H, W, C, stream())
+
+
+def upsample2x_bwd(gy, gx, accumulate):
+    B, H, W, C = gx.shape
+    lib().lgm_upsample2x_bwd(gy.data_ptr(), pitch(gy), gx.data_ptr(), pitch(gx), B, H, W, C,
+                             1 if accumulate else 0, stream())
+
+
+def pixel_unshuffle(hi, lo, inverse: bool, accumulate: bool = False):
+    """hi: [B,2H,2W,C], lo: [B,H,W,4C].  inverse=False: hi -> lo; True: lo -> hi."""
+    B, H, W, C4 = lo.shape
+    src, dst = (lo, hi) if inverse else (hi, lo)
+    lib().lgm_pixel_unshuffle(src.data_ptr(), pitch(src), dst.data_ptr(), pitch(dst), B, H, W, C4 // 4,
+                              1 if inverse else 0, 1 if accumulate else 0, stream())
+
+
+def nchw_to_nhwc(src, dst):
+    B, C, H, W = src.shape
+    assert src.is_contiguous()
+    lib().lgm_nchw_to_nhwc(src.data_ptr(), dst.data_ptr(), pitch(dst), B, C, H * W, dst.shape[-1], stream())
+
+
+def nhwc_to_nchw(src, dst):
+    B, C, H, W = dst.shape
+    assert dst.is_contiguous()
+    lib().lgm_nhwc_to_nchw(src.data_ptr(), pitch(src), dst.data_ptr(), B, C, H * W, stream())
+
+
+def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, step_dev=None, grad_scale=1.0, decoupled=False):
+    lib().lgm_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, b1, b2, eps, wd,
+                        float(step), _p(step_dev), grad_scale, 1 if decoupled else 0, stream())
+
+
+def ema_lerp(shadow, online, w):
+    lib().lgm_ema_lerp(shadow.data_ptr(), online.data_ptr(), shadow.numel(), w, stream())
+
+
+def fill(x, val):
+    lib().lgm_fill(x.data_ptr(), x.numel(), val, stream())

@@ -1,0 +1,138 @@
+"""Fused optimiser + EMA on flat HIP storage.
+
+FusedAdam: torch.optim.Adam semantics (coupled L2 ``weight_decay``; reference call sites
+ddpm.py:1053-1059, vqvae.py:207-214, wgan.py:183-195) as ONE streaming kernel per flat
+buffer.  EMA: ema_pytorch.EMA surface used by ddpm.py:998,1014,1033,1048 (``.model``,
+``.ema_model``, ``.update()``; state_dict keys ``online_model.*``, ``ema_model.*``,
+``initted``, ``step``) — upstream is unpinned, the schedule follows its published algorithm
+(see oracle/optim.py).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Iterable, List
+
+import torch
+from torch import nn
+
+from . import ops
+from .flat import FlatParams
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params: Iterable[nn.Parameter], lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, decoupled=False):
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, decoupled=decoupled)
+        super().__init__(params, defaults)
+        self._flat_state = {}   # id(FlatParams) -> dict(m, v, step, flat)
+
+    def _flats(self, group) -> List[FlatParams]:
+        seen, out = set(), []
+        for p in group["params"]:
+            fp = getattr(p, "_lgm_flat", None)
+            if fp is None:
+                raise RuntimeError("FusedAdam: parameter is not bound to flat HIP storage "
+                                   "(call prepare_hip() on the model before configure_optimizers/step)")
+            if id(fp) not in seen:
+                seen.add(id(fp))
+                out.append(fp)
+        return out
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for fp in self._flats(group):
+                st = self._flat_state.get(id(fp))
+                if st is None:
+                    st = dict(m=torch.zeros_like(fp.data), v=torch.zeros_like(fp.data), step=0, flat=fp)
+                    self._flat_state[id(fp)] = st
+                st["step"] += 1
+                ops.adam_step(fp.data, fp.grad, st["m"], st["v"], fp.total, group["lr"], b1, b2, group["eps"],
+                              group["weight_decay"], st["step"], None, 1.0, group["decoupled"])
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        for group in self.param_groups:
+            for fp in self._flats(group):
+                fp.zero_grad()
+
+
+class EMA(nn.Module):
+    """Shadow copy of a network updated every ``update_every`` calls of update()."""
+
+    def __init__(self, model: nn.Module, beta=0.9999, update_every=10, update_after_step=100,
+                 inv_gamma=1.0, power=2.0 / 3.0, min_value=0.0):
+        super().__init__()
+        self.online_model = model
+        self.ema_model = copy.deepcopy(model)
+        self.ema_model.requires_grad_(False)
+        self.beta, self.update_every, self.update_after_step = beta, update_every, update_after_step
+        self.inv_gamma, self.power, self.min_value = inv_gamma, power, min_value
+        self.register_buffer("initted", torch.tensor(False))
+        self.register_buffer("step", torch.tensor(0))
+        self._step_py = 0          # host mirrors: no device sync on the hot path
+        self._initted_py = False
+
+    @property
+    def model(self):
+        return self.online_model
+
+    def forward(self, *a, **k):
+        return self.ema_model(*a, **k)
+
+    def current_decay(self) -> float:
+        epoch = max(self._step_py - self.update_after_step - 1, 0)
+        if epoch <= 0:
+            return 0.0
+        value = 1 - (1 + epoch / self.inv_gamma) ** (-self.power)
+        return min(max(value, self.min_value), self.beta)
+
+    def _pairs(self):
+        on = dict(self.online_model.named_parameters())
+        on.update(dict(self.online_model.named_buffers()))
+        sh = dict(self.ema_model.named_parameters())
+        sh.update(dict(self.ema_model.named_buffers()))
+        for k, v in sh.items():
+            yield v, on[k]
+
+    @torch.no_grad()
+    def _lerp_all(self, w: float):
+        fo = _first_flat(self.online_model)
+        fs = _first_flat(self.ema_model)
+        if fo is not None and fs is not None and fo.total == fs.total:
+            ops.ema_lerp(fs.data, fo.data, w)          # one kernel over the flat storage
+            done = {id(s.param) for s in fs.slots}
+        else:
+            done = set()
+        for sh, on in self._pairs():
+            if id(sh) in done or not sh.dtype.is_floating_point:
+                if id(sh) not in done and w == 1.0:
+                    sh.copy_(on)
+                continue
+            if w == 1.0:
+                sh.copy_(on)
+            else:
+                sh.lerp_(on, w)
+
+    def update(self):
+        step = self._step_py
+        self._step_py += 1
+        self.step += 1
+        if step % self.update_every != 0:
+            return
+        if step <= self.update_after_step:
+            self._lerp_all(1.0)
+            return
+        if not self._initted_py:
+            self._lerp_all(1.0)
+            self._initted_py = True
+            self.initted.fill_(True)
+        self._lerp_all(1.0 - self.current_decay())
+
+
+def _first_flat(module: nn.Module):
+    for p in module.parameters():
+        return getattr(p, "_lgm_flat", None)
+    return None

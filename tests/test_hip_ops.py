@@ -1,0 +1,376 @@
+"""GPU: every HIP op (through the C-ABI) against a plain fp32 CPU reference of the same op.
+Tolerances: fp32 results within 1e-4 relative (north_star); integer/index work bit-exact."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda", 0)
+
+
+def nhwc(x, dev, cpad=None, extra=0, offset=0):
+    """NCHW cpu -> NHWC cuda tensor, optionally as a channel slice [offset:offset+C] of a wider buffer."""
+    B, C, H, W = x.shape
+    Cp = cpad or ((C + 3) // 4 * 4)
+    buf = torch.full((B, H, W, Cp + extra), float("nan"), device=dev)
+    view = buf[..., offset:offset + Cp]
+    view.zero_()
+    view[..., :C] = x.permute(0, 2, 3, 1).to(dev)
+    return view
+
+
+def nchw(t, C=None):
+    t = t.detach().cpu()
+    if C is not None:
+        t = t[..., :C]
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def phys_weight(w, dev):
+    """OIHW cpu -> physical [Np][T][Cp] cuda"""
+    N, C, KH, KW = w.shape
+    Np, Cp = (N + 3) // 4 * 4, (C + 3) // 4 * 4
+    p = torch.zeros(Np, KH * KW, Cp, device=dev)
+    p[:N, :, :C] = w.permute(0, 2, 3, 1).reshape(N, KH * KW, C).to(dev)
+    return p
+
+
+def vec(v, dev):
+    n = (v.numel() + 3) // 4 * 4
+    p = torch.zeros(n, device=dev)
+    p[:v.numel()] = v.reshape(-1).to(dev)
+    return p
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (3, 8, 8, 192, 128, 3, 1, 1),
+    (2, 32, 32, 3, 64, 7, 1, 3),      # init_conv (padded input channels)
+    (2, 16, 16, 64, 3, 1, 1, 0),      # final_conv (3 outputs)
+    (2, 8, 8, 256, 128, 1, 1, 0),
+    (2, 16, 16, 32, 64, 4, 2, 1),     # strided 4x4 (DCGAN D / VQ-VAE encoder)
+    (5, 4, 4, 512, 1, 4, 1, 0),       # DCGAN critic head
+    (1, 10, 6, 20, 36, 3, 1, 1),      # ragged sizes
+    (4, 16, 16, 128, 256, 3, 1, 1),   # N > 64: 128-wide tiles
+    (40, 32, 32, 64, 64, 3, 1, 1),    # enough rows for the 128x64 tile
+    (24, 16, 16, 128, 128, 3, 1, 1),  # 128x128 tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    from lgm_hip import ops
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    y_ref = F.conv2d(x, w, b, stride=s, padding=p)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    Cp, Np = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    geom = ops.make_geom(B, H, W, Cp, Np, k, k, s, p)
+    xd = nhwc(x.detach(), dev, extra=8, offset=4)          # exercise pitch != C
+    wd, bd = phys_weight(w.detach(), dev), vec(b.detach(), dev)
+    yd = torch.empty(B, geom.Ho, geom.Wo, Np + 4, device=dev)[..., :Np]
+    ops.conv_xy(geom, xd, wd.data_ptr(), bd.data_ptr(), None, yd)
+    assert rel(nchw(yd, Cout), y_ref) < RTOL
+    # residual epilogue aliasing the output
+    ops.conv_xy(geom, xd, wd.data_ptr(), None, yd, yd)
+    assert rel(nchw(yd, Cout), 2 * y_ref - b.detach()[None, :, None, None]) < RTOL
+    # input gradient
+    gyd = nhwc(gy, dev, extra=4, offset=0)
+    gxd = torch.empty(B, H, W, Cp, device=dev)
+    ops.conv_yx(geom, gyd, wd.data_ptr(), None, None, gxd)
+    assert rel(nchw(gxd, Cin), x.grad) < RTOL
+    # weight gradient (+ accumulate with beta = 1) and bias gradient
+    gw = torch.zeros_like(wd)
+    ops.conv_wgrad(geom, gyd, xd, gw.data_ptr(), 0.0)
+    gw_ref = phys_weight(w.grad, dev)
+    assert rel(gw, gw_ref) < RTOL
+    ops.conv_wgrad(geom, gyd, xd, gw.data_ptr(), 1.0)
+    assert rel(gw, 2 * gw_ref) < RTOL
+    gb = torch.zeros(Np, device=dev)
+    ops.colsum(gyd, gb.data_ptr(), 0.0)
+    assert rel(gb[:Cout], b.grad) < RTOL
+    # wgrad determinism: two runs are bit-identical
+    gw2 = torch.zeros_like(wd)
+    ops.conv_wgrad(geom, gyd, xd, gw2.data_ptr(), 0.0)
+    gw3 = torch.zeros_like(wd)
+    ops.conv_wgrad(geom, gyd, xd, gw3.data_ptr(), 0.0)
+    assert torch.equal(gw2, gw3)
+
+
+@pytest.mark.parametrize("case", [(2, 4, 4, 100, 256, 4, 1, 0), (2, 8, 8, 64, 32, 4, 2, 1), (3, 7, 7, 128, 1, 4, 2, 1)])
+def test_conv_transpose(dev, case):
+    """ConvTranspose2d forward = Y->X pass; its backward = X->Y pass + wgrad with swapped roles."""
+    from lgm_hip import ops
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cin, Cout, k, k, generator=g) / math.sqrt(Cin)).requires_grad_(True)
+    y_ref = F.conv_transpose2d(x, w, None, stride=s, padding=p)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    Ho, Wo = y_ref.shape[-2:]
+    Np, Cp = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    geom = ops.make_geom(B, Ho, Wo, Cp, Np, k, k, s, p)
+    assert (geom.Ho, geom.Wo) == (H, W)
+    xd, gyd = nhwc(x.detach(), dev), nhwc(gy, dev)
+    wd = phys_weight(w.detach(), dev)     # [Cin][T][Cout]: same formula with N = Cin, C = Cout
+    yd = torch.empty(B, Ho, Wo, Cp, device=dev)
+    ops.conv_yx(geom, xd, wd.data_ptr(), None, None, yd)
+    assert rel(nchw(yd, Cout), y_ref) < RTOL
+    gxd = torch.empty(B, H, W, Np, device=dev)
+    ops.conv_xy(geom, gyd, wd.data_ptr(), None, None, gxd)
+    assert rel(nchw(gxd, Cin), x.grad) < RTOL
+    gw = torch.zeros_like(wd)
+    ops.conv_wgrad(geom, xd, gyd, gw.data_ptr(), 0.0)
+    assert rel(gw, phys_weight(w.grad, dev)) < RTOL
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 16, 16, 8), (2, 128, 8, 8, 8), (2, 512, 4, 4, 8), (2, 16, 8, 8, 8), (5, 256, 4, 4, 8)])
+@pytest.mark.parametrize("film", [True, False])
+def test_groupnorm_film_silu(dev, shape, film):
+    from lgm_hip import ops
+    B, C, H, W, G = shape
+    g = torch.Generator().manual_seed(C + H + int(film))
+    x = (torch.randn(B, C, H, W, generator=g) * 1.7 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    ss = (0.5 * torch.randn(B, 2 * C, generator=g)).requires_grad_(True)
+    res = torch.randn(B, C, H, W, generator=g)
+    z = F.group_norm(x, G, gamma, beta, 1e-5)
+    if film:
+        sc, sh = ss[:, :C, None, None], ss[:, C:, None, None]
+        z = z * (sc + 1) + sh
+    y_ref = F.silu(z) + res
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd, resd, gyd = nhwc(x.detach(), dev, extra=4), nhwc(res, dev), nhwc(gy, dev, extra=8, offset=8)
+    gd, bd = vec(gamma.detach(), dev), vec(beta.detach(), dev)
+    ssd = torch.zeros(B, 2 * C + 12, device=dev)[:, 4:4 + 2 * C]
+    ssd.copy_(ss.detach())
+    yd = torch.empty(B, H, W, C, device=dev)
+    sv = ops.gn_fwd(xd, G, 1e-5, gd.data_ptr(), bd.data_ptr(), ssd if film else None, True, resd, yd)
+    assert rel(nchw(yd), y_ref) < RTOL
+    gxd = torch.zeros(B, H, W, C, device=dev)
+    gg, gb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    gss = torch.zeros(B, 2 * C, device=dev)
+    ops.gn_bwd(xd, gyd, G, gd.data_ptr(), bd.data_ptr(), ssd if film else None, True, sv, gxd, False,
+               gg.data_ptr(), gb.data_ptr(), 0.0, gss if film else None, 0.0)
+    assert rel(nchw(gxd), x.grad) < RTOL
+    assert rel(gg, gamma.grad) < RTOL and rel(gb, beta.grad) < RTOL
+    if film:
+        assert rel(gss, ss.grad) < RTOL
+    # accumulate into gx
+    ops.gn_bwd(xd, gyd, G, gd.data_ptr(), bd.data_ptr(), ssd if film else None, True, sv, gxd, True,
+               gg.data_ptr(), gb.data_ptr(), 1.0, None, 0.0)
+    assert rel(nchw(gxd), 2 * x.grad) < RTOL and rel(gg, 2 * gamma.grad) < RTOL
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 128, 8, 8), (2, 512, 4, 4), (2, 16, 8, 8), (130, 256, 4, 4)])
+def test_rmsnorm(dev, shape):
+    from lgm_hip import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    gp = (1 + 0.2 * torch.randn(1, C, 1, 1, generator=g)).requires_grad_(True)
+    res = torch.randn(B, C, H, W, generator=g)
+    y_ref = F.normalize(x, dim=1) * gp * (C ** 0.5) + res
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd, resd, gyd = nhwc(x.detach(), dev, extra=4, offset=4), nhwc(res, dev), nhwc(gy, dev)
+    gpd = vec(gp.detach(), dev)
+    yd = torch.empty(B, H, W, C, device=dev)
+    ops.rmsnorm_fwd(xd, gpd.data_ptr(), resd, yd)
+    assert rel(nchw(yd), y_ref) < RTOL
+    gxd = torch.empty(B, H, W, C, device=dev)
+    gg = torch.zeros(C, device=dev)
+    ops.rmsnorm_bwd(xd, gyd, gpd.data_ptr(), gxd, False, gg.data_ptr(), 0.0)
+    assert rel(nchw(gxd), x.grad) < RTOL
+    assert rel(gg, gp.grad.reshape(-1)) < RTOL
+
+
+def _lin_attn_core(q, k, v, mem, scale):
+    """q,k,v: [B, h, d, n]; mem: [2, h, d, M] (reference ddpm.py:227-237)."""
+    b = q.shape[0]
+    mk, mv = (m.unsqueeze(0).expand(b, -1, -1, -1) for m in mem)
+    k = torch.cat((mk, k), dim=-1)
+    v = torch.cat((mv, v), dim=-1)
+    q = q.softmax(dim=-2) * scale
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    return torch.einsum("bhde,bhdn->bhen", ctx, q)
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 16, 16), (3, 4, 8, 8), (2, 2, 5, 7), (1, 4, 32, 32)])
+def test_linear_attention_core(dev, shape):
+    from lgm_hip import ops
+    B, heads, H, W = shape
+    d, M, n = 32, 4, H * W
+    hidden = heads * d
+    g = torch.Generator().manual_seed(n)
+    qkv = (torch.randn(B, 3 * hidden, H, W, generator=g) * 1.5).requires_grad_(True)
+    mem = torch.randn(2, heads, d, M, generator=g, requires_grad=True)
+    q, k, v = (t.reshape(B, heads, d, n) for t in qkv.chunk(3, dim=1))
+    out_ref = _lin_attn_core(q, k, v, mem, d ** -0.5).reshape(B, hidden, H, W)
+    gout = torch.randn(out_ref.shape, generator=g)
+    out_ref.backward(gout)
+    qd, god = nhwc(qkv.detach(), dev), nhwc(gout, dev)
+    memd = vec(mem.detach(), dev)
+    od = torch.empty(B, H, W, hidden, device=dev)
+    ctx, kstat = ops.linattn_fwd(qd, memd.data_ptr(), heads, d, M, od)
+    assert rel(nchw(od), out_ref) < RTOL
+    gq = torch.empty(B, H, W, 3 * hidden, device=dev)
+    gm = torch.zeros(mem.numel(), device=dev)
+    ops.linattn_bwd(qd, memd.data_ptr(), god, ctx, kstat, heads, d, M, gq, gm.data_ptr(), 0.0)
+    assert rel(nchw(gq), qkv.grad) < RTOL
+    assert rel(gm, mem.grad.reshape(-1)) < RTOL
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 4, 4), (3, 4, 8, 8), (2, 2, 3, 5), (1, 4, 8, 16)])
+def test_full_attention_core(dev, shape):
+    from lgm_hip import ops
+    B, heads, H, W = shape
+    d, M, n = 32, 4, H * W
+    hidden = heads * d
+    g = torch.Generator().manual_seed(n + 1)
+    qkv = torch.randn(B, 3 * hidden, H, W, generator=g, requires_grad=True)
+    mem = torch.randn(2, heads, M, d, generator=g, requires_grad=True)
+    q, k, v = (t.reshape(B, heads, d, n).transpose(-1, -2) for t in qkv.chunk(3, dim=1))
+    mk, mv = (m.unsqueeze(0).expand(B, -1, -1, -1) for m in mem)
+    k = torch.cat((mk, k), dim=-2)
+    v = torch.cat((mv, v), dim=-2)
+    attn = (torch.einsum("bhid,bhjd->bhij", q, k) * d ** -0.5).softmax(dim=-1)
+    out_ref = torch.einsum("bhij,bhjd->bhid", attn, v).transpose(-1, -2).reshape(B, hidden, H, W)
+    gout = torch.randn(out_ref.shape, generator=g)
+    out_ref.backward(gout)
+    qd, god = nhwc(qkv.detach(), dev), nhwc(gout, dev)
+    memd = vec(mem.detach(), dev)
+    od = torch.empty(B, H, W, hidden, device=dev)
+    lse = ops.attn_fwd(qd, memd.data_ptr(), heads, d, M, od)
+    assert rel(nchw(od), out_ref) < RTOL
+    gq = torch.empty(B, H, W, 3 * hidden, device=dev)
+    gm = torch.zeros(mem.numel(), device=dev)
+    ops.attn_bwd(qd, memd.data_ptr(), od, god, lse, heads, d, M, gq, gm.data_ptr(), 0.0)
+    assert rel(nchw(gq), qkv.grad) < RTOL
+    assert rel(gm, mem.grad.reshape(-1)) < RTOL
+
+
+def test_elementwise_kernels(dev):
+    from lgm_hip import ops
+    g = torch.Generator().manual_seed(5)
+    # sinusoidal embedding: known answers from the reference and the oracle formula
+    t = torch.tensor([0, 1, 17, 999])
+    pe = torch.empty(4, 64, device=dev)
+    ops.posemb(t.to(dev), 64, 10000.0, pe)
+    half = 32
+    f = torch.exp(torch.arange(half) * -(math.log(10000.0) / (half - 1)))
+    ref = torch.cat(((t[:, None] * f).sin(), (t[:, None] * f).cos()), dim=-1)
+    assert (pe.cpu() - ref).abs().max() < 2e-4   # fp32 sin/cos of arguments up to 999 rad
+    assert abs(pe[1, 0].item() - 0.84147096) < 1e-6 and abs(pe[1, 32].item() - 0.54030234) < 1e-6
+    # activations
+    x = torch.randn(37, 64, generator=g, requires_grad=True)
+    gy = torch.randn(37, 64, generator=g)
+    for act, fn in ((ops.ACT_SILU, F.silu), (ops.ACT_GELU, F.gelu), (ops.ACT_RELU, F.relu),
+                    (ops.ACT_LRELU, lambda v: F.leaky_relu(v, 0.2)), (ops.ACT_TANH, torch.tanh)):
+        x.grad = None
+        y = fn(x)
+        y.backward(gy)
+        xd, gyd = x.detach().to(dev), gy.to(dev)
+        yd, gxd = torch.empty_like(xd), torch.empty_like(xd)
+        ops.act_fwd(xd, None, None, yd, act, 0.2)
+        ops.act_bwd(xd, None, gyd, gxd, False, act, 0.2)
+        assert rel(yd, y) < 1e-5 and rel(gxd, x.grad) < 1e-5
+    # upsample / unshuffle round trips against torch / einops-equivalent formulas
+    a = torch.randn(2, 8, 5, 6, generator=g)
+    ad = nhwc(a, dev)
+    up = torch.empty(2, 10, 12, 8, device=dev)
+    ops.upsample2x_fwd(ad, up)
+    assert torch.equal(nchw(up), F.interpolate(a, scale_factor=2, mode="nearest"))
+    gup = torch.randn(2, 8, 10, 12, generator=g)
+    gad = torch.empty(2, 5, 6, 8, device=dev)
+    ops.upsample2x_bwd(nhwc(gup, dev), gad, False)
+    assert rel(nchw(gad), F.avg_pool2d(gup, 2) * 4) < 1e-6
+    hi = torch.randn(2, 8, 6, 4, generator=g)
+    lo = torch.empty(2, 3, 2, 32, device=dev)
+    ops.pixel_unshuffle(nhwc(hi, dev), lo, inverse=False)
+    ref = hi.reshape(2, 8, 3, 2, 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(2, 32, 3, 2)
+    assert torch.equal(nchw(lo), ref)
+    back = torch.empty(2, 6, 4, 8, device=dev)
+    ops.pixel_unshuffle(back, lo, inverse=True)
+    assert torch.equal(nchw(back), hi)
+
+
+def test_qsample_loss_and_adam(dev):
+    from lgm_hip import ops
+    from oracle import diffusion as OD
+    from oracle import optim as OO
+    g = torch.Generator().manual_seed(9)
+    bufs = OD.diffusion_buffers(1000)
+    B, C, S = 5, 3, 8
+    img = torch.rand(B, C, S, S, generator=g)
+    noise = torch.randn(B, C, S, S, generator=g)
+    t = torch.tensor([0, 17, 500, 998, 999])
+    x0 = img * 2 - 1
+    xt_ref, v_ref = OD.q_sample(bufs, x0, t, noise), OD.predict_v(bufs, x0, t, noise)
+    L = ops.lib()
+    xt = torch.empty(B, S, S, 4, device=dev)
+    tg = torch.empty(B, S, S, 4, device=dev)
+    sa, sb, lw = (bufs[k].to(dev) for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "loss_weight"))
+    td = t.to(dev)
+    L.lgm_qsample_target(img.to(dev).data_ptr(), noise.to(dev).data_ptr(), td.data_ptr(), sa.data_ptr(), sb.data_ptr(),
+                         1, xt.data_ptr(), tg.data_ptr(), 4, B, C, S * S, 4, ops.stream())
+    assert rel(nchw(xt, 3), xt_ref) < 1e-6 and rel(nchw(tg, 3), v_ref) < 1e-6
+    assert float(xt[..., 3].abs().max()) == 0.0
+    out = torch.randn(B, C, S, S, generator=g, requires_grad=True)
+    loss_ref = (F.mse_loss(out, v_ref, reduction="none").reshape(B, -1).mean(1) * bufs["loss_weight"][t]).mean()
+    loss_ref.backward()
+    outd = nhwc(out.detach(), dev)
+    per, loss = torch.empty(B, device=dev), torch.empty(1, device=dev)
+    L.lgm_weighted_mse_fwd(outd.data_ptr(), tg.data_ptr(), 4, td.data_ptr(), lw.data_ptr(), B, C, S * S, 4,
+                           per.data_ptr(), loss.data_ptr(), ops.stream())
+    assert rel(loss, loss_ref.reshape(1)) < 1e-5
+    gout = torch.empty(B, S, S, 4, device=dev)
+    one = torch.ones(1, device=dev)
+    L.lgm_weighted_mse_bwd(outd.data_ptr(), tg.data_ptr(), 4, td.data_ptr(), lw.data_ptr(), one.data_ptr(), B, C,
+                           S * S, 4, gout.data_ptr(), ops.stream())
+    assert rel(nchw(gout, 3), out.grad) < 1e-5
+    # fused Adam against torch.optim.Adam and the oracle restatement, 5 steps, with coupled L2
+    n = 1003
+    p = torch.randn(n, generator=g)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-3, betas=(0.9, 0.99), weight_decay=1e-2)
+    pd = torch.zeros(1004, device=dev)
+    pd[:n] = p.to(dev)
+    md, vd = torch.zeros_like(pd), torch.zeros_like(pd)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        gd_ = torch.zeros(1004, device=dev)
+        gd_[:n] = gr.to(dev)
+        ops.adam_step(pd, gd_, md, vd, n, 2e-3, 0.9, 0.99, 1e-8, 1e-2, step)
+    assert rel(pd[:n], ref) < 1e-6
+    # EMA lerp
+    sh, on = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    shd, ond = sh.to(dev), on.to(dev)
+    ops.ema_lerp(shd, ond, 0.25)
+    assert rel(shd, OO.ema_apply(sh, on, "lerp", 0.25)) < 1e-6
