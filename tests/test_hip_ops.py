@@ -336,7 +336,8 @@ def test_qsample_loss_and_adam(dev):
     tg = torch.empty(B, S, S, 4, device=dev)
     sa, sb, lw = (bufs[k].to(dev) for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "loss_weight"))
     td = t.to(dev)
-    L.lgm_qsample_target(img.to(dev).data_ptr(), noise.to(dev).data_ptr(), td.data_ptr(), sa.data_ptr(), sb.data_ptr(),
+    imgd, noised = img.to(dev), noise.to(dev)     # keep the device copies alive across the launch
+    L.lgm_qsample_target(imgd.data_ptr(), noised.data_ptr(), td.data_ptr(), sa.data_ptr(), sb.data_ptr(),
                          1, xt.data_ptr(), tg.data_ptr(), 4, B, C, S * S, 4, ops.stream())
     assert rel(nchw(xt, 3), xt_ref) < 1e-6 and rel(nchw(tg, 3), v_ref) < 1e-6
     assert float(xt[..., 3].abs().max()) == 0.0

@@ -156,6 +156,8 @@ def test_ddpm_module_training_steps(dev):
         loss.backward()
         opt.step()
         m.on_train_batch_end(None, None, step)
+        if step == 0:   # ema.update() #0 hard-copies online -> shadow; #1, #2 are skipped (update_every = 10)
+            snap = m.ema.online_model.model.state_dict()["init_conv.weight"].detach().clone()
         ref_opt.zero_grad()
         lr = OD.diffusion_forward(Pr, bufs, img, t, noise, dim=16)
         lr.backward()
@@ -165,8 +167,8 @@ def test_ddpm_module_training_steps(dev):
     for k in ("init_conv.weight", "downs.0.0.block1.proj.weight", "mid_attn.mem_kv", "final_conv.bias",
               "ups.1.2.to_out.1.g", "time_mlp.3.weight", "downs.2.1.mlp.1.bias"):
         assert rel(sd[k], Pr[k]) < 5 * RTOL, k
-    # EMA shadow == online copy during warm-up (update_after_step = 100)
-    assert rel(m.ema.ema_model.model.state_dict()["init_conv.weight"], sd["init_conv.weight"]) < 1e-6
+    # EMA shadow == the online weights at the last executed update (hard copy during warm-up)
+    assert rel(m.ema.ema_model.model.state_dict()["init_conv.weight"], snap) < 1e-6
     # the stock training_step path (random t / noise on device) runs and returns a finite scalar
     out = m.training_step((torch.rand(4, 3, 16, 16, device=dev) * 2 - 1, torch.zeros(4, dtype=torch.long, device=dev)))
     assert out.dim() == 0 and torch.isfinite(out)
