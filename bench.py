@@ -39,7 +39,11 @@ def cpu_baseline(batch=16, warmup=1, steps=3):
     """The CPU oracle (validated against the reference by tests/golden) on this host's cores."""
     from oracle import diffusion as OD
     torch.manual_seed(10)
-    nthreads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        avail = os.cpu_count() or 1
+    nthreads = max(1, min(avail, 16))   # a 1-GPU box owns a 16-core share of the host
     torch.set_num_threads(nthreads)
     P = {k: v.requires_grad_(True) for k, v in OD.unet_init(dim=DIM, channels=3, seed=0).items()}
     bufs = OD.diffusion_buffers(1000)
@@ -47,6 +51,7 @@ def cpu_baseline(batch=16, warmup=1, steps=3):
     x = torch.rand(batch, 3, IMG, IMG) * 2 - 1
     times = []
     for i in range(warmup + steps):
+        print(f"[bench] cpu_baseline step {i} ({nthreads} threads)", file=sys.stderr, flush=True)
         t0 = time.perf_counter()
         t = torch.randint(0, 1000, (batch,))
         noise = torch.randn_like(x)
@@ -111,9 +116,12 @@ def main():
         model.on_train_batch_end(None, batch, i)
         return loss
 
+    tw = time.perf_counter()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] warm-up done: {args.warmup} steps in {time.perf_counter() - tw:.2f}s", file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -130,6 +138,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
+    if rank == 0:
+        print(f"[bench] timed region: {args.steps} steps in {elapsed:.3f}s "
+              f"({args.batch * args.steps / elapsed:.1f} img/s)", file=sys.stderr, flush=True)
 
     # ---- roofline leg: one extra instrumented step, per-launch HIP events on the launch stream
     ops.TIMER = ops.KernelTimer()
