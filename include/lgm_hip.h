@@ -68,8 +68,10 @@ int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch, const flo
  * Deterministic: split-K partials go to `workspace` and are reduced in a fixed order.
  * lgm_conv_wgrad_workspace() returns the bytes needed for the given geometry. */
 int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g);
+/* gbias (optional, [Nw]): fused bias gradient gbias[n] = beta*gbias + sum_{b,oh,ow} Y[b,oh,ow,n]
+ * (valid for Conv2d / Linear, where Y is the output gradient). */
 int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
-                   int64_t x_pitch, float* gw, float beta, void* workspace,
+                   int64_t x_pitch, float* gw, float* gbias, float beta, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
 /* Column sums of a [rows, cols] matrix with row pitch: out[c] = beta*out[c] + sum_r a[r,c].

@@ -326,8 +326,10 @@ constexpr int WBK = 16;  // pixels per chunk
 struct WgradArgs {
   const float* y;  // [P, Nw] rows
   const float* x;  // X-side NHWC
-  float* out;      // gw (splits == 1) or workspace [splits][Nw][Q]
+  float* out;      // gw (splits == 1) or workspace [splits][Nw*Q + Nw]
+  float* bias_out; // gbias (splits == 1), workspace slab tail (splits > 1), or null
   float beta;      // only for splits == 1
+  long slab;       // floats per split slab in the workspace
   long y_pitch, x_pitch;
   int B, H, W, Cw, Ho, Wo, Nw, KH, KW, stride, pad;
   int P, Q;        // pixels, T*Cw
@@ -412,9 +414,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     store_chunk(0);
   }
   __syncthreads();
+  // fused bias gradient: the tn == 0 blocks also column-sum their Y tile (thread -> column
+  // tid % BM, pixel lane tid / BM; fixed order => deterministic)
+  const bool do_bias = p.bias_out != nullptr && tn == 0;
+  constexpr int BL = 256 / BM;          // pixel lanes
+  const int bcol = tid % BM, blane = tid / BM;
+  float bsum = 0.f;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_chunk(p_begin + (kt + 1) * WBK);
+    if (do_bias) {
+#pragma unroll
+      for (int r = 0; r < WBK / BL; ++r) bsum += As[cur][(blane + BL * r) * BM + bcol];
+    }
     const float* as = &As[cur][lh * BM + wm * 32 * TM + lr];
     const float* bs = &Bs[cur][lh * BN + wn * 32 * TN + lr];
 #pragma unroll
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     __syncthreads();
   }
 
-  float* out = p.out + (p.splits > 1 ? (long)split * p.Nw * p.Q : 0L);
+  float* out = p.out + (p.splits > 1 ? (long)split * p.slab : 0L);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int qq = q0 + wn * 32 * TN + j * 32 + lr;
@@ -453,27 +465,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
       }
     }
   }
+  if (do_bias) {   // uniform per block; the K loop ended with a barrier, so LDS is free
+    As[0][blane * BM + bcol] = bsum;
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.Nw) {
+      float v = 0.f;
+#pragma unroll
+      for (int l = 0; l < BL; ++l) v += As[0][l * BM + tid];
+      float* bo = p.bias_out + (p.splits > 1 ? (long)split * p.slab : 0L) + m0 + tid;
+      if (p.splits == 1 && p.beta != 0.f) v += p.beta * bo[0];
+      bo[0] = v;
+    }
+  }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, long n,
-                                    int splits, float beta) {
-  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
-  if (i + 3 < n) {
-    f32x4 s = *reinterpret_cast<const f32x4*>(ws + i);
-    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(ws + (long)k * n + i);
-    if (beta != 0.f) {
-      f32x4 o = *reinterpret_cast<const f32x4*>(gw + i);
-      s += o * beta;
-    }
-    *reinterpret_cast<f32x4*>(gw + i) = s;
-  } else {
-    for (long j = i; j < n; ++j) {
-      float s = ws[j];
-      for (int k = 1; k < splits; ++k) s += ws[(long)k * n + j];
-      if (beta != 0.f) s += beta * gw[j];
-      gw[j] = s;
-    }
+// Deterministic split-K reduction: out[i] = beta*out[i] + sum_s ws[s*slab + i] (fixed order:
+// 4 split lanes summed in LDS in lane order).  i < n_w -> gw, n_w <= i < n_w + n_b -> gbias.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, long slab,
+                                                           float* __restrict__ gw, long n_w,
+                                                           float* __restrict__ gb, long n_b, int splits,
+                                                           float beta) {
+  __shared__ __align__(16) float sh[4][64 * 4];
+  const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + col) * 4;
+  const long n = n_w + n_b;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n)
+    for (int k = lane; k < splits; k += 4) s += *reinterpret_cast<const f32x4*>(ws + (long)k * slab + i);
+  *reinterpret_cast<f32x4*>(&sh[lane][col * 4]) = s;
+  __syncthreads();
+  if (lane == 0 && i < n) {
+    f32x4 t = (*reinterpret_cast<const f32x4*>(&sh[0][col * 4]) + *reinterpret_cast<const f32x4*>(&sh[1][col * 4])) +
+              (*reinterpret_cast<const f32x4*>(&sh[2][col * 4]) + *reinterpret_cast<const f32x4*>(&sh[3][col * 4]));
+    float* dst = i < n_w ? gw + i : gb + (i - n_w);
+    if (beta != 0.f) t += *reinterpret_cast<const f32x4*>(dst) * beta;
+    *reinterpret_cast<f32x4*>(dst) = t;
   }
 }
 
@@ -499,16 +525,18 @@ extern "C" int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g) {
   int splits, chunk;
   wgrad_plan(g, &splits, &chunk);
   if (splits == 1) return 16;
-  return (int64_t)splits * g->Nw * g->KH * g->KW * g->Cw * (int64_t)sizeof(float);
+  const int64_t slab = (int64_t)g->Nw * g->KH * g->KW * g->Cw + g->Nw;
+  return (int64_t)splits * slab * (int64_t)sizeof(float);
 }
 
 extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
-                              int64_t x_pitch, float* gw, float beta, void* workspace,
+                              int64_t x_pitch, float* gw, float* gbias, float beta, void* workspace,
                               int64_t workspace_bytes, void* stream) {
   if (int rc = check_geom(g)) return rc;
   LGM_REQUIRE(y && x && gw, "conv_wgrad: null pointer");
   LGM_REQUIRE(g->Cw % 4 == 0 && g->Nw % 4 == 0, "conv_wgrad: Cw=%d, Nw=%d must be multiples of 4", g->Cw, g->Nw);
-  LGM_REQUIRE(y_pitch % 4 == 0 && x_pitch % 4 == 0 && lgm_aligned16(y) && lgm_aligned16(x) && lgm_aligned16(gw),
+  LGM_REQUIRE(y_pitch % 4 == 0 && x_pitch % 4 == 0 && lgm_aligned16(y) && lgm_aligned16(x) && lgm_aligned16(gw) &&
+                  (!gbias || lgm_aligned16(gbias)),
               "conv_wgrad: tensors must be 16B aligned with pitch %% 4 == 0");
   WgradArgs a{};
   a.y = y; a.x = x; a.beta = beta; a.y_pitch = y_pitch; a.x_pitch = x_pitch;
@@ -516,13 +544,16 @@ extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pi
   a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
   a.P = g->B * g->Ho * g->Wo; a.Q = g->KH * g->KW * g->Cw;
   wgrad_plan(g, &a.splits, &a.chunk);
-  const long n = (long)a.Nw * a.Q;
+  const long n_w = (long)a.Nw * a.Q;
+  a.slab = n_w + a.Nw;
   if (a.splits > 1) {
-    LGM_REQUIRE(workspace && workspace_bytes >= (int64_t)a.splits * n * (int64_t)sizeof(float) && lgm_aligned16(workspace),
-                "conv_wgrad: workspace too small (%lld bytes needed)", (long long)a.splits * n * 4);
+    LGM_REQUIRE(workspace && workspace_bytes >= (int64_t)a.splits * a.slab * (int64_t)sizeof(float) && lgm_aligned16(workspace),
+                "conv_wgrad: workspace too small (%lld bytes needed)", (long long)a.splits * a.slab * 4);
     a.out = (float*)workspace;
+    a.bias_out = gbias ? (float*)workspace + n_w : nullptr;
   } else {
     a.out = gw;
+    a.bias_out = gbias;
   }
   a.tiles_m = lgm_cdiv(a.Nw, 64);
   a.tiles_n = lgm_cdiv(a.Q, 64);
@@ -530,9 +561,10 @@ extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pi
   hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
   LGM_LAUNCH_CHECK();
   if (a.splits > 1) {
-    const long nthreads = (n + 3) / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lgm_cdiv(nthreads, 256)), dim3(256), 0, s,
-                       (const float*)workspace, gw, n, a.splits, beta);
+    const long n_b = gbias ? a.Nw : 0;
+    const long groups = (n_w + n_b + 3) / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lgm_cdiv(groups, 64)), dim3(256), 0, s,
+                       (const float*)workspace, a.slab, gw, n_w, gbias, n_b, a.splits, beta);
     LGM_LAUNCH_CHECK();
   }
   return LGM_OK;

@@ -22,50 +22,62 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // colsum: out[c] = beta*out[c] + sum_r a[r, c]
 // ---------------------------------------------------------------------------------------
-constexpr int CS_ROWS = 256;  // rows per stage-1 block
+// rows per stage-1 block: at least 64, and at most 128 splits overall
+static inline long cs_rows(long rows) {
+  long r = (rows + 127) / 128;
+  if (r < 64) r = 64;
+  return (r + 3) / 4 * 4;
+}
 
-__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ a, long pitch, long rows, long cols,
-                                                     float* __restrict__ partial) {
-  // block = 64 columns x 4 row lanes
+// block = 64 columns x 4 row lanes; sums rows [r0, r1) of `a` (fixed order => deterministic)
+__global__ __launch_bounds__(256) void colsum_stage(const float* __restrict__ a, long pitch, long rows, long cols,
+                                                    long rows_per_block, float* __restrict__ out, long out_pitch,
+                                                    float beta) {
   __shared__ float sh[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const long c = (long)blockIdx.x * 64 + cl;
-  const long r0 = (long)blockIdx.y * CS_ROWS;
-  const long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
-  float s = 0.f;
-  if (c < cols)
-    for (long r = r0 + rl; r < r1; r += 4) s += a[r * pitch + c];
-  sh[rl][cl] = s;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    long r = r0 + rl;
+    for (; r + 4 < r1; r += 8) {   // two independent chains keep more loads in flight
+      s0 += a[r * pitch + c];
+      s1 += a[(r + 4) * pitch + c];
+    }
+    if (r < r1) s0 += a[r * pitch + c];
+  }
+  sh[rl][cl] = s0 + s1;
   __syncthreads();
-  if (rl == 0 && c < cols) partial[(long)blockIdx.y * cols + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
-}
-
-__global__ void colsum_stage2(const float* __restrict__ partial, long nsplit, long cols, float* __restrict__ out,
-                              float beta) {
-  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (long k = 0; k < nsplit; ++k) s += partial[k * cols + c];
-  if (beta != 0.f) s += beta * out[c];
-  out[c] = s;
+  if (rl == 0 && c < cols) {
+    float v = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    float* o = out + (long)blockIdx.y * out_pitch + c;
+    if (beta != 0.f) v += beta * o[0];
+    o[0] = v;
+  }
 }
 
 }  // namespace
 
 extern "C" int64_t lgm_colsum_workspace(int64_t rows, int64_t cols) {
-  return (int64_t)lgm_cdiv(rows, CS_ROWS) * cols * (int64_t)sizeof(float) + 16;
+  return (int64_t)lgm_cdiv(rows, cs_rows(rows)) * cols * (int64_t)sizeof(float) + 16;
 }
 
 extern "C" int lgm_colsum(const float* a, int64_t pitch, int64_t rows, int64_t cols, float* out, float beta,
                           void* workspace, void* stream) {
   LGM_REQUIRE(a && out && workspace && rows > 0 && cols > 0, "colsum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  const int ns = lgm_cdiv(rows, CS_ROWS);
-  LGM_REQUIRE(ns <= 65535, "colsum: too many rows");
-  hipLaunchKernelGGL(colsum_stage1, dim3(lgm_cdiv(cols, 64), ns), dim3(256), 0, s, a, (long)pitch, (long)rows,
-                     (long)cols, (float*)workspace);
-  hipLaunchKernelGGL(colsum_stage2, dim3(lgm_cdiv(cols, 256)), dim3(256), 0, s, (const float*)workspace, (long)ns,
-                     (long)cols, out, beta);
+  const long rpb = cs_rows(rows);
+  const int ns = lgm_cdiv(rows, rpb);
+  if (ns == 1) {
+    hipLaunchKernelGGL(colsum_stage, dim3(lgm_cdiv(cols, 64), 1), dim3(256), 0, s, a, (long)pitch, (long)rows,
+                       (long)cols, rpb, out, 0L, beta);
+  } else {
+    hipLaunchKernelGGL(colsum_stage, dim3(lgm_cdiv(cols, 64), ns), dim3(256), 0, s, a, (long)pitch, (long)rows,
+                       (long)cols, rpb, (float*)workspace, (long)cols, 0.f);
+    hipLaunchKernelGGL(colsum_stage, dim3(lgm_cdiv(cols, 64), 1), dim3(256), 0, s, (const float*)workspace,
+                       (long)cols, (long)ns, (long)cols, (long)ns, out, 0L, beta);
+  }
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

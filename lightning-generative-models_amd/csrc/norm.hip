@@ -221,20 +221,30 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ S1, const float* __
 __global__ void gn_bwd_affine_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
                                      const float* __restrict__ ss, long ss_pitch, int B, int C,
                                      float* __restrict__ ggamma, float* __restrict__ gbeta, float beta_acc) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // block = 64 channels x 4 batch lanes (fixed-order LDS combine => deterministic)
+  __shared__ float sg[4][64], sb[4][64];
+  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float gg = 0.f, gb = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float sc = ss ? ss[(long)b * ss_pitch + c] + 1.f : 1.f;
-    gg += sc * S2[(long)b * C + c];
-    gb += sc * S1[(long)b * C + c];
+  if (c < C)
+    for (int b = bl; b < B; b += 4) {
+      const float sc = ss ? ss[(long)b * ss_pitch + c] + 1.f : 1.f;
+      gg += sc * S2[(long)b * C + c];
+      gb += sc * S1[(long)b * C + c];
+    }
+  sg[bl][cl] = gg;
+  sb[bl][cl] = gb;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    gg = (sg[0][cl] + sg[1][cl]) + (sg[2][cl] + sg[3][cl]);
+    gb = (sb[0][cl] + sb[1][cl]) + (sb[2][cl] + sb[3][cl]);
+    if (beta_acc != 0.f) {
+      gg += beta_acc * ggamma[c];
+      gb += beta_acc * gbeta[c];
+    }
+    ggamma[c] = gg;
+    gbeta[c] = gb;
   }
-  if (beta_acc != 0.f) {
-    gg += beta_acc * ggamma[c];
-    gb += beta_acc * gbeta[c];
-  }
-  ggamma[c] = gg;
-  gbeta[c] = gb;
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, long x_pitch,
@@ -322,7 +332,7 @@ extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int6
                      coefA, coefB, mean, rstd, HW, C, G, cb, act, S1, S2);
   hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(B), dim3(256), 0, s, S1, S2, mean, rstd, gamma, beta, ss, (long)ss_pitch,
                      gss, (long)gss_pitch, gss_beta, B, C, G, HW, P, Qc, Rc);
-  hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(lgm_cdiv(C, 64)), dim3(64), 0, s, S1, S2, ss, (long)ss_pitch, B, C,
+  hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(lgm_cdiv(C, 64)), dim3(256), 0, s, S1, S2, ss, (long)ss_pitch, B, C,
                      ggamma, gbeta, affine_beta);
   const long npix = (long)B * HW;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(lgm_cdiv(npix * (C / 4), 256)), dim3(256), 0, s, x, (long)x_pitch, gy,

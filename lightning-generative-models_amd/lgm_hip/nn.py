@@ -84,9 +84,15 @@ class Conv2d(nn.Module):
         B, H, W, _ = x.shape
         g = self.geom(B, H, W)
         fp = gc.flat
-        ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), gc.beta(self.weight))
+        bw = gc.beta(self.weight)
+        gb = None
         if self.bias is not None:
-            ops.colsum(gy, fp.gptr(self.bias), gc.beta(self.bias))
+            bb = gc.beta(self.bias)
+            if bb == bw:
+                gb = fp.gptr(self.bias)              # bias gradient fused into the wgrad kernel
+            else:
+                ops.colsum(gy, fp.gptr(self.bias), bb)
+        ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb)
         if not need_gx:
             return None
         if gx is None:

@@ -128,13 +128,13 @@ def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x):
         TIMER.end()
 
 
-def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float):
+def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[int] = None):
     L = lib()
     nbytes = L.lgm_conv_wgrad_workspace(ctypes.byref(g))
     ws = workspace(nbytes, y.device)
     if TIMER is not None:
         TIMER.begin("wgrad", _conv_flops(g))
-    L.lgm_conv_wgrad(ctypes.byref(g), y.data_ptr(), pitch(y), x.data_ptr(), pitch(x), gw_ptr, beta,
+    L.lgm_conv_wgrad(ctypes.byref(g), y.data_ptr(), pitch(y), x.data_ptr(), pitch(x), gw_ptr, gbias_ptr, beta,
                      ws.data_ptr(), ws.numel() * 4, stream())
     if TIMER is not None:
         TIMER.end()

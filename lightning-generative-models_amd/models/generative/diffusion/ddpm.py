@@ -352,8 +352,7 @@ class Unet(nn.Module):
         l1, l2 = self.time_mlp[1], self.time_mlp[3]
         rbs = self.resblocks()
         g = self._mlp_geoms[B]
-        ops.conv_wgrad(g, gss_all, st, fp.gptr(rbs[0].mlp[1].weight), gc.beta0)
-        ops.colsum(gss_all, fp.gptr(rbs[0].mlp[1].bias), gc.beta0)
+        ops.conv_wgrad(g, gss_all, st, fp.gptr(rbs[0].mlp[1].weight), gc.beta0, fp.gptr(rbs[0].mlp[1].bias))
         for rb in rbs:
             gc.written.add(id(rb.mlp[1].weight))
             gc.written.add(id(rb.mlp[1].bias))
@@ -361,14 +360,14 @@ class Unet(nn.Module):
         ops.conv_yx(g, gss_all, fp.ptr(rbs[0].mlp[1].weight), None, None, gst)
         gtemb = ops.new(st.shape, st)
         ops.act_bwd(temb, None, gst, gtemb, False, ops.ACT_SILU)
-        ops.conv_wgrad(l2.geom(B), gtemb, h, fp.gptr(l2.weight), gc.beta(l2.weight))
-        ops.colsum(gtemb, fp.gptr(l2.bias), gc.beta(l2.bias))
+        ops.conv_wgrad(l2.geom(B), gtemb, h, fp.gptr(l2.weight), gc.beta(l2.weight), fp.gptr(l2.bias))
+        gc.beta(l2.bias)
         gh = ops.new(h.shape, h)
         ops.conv_yx(l2.geom(B), gtemb, fp.ptr(l2.weight), None, None, gh)
         ga1 = ops.new(a1.shape, a1)
         ops.act_bwd(a1, None, gh, ga1, False, ops.ACT_GELU)
-        ops.conv_wgrad(l1.geom(B), ga1, pe, fp.gptr(l1.weight), gc.beta(l1.weight))
-        ops.colsum(ga1, fp.gptr(l1.bias), gc.beta(l1.bias))
+        ops.conv_wgrad(l1.geom(B), ga1, pe, fp.gptr(l1.weight), gc.beta(l1.weight), fp.gptr(l1.bias))
+        gc.beta(l1.bias)
 
     # ---- network ----------------------------------------------------------------------------
     def forward_nhwc(self, x, t, save: bool):

@@ -109,6 +109,12 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     gb = torch.zeros(Np, device=dev)
     ops.colsum(gyd, gb.data_ptr(), 0.0)
     assert rel(gb[:Cout], b.grad) < RTOL
+    # bias gradient fused into the wgrad kernel (+ accumulate)
+    gw_f, gb_f = torch.zeros_like(wd), torch.zeros(Np, device=dev)
+    ops.conv_wgrad(geom, gyd, xd, gw_f.data_ptr(), 0.0, gb_f.data_ptr())
+    assert rel(gw_f, gw_ref) < RTOL and rel(gb_f[:Cout], b.grad) < RTOL
+    ops.conv_wgrad(geom, gyd, xd, gw_f.data_ptr(), 1.0, gb_f.data_ptr())
+    assert rel(gw_f, 2 * gw_ref) < RTOL and rel(gb_f[:Cout], 2 * b.grad) < RTOL
     # wgrad determinism: two runs are bit-identical
     gw2 = torch.zeros_like(wd)
     ops.conv_wgrad(geom, gyd, xd, gw2.data_ptr(), 0.0)
