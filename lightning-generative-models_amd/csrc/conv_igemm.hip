@@ -12,7 +12,29 @@
 // lane (r = l&31, h = l>>5) reads k = 8*kc + 4*h .. +3 of its row, and MFMA step s consumes
 // element s of that float4 from both operands (the k -> (half, step) assignment is arbitrary as
 // long as A and B agree; fp32 accumulation order inside a chunk is fixed => deterministic).
+#include <stdlib.h>
+
 #include "lgm_common.h"
+
+// specialised 3x3 / stride 1 / pad 1 kernels (conv3x3.hip)
+bool lgm_conv3x3_supported(const LgmConvGeom* g, int gather_channels, int out_channels);
+int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pitch, const float* w,
+                       const float* bias, const float* res, long res_pitch, float* out, long out_pitch,
+                       hipStream_t s);
+bool lgm_wgrad3x3_supported(const LgmConvGeom* g);
+void lgm_wgrad3x3_plan(const LgmConvGeom* g, int* splits, int* tps, int* total_ts);
+int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch,
+                        float* out, float* bias_out, float beta, long slab, int splits, int tps, int total_ts,
+                        hipStream_t s);
+
+static bool use_3x3() {   // LGM_NO_3X3=1 forces the generic implicit-GEMM path (A/B comparisons)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("LGM_NO_3X3");
+    v = (e && e[0] == '1') ? 0 : 1;
+  }
+  return v == 1;
+}
 
 namespace {
 
@@ -222,14 +244,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float rv[16];
+      if (p.res) {   // issue all residual loads before the first use (one wait, not sixteen)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          rv[r] = m < p.M ? p.res[(long)m * p.res_pitch + n] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.M) {
-          float v = acc[i][j][r] + bv;
-          if (p.res) v += p.res[(long)m * p.res_pitch + n];
-          p.out[(long)m * p.out_pitch + n] = v;
-        }
+        if (m < p.M) p.out[(long)m * p.out_pitch + n] = acc[i][j][r] + bv + rv[r];
       }
     }
   }
@@ -287,6 +316,8 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
   LGM_REQUIRE(x_pitch % 4 == 0 && x_pitch >= g->Cw && lgm_aligned16(x) && lgm_aligned16(w),
               "conv_xy: x/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(y_pitch >= g->Nw && (!res || res_pitch >= g->Nw), "conv_xy: output pitch < Nw");
+  if (use_3x3() && lgm_conv3x3_supported(g, g->Cw, g->Nw))
+    return lgm_conv3x3_launch(0, g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, (hipStream_t)stream);
   IgemmArgs a{};
   a.a = x; a.w = w; a.bias = bias; a.res = res; a.out = y;
   a.a_pitch = x_pitch; a.res_pitch = res_pitch; a.out_pitch = y_pitch;
@@ -305,6 +336,8 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
   LGM_REQUIRE(y_pitch % 4 == 0 && y_pitch >= g->Nw && lgm_aligned16(y) && lgm_aligned16(w),
               "conv_yx: y/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(x_pitch >= g->Cw && (!res || res_pitch >= g->Cw), "conv_yx: output pitch < Cw");
+  if (use_3x3() && lgm_conv3x3_supported(g, g->Nw, g->Cw))
+    return lgm_conv3x3_launch(1, g, y, y_pitch, w, bias, res, res_pitch, x, x_pitch, (hipStream_t)stream);
   IgemmArgs a{};
   a.a = y; a.w = w; a.bias = bias; a.res = res; a.out = x;
   a.a_pitch = y_pitch; a.res_pitch = res_pitch; a.out_pitch = x_pitch;
@@ -523,7 +556,12 @@ void wgrad_plan(const LgmConvGeom* g, int* splits, int* chunk) {
 extern "C" int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g) {
   if (check_geom(g) != LGM_OK) return -1;
   int splits, chunk;
-  wgrad_plan(g, &splits, &chunk);
+  if (use_3x3() && lgm_wgrad3x3_supported(g)) {
+    int tps, total;
+    lgm_wgrad3x3_plan(g, &splits, &tps, &total);
+  } else {
+    wgrad_plan(g, &splits, &chunk);
+  }
   if (splits == 1) return 16;
   const int64_t slab = (int64_t)g->Nw * g->KH * g->KW * g->Cw + g->Nw;
   return (int64_t)splits * slab * (int64_t)sizeof(float);
@@ -543,7 +581,12 @@ extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pi
   a.B = g->B; a.H = g->H; a.W = g->W; a.Cw = g->Cw; a.Ho = g->Ho; a.Wo = g->Wo; a.Nw = g->Nw;
   a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
   a.P = g->B * g->Ho * g->Wo; a.Q = g->KH * g->KW * g->Cw;
-  wgrad_plan(g, &a.splits, &a.chunk);
+  const bool fast3 = use_3x3() && lgm_wgrad3x3_supported(g);
+  int tps3 = 0, total3 = 0;
+  if (fast3)
+    lgm_wgrad3x3_plan(g, &a.splits, &tps3, &total3);
+  else
+    wgrad_plan(g, &a.splits, &a.chunk);
   const long n_w = (long)a.Nw * a.Q;
   a.slab = n_w + a.Nw;
   if (a.splits > 1) {
@@ -558,8 +601,14 @@ extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pi
   a.tiles_m = lgm_cdiv(a.Nw, 64);
   a.tiles_n = lgm_cdiv(a.Q, 64);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
-  LGM_LAUNCH_CHECK();
+  if (fast3) {
+    if (int rc = lgm_wgrad3x3_launch(g, y, y_pitch, x, x_pitch, a.out, a.bias_out, beta, a.slab, a.splits, tps3,
+                                     total3, s))
+      return rc;
+  } else {
+    hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
+    LGM_LAUNCH_CHECK();
+  }
   if (a.splits > 1) {
     const long n_b = gbias ? a.Nw : 0;
     const long groups = (n_w + n_b + 3) / 4;

@@ -70,6 +70,10 @@ CONV_CASES = [
     (4, 16, 16, 128, 256, 3, 1, 1),   # N > 64: 128-wide tiles
     (40, 32, 32, 64, 64, 3, 1, 1),    # enough rows for the 128x64 tile
     (24, 16, 16, 128, 128, 3, 1, 1),  # 128x128 tile
+    (11, 4, 4, 256, 256, 3, 1, 1),    # 3x3 patch kernel: 8 images per tile, ragged batch
+    (1, 64, 64, 64, 64, 3, 1, 1),     # 3x3 patch kernel: 64x64 images (two column tiles)
+    (5, 8, 8, 96, 64, 3, 1, 1),       # 3x3 patch kernel with 32-channel chunks (C % 64 != 0)
+    (3, 32, 32, 128, 64, 3, 1, 1),    # 3x3 patch kernel, two channel chunks
 ]
 
 
