@@ -55,13 +55,18 @@ typedef struct {
  * y = conv(x, w) + bias[n] + res   (bias, res optional = NULL; res may alias y). */
 int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w,
                 const float* bias, const float* res, int64_t res_pitch,
-                float* y, int64_t y_pitch, void* stream);
+                float* y, int64_t y_pitch, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Y -> X  (Conv2d input-gradient; ConvTranspose2d.forward).
  * x = conv_transpose(y, w) + bias[c] + res   (bias, res optional; res may alias x). */
 int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
                 const float* bias, const float* res, int64_t res_pitch,
-                float* x, int64_t x_pitch, void* stream);
+                float* x, int64_t x_pitch, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Optional workspace (bytes) for lgm_conv_xy (yx = 0) / lgm_conv_yx (yx = 1): small-image 3x3
+ * layers split the reduction over workgroups and combine the partials in a fixed order.
+ * Passing NULL / too few bytes is legal (no split, slower on tiny feature maps). */
+int64_t lgm_conv_workspace(const LgmConvGeom* g, int yx);
 
 /* Weight gradient: gw[n][tap][c] = beta*gw + sum_{b,oh,ow} Y[b,oh,ow,n] * X[b,ih,iw,c].
  * (Conv2d: Y = grad_output, X = input;  ConvTranspose2d: Y = input, X = grad_output.)

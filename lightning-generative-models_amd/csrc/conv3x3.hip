@@ -38,7 +38,27 @@ struct Args {
   int Wn;             // inner dim of the weight tensor (Cw)
   int TH, TW, NI, lgTW, lgTT;   // tile: TH x TW pixels of NI images; lgTT = log2(TH*TW)
   int tiles_h, tiles_w, tiles_n, NP;
+  int splits;         // split-K over the (channel chunk, tap) sequence; > 1 => partials to ws
+  float* ws;          // [splits][B*H*W][N]
+  long ws_stride;
 };
+
+// out[m][n] = sum_s ws[s][m][n] + bias[n] + res[m][n]   (fixed order => deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, long ws_stride, int splits,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ res, long res_pitch,
+                                                            float* __restrict__ out, long out_pitch, long M, int N) {
+  const int n4 = N / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * n4) return;
+  const long m = i / n4;
+  const int n = (int)(i % n4) * 4;
+  f32x4 s = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+  for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(ws + (long)k * ws_stride + m * N + n);
+  if (bias) s += *reinterpret_cast<const f32x4*>(bias + n);
+  if (res) s += *reinterpret_cast<const f32x4*>(res + m * res_pitch + n);
+  *reinterpret_cast<f32x4*>(out + m * out_pitch + n) = s;
+}
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
   // blocks b, b+8, b+16, ... share an XCD (and its L2): give them consecutive logical ids
@@ -52,10 +72,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
   constexpr int PPP = 256 / TPP;         // positions per pass
   constexpr int NJ = (288 + PPP - 1) / PPP;
   constexpr int KS = CK / BK;            // weight chunks per (chunk, tap)
-  constexpr int B_TILE = (MODE == MODE_XY) ? BN * LDB : BK * BN;
   extern __shared__ __align__(16) float smem[];
   float* Ps = smem;
-  float* Bs = smem + p.NP * LDP;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -65,6 +83,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
   const int L = xcd_swizzle(blockIdx.x, gridDim.x);
   const int tn = L % p.tiles_n;
   int ts = L / p.tiles_n;
+  const int split = ts % p.splits;
+  ts /= p.splits;
   const int twi = ts % p.tiles_w;
   ts /= p.tiles_w;
   const int thi = ts % p.tiles_h;
@@ -119,30 +139,25 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
     abase[i] = ((img * (p.TH + 2) + ph) * PW + pw) * LDP + lh * 4;
   }
 
-  // ---- weight chunk q = (cc, tap, ks) ----
-  f32x4 rb[2];
-  auto load_b = [&](int q) {
+  // ---- weight fragments of chunk q = (cc, tap, ks): every lane fetches ITS OWN B operand values
+  // straight from global memory (the weight tile is tiny and L1/L2 resident), one chunk ahead.
+  // No LDS staging of weights => no barrier in the main loop: the four waves run decoupled.
+  const float* wlane = (MODE == MODE_XY) ? p.w + (long)(n0 + wn * 32 + lr) * (9 * p.C) + lh * 4
+                                         : p.w + (long)(lh * 4) * 9 * p.Wn + n0 + wn * 32 + lr;
+  auto load_b = [&](int q, f32x4 (&fb)[4]) {
     const int ks = q % KS, t2 = q / KS;
     const int tap = t2 % 9, cc = t2 / 9;
     if (MODE == MODE_XY) {
-      const float* src = p.w + (long)(n0 + (tid >> 3)) * (9 * p.C) + tap * p.C + cc * CK + ks * BK + (tid & 7) * 4;
-      rb[0] = *reinterpret_cast<const f32x4*>(src);
-      rb[1] = *reinterpret_cast<const f32x4*>(src + (long)32 * 9 * p.C);
+      const float* src = wlane + tap * p.C + cc * CK + ks * BK;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) fb[kc] = *reinterpret_cast<const f32x4*>(src + kc * 8);
     } else {
-      const int krow = tid >> 4, ncol = (tid & 15) * 4;
-      const float* src = p.w + ((long)(cc * CK + ks * BK + krow) * 9 + tap) * p.Wn + n0 + ncol;
-      rb[0] = *reinterpret_cast<const f32x4*>(src);
-      rb[1] = *reinterpret_cast<const f32x4*>(src + (long)16 * 9 * p.Wn);
-    }
-  };
-  auto store_b = [&](int buf) {
-    float* bs = Bs + buf * B_TILE;
-    if (MODE == MODE_XY) {
-      *reinterpret_cast<f32x4*>(bs + (tid >> 3) * LDB + (tid & 7) * 4) = rb[0];
-      *reinterpret_cast<f32x4*>(bs + ((tid >> 3) + 32) * LDB + (tid & 7) * 4) = rb[1];
-    } else {
-      *reinterpret_cast<f32x4*>(bs + (tid >> 4) * BN + (tid & 15) * 4) = rb[0];
-      *reinterpret_cast<f32x4*>(bs + ((tid >> 4) + 16) * BN + (tid & 15) * 4) = rb[1];
+      const float* src = wlane + ((long)(cc * CK + ks * BK) * 9 + tap) * p.Wn;
+      const long kstride = (long)9 * p.Wn;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fb[kc][s] = src[(kc * 8 + s) * kstride];
     }
   };
 
@@ -154,54 +169,63 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
 
   const int ncc = p.C / CK;
   const int nq = ncc * 9 * KS;
-  load_b(0);
-  load_patch(0);
-  store_b(0);
+  const int cps = (nq + p.splits - 1) / p.splits;
+  const int q_begin = split * cps;
+  const int q_end = min(nq, q_begin + cps);
+
+  f32x4 cb[4], nb[4];
+  if (q_begin < q_end) {
+    load_b(q_begin, cb);
+    load_patch((q_begin / KS) / 9);
+  }
   __syncthreads();
 
-  for (int q = 0; q < nq; ++q) {
-    const int cur = q & 1;
+  for (int q = q_begin; q < q_end; ++q) {
     const int ks = q % KS, t2 = q / KS;
     const int tap = t2 % 9, cc = t2 / 9;
     const int kh = tap / 3, kw = tap - kh * 3;
-    const bool more = q + 1 < nq;
-    if (more) load_b(q + 1);
+    const bool more = q + 1 < q_end;
+    if (more) load_b(q + 1, nb);
 
     const int tapoff = (MODE == MODE_XY) ? (kh * PW + kw) * LDP : ((2 - kh) * PW + (2 - kw)) * LDP;
     const float* a0 = Ps + abase[0] + tapoff + ks * BK;
     const float* a1 = Ps + abase[1] + tapoff + ks * BK;
-    const float* bs = (MODE == MODE_XY) ? Bs + cur * B_TILE + (wn * 32 + lr) * LDB + lh * 4
-                                        : Bs + cur * B_TILE + (lh * 4) * BN + wn * 32 + lr;
 #pragma unroll
     for (int kc = 0; kc < BK / 8; ++kc) {
       const f32x4 fa0 = *reinterpret_cast<const f32x4*>(a0 + kc * 8);
       const f32x4 fa1 = *reinterpret_cast<const f32x4*>(a1 + kc * 8);
-      f32x4 fb;
-      if (MODE == MODE_XY) {
-        fb = *reinterpret_cast<const f32x4*>(bs + kc * 8);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) fb[s] = bs[(kc * 8 + s) * BN];
-      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], fb[s], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], fb[s], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], cb[kc][s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], cb[kc][s], acc[1], 0, 0, 0);
       }
     }
     if (more) {
-      const bool new_patch = (ks == KS - 1) && (tap == 8);
-      if (new_patch) {
-        __syncthreads();          // everyone is done reading the current patch
+      if ((ks == KS - 1) && (tap == 8)) {   // next chunk starts a new channel chunk: swap the patch
+        __syncthreads();
         load_patch(cc + 1);
+        __syncthreads();
       }
-      store_b(cur ^ 1);
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) cb[kc] = nb[kc];
     }
-    __syncthreads();
   }
 
   // ---- epilogue ----
   const int n = n0 + wn * 32 + lr;
+  if (p.splits > 1) {   // split-K partial: plain store into this split's slab; bias/res added by the reducer
+    float* ws = p.ws + (long)split * p.ws_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rt = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int img = rt >> p.lgTT, rr = rt & ((1 << p.lgTT) - 1);
+        const int oh = h0 + (rr >> p.lgTW), ow = w0 + (rr & (p.TW - 1)), b = b0 + img;
+        if (b < p.B && oh < p.H && ow < p.W) ws[(long)((b * p.H + oh) * p.W + ow) * p.N + n] = acc[i][r];
+      }
+    return;
+  }
   const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -419,9 +443,24 @@ bool lgm_conv3x3_supported(const LgmConvGeom* g, int gather_channels, int out_ch
   return plan_tile(g->H, g->W, &TH, &TW, &NI);
 }
 
+// split-K factor for a given geometry (1 = none); also the workspace it needs
+int lgm_conv3x3_splits(const LgmConvGeom* g, int gather_channels, int out_channels) {
+  using namespace lgm3x3;
+  int TH, TW, NI;
+  if (!plan_tile(g->H, g->W, &TH, &TW, &NI)) return 1;
+  const long base = (long)lgm_cdiv(g->B, NI) * (g->H / TH) * (g->W / TW) * (out_channels / BN);
+  if (base >= 400) return 1;
+  const int ck = gather_channels % 64 == 0 ? 64 : 32;
+  const int nq = (gather_channels / ck) * 9 * (ck / BK);
+  long s = (512 + base - 1) / base;
+  if (s > nq / 6) s = nq / 6;        // at least 6 chunks (192 k) per split
+  if (s > 8) s = 8;
+  return s < 1 ? 1 : (int)s;
+}
+
 int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pitch, const float* w,
                        const float* bias, const float* res, long res_pitch, float* out, long out_pitch,
-                       hipStream_t s) {
+                       void* workspace, long workspace_bytes, hipStream_t s) {
   using namespace lgm3x3;
   Args p{};
   p.a = a; p.w = w; p.bias = bias; p.res = res; p.out = out;
@@ -438,11 +477,19 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
   p.tiles_n = p.N / BN;
   p.NP = p.NI * (p.TH + 2) * (p.TW + 2);
   const int groups = lgm_cdiv(g->B, p.NI);
-  const unsigned nblocks = (unsigned)((long)groups * p.tiles_h * p.tiles_w * p.tiles_n);
-  const size_t btile = (mode == MODE_XY ? BN * LDB : BK * BN) * sizeof(float);
-  const size_t smem64 = (size_t)p.NP * 68 * 4 + 2 * btile;
-  const bool ck64 = (p.C % 64 == 0) && smem64 <= 80 * 1024;
-  const size_t smem = ck64 ? smem64 : (size_t)p.NP * 36 * 4 + 2 * btile;
+  const long M = (long)g->B * g->H * g->W;
+  p.splits = lgm_conv3x3_splits(g, p.C, p.N);
+  if (p.splits > 1) {
+    const long need = (long)p.splits * M * p.N * (long)sizeof(float);
+    const bool aligned = lgm_aligned16(out) && out_pitch % 4 == 0 && (!res || (lgm_aligned16(res) && res_pitch % 4 == 0)) &&
+                         lgm_aligned16(workspace);
+    if (!workspace || workspace_bytes < need || !aligned) p.splits = 1;
+  }
+  p.ws = (float*)workspace;
+  p.ws_stride = M * p.N;
+  const unsigned nblocks = (unsigned)((long)groups * p.tiles_h * p.tiles_w * p.tiles_n * p.splits);
+  const bool ck64 = (p.C % 64 == 0);
+  const size_t smem = (size_t)p.NP * (ck64 ? 68 : 36) * sizeof(float);
 #define LGM_C3_LAUNCH(M, CKV)                                                                          \
   do {                                                                                                 \
     auto kern = conv3x3_kernel<M, CKV>;                                                                \
@@ -459,6 +506,11 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
     if (ck64) LGM_C3_LAUNCH(MODE_YX, 64); else LGM_C3_LAUNCH(MODE_YX, 32);
   }
 #undef LGM_C3_LAUNCH
+  if (p.splits > 1) {
+    const long items = M * (p.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)lgm_cdiv(items, 256)), dim3(256), 0, s,
+                       (const float*)p.ws, p.ws_stride, p.splits, bias, res, res_pitch, out, out_pitch, M, p.N);
+  }
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

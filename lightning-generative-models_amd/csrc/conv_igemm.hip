@@ -18,9 +18,10 @@
 
 // specialised 3x3 / stride 1 / pad 1 kernels (conv3x3.hip)
 bool lgm_conv3x3_supported(const LgmConvGeom* g, int gather_channels, int out_channels);
+int lgm_conv3x3_splits(const LgmConvGeom* g, int gather_channels, int out_channels);
 int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pitch, const float* w,
                        const float* bias, const float* res, long res_pitch, float* out, long out_pitch,
-                       hipStream_t s);
+                       void* workspace, long workspace_bytes, hipStream_t s);
 bool lgm_wgrad3x3_supported(const LgmConvGeom* g);
 void lgm_wgrad3x3_plan(const LgmConvGeom* g, int* splits, int* tps, int* total_ts);
 int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch,
@@ -307,9 +308,18 @@ int check_geom(const LgmConvGeom* g) {
 
 }  // namespace
 
+// bytes of workspace that let lgm_conv_xy (yx = 0) / lgm_conv_yx (yx = 1) use deterministic split-K
+extern "C" int64_t lgm_conv_workspace(const LgmConvGeom* g, int yx) {
+  if (check_geom(g) != LGM_OK) return -1;
+  const int gc = yx ? g->Nw : g->Cw, oc = yx ? g->Cw : g->Nw;
+  if (!use_3x3() || !lgm_conv3x3_supported(g, gc, oc)) return 0;
+  const int s = lgm_conv3x3_splits(g, gc, oc);
+  return s > 1 ? (int64_t)s * g->B * g->H * g->W * oc * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w,
                            const float* bias, const float* res, int64_t res_pitch, float* y,
-                           int64_t y_pitch, void* stream) {
+                           int64_t y_pitch, void* workspace, int64_t workspace_bytes, void* stream) {
   if (int rc = check_geom(g)) return rc;
   LGM_REQUIRE(x && w && y, "conv_xy: null pointer");
   LGM_REQUIRE(g->Cw % 4 == 0, "conv_xy: Cw=%d must be a multiple of 4 (pad channels)", g->Cw);
@@ -317,7 +327,8 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
               "conv_xy: x/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(y_pitch >= g->Nw && (!res || res_pitch >= g->Nw), "conv_xy: output pitch < Nw");
   if (use_3x3() && lgm_conv3x3_supported(g, g->Cw, g->Nw))
-    return lgm_conv3x3_launch(0, g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, (hipStream_t)stream);
+    return lgm_conv3x3_launch(0, g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, workspace, workspace_bytes,
+                              (hipStream_t)stream);
   IgemmArgs a{};
   a.a = x; a.w = w; a.bias = bias; a.res = res; a.out = y;
   a.a_pitch = x_pitch; a.res_pitch = res_pitch; a.out_pitch = y_pitch;
@@ -329,7 +340,7 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
 
 extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
                            const float* bias, const float* res, int64_t res_pitch, float* x,
-                           int64_t x_pitch, void* stream) {
+                           int64_t x_pitch, void* workspace, int64_t workspace_bytes, void* stream) {
   if (int rc = check_geom(g)) return rc;
   LGM_REQUIRE(x && w && y, "conv_yx: null pointer");
   LGM_REQUIRE(g->Nw % 4 == 0 && g->Cw % 4 == 0, "conv_yx: Nw=%d, Cw=%d must be multiples of 4", g->Nw, g->Cw);
@@ -337,7 +348,8 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
               "conv_yx: y/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(x_pitch >= g->Cw && (!res || res_pitch >= g->Cw), "conv_yx: output pitch < Cw");
   if (use_3x3() && lgm_conv3x3_supported(g, g->Nw, g->Cw))
-    return lgm_conv3x3_launch(1, g, y, y_pitch, w, bias, res, res_pitch, x, x_pitch, (hipStream_t)stream);
+    return lgm_conv3x3_launch(1, g, y, y_pitch, w, bias, res, res_pitch, x, x_pitch, workspace, workspace_bytes,
+                              (hipStream_t)stream);
   IgemmArgs a{};
   a.a = y; a.w = w; a.bias = bias; a.res = res; a.out = x;
   a.a_pitch = y_pitch; a.res_pitch = res_pitch; a.out_pitch = x_pitch;

@@ -110,11 +110,25 @@ def _conv_flops(g: ConvGeom) -> float:
     return 2.0 * g.B * g.Ho * g.Wo * g.Nw * g.KH * g.KW * g.Cw
 
 
+_CONV_WS_BYTES = {}
+
+
+def _conv_ws(g: ConvGeom, yx: int, device):
+    key = (g.B, g.H, g.W, g.Cw, g.Nw, g.KH, g.stride, g.pad, yx)
+    n = _CONV_WS_BYTES.get(key)
+    if n is None:
+        n = lib().lgm_conv_workspace(ctypes.byref(g), yx)
+        _CONV_WS_BYTES[key] = n
+    return workspace(n, device) if n > 0 else None
+
+
 def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
     if TIMER is not None:
         TIMER.begin("igemm_xy", _conv_flops(g))
+    ws = _conv_ws(g, 0, x.device)
     lib().lgm_conv_xy(ctypes.byref(g), x.data_ptr(), pitch(x), w_ptr, bias_ptr, _p(res),
-                      pitch(res) if res is not None else 0, y.data_ptr(), pitch(y), stream())
+                      pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
+                      None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
     if TIMER is not None:
         TIMER.end()
 
@@ -122,8 +136,10 @@ def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
 def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x):
     if TIMER is not None:
         TIMER.begin("igemm_yx", _conv_flops(g))
+    ws = _conv_ws(g, 1, y.device)
     lib().lgm_conv_yx(ctypes.byref(g), y.data_ptr(), pitch(y), w_ptr, bias_ptr, _p(res),
-                      pitch(res) if res is not None else 0, x.data_ptr(), pitch(x), stream())
+                      pitch(res) if res is not None else 0, x.data_ptr(), pitch(x),
+                      None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
     if TIMER is not None:
         TIMER.end()
 

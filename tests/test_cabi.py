@@ -25,7 +25,7 @@ def test_abi_version_and_error_string():
     assert L.lgm_abi_version() == 1
     # invalid-argument path works without a GPU: null geometry is rejected before any launch
     with pytest.raises(_lib.LgmError) as e:
-        L.lgm_conv_xy(None, None, 0, None, None, None, 0, None, 0, None)
+        L.lgm_conv_xy(None, None, 0, None, None, None, 0, None, 0, None, 0, None)
     assert "conv" in str(e.value)
 
 
@@ -33,5 +33,5 @@ def test_geometry_validation_rejects_inconsistent_shapes():
     L = _lib.lib()
     g = _lib.ConvGeom(1, 8, 8, 4, 9, 8, 4, 3, 3, 1, 1)   # Ho should be 8
     with pytest.raises(_lib.LgmError):
-        L.lgm_conv_xy(ctypes.byref(g), 16, 4, 16, None, None, 0, 16, 4, None)
+        L.lgm_conv_xy(ctypes.byref(g), 16, 4, 16, None, None, 0, 16, 4, None, 0, None)
     assert L.lgm_conv_wgrad_workspace(ctypes.byref(g)) == -1
