@@ -9,6 +9,15 @@
 // Everything a (batch, head) pair needs lives in LDS/registers; reductions use fixed orders.
 #include "lgm_common.h"
 
+// MFMA kernels for the linear-attention contractions (linattn_mfma.hip)
+int lgm_linattn_ctx_launch(int mode, const float* qkv, long pitch, const float* mem_kv, const float* gout,
+                           long gout_pitch, const float* ctx_in, int B, int n, int heads, int M, float scale,
+                           float* ctx_out, float* kmax, float* ksum, float* r_out, hipStream_t s);
+int lgm_linattn_bwd_launch(const float* qkv, long pitch, const float* mem_kv, const float* gout, long gout_pitch,
+                           const float* ctx, const float* gctx, const float* kmax, const float* ksum,
+                           const float* rvec, int B, int n, int heads, int M, float scale, float* gqkv,
+                           long gq_pitch, float* gmem_partial, hipStream_t s);
+
 namespace {
 
 constexpr int DH = 32;    // dim_head
@@ -17,124 +26,6 @@ constexpr int TI = 64;    // pixel tile
 // =====================================================================================
 // Linear attention
 // =====================================================================================
-
-// ctx_like[d][e] = sum_i W(i,d) * U(i,e)   over the n pixels (+ M memory columns when MEM).
-//   FWD  (mode 0): W = exp(k - kmax[d]),      U = v      -> ctx = . / ksum[d]; writes kmax, ksum
-//   BWD  (mode 1): W = softmax_d(q)*scale,    U = gout   -> gctx;  also r[d] = sum_e gctx*ctx
-__global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restrict__ qkv, long pitch,
-                                                          const float* __restrict__ mem_kv,
-                                                          const float* __restrict__ gout, long gout_pitch,
-                                                          const float* __restrict__ ctx_in, int n, int heads, int M,
-                                                          int mode, float scale, float* __restrict__ ctx_out,
-                                                          float* __restrict__ kmax_out, float* __restrict__ ksum_out,
-                                                          float* __restrict__ r_out) {
-  __shared__ float Ws[TI][DH + 1];
-  __shared__ __align__(16) float Us[TI][DH];
-  __shared__ float red[8][DH];
-  __shared__ float kmax_s[DH], ksum_s[DH];
-  const int bh = blockIdx.x;
-  const int b = bh / heads, h = bh % heads;
-  const int hidden = heads * DH;
-  const int tid = threadIdx.x;
-  const int d_l = tid % DH, pl = tid / DH;  // load mapping: 8 pixel lanes x 32 channels
-  const float* base = qkv + (long)b * n * pitch + h * DH;
-  const float* memk = mem_kv + ((long)(0 * heads + h) * DH) * M;  // [d][j]
-  const float* memv = mem_kv + ((long)(1 * heads + h) * DH) * M;
-
-  if (mode == 0) {
-    // pass 1: max over keys
-    float mx = -INFINITY;
-    for (int i = pl; i < n; i += 8) mx = fmaxf(mx, base[(long)i * pitch + hidden + d_l]);
-    if (pl == 0)
-      for (int j = 0; j < M; ++j) mx = fmaxf(mx, memk[d_l * M + j]);
-    red[pl][d_l] = mx;
-    __syncthreads();
-    if (tid < DH) {
-      float m = red[0][tid];
-      for (int k = 1; k < 8; ++k) m = fmaxf(m, red[k][tid]);
-      kmax_s[tid] = m;
-    }
-    __syncthreads();
-  }
-
-  // accumulate: thread -> (d = tid/8, e0 = (tid%8)*4)
-  const int d_c = tid / 8, e0 = (tid % 8) * 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  float wsum = 0.f;
-  const int total = n + (mode == 0 ? M : 0);
-  for (int i0 = 0; i0 < total; i0 += TI) {
-    __syncthreads();
-    // stage tile: rows i0..i0+TI-1 ; rows >= n are memory columns (mode 0 only)
-    for (int r = pl; r < TI; r += 8) {
-      const int i = i0 + r;
-      float wv = 0.f, uv = 0.f;
-      if (i < n) {
-        if (mode == 0) {
-          wv = __expf(base[(long)i * pitch + hidden + d_l] - kmax_s[d_l]);
-          uv = base[(long)i * pitch + 2 * hidden + d_l];
-        } else {
-          wv = base[(long)i * pitch + d_l];  // raw q; softmax over d below
-          uv = gout[((long)b * n + i) * gout_pitch + h * DH + d_l];
-        }
-      } else if (i < total) {
-        const int j = i - n;
-        wv = __expf(memk[d_l * M + j] - kmax_s[d_l]);
-        uv = memv[d_l * M + j];
-      }
-      Ws[r][d_l] = wv;
-      Us[r][d_l] = uv;
-    }
-    __syncthreads();
-    if (mode == 1) {
-      // softmax over d for each pixel row: 4 threads per row, 8 channels each
-      const int r = tid / 4, part = tid % 4;
-      float v[8], mx = -INFINITY;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        v[k] = Ws[r][part * 8 + k];
-        mx = fmaxf(mx, v[k]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-      float sm = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        v[k] = __expf(v[k] - mx);
-        sm += v[k];
-      }
-      sm += __shfl_xor(sm, 1, 64);
-      sm += __shfl_xor(sm, 2, 64);
-      const float inv = (i0 + r < n) ? scale / sm : 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) Ws[r][part * 8 + k] = v[k] * inv;
-      __syncthreads();
-    }
-    const int lim = min(TI, total - i0);
-    for (int r = 0; r < lim; ++r) {
-      const float w = Ws[r][d_c];
-      const f32x4 u = *reinterpret_cast<const f32x4*>(&Us[r][e0]);
-      acc += u * w;
-      wsum += w;
-    }
-  }
-  float* co = ctx_out + ((long)bh * DH + d_c) * DH + e0;
-  if (mode == 0) {
-    const float inv = 1.f / wsum;
-    *reinterpret_cast<f32x4*>(co) = acc * inv;
-    if ((tid % 8) == 0) {
-      kmax_out[bh * DH + d_c] = kmax_s[d_c];
-      ksum_out[bh * DH + d_c] = wsum;
-    }
-  } else {
-    *reinterpret_cast<f32x4*>(co) = acc;
-    const f32x4 c = *reinterpret_cast<const f32x4*>(ctx_in + ((long)bh * DH + d_c) * DH + e0);
-    float r = acc[0] * c[0] + acc[1] * c[1] + acc[2] * c[2] + acc[3] * c[3];
-    r += __shfl_xor(r, 1, 64);
-    r += __shfl_xor(r, 2, 64);
-    r += __shfl_xor(r, 4, 64);
-    if ((tid % 8) == 0) r_out[bh * DH + d_c] = r;
-  }
-}
 
 // out[i, h*32+e] = sum_d ctx[d][e] * softmax_d(q[i,:])[d] * scale
 __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restrict__ qkv, long pitch,
@@ -189,136 +80,6 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restric
     float* o = out + ((long)b * n + i) * out_pitch + h * DH + e0;
     *reinterpret_cast<f32x4*>(o) = a0;
     *reinterpret_cast<f32x4*>(o + 4) = a1;
-  }
-}
-
-// backward of q/k/v for one pixel tile (or the memory columns when blockIdx.y == ntiles)
-__global__ __launch_bounds__(256) void linattn_bwd_qkv_kernel(
-    const float* __restrict__ qkv, long pitch, const float* __restrict__ mem_kv, const float* __restrict__ gout,
-    long gout_pitch, const float* __restrict__ ctx, const float* __restrict__ gctx, const float* __restrict__ kmax,
-    const float* __restrict__ ksum, const float* __restrict__ rvec, int n, int heads, int M, float scale,
-    float* __restrict__ gqkv, long gq_pitch, float* __restrict__ gmem_partial) {
-  __shared__ float Qs[TI][DH + 1], Ks[TI][DH + 1], Vs[TI][DH + 1], Gs[TI][DH + 1];
-  __shared__ __align__(16) float Cs[DH][DH];    // ctx[d][e]
-  __shared__ __align__(16) float GCs[DH][DH];   // gctx[d][e]
-  __shared__ float kmx[DH], kinv[DH], rr[DH];
-  const int bh = blockIdx.x;
-  const int b = bh / heads, h = bh % heads;
-  const int hidden = heads * DH;
-  const int ntiles = (n + TI - 1) / TI;
-  const bool is_mem = (int)blockIdx.y == ntiles;
-  const int i0 = blockIdx.y * TI;
-  const int tid = threadIdx.x;
-  const int d_l = tid % DH, pl = tid / DH;
-  const float* memk = mem_kv + ((long)(0 * heads + h) * DH) * M;
-  const float* memv = mem_kv + ((long)(1 * heads + h) * DH) * M;
-  for (int k = tid; k < DH * DH; k += 256) {
-    Cs[k / DH][k % DH] = ctx[(long)bh * DH * DH + k];
-    GCs[k / DH][k % DH] = gctx[(long)bh * DH * DH + k];
-  }
-  if (tid < DH) {
-    kmx[tid] = kmax[bh * DH + tid];
-    kinv[tid] = 1.f / ksum[bh * DH + tid];
-    rr[tid] = rvec[bh * DH + tid];
-  }
-  const int rows = is_mem ? M : min(TI, n - i0);
-  for (int r = pl; r < TI; r += 8) {
-    float qv = 0.f, kv = 0.f, vv = 0.f, gv = 0.f;
-    if (r < rows) {
-      if (is_mem) {
-        kv = memk[d_l * M + r];
-        vv = memv[d_l * M + r];
-      } else {
-        const long row = ((long)b * n + i0 + r);
-        qv = qkv[row * pitch + h * DH + d_l];
-        kv = qkv[row * pitch + hidden + h * DH + d_l];
-        vv = qkv[row * pitch + 2 * hidden + h * DH + d_l];
-        gv = gout[row * gout_pitch + h * DH + d_l];
-      }
-    }
-    Qs[r][d_l] = qv;
-    Ks[r][d_l] = kv;
-    Vs[r][d_l] = vv;
-    Gs[r][d_l] = gv;
-  }
-  __syncthreads();
-  // thread -> (row r = tid/4, 8 channels)
-  const int r = tid / 4, part = tid % 4, c0 = part * 8;
-  // ---- q path: s = softmax_d(q); gqs[d] = scale * sum_e ctx[d][e] gout[e]; gq = s*(gqs - sum_d s*gqs)
-  float s[8], gqs[8];
-  {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      s[k] = Qs[r][c0 + k];
-      mx = fmaxf(mx, s[k]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-    float sm = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      s[k] = __expf(s[k] - mx);
-      sm += s[k];
-    }
-    sm += __shfl_xor(sm, 1, 64);
-    sm += __shfl_xor(sm, 2, 64);
-    const float inv = 1.f / sm;
-    float dot = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      s[k] *= inv;
-      float a = 0.f;
-      for (int e = 0; e < DH; ++e) a += Cs[c0 + k][e] * Gs[r][e];
-      gqs[k] = a * scale;
-      dot += s[k] * gqs[k];
-    }
-    dot += __shfl_xor(dot, 1, 64);
-    dot += __shfl_xor(dot, 2, 64);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) gqs[k] = s[k] * (gqs[k] - dot);  // = gq
-  }
-  // ---- k path: ks = exp(k-kmax)/ksum ; gks[d] = sum_e gctx[d][e] v[e] ; gk = ks * (gks - r[d])
-  float gk[8], ksv[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int d = c0 + k;
-    ksv[k] = __expf(Ks[r][d] - kmx[d]) * kinv[d];
-    float a = 0.f;
-    for (int e = 0; e < DH; ++e) a += GCs[d][e] * Vs[r][e];
-    gk[k] = ksv[k] * (a - rr[d]);
-  }
-  __syncthreads();
-  // publish ks into Ks (needed across the 4 threads of a row for gv)
-#pragma unroll
-  for (int k = 0; k < 8; ++k) Ks[r][c0 + k] = ksv[k];
-  __syncthreads();
-  // ---- v path: gv[e] = sum_d gctx[d][e] * ks[d]
-  float gvv[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float a = 0.f;
-    for (int d = 0; d < DH; ++d) a += GCs[d][c0 + k] * Ks[r][d];
-    gvv[k] = a;
-  }
-  if (r < rows) {
-    if (is_mem) {
-      // partial layout [B][2][heads][32][M]
-      float* gm = gmem_partial + (long)b * 2 * heads * DH * M;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        gm[((long)(0 * heads + h) * DH + c0 + k) * M + r] = gk[k];
-        gm[((long)(1 * heads + h) * DH + c0 + k) * M + r] = gvv[k];
-      }
-    } else {
-      float* o = gqkv + ((long)b * n + i0 + r) * gq_pitch + h * DH + c0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        o[k] = gqs[k];
-        o[hidden + k] = gk[k];
-        o[2 * hidden + k] = gvv[k];
-      }
-    }
   }
 }
 
@@ -517,9 +278,9 @@ extern "C" int lgm_linattn_fwd(const float* qkv, int64_t qkv_pitch, const float*
   LGM_REQUIRE(out_pitch % 4 == 0 && lgm_aligned16(out) && lgm_aligned16(ctx), "linattn_fwd: out must be 16B aligned");
   hipStream_t s = (hipStream_t)stream;
   const float scale = 1.f / sqrtf((float)dim_head);
-  hipLaunchKernelGGL(linattn_ctx_kernel, dim3(B * heads), dim3(256), 0, s, qkv, (long)qkv_pitch, mem_kv,
-                     (const float*)nullptr, 0L, (const float*)nullptr, n, heads, M, 0, scale, ctx, kmax, ksum,
-                     (float*)nullptr);
+  if (int rc = lgm_linattn_ctx_launch(0, qkv, (long)qkv_pitch, mem_kv, nullptr, 0L, nullptr, B, n, heads, M, scale, ctx,
+                                      kmax, ksum, nullptr, s))
+    return rc;
   hipLaunchKernelGGL(linattn_out_kernel, dim3(B * heads, lgm_cdiv(n, TI)), dim3(256), 0, s, qkv, (long)qkv_pitch,
                      (const float*)ctx, n, heads, scale, out, (long)out_pitch);
   LGM_LAUNCH_CHECK();
@@ -547,12 +308,12 @@ extern "C" int lgm_linattn_bwd(const float* qkv, int64_t qkv_pitch, const float*
   float* part = rvec + bh * DH;
   const long ncols = 2L * heads * DH * M;
   float* cs_ws = part + (long)B * ncols;
-  hipLaunchKernelGGL(linattn_ctx_kernel, dim3(B * heads), dim3(256), 0, s, qkv, (long)qkv_pitch, mem_kv, gout,
-                     (long)gout_pitch, ctx, n, heads, M, 1, scale, gctx, (float*)nullptr, (float*)nullptr, rvec);
-  hipLaunchKernelGGL(linattn_bwd_qkv_kernel, dim3(B * heads, lgm_cdiv(n, TI) + (M > 0 ? 1 : 0)), dim3(256), 0, s, qkv,
-                     (long)qkv_pitch, mem_kv, gout, (long)gout_pitch, ctx, (const float*)gctx, kmax, ksum,
-                     (const float*)rvec, n, heads, M, scale, gqkv, (long)gqkv_pitch, part);
-  LGM_LAUNCH_CHECK();
+  if (int rc = lgm_linattn_ctx_launch(1, qkv, (long)qkv_pitch, mem_kv, gout, (long)gout_pitch, ctx, B, n, heads, M, scale,
+                                      gctx, nullptr, nullptr, rvec, s))
+    return rc;
+  if (int rc = lgm_linattn_bwd_launch(qkv, (long)qkv_pitch, mem_kv, gout, (long)gout_pitch, ctx, gctx, kmax, ksum, rvec,
+                                      B, n, heads, M, scale, gqkv, (long)gqkv_pitch, part, s))
+    return rc;
   if (M > 0) return lgm_colsum(part, ncols, B, ncols, gmem_kv, gmem_beta, cs_ws, stream);
   return LGM_OK;
 }

@@ -1,0 +1,327 @@
+// MFMA versions of the two heavy LinearAttention kernels (ddpm.py:217-239):
+//   linattn_ctx   : ctx[d][e]  = sum_n softmax_n(k)[d,n] v[e,n]          (forward, mode 0)
+//                   gctx[d][e] = sum_n (softmax_d(q) scale)[d,n] gout[e,n] (backward, mode 1)
+//   linattn_bwd   : gq, gk, gv for a 128-pixel tile = three [128x32]x[32x32] products
+// All contractions run on v_mfma_f32_32x32x2_f32; cross-wave sums use fixed orders (deterministic).
+#include "lgm_common.h"
+
+namespace {
+
+constexpr int DH = 32;
+constexpr int LDW = 33;   // padded row stride (softmax passes walk rows with a 4-thread team)
+constexpr int TP = 128;   // pixels per tile (32 per wave)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict__ qkv, long pitch,
+                                                        const float* __restrict__ mem_kv,
+                                                        const float* __restrict__ gout, long gout_pitch,
+                                                        const float* __restrict__ ctx_in, int n, int heads, int M,
+                                                        float scale, float* __restrict__ ctx_out,
+                                                        float* __restrict__ kmax_out, float* __restrict__ ksum_out,
+                                                        float* __restrict__ r_out) {
+  __shared__ float Ws[TP * LDW];
+  __shared__ float Us[TP * DH];
+  __shared__ __align__(16) float Red[4][DH][DH];
+  __shared__ float red8[8][DH];
+  __shared__ float kmax_s[DH];
+  const int bh = blockIdx.x;
+  const int b = bh / heads, h = bh % heads;
+  const int hidden = heads * DH;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int d_l = tid % DH, pl = tid / DH;   // staging map: 8 pixel lanes x 32 channels
+  const float* base = qkv + (long)b * n * pitch + h * DH;
+  const float* memk = mem_kv + ((long)(0 * heads + h) * DH) * M;  // [d][j]
+  const float* memv = mem_kv + ((long)(1 * heads + h) * DH) * M;
+
+  if (MODE == 0) {
+    float mx = -INFINITY;
+    for (int i = pl; i < n; i += 8) mx = fmaxf(mx, base[(long)i * pitch + hidden + d_l]);
+    if (pl == 0)
+      for (int j = 0; j < M; ++j) mx = fmaxf(mx, memk[d_l * M + j]);
+    red8[pl][d_l] = mx;
+    __syncthreads();
+    if (tid < DH) {
+      float m = red8[0][tid];
+      for (int k = 1; k < 8; ++k) m = fmaxf(m, red8[k][tid]);
+      kmax_s[tid] = m;
+    }
+    __syncthreads();
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float wsum = 0.f;
+  const int total = n + (MODE == 0 ? M : 0);
+  for (int i0 = 0; i0 < total; i0 += TP) {
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < TP / 8; ++j) {
+      const int r = pl + 8 * j;
+      const int i = i0 + r;
+      float wv = 0.f, uv = 0.f;
+      if (i < n) {
+        if (MODE == 0) {
+          wv = __expf(base[(long)i * pitch + hidden + d_l] - kmax_s[d_l]);
+          uv = base[(long)i * pitch + 2 * hidden + d_l];
+        } else {
+          wv = base[(long)i * pitch + d_l];
+          uv = gout[((long)b * n + i) * gout_pitch + h * DH + d_l];
+        }
+      } else if (i < total) {
+        const int jm = i - n;
+        wv = __expf(memk[d_l * M + jm] - kmax_s[d_l]);
+        uv = memv[d_l * M + jm];
+      }
+      Ws[r * LDW + d_l] = wv;
+      Us[r * DH + d_l] = uv;
+    }
+    __syncthreads();
+    if (MODE == 1) {
+      // softmax over d for every pixel row: 4 threads per row, 8 channels each, two passes of 64 rows
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int r = (tid >> 2) + 64 * ps, part = tid & 3;
+        float v[8], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          v[k] = Ws[r * LDW + part * 8 + k];
+          mx = fmaxf(mx, v[k]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          v[k] = __expf(v[k] - mx);
+          sm += v[k];
+        }
+        sm += __shfl_xor(sm, 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        const float inv = (i0 + r < n) ? scale / sm : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Ws[r * LDW + part * 8 + k] = v[k] * inv;
+      }
+      __syncthreads();
+    }
+    if (MODE == 0) {
+#pragma unroll 4
+      for (int j = 0; j < TP / 8; ++j) wsum += Ws[(pl + 8 * j) * LDW + d_l];
+    }
+    // MFMA: k = pixel; wave w owns pixels [32 w, 32 w + 32) of the tile.  A[i = d][k], B[k][j = e]
+    const float* ap = Ws + (32 * wid + lh) * LDW + lr;
+    const float* bp = Us + (32 * wid + lh) * DH + lr;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * LDW], bp[2 * s * DH], acc, 0, 0, 0);
+  }
+  // cross-wave reduction in a fixed order
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
+  if (MODE == 0) red8[pl][d_l] = wsum;
+  __syncthreads();
+  const int d_c = tid / 8, e0 = (tid % 8) * 4;
+  f32x4 cv = (*reinterpret_cast<const f32x4*>(&Red[0][d_c][e0]) + *reinterpret_cast<const f32x4*>(&Red[1][d_c][e0])) +
+             (*reinterpret_cast<const f32x4*>(&Red[2][d_c][e0]) + *reinterpret_cast<const f32x4*>(&Red[3][d_c][e0]));
+  float* co = ctx_out + ((long)bh * DH + d_c) * DH + e0;
+  if (MODE == 0) {
+    float ws = 0.f;
+    for (int k = 0; k < 8; ++k) ws += red8[k][d_c];
+    *reinterpret_cast<f32x4*>(co) = cv * (1.f / ws);
+    if ((tid % 8) == 0) {
+      kmax_out[bh * DH + d_c] = kmax_s[d_c];
+      ksum_out[bh * DH + d_c] = ws;
+    }
+  } else {
+    *reinterpret_cast<f32x4*>(co) = cv;
+    const f32x4 c = *reinterpret_cast<const f32x4*>(ctx_in + ((long)bh * DH + d_c) * DH + e0);
+    float r = cv[0] * c[0] + cv[1] * c[1] + cv[2] * c[2] + cv[3] * c[3];
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 4, 64);
+    if ((tid % 8) == 0) r_out[bh * DH + d_c] = r;
+  }
+}
+
+// backward of q / k / v for one 128-pixel tile (blockIdx.y == ntiles: the M memory columns)
+__global__ __launch_bounds__(256) void linattn_bwd_mfma(
+    const float* __restrict__ qkv, long pitch, const float* __restrict__ mem_kv, const float* __restrict__ gout,
+    long gout_pitch, const float* __restrict__ ctx, const float* __restrict__ gctx, const float* __restrict__ kmax,
+    const float* __restrict__ ksum, const float* __restrict__ rvec, int n, int heads, int M, float scale,
+    float* __restrict__ gqkv, long gq_pitch, float* __restrict__ gmem_partial) {
+  extern __shared__ __align__(16) float sm[];
+  float* Qs = sm;                    // [128][33]  q -> softmax_d(q)
+  float* Ks = Qs + TP * LDW;         // ks = softmax_n(k)
+  float* Vs = Ks + TP * LDW;         // v   -> T2 = V gctx^T
+  float* Gs = Vs + TP * LDW;         // gout -> T1 = G ctx^T
+  float* Cs = Gs + TP * LDW;         // ctx  [32][33]
+  float* GCs = Cs + DH * LDW;        // gctx [32][33]
+  float* kmx = GCs + DH * LDW;
+  float* kinv = kmx + DH;
+  float* rr = kinv + DH;
+  const int bh = blockIdx.x;
+  const int b = bh / heads, h = bh % heads;
+  const int hidden = heads * DH;
+  const int ntiles = (n + TP - 1) / TP;
+  const bool is_mem = (int)blockIdx.y == ntiles;
+  const int i0 = blockIdx.y * TP;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int d_l = tid % DH, pl = tid / DH;
+  const float* memk = mem_kv + ((long)(0 * heads + h) * DH) * M;
+  const float* memv = mem_kv + ((long)(1 * heads + h) * DH) * M;
+  for (int k = tid; k < DH * DH; k += 256) {
+    Cs[(k / DH) * LDW + (k % DH)] = ctx[(long)bh * DH * DH + k];
+    GCs[(k / DH) * LDW + (k % DH)] = gctx[(long)bh * DH * DH + k];
+  }
+  if (tid < DH) {
+    kmx[tid] = kmax[bh * DH + tid];
+    kinv[tid] = 1.f / ksum[bh * DH + tid];
+    rr[tid] = rvec[bh * DH + tid];
+  }
+  __syncthreads();
+  const int rows = is_mem ? M : min(TP, n - i0);
+#pragma unroll 4
+  for (int j = 0; j < TP / 8; ++j) {
+    const int r = pl + 8 * j;
+    float qv = 0.f, kv = 0.f, vv = 0.f, gv = 0.f;
+    if (r < rows) {
+      if (is_mem) {
+        kv = __expf(memk[d_l * M + r] - kmx[d_l]) * kinv[d_l];
+        vv = memv[d_l * M + r];
+      } else {
+        const long row = (long)b * n + i0 + r;
+        qv = qkv[row * pitch + h * DH + d_l];
+        kv = __expf(qkv[row * pitch + hidden + h * DH + d_l] - kmx[d_l]) * kinv[d_l];
+        vv = qkv[row * pitch + 2 * hidden + h * DH + d_l];
+        gv = gout[row * gout_pitch + h * DH + d_l];
+      }
+    }
+    Qs[r * LDW + d_l] = qv;
+    Ks[r * LDW + d_l] = kv;
+    Vs[r * LDW + d_l] = vv;
+    Gs[r * LDW + d_l] = gv;
+  }
+  __syncthreads();
+  // ---- phase A: s = softmax_d(q) in place ----
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int r = (tid >> 2) + 64 * ps, part = tid & 3;
+    float v[8], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = Qs[r * LDW + part * 8 + k];
+      mx = fmaxf(mx, v[k]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = __expf(v[k] - mx);
+      sum += v[k];
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Qs[r * LDW + part * 8 + k] = v[k] * inv;
+  }
+  // ---- phase B: wave w owns rows [32 w, 32 w + 32): three 32x32x32 products on MFMA ----
+  f32x16 a1, a2, a3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a1[r] = a2[r] = a3[r] = 0.f;
+  {
+    const float* gp = Gs + (32 * wid + lr) * LDW + lh;
+    const float* vp = Vs + (32 * wid + lr) * LDW + lh;
+    const float* kp = Ks + (32 * wid + lr) * LDW + lh;
+    const float* cT = Cs + lr * LDW + lh;      // B[k = e][j = d] = ctx[d][e]
+    const float* gT = GCs + lr * LDW + lh;     // B[k = e][j = d] = gctx[d][e]
+    const float* gN = GCs + lh * LDW + lr;     // B[k = d][j = e] = gctx[d][e]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[2 * s], cT[2 * s], a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[2 * s], gT[2 * s], a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], gN[2 * s * LDW], a3, 0, 0, 0);
+    }
+  }
+  // T1 -> Gs, T2 -> Vs (rows owned by this wave only), gv -> global
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * wid + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    Gs[row * LDW + lr] = a1[r];
+    Vs[row * LDW + lr] = a2[r];
+    if (row < rows) {
+      if (is_mem)
+        gmem_partial[(long)b * 2 * heads * DH * M + ((long)(1 * heads + h) * DH + lr) * M + row] = a3[r];
+      else
+        gqkv[((long)b * n + i0 + row) * gq_pitch + 2 * hidden + h * DH + lr] = a3[r];
+    }
+  }
+  __syncthreads();
+  // ---- phase C: softmax backward for q, and gk = ks * (T2 - r) ----
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int r = (tid >> 2) + 64 * ps, part = tid & 3, c0 = part * 8;
+    float s[8], g1[8], gk[8], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s[k] = Qs[r * LDW + c0 + k];
+      g1[k] = Gs[r * LDW + c0 + k] * scale;
+      dot += s[k] * g1[k];
+      gk[k] = Ks[r * LDW + c0 + k] * (Vs[r * LDW + c0 + k] - rr[c0 + k]);
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    if (r < rows) {
+      if (is_mem) {
+        float* gm = gmem_partial + (long)b * 2 * heads * DH * M;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gm[((long)(0 * heads + h) * DH + c0 + k) * M + r] = gk[k];
+      } else {
+        float* o = gqkv + ((long)b * n + i0 + r) * gq_pitch + h * DH + c0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          o[k] = s[k] * (g1[k] - dot);
+          o[hidden + k] = gk[k];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int lgm_linattn_ctx_launch(int mode, const float* qkv, long pitch, const float* mem_kv, const float* gout,
+                           long gout_pitch, const float* ctx_in, int B, int n, int heads, int M, float scale,
+                           float* ctx_out, float* kmax, float* ksum, float* r_out, hipStream_t s) {
+  if (mode == 0)
+    hipLaunchKernelGGL(linattn_ctx_mfma<0>, dim3(B * heads), dim3(256), 0, s, qkv, pitch, mem_kv, gout, gout_pitch,
+                       ctx_in, n, heads, M, scale, ctx_out, kmax, ksum, r_out);
+  else
+    hipLaunchKernelGGL(linattn_ctx_mfma<1>, dim3(B * heads), dim3(256), 0, s, qkv, pitch, mem_kv, gout, gout_pitch,
+                       ctx_in, n, heads, M, scale, ctx_out, kmax, ksum, r_out);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+int lgm_linattn_bwd_launch(const float* qkv, long pitch, const float* mem_kv, const float* gout, long gout_pitch,
+                           const float* ctx, const float* gctx, const float* kmax, const float* ksum,
+                           const float* rvec, int B, int n, int heads, int M, float scale, float* gqkv,
+                           long gq_pitch, float* gmem_partial, hipStream_t s) {
+  const size_t smem = ((size_t)4 * TP * LDW + 2 * DH * LDW + 3 * DH) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_bwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)smem);
+    attr = true;
+  }
+  hipLaunchKernelGGL(linattn_bwd_mfma, dim3(B * heads, lgm_cdiv(n, TP) + (M > 0 ? 1 : 0)), dim3(256), smem, s, qkv,
+                     pitch, mem_kv, gout, gout_pitch, ctx, gctx, kmax, ksum, rvec, n, heads, M, scale, gqkv, gq_pitch,
+                     gmem_partial);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}

@@ -20,9 +20,13 @@ __device__ __forceinline__ float silu_grad(float z) {
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long pitch, int HW,
                                                        int C, int G, int CB, float eps,
-                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ ss, long ss_pitch,
+                                                       float* __restrict__ mean, float* __restrict__ rstd,
+                                                       float* __restrict__ A, float* __restrict__ Bc) {
   __shared__ float sh[256 * 4];
-  __shared__ float gmean[64];
+  __shared__ float chs[256];
+  __shared__ float gmean[64], grstd[64];
   const int nb = C / CB;
   const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
   const int c0 = cb * CB;
@@ -36,18 +40,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   const int ngl = CB / Cg;            // groups in this block
   const float inv_n = 1.f / ((float)Cg * (float)HW);
 
+  // two-level fixed-order reduction of the per-thread partials in sh ([pixel lane][channel]):
+  // one thread per channel over the pixel lanes, then one thread per group over its channels
+  auto group_reduce = [&](float* dst, bool second) {
+    __syncthreads();
+    if (tid < CB) {
+      float acc = 0.f;
+      for (int pp = 0; pp < ppb; ++pp) acc += sh[pp * CB + tid];
+      chs[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < ngl) {
+      float acc = 0.f;
+      for (int c = 0; c < Cg; ++c) acc += chs[tid * Cg + c];
+      dst[tid] = second ? rsqrtf(acc * inv_n + eps) : acc * inv_n;
+    }
+    __syncthreads();
+  };
+
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (active)
     for (int p = pl; p < HW; p += ppb) s += *reinterpret_cast<const f32x4*>(xb + (long)p * pitch);
   *reinterpret_cast<f32x4*>(&sh[tid * 4]) = s;
-  __syncthreads();
-  if (tid < ngl) {
-    float acc = 0.f;
-    for (int pp = 0; pp < ppb; ++pp)
-      for (int c = 0; c < Cg; ++c) acc += sh[(pp * tq) * 4 + tid * Cg + c];
-    gmean[tid] = acc * inv_n;
-  }
-  __syncthreads();
+  group_reduce(gmean, false);
   f32x4 mu;
 #pragma unroll
   for (int k = 0; k < 4; ++k) mu[k] = gmean[(q * 4 + k) / Cg];
@@ -57,39 +72,28 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
       f32x4 d = *reinterpret_cast<const f32x4*>(xb + (long)p * pitch) - mu;
       s2 += d * d;
     }
-  __syncthreads();
   *reinterpret_cast<f32x4*>(&sh[tid * 4]) = s2;
-  __syncthreads();
+  group_reduce(grstd, true);
   if (tid < ngl) {
-    float acc = 0.f;
-    for (int pp = 0; pp < ppb; ++pp)
-      for (int c = 0; c < Cg; ++c) acc += sh[(pp * tq) * 4 + tid * Cg + c];
     const int g = c0 / Cg + tid;
     mean[b * G + g] = gmean[tid];
-    rstd[b * G + g] = rsqrtf(acc * inv_n + eps);
+    rstd[b * G + g] = grstd[tid];
   }
-}
-
-// coefficients: z = x * A[b,c] + Bc[b,c]
-__global__ void gn_coef_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
-                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                               const float* __restrict__ ss, long ss_pitch, int B, int C, int G,
-                               float* __restrict__ A, float* __restrict__ Bc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i % C;
-  const int g = c / (C / G);
-  const float mu = mean[b * G + g], rs = rstd[b * G + g];
-  float a = rs * gamma[c];
-  float bb = beta[c] - mu * a;
-  if (ss) {
-    const float sc = ss[(long)b * ss_pitch + c] + 1.f;
-    const float sh = ss[(long)b * ss_pitch + C + c];
-    a *= sc;
-    bb = bb * sc + sh;
+  // fused coefficient computation: z = x * A[b,c] + Bc[b,c]
+  if (tid < CB) {
+    const int c = c0 + tid;
+    const float m = gmean[tid / Cg], rs = grstd[tid / Cg];
+    float a = rs * gamma[c];
+    float bb = beta[c] - m * a;
+    if (ss) {
+      const float sc = ss[(long)b * ss_pitch + c] + 1.f;
+      const float shf = ss[(long)b * ss_pitch + C + c];
+      a *= sc;
+      bb = bb * sc + shf;
+    }
+    A[(long)b * C + c] = a;
+    Bc[(long)b * C + c] = bb;
   }
-  A[i] = a;
-  Bc[i] = bb;
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, long x_pitch,
@@ -121,7 +125,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ A, const float* __restrict__ Bc,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             int HW, int C, int G, int CB, int act,
-                                                            float* __restrict__ S1, float* __restrict__ S2) {
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ ss, long ss_pitch,
+                                                            float* __restrict__ gss, long gss_pitch, float gss_beta,
+                                                            float* __restrict__ S1, float* __restrict__ S2,
+                                                            float* __restrict__ P, float* __restrict__ Qc,
+                                                            float* __restrict__ Rc) {
   __shared__ float sh[256 * 8];
   const int nb = C / CB;
   const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
@@ -158,61 +167,50 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   *reinterpret_cast<f32x4*>(&sh[tid * 8]) = s1;
   *reinterpret_cast<f32x4*>(&sh[tid * 8 + 4]) = s2;
   __syncthreads();
+  __shared__ float wa1[256], wa2[256];
+  float a1 = 0.f, a2 = 0.f, scv = 1.f;
   if (tid < CB) {  // one thread per channel, fixed-order sum over pixel lanes
     const int qq = tid / 4, k = tid % 4;
-    float a1 = 0.f, a2 = 0.f;
     for (int pp = 0; pp < ppb; ++pp) {
       a1 += sh[(pp * tq + qq) * 8 + k];
       a2 += sh[(pp * tq + qq) * 8 + 4 + k];
     }
-    S1[(long)b * C + c0 + tid] = a1;
-    S2[(long)b * C + c0 + tid] = a2;
-  }
-}
-
-// backward pass 2 (tiny): per-(b,c) coefficients P,Qc,Rc for gx = P*gz + Qc + x*Rc, and g_scale/g_shift.
-__global__ void gn_bwd_coef_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
-                                   const float* __restrict__ mean, const float* __restrict__ rstd,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   const float* __restrict__ ss, long ss_pitch, float* __restrict__ gss,
-                                   long gss_pitch, float gss_beta, int B, int C, int G, int HW,
-                                   float* __restrict__ P, float* __restrict__ Qc, float* __restrict__ Rc) {
-  // one block per image; blockDim = 256; loops over channels
-  __shared__ float m1s[64], m2s[64];
-  const int b = blockIdx.x;
-  const int Cg = C / G;
-  const float inv_n = 1.f / ((float)Cg * (float)HW);
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    float a1 = 0.f, a2 = 0.f;
-    for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
-      const float sc = ss ? ss[(long)b * ss_pitch + c] + 1.f : 1.f;
-      const float w = gamma[c] * sc;
-      a1 += w * S1[(long)b * C + c];
-      a2 += w * S2[(long)b * C + c];
-    }
-    m1s[g] = a1 * inv_n;
-    m2s[g] = a2 * inv_n;
+    const int cc = c0 + tid;
+    S1[(long)b * C + cc] = a1;
+    S2[(long)b * C + cc] = a2;
+    scv = ss ? ss[(long)b * ss_pitch + cc] + 1.f : 1.f;
+    const float w = gamma[cc] * scv;
+    wa1[tid] = w * a1;
+    wa2[tid] = w * a2;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int g = c / Cg;
-    const float mu = mean[b * G + g], rs = rstd[b * G + g];
-    const float sc = ss ? ss[(long)b * ss_pitch + c] + 1.f : 1.f;
-    const long i = (long)b * C + c;
-    P[i] = rs * gamma[c] * sc;
-    const float R = -rs * m2s[g];          // multiplies xhat
-    Rc[i] = R * rs;                        // multiplies x
-    Qc[i] = -rs * m1s[g] - mu * rs * R;
+  // fused pass 2: coefficients for gx = P*gz + Qc + x*Rc and the FiLM scale/shift gradients
+  if (tid < CB) {
+    const int cc = c0 + tid;
+    const int g0 = (tid / Cg) * Cg;
+    float m1 = 0.f, m2 = 0.f;
+    for (int j = 0; j < Cg; ++j) {
+      m1 += wa1[g0 + j];
+      m2 += wa2[g0 + j];
+    }
+    const float inv_n = 1.f / ((float)Cg * (float)HW);
+    m1 *= inv_n;
+    m2 *= inv_n;
+    const float m = mean[b * G + cc / Cg], r = rstd[b * G + cc / Cg];
+    const long i = (long)b * C + cc;
+    P[i] = r * gamma[cc] * scv;
+    const float R = -r * m2;          // multiplies xhat
+    Rc[i] = R * r;                    // multiplies x
+    Qc[i] = -r * m1 - m * r * R;
     if (gss) {
-      const float s1 = S1[i], s2 = S2[i];
-      float gsc = gamma[c] * s2 + beta[c] * s1;
-      float gsh = s1;
+      float gsc = gamma[cc] * a2 + beta[cc] * a1;
+      float gsh = a1;
       if (gss_beta != 0.f) {
-        gsc += gss_beta * gss[(long)b * gss_pitch + c];
-        gsh += gss_beta * gss[(long)b * gss_pitch + C + c];
+        gsc += gss_beta * gss[(long)b * gss_pitch + cc];
+        gsh += gss_beta * gss[(long)b * gss_pitch + C + cc];
       }
-      gss[(long)b * gss_pitch + c] = gsc;
-      gss[(long)b * gss_pitch + C + c] = gsh;
+      gss[(long)b * gss_pitch + cc] = gsc;
+      gss[(long)b * gss_pitch + C + cc] = gsh;
     }
   }
 }
@@ -300,9 +298,8 @@ extern "C" int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C,
   LGM_REQUIRE(x_pitch % 4 == 0 && y_pitch % 4 == 0 && (!res || res_pitch % 4 == 0), "gn_fwd: pitch %% 4 != 0");
   hipStream_t s = (hipStream_t)stream;
   const int cb = gn_cb(C, G);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(B * (C / cb)), dim3(256), 0, s, x, (long)x_pitch, HW, C, G, cb, eps, mean, rstd);
-  hipLaunchKernelGGL(gn_coef_kernel, dim3(lgm_cdiv((long)B * C, 256)), dim3(256), 0, s, mean, rstd, gamma, beta, ss,
-                     (long)ss_pitch, B, C, G, coefA, coefB);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(B * (C / cb)), dim3(256), 0, s, x, (long)x_pitch, HW, C, G, cb, eps, gamma,
+                     beta, ss, (long)ss_pitch, mean, rstd, coefA, coefB);
   const long npix = (long)B * HW;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(lgm_cdiv(npix * (C / 4), 256)), dim3(256), 0, s, x, (long)x_pitch, coefA,
                      coefB, res, (long)res_pitch, y, (long)y_pitch, npix, HW, C, act);
@@ -329,9 +326,8 @@ extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int6
   float* Rc = Qc + bc;
   const int cb = gn_cb(C, G);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * (C / cb)), dim3(256), 0, s, x, (long)x_pitch, gy, (long)gy_pitch,
-                     coefA, coefB, mean, rstd, HW, C, G, cb, act, S1, S2);
-  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(B), dim3(256), 0, s, S1, S2, mean, rstd, gamma, beta, ss, (long)ss_pitch,
-                     gss, (long)gss_pitch, gss_beta, B, C, G, HW, P, Qc, Rc);
+                     coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss, (long)gss_pitch,
+                     gss_beta, S1, S2, P, Qc, Rc);
   hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(lgm_cdiv(C, 64)), dim3(256), 0, s, S1, S2, ss, (long)ss_pitch, B, C,
                      ggamma, gbeta, affine_beta);
   const long npix = (long)B * HW;
