@@ -194,6 +194,78 @@ int lgm_sample_step(const float* x, const float* v, const float* noise, float* o
                     float C0, float C1, float C2, float C3, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Vector quantiser (VQ-VAE) — models/modules/vector_quantizer.py.
+ * x: latents as [N = B*H*W, D] rows (NHWC), codebook [K, D].
+ * ------------------------------------------------------------------------------------- */
+/* _quantize :53-60: indices[n] = argmin_k ( ||x_n||^2 + ||e_k||^2 - (2 x_n).e_k ), int64, lowest
+ * index on ties; min_dist optional.  The [N,K] distance matrix is never materialised. */
+int lgm_vq_assign(const float* x, int64_t x_pitch, const float* codebook, int N, int K, int D,
+                  int64_t* indices, float* min_dist, void* stream);
+/* one-hot^T @ x and one-hot.sum(0) (:132-143) without the one-hot: dw [K,D], counts [K];
+ * deterministic (rows visited in ascending order). */
+int lgm_vq_segment_sum(const float* x, int64_t x_pitch, const int64_t* indices, int N, int K, int D,
+                       float* dw, float* counts, void* stream);
+/* VectorQuantizerEMA._ema_update :128-147 (in place on the two buffers and the codebook). */
+int lgm_vq_ema_update(float* cluster_size, float* ema_embedding, float* codebook,
+                      const float* counts, const float* dw, int K, int D, float decay, float eps,
+                      void* stream);
+/* q[n] = codebook[indices[n]]; out3 = { vq_loss = mse + commitment*mse (:76-78),
+ * perplexity (:87-88), mse }.  workspace: lgm_vq_gather_workspace bytes. */
+int64_t lgm_vq_gather_workspace(int N, int D);
+int lgm_vq_gather_loss(const float* x, int64_t x_pitch, const float* codebook,
+                       const int64_t* indices, const float* counts, int N, int K, int D,
+                       float commitment, float* q, int64_t q_pitch, float* out3, void* workspace,
+                       void* stream);
+/* Backward: gx = gq (straight-through :90-93, optional) + g*commitment*2(x-q)/(ND);
+ * gcodebook = beta*gcodebook + g*2(counts*e - dw)/(ND);  g = *g_vq_loss (device scalar). */
+int lgm_vq_bwd(const float* x, int64_t x_pitch, const float* q, int64_t q_pitch, const float* gq,
+               int64_t gq_pitch, const float* codebook, const float* dw, const float* counts,
+               const float* g_vq_loss, float commitment, int N, int K, int D, float* gx,
+               int64_t gx_pitch, float* gcodebook, float gcb_beta, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Train-mode BatchNorm2d primitives over [M = B*H*W, C] NHWC matrices (dcgan.py:86-90,158-161)
+ * and the WGAN-GP loss pieces (wgan.py:84-156).  xhat = (a - mean) * rstd per channel.
+ * ------------------------------------------------------------------------------------- */
+int64_t lgm_bn_workspace(int64_t rows, int C);
+/* batch mean / rstd (biased variance, eps), running stats updated with torch semantics */
+int lgm_bn_stats(const float* a, int64_t a_pitch, int64_t rows, int C, float eps, float momentum,
+                 float* mean, float* rstd, float* running_mean, float* running_var, void* workspace,
+                 void* stream);
+/* sums3 = [sum v1, sum v1*xhat, sum v1*v2] per channel ([3][C]); a / v2 optional */
+int lgm_bn_reduce3(const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch,
+                   const float* a, int64_t a_pitch, const float* mean, const float* rstd,
+                   int64_t rows, int C, float* sums3, void* workspace, void* stream);
+/* per-channel coefficient vectors coef4 = [A1,A2,A3,A4][C]:
+ * mode 0: BN backward operator T(v) = c (v - mean v - xhat mean(v xhat)); optional ggamma/gbeta
+ *         (= beta_acc*old + sums) and m_out = [mean v, mean v*xhat];
+ * mode 1: adjoint of T's dependence on the batch statistics (gradient-penalty second order). */
+int lgm_bn_coef(int mode, const float* sums3, const float* gamma, const float* rstd,
+                const float* saved_m, int C, int64_t M, float* coef4, float* ggamma, float* gbeta,
+                float beta_acc, float* m_out, void* stream);
+/* out (+)= act( A1*v1 + A2*v2 + A3*xhat + A4 )   (any of the terms optional = NULL) */
+int lgm_bn_affine3(const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch,
+                   const float* a, int64_t a_pitch, const float* mean, const float* rstd,
+                   const float* A1, const float* A2, const float* A3, const float* A4, float* out,
+                   int64_t out_pitch, int accumulate, int act, float slope, int64_t rows, int C,
+                   void* stream);
+/* interpolated_images = alpha*x + (1-alpha)*x_hat (wgan.py:137), alpha [B] */
+int lgm_lerp_rows(const float* x, const float* y, const float* alpha, float* out, int64_t B,
+                  int64_t rowlen, void* stream);
+/* gradient penalty with the reference's channel-only norm (wgan.py:153-156):
+ * loss_out = lambda * mean_p (||g_p||_c - 1)^2 ; gbar = d(gscale*loss)/dg.  g, gbar dense NHWC4. */
+int64_t lgm_gp_penalty_workspace(int64_t npix);
+int lgm_gp_penalty(const float* g, int64_t npix, int C, float lambda, const float* gscale,
+                   float* loss_out, float* gbar, void* workspace, void* stream);
+/* out = scale * mean_i v[i*pitch]  (critic score means, wgan.py:85-87) */
+int lgm_mean_col(const float* v, int64_t pitch, int64_t n, float scale, float* out, void* stream);
+/* out[r][c] = (c == col) ? scale * (vptr ? *vptr : 1) : 0 */
+int lgm_fill_col(float* out, int64_t pitch, int64_t n, int ncols, int col, float scale,
+                 const float* vptr, void* stream);
+/* vals4 = (real, fake, gp, d_loss): d_loss = fake - real + gp (wgan.py:87,98) */
+int lgm_wgan_dloss(float* vals4, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimiser kernels on flat storage.
  * torch.optim.Adam (coupled L2; decoupled=1 gives AdamW) — ddpm.py:1053-1059, vqvae.py:207-214,
  * wgan.py:183-195.  step: 1-based count (host value, or read from step_dev when non-NULL).

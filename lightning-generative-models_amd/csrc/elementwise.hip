@@ -547,3 +547,122 @@ extern "C" int lgm_sample_step(const float* x, const float* v, const float* nois
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// WGAN-GP helpers (wgan.py:84-156)
+// ---------------------------------------------------------------------------------------
+namespace {
+
+// interpolates: out[b] = alpha[b]*x[b] + (1-alpha[b])*y[b]   (dense rows of `rowlen` floats)
+__global__ __launch_bounds__(256) void lerp_rows_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ alpha, float* __restrict__ out,
+                                                        long B, long rowlen) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * rowlen) return;
+  const float a = alpha[i / rowlen];
+  out[i] = a * x[i] + (1.f - a) * y[i];
+}
+
+// gradient penalty with the reference's CHANNEL-ONLY norm (wgan.py:153-154):
+//   r[p] = sqrt(sum_c g[p,c]^2);  partial[block] = sum_p (r-1)^2;  gbar[p,c] = coef*(r-1)/r * g[p,c],
+//   coef = gscale * lambda * 2 / npix.  One thread per pixel, C <= 4 (padded to 4 floats).
+__global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict__ g, long npix, int C, float lambda,
+                                                         const float* __restrict__ gscale, float* __restrict__ partial,
+                                                         float* __restrict__ gbar) {
+  __shared__ float sh[16];
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float pen = 0.f;
+  if (p < npix) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + p * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < C) s += v[c] * v[c];
+    const float r = sqrtf(s);
+    pen = (r - 1.f) * (r - 1.f);
+    if (gbar) {
+      const float k = gscale[0] * lambda * 2.f / (float)npix * (r - 1.f) / r;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) o[c] = k * v[c];
+      *reinterpret_cast<f32x4*>(gbar + p * 4) = o;
+    }
+  }
+  pen = lgm_block_sum(pen, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = pen;
+}
+
+// vals[slot] = scale * sum_i partial[i]   (single block, fixed order)
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ partial, long n, long stride,
+                                                        float scale, float* __restrict__ out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) s += partial[i * stride];
+  s = lgm_block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// out[r][c] = (c == col) ? scale * (vptr ? vptr[0] : 1) : 0
+__global__ void fill_col_kernel(float* __restrict__ out, long pitch, long n, int ncols, int col, float scale,
+                                const float* __restrict__ vptr) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * ncols) return;
+  const long r = i / ncols;
+  const int c = (int)(i % ncols);
+  out[r * pitch + c] = (c == col) ? scale * (vptr ? vptr[0] : 1.f) : 0.f;
+}
+
+// vals = (real, fake, gp, d_loss): d_loss = fake - real + gp
+__global__ void wgan_dloss_kernel(float* __restrict__ vals) { vals[3] = vals[1] - vals[0] + vals[2]; }
+
+}  // namespace
+
+extern "C" int lgm_lerp_rows(const float* x, const float* y, const float* alpha, float* out, int64_t B,
+                             int64_t rowlen, void* stream) {
+  LGM_REQUIRE(x && y && alpha && out && B > 0 && rowlen > 0, "lerp_rows: bad arguments");
+  hipLaunchKernelGGL(lerp_rows_kernel, dim3(lgm_cdiv(B * rowlen, 256)), dim3(256), 0, (hipStream_t)stream, x, y, alpha,
+                     out, (long)B, (long)rowlen);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int64_t lgm_gp_penalty_workspace(int64_t npix) { return (int64_t)lgm_cdiv(npix, 256) * 4 + 16; }
+
+extern "C" int lgm_gp_penalty(const float* g, int64_t npix, int C, float lambda, const float* gscale, float* loss_out,
+                              float* gbar, void* workspace, void* stream) {
+  LGM_REQUIRE(g && loss_out && workspace && npix > 0 && C >= 1 && C <= 4 && (!gbar || gscale) && lgm_aligned16(g),
+              "gp_penalty: bad arguments (dense NHWC4 gradient expected)");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = lgm_cdiv(npix, 256);
+  hipLaunchKernelGGL(gp_penalty_kernel, dim3(nb), dim3(256), 0, s, g, (long)npix, C, lambda, gscale, (float*)workspace,
+                     gbar);
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, (long)nb, 1L,
+                     lambda / (float)npix, loss_out);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_mean_col(const float* v, int64_t pitch, int64_t n, float scale, float* out, void* stream) {
+  LGM_REQUIRE(v && out && n > 0, "mean_col: bad arguments");
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, v, (long)n, (long)pitch,
+                     scale / (float)n, out);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_fill_col(float* out, int64_t pitch, int64_t n, int ncols, int col, float scale, const float* vptr,
+                            void* stream) {
+  LGM_REQUIRE(out && n > 0 && ncols > 0 && col < ncols && pitch >= ncols, "fill_col: bad arguments");
+  hipLaunchKernelGGL(fill_col_kernel, dim3(lgm_cdiv(n * ncols, 256)), dim3(256), 0, (hipStream_t)stream, out,
+                     (long)pitch, (long)n, ncols, col, scale, vptr);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_wgan_dloss(float* vals4, void* stream) {
+  LGM_REQUIRE(vals4, "wgan_dloss: null pointer");
+  hipLaunchKernelGGL(wgan_dloss_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, vals4);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}

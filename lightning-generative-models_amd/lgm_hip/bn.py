@@ -1,0 +1,121 @@
+"""Train-mode BatchNorm2d on the HIP primitives (lgm_bn_*), including the adjoint pieces the
+WGAN-GP double backward needs.  Notation (per channel, M = B*H*W rows):
+    xhat = (a - mean) * rstd,   n = gamma*xhat + beta,   c = gamma*rstd
+    T(v) = c * (v - mean(v) - xhat * mean(v*xhat))        (BatchNorm's backward operator)
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+from .nn import GradCtx, _flat
+
+
+class BNSaved:
+    __slots__ = ("a", "mean", "rstd")
+
+    def __init__(self, a, mean, rstd):
+        self.a, self.mean, self.rstd = a, mean, rstd
+
+
+def _ws(a):
+    rows, C = ops.rows(a), a.shape[-1]
+    return ops.workspace(ops.lib().lgm_bn_workspace(rows, C), a.device)
+
+
+class BatchNorm2d(nn.Module):
+    """Parameters/buffers named as nn.BatchNorm2d (weight, bias, running_mean, running_var,
+    num_batches_tracked).  Only train-mode (batch statistics) is on the hot path; eval mode uses
+    the running statistics through the same affine kernel."""
+
+    def __init__(self, channels, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.channels, self.eps, self.momentum = channels, eps, momentum
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.register_buffer("running_mean", torch.zeros(channels))
+        self.register_buffer("running_var", torch.ones(channels))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    # ---- forward: h = act(gamma*xhat + beta) ------------------------------------------------
+    def fwd(self, a, act: int, slope: float = 0.0, training: bool = True):
+        C = a.shape[-1]
+        fp = _flat(self.weight)
+        st = torch.empty((2, C), dtype=torch.float32, device=a.device)
+        mean, rstd = st[0], st[1]
+        L = ops.lib()
+        if training:
+            L.lgm_bn_stats(a.data_ptr(), ops.pitch(a), ops.rows(a), C, self.eps, self.momentum, mean.data_ptr(),
+                           rstd.data_ptr(), self.running_mean.data_ptr(), self.running_var.data_ptr(),
+                           _ws(a).data_ptr(), ops.stream())
+            self.num_batches_tracked += 1
+        else:
+            mean.copy_(self.running_mean)
+            rstd.copy_((self.running_var + self.eps).rsqrt())
+        h = ops.new(a.shape, a)
+        L.lgm_bn_affine3(None, 0, None, 0, a.data_ptr(), ops.pitch(a), mean.data_ptr(), rstd.data_ptr(), None, None,
+                         fp.ptr(self.weight), fp.ptr(self.bias), h.data_ptr(), ops.pitch(h), 0, act, slope,
+                         ops.rows(a), C, ops.stream())
+        return h, BNSaved(a, mean, rstd)
+
+    # ---- T(v), optionally with the parameter gradients of the forward node -------------------
+    def apply_T(self, sv: BNSaved, v, gc: GradCtx = None, want_m: bool = False, out=None, accumulate=False):
+        """returns (T(v), mvec) where mvec = [mean v, mean v*xhat] (when want_m)."""
+        a = sv.a
+        C = a.shape[-1]
+        rows = ops.rows(a)
+        L = ops.lib()
+        fp = _flat(self.weight)
+        sums = torch.empty((3, C), dtype=torch.float32, device=a.device)
+        L.lgm_bn_reduce3(v.data_ptr(), ops.pitch(v), None, 0, a.data_ptr(), ops.pitch(a), sv.mean.data_ptr(),
+                         sv.rstd.data_ptr(), rows, C, sums.data_ptr(), _ws(a).data_ptr(), ops.stream())
+        coef = torch.empty((4, C), dtype=torch.float32, device=a.device)
+        mvec = torch.empty((2, C), dtype=torch.float32, device=a.device) if want_m else None
+        gg = gb = None
+        beta = 0.0
+        if gc is not None:
+            gg, gb = gc.flat.gptr(self.weight), gc.flat.gptr(self.bias)
+            beta = gc.beta(self.weight)
+            gc.beta(self.bias)
+        L.lgm_bn_coef(0, sums.data_ptr(), fp.ptr(self.weight), sv.rstd.data_ptr(), None, C, rows, coef.data_ptr(),
+                      gg, gb, beta, None if mvec is None else mvec.data_ptr(), ops.stream())
+        if out is None:
+            out = ops.new(a.shape, a)
+            accumulate = False
+        L.lgm_bn_affine3(v.data_ptr(), ops.pitch(v), None, 0, a.data_ptr(), ops.pitch(a), sv.mean.data_ptr(),
+                         sv.rstd.data_ptr(), coef[0].data_ptr(), None, coef[2].data_ptr(), coef[3].data_ptr(),
+                         out.data_ptr(), ops.pitch(out), 1 if accumulate else 0, 0, 0.0, rows, C, ops.stream())
+        return out, mvec
+
+    # ---- second-order pieces (gradient penalty) ----------------------------------------------
+    def adjoint_T(self, sv: BNSaved, u, gn, mvec, gc: GradCtx):
+        """Node ga = T(gn) of the first backward pass received the adjoint ``u`` (w.r.t. ga).
+        Returns (adjoint w.r.t. gn, adjoint w.r.t. the forward activation a through the batch
+        statistics) and accumulates the adjoint w.r.t. gamma."""
+        a = sv.a
+        C = a.shape[-1]
+        rows = ops.rows(a)
+        L = ops.lib()
+        fp = _flat(self.weight)
+        sums = torch.empty((3, C), dtype=torch.float32, device=a.device)
+        L.lgm_bn_reduce3(u.data_ptr(), ops.pitch(u), gn.data_ptr(), ops.pitch(gn), a.data_ptr(), ops.pitch(a),
+                         sv.mean.data_ptr(), sv.rstd.data_ptr(), rows, C, sums.data_ptr(), _ws(a).data_ptr(),
+                         ops.stream())
+        coef = torch.empty((2, 4, C), dtype=torch.float32, device=a.device)
+        # (1) T is self-adjoint in its argument: adjoint w.r.t. gn = T(u)
+        L.lgm_bn_coef(0, sums.data_ptr(), fp.ptr(self.weight), sv.rstd.data_ptr(), None, C, rows,
+                      coef[0].data_ptr(), None, None, 0.0, None, ops.stream())
+        gn_bar = ops.new(a.shape, a)
+        L.lgm_bn_affine3(u.data_ptr(), ops.pitch(u), None, 0, a.data_ptr(), ops.pitch(a), sv.mean.data_ptr(),
+                         sv.rstd.data_ptr(), coef[0, 0].data_ptr(), None, coef[0, 2].data_ptr(), coef[0, 3].data_ptr(),
+                         gn_bar.data_ptr(), ops.pitch(gn_bar), 0, 0, 0.0, rows, C, ops.stream())
+        # (2) dependence of T on xhat / sigma (hence on a) and on gamma
+        L.lgm_bn_coef(1, sums.data_ptr(), fp.ptr(self.weight), sv.rstd.data_ptr(), mvec.data_ptr(), C, rows,
+                      coef[1].data_ptr(), gc.flat.gptr(self.weight), None, gc.beta(self.weight), None, ops.stream())
+        a_bar = ops.new(a.shape, a)
+        L.lgm_bn_affine3(u.data_ptr(), ops.pitch(u), gn.data_ptr(), ops.pitch(gn), a.data_ptr(), ops.pitch(a),
+                         sv.mean.data_ptr(), sv.rstd.data_ptr(), coef[1, 0].data_ptr(), coef[1, 1].data_ptr(),
+                         coef[1, 2].data_ptr(), coef[1, 3].data_ptr(), a_bar.data_ptr(), ops.pitch(a_bar), 0, 0, 0.0,
+                         rows, C, ops.stream())
+        return gn_bar, a_bar

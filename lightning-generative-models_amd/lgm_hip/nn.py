@@ -105,6 +105,39 @@ class Conv2d(nn.Module):
         return gx
 
 
+def _conv_linear(self, x, out=None):
+    """W * x without bias (the convolution as a linear map; used by second-order passes)."""
+    B, H, W, _ = x.shape
+    g = self.geom(B, H, W)
+    fp = _flat(self.weight)
+    y = out if out is not None else ops.new((B, g.Ho, g.Wo, _r4(self.cout)), x)
+    ops.conv_xy(g, x, fp.ptr(self.weight), None, None, y)
+    return y
+
+
+def _conv_dgrad(self, gy, in_shape, gx=None, accumulate=False):
+    """W^T * gy (input gradient only, no parameter gradients)."""
+    B, H, W, _ = in_shape
+    g = self.geom(B, H, W)
+    fp = _flat(self.weight)
+    if gx is None:
+        gx = ops.new(tuple(in_shape), gy)
+        accumulate = False
+    ops.conv_yx(g, gy, fp.ptr(self.weight), None, gx if accumulate else None, gx)
+    return gx
+
+
+def _conv_wgrad(self, gc: GradCtx, y, x):
+    """gW (+)= sum y (x) x  for an arbitrary (y, x) pair of this layer's geometry."""
+    B, H, W, _ = x.shape
+    ops.conv_wgrad(self.geom(B, H, W), y, x, gc.flat.gptr(self.weight), gc.beta(self.weight), None)
+
+
+Conv2d.linear = _conv_linear
+Conv2d.dgrad = _conv_dgrad
+Conv2d.wgrad = _conv_wgrad
+
+
 class ConvTranspose2d(nn.Module):
     """nn.ConvTranspose2d replacement: forward is the Y->X pass of the equivalent convolution."""
 

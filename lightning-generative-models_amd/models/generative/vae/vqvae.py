@@ -1,0 +1,321 @@
+"""VQ-VAE on the MI355X HIP engine — drop-in for the reference's models/generative/vae/vqvae.py
+(+ models/modules/vector_quantizer.py, residual.py): same class names, constructor arguments,
+state_dict keys and training_step / configure_optimizers surface.
+
+Encoder / decoder convolutions run on the implicit-GEMM MFMA kernels (stride-2 4x4 conv and
+conv-transpose included), the quantiser on lgm_vq_* (no [N,K] distance / one-hot matrices, int64
+indices, deterministic segmented sums for the EMA statistics and the codebook gradient).
+Forward and backward are explicit kernel sequences; autograd only sees one Function.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from lgm_hip import ops
+from lgm_hip.flat import FlatParams, _r4
+from lgm_hip.lightning import LightningModule
+from lgm_hip.nn import Conv2d, ConvTranspose2d, GradCtx, param_kind
+from lgm_hip.optim import FusedAdam
+
+
+class ResidualBlock(nn.Module):
+    """reference residual.py:5-21 — note the in-place first ReLU: the block returns
+    relu(x) + conv1x1(relu(conv3x3(relu(x))))."""
+
+    def __init__(self, in_channels, hidden_dim, num_residual_hiddens):
+        super().__init__()
+        self.block = nn.Sequential(nn.Identity(), Conv2d(in_channels, num_residual_hiddens, 3, padding=1, bias=False),
+                                   nn.Identity(), Conv2d(num_residual_hiddens, hidden_dim, 1, bias=False))
+
+
+class ResidualStack(nn.Module):
+    def __init__(self, in_channels, hidden_dim, num_residual_layers, num_residual_hiddens):
+        super().__init__()
+        self.layers = nn.ModuleList([ResidualBlock(in_channels, hidden_dim, num_residual_hiddens)
+                                     for _ in range(num_residual_layers)])
+
+    def fwd(self, cur, save):
+        tape = []
+        for blk in self.layers:
+            ops.act_fwd(cur, None, None, cur, ops.ACT_RELU)          # in place: cur := relu(cur)
+            y = blk.block[1].fwd(cur)
+            ops.act_fwd(y, None, None, y, ops.ACT_RELU)
+            z = blk.block[3].fwd(y, res=cur)
+            tape.append((cur, y))
+            cur = z
+        ops.act_fwd(cur, None, None, cur, ops.ACT_RELU)
+        return cur, (tape, cur)
+
+    def bwd(self, gc, saved, g):
+        tape, out = saved
+        ops.act_bwd(out, None, g, g, False, ops.ACT_RELU)
+        for blk, (r, y) in zip(reversed(self.layers), reversed(tape)):
+            gy = blk.block[3].bwd(gc, y, g)
+            ops.act_bwd(y, None, gy, gy, False, ops.ACT_RELU)
+            blk.block[1].bwd(gc, r, gy, g, True)                        # g (= residual path) += dgrad
+            ops.act_bwd(r, None, g, g, False, ops.ACT_RELU)
+        return g
+
+
+class Encoder(nn.Module):
+    """reference vqvae.py:17-54"""
+
+    def __init__(self, img_channels, embedding_dim, hidden_dim, num_residual_layers, num_residual_hiddens):
+        super().__init__()
+        h = hidden_dim
+        self.layers = nn.Sequential(
+            Conv2d(img_channels, h // 4, 4, 2, 1), nn.Identity(),
+            Conv2d(h // 4, h // 2, 4, 2, 1), nn.Identity(),
+            Conv2d(h // 2, h, 4, 2, 1), nn.Identity(),
+            Conv2d(h, h, 3, 1, 1),
+            ResidualStack(h, h, num_residual_layers, num_residual_hiddens),
+            Conv2d(h, embedding_dim, 1))
+
+    def fwd(self, x):
+        L = self.layers
+        acts = [x]
+        cur = x
+        for i in (0, 2, 4):
+            cur = L[i].fwd(cur)
+            ops.act_fwd(cur, None, None, cur, ops.ACT_RELU)
+            acts.append(cur)
+        a3 = L[6].fwd(cur)
+        s, st = L[7].fwd(a3, True)
+        lat = L[8].fwd(s)
+        return lat, (acts, st, s)
+
+    def bwd(self, gc, saved, glat):
+        acts, st, s = saved
+        L = self.layers
+        g = L[8].bwd(gc, s, glat)
+        g = L[7].bwd(gc, st, g)
+        g = L[6].bwd(gc, acts[3], g)
+        for k, i in ((3, 4), (2, 2), (1, 0)):
+            ops.act_bwd(acts[k], None, g, g, False, ops.ACT_RELU)
+            g = L[i].bwd(gc, acts[k - 1], g, need_gx=(i != 0))
+
+
+class Decoder(nn.Module):
+    """reference vqvae.py:57-88"""
+
+    def __init__(self, img_channels, embedding_dim, hidden_dim, num_residual_layers, num_residual_hiddens):
+        super().__init__()
+        h = hidden_dim
+        self.layers = nn.Sequential(
+            Conv2d(embedding_dim, h, 3, 1, 1),
+            ResidualStack(h, h, num_residual_layers, num_residual_hiddens),
+            ConvTranspose2d(h, h // 2, 4, 2, 1), nn.Identity(),
+            ConvTranspose2d(h // 2, h // 4, 4, 2, 1), nn.Identity(),
+            ConvTranspose2d(h // 4, img_channels, 4, 2, 1), nn.Identity())
+
+    def fwd(self, q):
+        L = self.layers
+        a0 = L[0].fwd(q)
+        s, st = L[1].fwd(a0, True)
+        u1 = L[2].fwd(s)
+        ops.act_fwd(u1, None, None, u1, ops.ACT_RELU)
+        u2 = L[4].fwd(u1)
+        ops.act_fwd(u2, None, None, u2, ops.ACT_RELU)
+        pre = L[6].fwd(u2)
+        xh = ops.new(pre.shape, pre)
+        ops.act_fwd(pre, None, None, xh, ops.ACT_TANH)
+        return xh, (q, st, s, u1, u2, pre)
+
+    def bwd(self, gc, saved, gxh):
+        q, st, s, u1, u2, pre = saved
+        L = self.layers
+        ops.act_bwd(pre, None, gxh, gxh, False, ops.ACT_TANH)
+        g = L[6].bwd(gc, u2, gxh)
+        ops.act_bwd(u2, None, g, g, False, ops.ACT_RELU)
+        g = L[4].bwd(gc, u1, g)
+        ops.act_bwd(u1, None, g, g, False, ops.ACT_RELU)
+        g = L[2].bwd(gc, s, g)
+        g = L[1].bwd(gc, st, g)
+        return L[0].bwd(gc, q, g)
+
+
+class _Embedding(nn.Module):
+    def __init__(self, num_embeddings, embedding_dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim).uniform_(
+            -1 / num_embeddings, 1 / num_embeddings))          # vector_quantizer.py:39-43
+
+
+class VectorQuantizer(nn.Module):
+    """reference vector_quantizer.py:8-93 (state: ``embedding.weight``)."""
+
+    use_ema = False
+
+    def __init__(self, num_embeddings, embedding_dim, commitment_cost=0.25):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim, self.commitment_cost = num_embeddings, embedding_dim, commitment_cost
+        self.embedding = _Embedding(num_embeddings, embedding_dim)
+
+    def fwd(self, lat, training: bool):
+        """lat: [B,H,W,D] dense NHWC.  Returns (q, scalars[3] = vq_loss, perplexity, mse, saved)."""
+        B, H, W, D = lat.shape
+        N, K = B * H * W, self.num_embeddings
+        L = ops.lib()
+        st = ops.stream()
+        fp = self.embedding.weight._lgm_flat
+        cb = fp.ptr(self.embedding.weight)
+        idx = torch.empty(N, dtype=torch.long, device=lat.device)
+        L.lgm_vq_assign(lat.data_ptr(), D, cb, N, K, D, idx.data_ptr(), None, st)
+        dw = ops.new((K, D), lat)
+        counts = ops.new((K,), lat)
+        L.lgm_vq_segment_sum(lat.data_ptr(), D, idx.data_ptr(), N, K, D, dw.data_ptr(), counts.data_ptr(), st)
+        if self.use_ema and training:      # codebook is replaced BEFORE the lookup (:168-177)
+            L.lgm_vq_ema_update(self._ema_cluster_size.data_ptr(), self._ema_embedding.data_ptr(), cb,
+                                counts.data_ptr(), dw.data_ptr(), K, D, self.decay, self.epsilon, st)
+        q = ops.new(lat.shape, lat)
+        out3 = ops.new((3,), lat)
+        ws = ops.workspace(L.lgm_vq_gather_workspace(N, D), lat.device)
+        L.lgm_vq_gather_loss(lat.data_ptr(), D, cb, idx.data_ptr(), counts.data_ptr(), N, K, D,
+                             self.commitment_cost, q.data_ptr(), D, out3.data_ptr(), ws.data_ptr(), st)
+        return q, out3, (lat, q, idx, dw, counts)
+
+    def bwd(self, gc: GradCtx, saved, gq, g_vq):
+        lat, q, idx, dw, counts = saved
+        B, H, W, D = lat.shape
+        N, K = B * H * W, self.num_embeddings
+        fp = gc.flat
+        w = self.embedding.weight
+        glat = ops.new(lat.shape, lat)
+        ops.lib().lgm_vq_bwd(lat.data_ptr(), D, q.data_ptr(), D, gq.data_ptr(), D, fp.ptr(w), dw.data_ptr(),
+                             counts.data_ptr(), g_vq.data_ptr(), self.commitment_cost, N, K, D, glat.data_ptr(), D,
+                             fp.gptr(w), gc.beta(w), ops.stream())
+        return glat
+
+
+class VectorQuantizerEMA(VectorQuantizer):
+    """reference vector_quantizer.py:96-179 (buffers ``_ema_cluster_size``, ``_ema_embedding``)."""
+
+    use_ema = True
+
+    def __init__(self, num_embeddings, embedding_dim, commitment_cost=0.25, decay=0.99, epsilon=1e-5):
+        super().__init__(num_embeddings, embedding_dim, commitment_cost)
+        self.register_buffer("_ema_cluster_size", torch.zeros(num_embeddings))
+        self.register_buffer("_ema_embedding", self.embedding.weight.data.clone())
+        self.decay, self.epsilon = decay, epsilon
+
+
+class VQVAE(LightningModule):
+    def __init__(self, img_channels: int = 3, img_size: int = 64, embedding_dim: int = 64, num_embeddings: int = 512,
+                 hidden_dim: int = 256, num_residual_layers: int = 2, num_residual_hiddens: int = 256,
+                 commitment_cost: float = 0.25, use_ema: bool = True, decay: float = 0.99, epsilon: float = 1e-5,
+                 lr: float = 1e-4, b1: float = 0.5, b2: float = 0.999, weight_decay: float = 1e-5,
+                 loss_weights: Dict = {"recon_loss": 1.0, "vq_loss": 1.0}) -> None:
+        super().__init__()
+        self.save_hyperparameters()
+        kw = dict(img_channels=img_channels, embedding_dim=embedding_dim, hidden_dim=hidden_dim,
+                  num_residual_layers=num_residual_layers, num_residual_hiddens=num_residual_hiddens)
+        self.encoder = Encoder(**kw)
+        self.decoder = Decoder(**kw)
+        if use_ema:
+            self.vector_quantizer = VectorQuantizerEMA(num_embeddings, embedding_dim, commitment_cost, decay, epsilon)
+        else:
+            self.vector_quantizer = VectorQuantizer(num_embeddings, embedding_dim, commitment_cost)
+        self._flat: Optional[FlatParams] = None
+        self.last = {}
+
+    # ---- flat storage ---------------------------------------------------------------------
+    def prepare_hip(self, device) -> FlatParams:
+        device = torch.device(device)
+        if self._flat is not None and self._flat.device == device and self._flat.still_bound():
+            return self._flat
+        named = [(n, p, param_kind(n, p)) for n, p in self.named_parameters()]
+        self._flat = FlatParams(named, device)
+        return self._flat
+
+    def _anchor(self, device):
+        self.prepare_hip(device)
+        a = getattr(self, "_anchor_t", None)
+        if a is None or a.device != torch.device(device):
+            a = torch.zeros(1, device=device, requires_grad=True)
+            self._anchor_t = a
+        return a
+
+    # ---- engine ---------------------------------------------------------------------------
+    def run(self, x: torch.Tensor, save: bool):
+        """x NCHW.  Returns dict(loss terms, x_hat nhwc) and the tape."""
+        B, C, H, W = x.shape
+        Cp = _r4(C)
+        x4 = ops.new((B, H, W, Cp), x)
+        ops.nchw_to_nhwc(x.contiguous(), x4)
+        lat, enc_saved = self.encoder.fwd(x4)
+        q, out3, vq_saved = self.vector_quantizer.fwd(lat, self.training)
+        xh, dec_saved = self.decoder.fwd(q)
+        per = ops.new((B,), x)
+        recon = ops.new((1,), x)
+        ops.lib().lgm_weighted_mse_fwd(xh.data_ptr(), x4.data_ptr(), Cp, None, None, B, C, H * W, Cp,
+                                       per.data_ptr(), recon.data_ptr(), ops.stream())
+        tape = (x4, enc_saved, vq_saved, dec_saved, xh) if save else None
+        return dict(recon=recon, out3=out3, x_hat=xh, indices=vq_saved[2], latents=lat), tape
+
+    def backward_hip(self, tape, g_recon, g_vq):
+        x4, enc_saved, vq_saved, dec_saved, xh = tape
+        B, H, W, Cp = x4.shape
+        C = self.hparams.img_channels
+        gc = GradCtx(self._flat)
+        gxh = ops.new(xh.shape, xh)
+        ops.lib().lgm_weighted_mse_bwd(xh.data_ptr(), x4.data_ptr(), Cp, None, None, g_recon.data_ptr(), B, C, H * W,
+                                       Cp, gxh.data_ptr(), ops.stream())
+        gq = self.decoder.bwd(gc, dec_saved, gxh)
+        glat = self.vector_quantizer.bwd(gc, vq_saved, gq, g_vq)
+        self.encoder.bwd(gc, enc_saved, glat)
+        self._flat.bind_grad_views()
+
+    def forward(self, x: torch.Tensor):
+        """(x_hat NCHW, vq_loss, perplexity) like the reference forward (inference / no-grad use)."""
+        self.prepare_hip(x.device)
+        r, _ = self.run(x.detach().float(), False)
+        B, C, H, W = x.shape
+        xh = ops.new((B, C, H, W), x)
+        ops.nhwc_to_nchw(r["x_hat"], xh)
+        return xh, r["out3"][0], r["out3"][1]
+
+    def _common_step(self, batch, batch_idx: int, split: str):
+        x, _ = batch
+        w = self.hparams.loss_weights
+        loss, recon, vq, ppl = _VQVAEStepFn.apply(self._anchor(x.device), self, x, float(w["recon_loss"]),
+                                                  float(w["vq_loss"]))
+        self.log_dict({f"{split}_loss": loss, f"{split}_recon_loss": recon, f"{split}_vq_loss": vq,
+                       f"{split}_perplexity": ppl}, prog_bar=True, logger=True, sync_dist=False)
+        return loss
+
+    def training_step(self, batch, batch_idx):
+        return self._common_step(batch, batch_idx, "train")
+
+    def validation_step(self, batch, batch_idx):
+        return self._common_step(batch, batch_idx, "val")
+
+    def configure_optimizers(self):
+        return FusedAdam(self.parameters(), lr=self.hparams.lr, betas=(self.hparams.b1, self.hparams.b2),
+                         weight_decay=self.hparams.weight_decay)
+
+
+class _VQVAEStepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, m: VQVAE, x, w_recon, w_vq):
+        save = bool(ctx.needs_input_grad[0])
+        r, tape = m.run(x.detach().float(), save)
+        out3 = r["out3"]
+        loss = r["recon"] * w_recon + out3[0:1] * w_vq          # two scalar ops (plumbing)
+        m.last = r
+        ctx.stuff = (m, tape, w_recon, w_vq)
+        recon_o, vq_o, ppl_o = r["recon"].view(()).clone(), out3[0].clone(), out3[1].clone()
+        ctx.mark_non_differentiable(recon_o, vq_o, ppl_o)
+        return loss.view(()), recon_o, vq_o, ppl_o
+
+    @staticmethod
+    def backward(ctx, gloss, *_unused):
+        m, tape, w_recon, w_vq = ctx.stuff
+        if tape is None:
+            raise RuntimeError("VQVAE step ran without saving activations")
+        gl = gloss.detach().float().reshape(1)
+        m.backward_hip(tape, (gl * w_recon).contiguous(), (gl * w_vq).contiguous())
+        ctx.stuff = None
+        return None, None, None, None, None

@@ -1,0 +1,152 @@
+"""GPU: DCGAN generator / critic and the WGAN-GP step (incl. the hand-derived double backward
+through train-mode BatchNorm) against fixtures captured from the real reference and against
+torch autograd on CPU.  fp32, 1e-4 relative on losses; gradients a few 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def test_batchnorm_first_and_second_order(dev):
+    """y = lrelu(BN(a)); L1 = <y, w>;  g = dL1/da;  L2 = sum(g^2 * v)  -> dL2/da, dL2/dgamma.
+    Checks lgm_bn_* forward, the T operator with parameter grads, and adjoint_T against autograd."""
+    from lgm_hip import ops
+    from lgm_hip.bn import BatchNorm2d
+    from lgm_hip.flat import FlatParams
+    from lgm_hip.nn import GradCtx
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 6, 16, 5, 4
+    a = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    w = torch.randn(B, C, H, W, generator=g)
+    v = torch.rand(B, C, H, W, generator=g) + 0.5
+    y = F.leaky_relu(F.batch_norm(a, None, None, gamma, beta, True, 0.1, 1e-5), 0.2)
+    L1 = (y * w).sum()
+    (g1,) = torch.autograd.grad(L1, a, create_graph=True)
+    L2 = (g1 * g1 * v).sum()
+    ga2, gg2 = torch.autograd.grad(L2, [a, gamma])
+    # ---- HIP ----
+    bn = BatchNorm2d(C)
+    bn.weight.data.copy_(gamma.detach())
+    bn.bias.data.copy_(beta.detach())
+    bn.to(dev)
+    fp = FlatParams([("weight", bn.weight, "vector"), ("bias", bn.bias, "vector")], dev)
+    ad = a.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    vd = v.permute(0, 2, 3, 1).contiguous().to(dev)
+    h, sv = bn.fwd(ad, ops.ACT_LRELU, 0.2, True)
+    assert rel(h.permute(0, 3, 1, 2), y) < 1e-5
+    assert rel(bn.running_mean, 0.1 * a.detach().mean((0, 2, 3))) < 1e-5
+    assert rel(bn.running_var, 0.9 + 0.1 * a.detach().var((0, 2, 3), unbiased=True)) < 1e-5
+    gn = torch.empty_like(wd)
+    ops.act_bwd(h, None, wd, gn, False, ops.ACT_LRELU, 0.2)
+    gc = GradCtx(fp)
+    ga, mvec = bn.apply_T(sv, gn, gc, want_m=True)
+    assert rel(ga.permute(0, 3, 1, 2), g1) < RTOL
+    L1.backward(retain_graph=True)
+    assert rel(fp.grad[:C], gamma.grad) < RTOL and rel(fp.grad[C:2 * C], beta.grad) < RTOL
+    # second order: adjoint u = dL2/dg1 = 2 g1 v
+    u = (2 * ga * vd).contiguous()
+    gc2 = GradCtx(fp)
+    fp.fresh = True
+    gc2 = GradCtx(fp)
+    gn_bar, a_bar = bn.adjoint_T(sv, u, gn, mvec, gc2)
+    assert rel(a_bar.permute(0, 3, 1, 2), ga2) < 5 * RTOL
+    assert rel(fp.grad[:C], gg2) < 5 * RTOL
+
+
+def _load_wgan(img_size, ch, latent, dev):
+    from models.generative.gan.wgan import WGAN
+    from oracle import gan as OG
+    m = WGAN(img_channels=ch, img_size=img_size, latent_dim=latent, lr=1e-4, b1=0.5, b2=0.9, weight_decay=0,
+             n_critic=5, grad_penalty=10, constraint_method="gp")
+    G, D = OG.gan_init(img_size, ch, latent, seed=21)
+    gsd = m.G.state_dict()
+    gsd.update(G)
+    m.G.load_state_dict(gsd, strict=True)
+    dsd = m.D.state_dict()
+    dsd.update(D)
+    m.D.load_state_dict(dsd, strict=True)
+    m.to(dev)
+    m.prepare_hip(dev)
+    m.train()
+    return m
+
+
+@pytest.mark.parametrize("cfg", [(64, 3, 100), (28, 1, 128)])
+def test_wgan_gp_losses_and_gradients_match_reference_fixture(dev, golden_dir, cfg):
+    img_size, ch, latent = cfg
+    B = 4
+    tag = str(img_size)
+    fx = dict(np.load(os.path.join(golden_dir, "wgan.npz")))
+    m = _load_wgan(img_size, ch, latent, dev)
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(B, ch, img_size, img_size, generator=g) * 2 - 1
+    z = torch.randn(B, latent, 1, 1, generator=g)
+    x_hat = m.G(z.to(dev))
+    assert rel(x_hat, fx[f"x_hat_{tag}"]) < RTOL
+    alpha = torch.as_tensor(fx[f"alpha_{tag}"]).to(dev)
+    ld = m._calculate_d_loss(x.to(dev), x_hat, alpha=alpha)
+    for k in ("d_loss", "d_loss_real", "d_loss_fake", "gradient_penalty"):
+        assert rel(ld[k], fx[f"{k}_{tag}"]) < 2 * RTOL, (k, float(ld[k]), float(fx[f"{k}_{tag}"]))
+    d_opt, g_opt = m.configure_optimizers()[0]
+    d_opt.zero_grad()
+    ld["d_loss"].backward()
+    for n, p in m.D.named_parameters():
+        ref_norm = float(fx[f"dgradnorm_{tag}:{n}"])
+        gn = p.grad.double().norm().item()
+        assert abs(gn - ref_norm) / max(ref_norm, 1e-12) < 1e-3, (n, gn, ref_norm)
+        ref = fx[f"dgrad_{tag}:{n}"]
+        got = p.grad if p.numel() < 20000 else p.grad.reshape(-1)[:: p.numel() // 256][:256]
+        assert rel(got, ref) < 2e-3, n
+    # generator loss / gradients
+    g_opt.zero_grad()
+    x_hat2 = m.G(z.to(dev))
+    gl = m._calculate_g_loss(x_hat2)["g_loss"]
+    assert rel(gl, fx[f"g_loss_{tag}"]) < 2 * RTOL
+    gl.backward()
+    for n, p in m.G.named_parameters():
+        ref_norm = float(fx[f"ggradnorm_{tag}:{n}"])
+        assert abs(p.grad.double().norm().item() - ref_norm) / max(ref_norm, 1e-12) < 1e-3, n
+
+
+def test_wgan_training_schedule_and_steps(dev):
+    """LightningModule surface: n_critic = 5 critic steps per generator step keyed on global_step
+    (reference wgan.py:64), manual optimisation, both fused optimisers step."""
+    from lgm_hip.lightning import _CountingOptimizer
+    m = _load_wgan(28, 1, 128, dev)
+    opts = m.configure_optimizers()[0]
+    m._optimizers = [_CountingOptimizer(o, m) for o in opts]
+    steps = {"d": 0, "g": 0}
+    d0 = m.D.model[0][0].weight.detach().clone()
+    g0 = m.G.model[0][0].weight.detach().clone()
+    kinds = []
+    x = torch.rand(8, 1, 28, 28, device=dev) * 2 - 1
+    for it in range(12):
+        before = m.global_step
+        m.training_step((x, None))
+        assert m.global_step == before + 1
+        kinds.append("g" if "g_loss" in m.logged and (before + 1) % 6 == 0 else "d")
+        for k in ("d_loss", "g_loss"):
+            if k in m.logged:
+                assert torch.isfinite(m.logged[k])
+    assert kinds == ["d"] * 5 + ["g"] + ["d"] * 5 + ["g"]
+    assert not torch.equal(m.D.model[0][0].weight, d0) and not torch.equal(m.G.model[0][0].weight, g0)
