@@ -53,7 +53,8 @@ def test_vq_kernels_match_reference_fixture(dev, golden_dir):
     L.lgm_vq_gather_loss(xd.data_ptr(), D, cbd.data_ptr(), idx.data_ptr(), counts.data_ptr(), N, K, D, 0.25,
                          q.data_ptr(), D, out3.data_ptr(), ws.data_ptr(), ops.stream())
     assert rel(out3[0], fx["vq_loss"]) < RTOL and rel(out3[1], fx["perplexity"]) < RTOL
-    assert rel(q.reshape(8, 4, 4, D).permute(0, 3, 1, 2), fx["quantized"]) < 1e-6
+    # the fixture holds the straight-through value x + (q - x), equal to q up to fp32 rounding
+    assert rel(q.reshape(8, 4, 4, D).permute(0, 3, 1, 2), fx["quantized"]) < 1e-5
     # backward: reference loss was (q_ste.sum()*0.5 + vq_loss)
     gq = torch.full((N, D), 0.5, device=dev)
     one = torch.ones(1, device=dev)
