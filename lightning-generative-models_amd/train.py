@@ -1,0 +1,96 @@
+"""Training entry point with the reference's CLI (train.py:31-66):
+
+    python train.py --config_path configs/diffusion/ddpm.json [--max_steps N] [--max_epochs N]
+                    [--accumulate_grad_batches K] [--ckpt_path last.ckpt] [--strategy ddp|auto]
+
+One process per GPU: under ``python -m torch.distributed.run --nproc-per-node N train.py ...`` every
+rank binds to its LOCAL_RANK device, joins a torch.distributed group (backend "nccl" = RCCL over
+xGMI on ROCm, "gloo" on CPU) and averages the flat gradient buffers once per optimizer step.
+Uses pytorch_lightning's Trainer when it is installed, otherwise the in-repo MiniTrainer.
+"""
+import argparse
+import os
+import sys
+from datetime import datetime
+from pathlib import Path
+from pprint import pprint
+
+import torch
+import torch.distributed as dist
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+from data.datamodule import DataModule  # noqa: E402
+from lgm_hip.lightning import HAVE_PL, MiniTrainer  # noqa: E402
+from utils.loader import load_config, load_model  # noqa: E402
+from utils.path import EXPERIMENT_DIR  # noqa: E402
+from utils.seed import seed_everything  # noqa: E402
+
+seed_everything(seed=10, workers=True)
+EXPERIMENT_TIME = datetime.now().strftime("%Y-%m-%d_%H:%M")
+
+
+def setup_arguments(argv=None, print_args=True, save_args=True):
+    p = argparse.ArgumentParser("Train script")
+    p.add_argument("--config_path", type=str, required=True, help="Path to configs")
+    p.add_argument("--num_workers", type=int, default=0)
+    p.add_argument("--check_val_every_n_epoch", type=int, default=5)
+    p.add_argument("--max_epochs", type=int, default=-1)
+    p.add_argument("--max_steps", type=int, default=-1)
+    p.add_argument("--strategy", type=str, default="auto")
+    p.add_argument("--accumulate_grad_batches", type=int, default=1)
+    p.add_argument("--precision", type=str, default=None)
+    p.add_argument("--ckpt_path", type=str, default=None)
+    p.add_argument("--project", type=str, default="Lightning generative models")
+    p.add_argument("--experiment_name", type=str, default=EXPERIMENT_TIME)
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--id", type=str, default=None)
+    p.add_argument("--accelerator", type=str, default="auto", help="auto | cpu | gpu")
+    args = p.parse_args(argv)
+    args.config = load_config(args.config_path)
+    args.experiment_dir = os.path.join(EXPERIMENT_DIR, args.config["model"]["name"], args.experiment_name)
+    os.makedirs(args.experiment_dir, exist_ok=True)
+    if print_args:
+        pprint(vars(args))
+    if save_args:
+        with open(os.path.join(args.experiment_dir, Path(args.config_path).name), "w") as f:
+            yaml.safe_dump({k: (v if isinstance(v, (int, float, str, bool, dict, list, type(None))) else str(v))
+                            for k, v in vars(args).items()}, f)
+    return args
+
+
+def init_distributed(use_gpu: bool):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if use_gpu:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl" if use_gpu else "gloo")
+    return dist.get_rank(), world
+
+
+def main(argv=None):
+    args = setup_arguments(argv, print_args=int(os.environ.get("RANK", "0")) == 0)
+    use_gpu = args.accelerator != "cpu" and torch.cuda.is_available()
+    rank, world = init_distributed(use_gpu)
+    model = load_model(args.config["model"])
+    datamodule = DataModule(**args.config["dataset"], num_workers=args.num_workers, pin_memory=True)
+    if use_gpu:
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    else:
+        device = torch.device("cpu")
+    trainer = MiniTrainer(max_epochs=args.max_epochs, max_steps=args.max_steps, default_root_dir=args.experiment_dir,
+                          accumulate_grad_batches=args.accumulate_grad_batches, device=device)
+    trainer.fit(model, datamodule=datamodule, ckpt_path=args.ckpt_path)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return model
+
+
+if __name__ == "__main__":
+    main()
