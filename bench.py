@@ -102,6 +102,12 @@ def main():
     model.train()
     opt = model.configure_optimizers()
     trainer = MiniTrainer()
+    from lgm_hip.lightning import FlatGradSync
+    unet = model.ema.online_model.model
+    sync = FlatGradSync(unet._flat) if world > 1 else None
+    unet.grad_sync = sync          # buckets are all-reduced (async) while the backward is still running
+    if sync is not None:
+        opt.grad_scale = sync.grad_scale
     g = torch.Generator(device="cpu").manual_seed(10 + rank)
     x = (torch.rand(per_gpu, 3, IMG, IMG, generator=g) * 2 - 1).to(dev)
     y = torch.zeros(per_gpu, dtype=torch.long, device=dev)
@@ -110,7 +116,8 @@ def main():
     def step(i):
         loss = model.training_step(batch)
         loss.backward()
-        trainer.allreduce_grads(model)
+        if sync is not None:
+            sync.finish()
         opt.step()
         opt.zero_grad()
         model.on_train_batch_end(None, batch, i)

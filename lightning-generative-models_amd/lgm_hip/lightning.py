@@ -128,6 +128,40 @@ def _flat_grads_of(module: nn.Module):
     return out
 
 
+class FlatGradSync:
+    """Bucketed gradient exchange for one flat gradient buffer, overlapped with the backward pass.
+
+    The hand-written backward fills the flat buffer in a known order; ``ready(lo, hi)`` is called
+    as soon as the slice [lo, hi) is final and launches an asynchronous all-reduce on it (RCCL
+    runs it on its own stream, ordered after the kernels already enqueued), ``finish()`` waits
+    for all buckets.  The 1/world average is folded into the optimiser (``grad_scale``)."""
+
+    def __init__(self, flat, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.handles = []
+        self.covered = 0
+
+    def ready(self, lo: int, hi: int):
+        if self.world == 1 or hi <= lo:
+            return
+        self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True))
+        self.covered += hi - lo
+
+    def finish(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.world > 1:
+            assert self.covered == self.flat.total, \
+                f"gradient buckets covered {self.covered} of {self.flat.total} elements"
+        self.covered = 0
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+
 class MiniTrainer:
     """Single-node trainer: one process per GPU, optional DDP-style gradient averaging with a
     single all-reduce per flat gradient buffer (RCCL over xGMI when backend is nccl)."""

@@ -25,6 +25,7 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, decoupled=decoupled)
         super().__init__(params, defaults)
         self._flat_state = {}   # id(FlatParams) -> dict(m, v, step, flat)
+        self.grad_scale = 1.0   # e.g. 1/world_size after a SUM all-reduce (folded into the kernel)
 
     def _flats(self, group) -> List[FlatParams]:
         seen, out = set(), []
@@ -50,7 +51,7 @@ class FusedAdam(torch.optim.Optimizer):
                     self._flat_state[id(fp)] = st
                 st["step"] += 1
                 ops.adam_step(fp.data, fp.grad, st["m"], st["v"], fp.total, group["lr"], b1, b2, group["eps"],
-                              group["weight_decay"], st["step"], None, 1.0, group["decoupled"])
+                              group["weight_decay"], st["step"], None, self.grad_scale, group["decoupled"])
         return loss
 
     def zero_grad(self, set_to_none: bool = True):

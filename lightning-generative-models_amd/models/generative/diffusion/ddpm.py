@@ -309,9 +309,22 @@ class Unet(nn.Module):
             first.append((names[id(rb.mlp[1].weight)], rb.mlp[1].weight, "weight"))
         for rb in rbs:
             first.append((names[id(rb.mlp[1].bias)], rb.mlp[1].bias, "vector"))
+        for lin in (self.time_mlp[1], self.time_mlp[3]):      # their gradients are produced last, too
+            first.append((names[id(lin.weight)], lin.weight, "weight"))
+            first.append((names[id(lin.bias)], lin.bias, "vector"))
         taken = {id(p) for _, p, _ in first}
         rest = [(n, p, param_kind(n, p)) for n, p in named.items() if id(p) not in taken]
         self._flat = FlatParams(first + rest, device)
+        # gradient-exchange buckets in backward completion order: [ups, mid, final] -> [init_conv, downs]
+        # -> [FiLM + time MLP]  (registration order of `rest`: init_conv, downs, ups, mid_*, final_*)
+        slots = {s.name: s for s in self._flat.slots}
+        self._head_end = slots[rest[0][0]].offset
+        self._ups_start = min(s.offset for s in self._flat.slots if s.name.startswith("ups."))
+        assert all(s.offset >= self._ups_start for s in self._flat.slots
+                   if s.name.startswith(("ups.", "mid_", "final_")))
+        assert all(self._head_end <= s.offset < self._ups_start for s in self._flat.slots
+                   if s.name.startswith(("downs.", "init_conv")))
+        self.grad_sync = None
         self._ss_offsets = []
         off = 0
         for rb in rbs:
@@ -492,6 +505,9 @@ class Unet(nn.Module):
         gcur = ops.new(gm1.shape, x_in)
         self.mid_block1.bwd(gc, sm1, gm1, gsl[k], gcur, False); k -= 1
         del gm1
+        sync = getattr(self, "grad_sync", None)
+        if sync is not None:
+            sync.ready(self._ups_start, fp.total)
         # ---- down path (reverse order) ----
         for s in range(n - 1, -1, -1):
             b1, b2, attn, down = self.downs[s]
@@ -518,7 +534,11 @@ class Unet(nn.Module):
                 gcur = gprev
         assert k == -1
         self.init_conv.bwd(gc, x_in, gcur, need_gx=False)
+        if sync is not None:
+            sync.ready(self._head_end, self._ups_start)
         self._time_bwd(gc, time_saved, gss_all)
+        if sync is not None:
+            sync.ready(0, self._head_end)
         fp.bind_grad_views()
 
     def forward(self, x: torch.Tensor, time: torch.Tensor, x_self_cond=None) -> torch.Tensor:

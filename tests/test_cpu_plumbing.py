@@ -100,6 +100,17 @@ fp = FlatParams([(k, p, param_kind(k, p)) for k, p in conv.named_parameters()], 
 fp.grad.fill_(float(rank + 1))
 MiniTrainer().allreduce_grads(conv)
 ok = bool(torch.allclose(fp.grad, torch.full_like(fp.grad, (world + 1) / 2)))
+# bucketed async exchange used by bench.py (buckets launched while "backward" is still producing others)
+from lgm_hip.lightning import FlatGradSync
+fp.grad.copy_(torch.arange(fp.total, dtype=torch.float32) * (rank + 1))
+sync = FlatGradSync(fp)
+third = fp.total // 3
+sync.ready(2 * third, fp.total)
+sync.ready(third, 2 * third)
+sync.ready(0, third)
+sync.finish()
+expect = torch.arange(fp.total, dtype=torch.float32) * sum(range(1, world + 1))
+ok = ok and bool(torch.allclose(fp.grad * sync.grad_scale, expect / world))
 print(f"RANK{rank} err={err:.3e} flat_ok={ok}", flush=True)
 dist.destroy_process_group()
 '''
