@@ -319,11 +319,12 @@ class Unet(nn.Module):
         # -> [FiLM + time MLP]  (registration order of `rest`: init_conv, downs, ups, mid_*, final_*)
         slots = {s.name: s for s in self._flat.slots}
         self._head_end = slots[rest[0][0]].offset
-        self._ups_start = min(s.offset for s in self._flat.slots if s.name.startswith("ups."))
-        assert all(s.offset >= self._ups_start for s in self._flat.slots
-                   if s.name.startswith(("ups.", "mid_", "final_")))
-        assert all(self._head_end <= s.offset < self._ups_start for s in self._flat.slots
-                   if s.name.startswith(("downs.", "init_conv")))
+        rest_names = [n for n, _, _ in rest]
+        self._ups_start = min(slots[n].offset for n in rest_names if n.startswith("ups."))
+        assert all(slots[n].offset >= self._ups_start for n in rest_names
+                   if n.startswith(("ups.", "mid_", "final_")))
+        assert all(self._head_end <= slots[n].offset < self._ups_start for n in rest_names
+                   if n.startswith(("downs.", "init_conv")))
         self.grad_sync = None
         self._ss_offsets = []
         off = 0
