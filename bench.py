@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python (no HIP-graph replay)")
     ap.add_argument("--batch", type=int, default=GLOBAL_BATCH, help="global batch (default 128 = the metric)")
     args = ap.parse_args()
 
@@ -123,6 +124,17 @@ def main():
         model.on_train_batch_end(None, batch, i)
         return loss
 
+    eager_step = step
+    graphed = None
+    if not args.no_graph:
+        try:
+            from lgm_hip.graph import GraphedDDPMStep
+            graphed = GraphedDDPMStep(model, opt, x, sync)
+            step = graphed.step
+        except Exception as e:  # capture is an optimisation: fall back to eager launches
+            unet.grad_sync = sync
+            print(f"[bench] rank {rank}: HIP-graph capture unavailable ({type(e).__name__}: {e}); eager launches",
+                  file=sys.stderr, flush=True)
     tw = time.perf_counter()
     for i in range(args.warmup):
         step(i)
@@ -150,8 +162,9 @@ def main():
               f"({args.batch * args.steps / elapsed:.1f} img/s)", file=sys.stderr, flush=True)
 
     # ---- roofline leg: one extra instrumented step, per-launch HIP events on the launch stream
+    unet.grad_sync = sync
     ops.TIMER = ops.KernelTimer()
-    step(args.warmup + args.steps)
+    eager_step(args.warmup + args.steps)
     summ = ops.TIMER.summary()
     ops.TIMER = None
 
@@ -177,7 +190,8 @@ def main():
                 "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "configs/diffusion/ddpm.json UNet dim=64, 3x32x32 synthetic NCHW fp32, "
                                        "training_step+backward+Adam+EMA", "global_batch": args.batch,
-                           "per_gpu_batch": per_gpu, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5)},
+                           "per_gpu_batch": per_gpu, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),
+                           "launch": "hipGraph replay (2 graphs/step)" if graphed is not None else "eager"},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

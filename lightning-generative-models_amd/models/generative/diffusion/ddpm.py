@@ -458,6 +458,12 @@ class Unet(nn.Module):
 
     def backward_nhwc(self, tape_all, gout):
         """Hand-written backward pass: parameter gradients into the flat gradient buffer."""
+        st = self.backward_phase1(tape_all, gout)
+        self.backward_phase2(st)
+
+    def backward_phase1(self, tape_all, gout):
+        """final conv -> final block -> up path -> middle.  After it the gradient slice
+        [_ups_start, total) of the flat buffer is final (first exchange bucket)."""
         time_saved, tape, sm1, sm2, sm3, ups_tape, sf, fin, x_in, cat_shapes = tape_all
         fp = self._flat
         gc = GradCtx(fp)
@@ -473,7 +479,6 @@ class Unet(nn.Module):
         self.final_res_block.bwd(gc, sf, gfin, gsl[k], gcatF, False); k -= 1
         del gfin
         gcats = [None] * n
-        # ---- up path (reverse order) ----
         g_next = _chan(gcatF, 0, dim)     # grad of the last up-stage output
         for u in range(n - 1, -1, -1):
             b1, b2, attn, up = self.ups[u]
@@ -497,7 +502,6 @@ class Unet(nn.Module):
             b1.bwd(gc, s1, _chan(gcat2, 0, co), gsl[k], gcat1, False); k -= 1
             gcats[s] = (gcat1, gcat2)
             g_next = _chan(gcat1, 0, co)
-        # ---- middle ----
         gm2 = ops.new(sm3[0].shape, x_in)
         self.mid_block2.bwd(gc, sm3, g_next, gsl[k], gm2, False); k -= 1
         gm1 = ops.new(gm2.shape, x_in)
@@ -509,7 +513,17 @@ class Unet(nn.Module):
         sync = getattr(self, "grad_sync", None)
         if sync is not None:
             sync.ready(self._ups_start, fp.total)
-        # ---- down path (reverse order) ----
+        return dict(gc=gc, tape=tape, time_saved=time_saved, gss_all=gss_all, gsl=gsl, k=k, gcats=gcats,
+                    gcatF=gcatF, gcur=gcur, x_in=x_in)
+
+    def backward_phase2(self, st):
+        """down path -> init conv -> time embedding / FiLM projections."""
+        gc, tape, gsl, k, gcats, gcatF, gcur, x_in = (st[key] for key in
+                                                      ("gc", "tape", "gsl", "k", "gcats", "gcatF", "gcur", "x_in"))
+        fp = self._flat
+        dim = self.dim
+        n = len(self.in_out)
+        sync = getattr(self, "grad_sync", None)
         for s in range(n - 1, -1, -1):
             b1, b2, attn, down = self.downs[s]
             ci, co = self.in_out[s]
@@ -537,7 +551,7 @@ class Unet(nn.Module):
         self.init_conv.bwd(gc, x_in, gcur, need_gx=False)
         if sync is not None:
             sync.ready(self._head_end, self._ups_start)
-        self._time_bwd(gc, time_saved, gss_all)
+        self._time_bwd(gc, st["time_saved"], st["gss_all"])
         if sync is not None:
             sync.ready(0, self._head_end)
         fp.bind_grad_views()
@@ -685,45 +699,55 @@ class GaussianDiffusion(nn.Module):
         return fn(self, (batch_size, self.channels, self.img_size, self.img_size), return_all_timesteps)
 
 
+def hip_loss_forward(gd: "GaussianDiffusion", img, t, noise, normalize: bool, save: bool):
+    """q_sample + UNet + v-target + weighted MSE on the HIP engine.  Returns (loss[1], ctx)."""
+    net = gd.model
+    B, C, H, W = img.shape
+    Cp = _r4(C)
+    img = img.detach().float().contiguous()
+    noise = noise.detach().float().contiguous()
+    t = t.contiguous()
+    xt = ops.new((B, H, W, Cp), img)
+    target = ops.new((B, H, W, Cp), img)
+    L = ops.lib()
+    st = ops.stream()
+    L.lgm_qsample_target(img.data_ptr(), noise.data_ptr(), t.data_ptr(), gd.sqrt_alphas_cumprod.data_ptr(),
+                         gd.sqrt_one_minus_alphas_cumprod.data_ptr(), 1 if normalize else 0, xt.data_ptr(),
+                         target.data_ptr(), Cp, B, C, H * W, Cp, st)
+    out, tape = net.forward_nhwc(xt, t, save)
+    per = ops.new((B,), img)
+    loss = ops.new((1,), img)
+    L.lgm_weighted_mse_fwd(out.data_ptr(), target.data_ptr(), Cp, t.data_ptr(), gd.loss_weight.data_ptr(),
+                           B, C, H * W, Cp, per.data_ptr(), loss.data_ptr(), st)
+    return loss, (gd, tape, out, target, t, (B, C, H, W), img, noise)
+
+
+def hip_loss_backward_phase1(ctx, gl):
+    """Loss gradient + first half of the UNet backward.  ``gl``: device scalar [1] = dL/dloss."""
+    gd, tape, out, target, t, (B, C, H, W) = ctx[:6]
+    if tape is None:
+        raise RuntimeError("p_losses forward ran without saving activations")
+    Cp = _r4(C)
+    gout = ops.new(out.shape, out)
+    ops.lib().lgm_weighted_mse_bwd(out.data_ptr(), target.data_ptr(), Cp, t.data_ptr(),
+                                   gd.loss_weight.data_ptr(), gl.data_ptr(), B, C, H * W, Cp,
+                                   gout.data_ptr(), ops.stream())
+    return gd.model.backward_phase1(tape, gout)
+
+
 class _PLossFn(torch.autograd.Function):
     """q_sample + UNet + v-target + weighted MSE, forward and hand-written backward."""
 
     @staticmethod
     def forward(ctx, anchor, gd: GaussianDiffusion, img, t, noise, normalize):
-        net = gd.model
-        save = bool(ctx.needs_input_grad[0])
-        B, C, H, W = img.shape
-        Cp = _r4(C)
-        img = img.detach().float().contiguous()
-        noise = noise.detach().float().contiguous()
-        t = t.contiguous()
-        xt = ops.new((B, H, W, Cp), img)
-        target = ops.new((B, H, W, Cp), img)
-        L = ops.lib()
-        st = ops.stream()
-        L.lgm_qsample_target(img.data_ptr(), noise.data_ptr(), t.data_ptr(), gd.sqrt_alphas_cumprod.data_ptr(),
-                             gd.sqrt_one_minus_alphas_cumprod.data_ptr(), 1 if normalize else 0, xt.data_ptr(),
-                             target.data_ptr(), Cp, B, C, H * W, Cp, st)
-        out, tape = net.forward_nhwc(xt, t, save)
-        per = ops.new((B,), img)
-        loss = ops.new((1,), img)
-        L.lgm_weighted_mse_fwd(out.data_ptr(), target.data_ptr(), Cp, t.data_ptr(), gd.loss_weight.data_ptr(),
-                               B, C, H * W, Cp, per.data_ptr(), loss.data_ptr(), st)
-        ctx.stuff = (gd, tape, out, target, t, (B, C, H, W))
+        loss, ctx.stuff = hip_loss_forward(gd, img, t, noise, normalize, bool(ctx.needs_input_grad[0]))
         return loss.view(())
 
     @staticmethod
     def backward(ctx, gloss):
-        gd, tape, out, target, t, (B, C, H, W) = ctx.stuff
-        if tape is None:
-            raise RuntimeError("p_losses forward ran without saving activations")
-        Cp = _r4(C)
         gl = gloss.detach().float().reshape(1).contiguous()
-        gout = ops.new(out.shape, out)
-        ops.lib().lgm_weighted_mse_bwd(out.data_ptr(), target.data_ptr(), Cp, t.data_ptr(),
-                                       gd.loss_weight.data_ptr(), gl.data_ptr(), B, C, H * W, Cp,
-                                       gout.data_ptr(), ops.stream())
-        gd.model.backward_nhwc(tape, gout)
+        st = hip_loss_backward_phase1(ctx.stuff, gl)
+        ctx.stuff[0].model.backward_phase2(st)
         ctx.stuff = None
         return None, None, None, None, None, None
 
