@@ -300,57 +300,54 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
 
   const int ts_begin = split * p.tps;
   const int ts_end = min(p.total_ts, ts_begin + p.tps);
-  for (int ts = ts_begin; ts < ts_end; ++ts) {
+  // Register-staged tiles: the global loads of tile t+1 are issued right after tile t has been
+  // committed to LDS, so they are in flight during tile t's 576 MFMAs per wave.
+  constexpr int NJW = 18;              // patch positions per thread (NP <= 288, 16 positions per pass)
+  const int c4 = (tid & 15) * 4;
+  f32x4 ry[8], rp[NJW];
+  auto load_tile = [&](int ts) {
     int t = ts;
     const int twi = t % p.tiles_w;
     t /= p.tiles_w;
     const int thi = t % p.tiles_h;
     const int b0 = (t / p.tiles_h) * p.NI;
     const int h0 = thi * p.TH, w0 = twi * TW;
-    __syncthreads();   // previous tile fully consumed
-    // ---- Y tile: thread -> (row tid/16 + 16 j, float4 column tid%16) ----
-    {
-      const int c4 = (tid & 15) * 4;
-      f32x4 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = (tid >> 4) + 16 * j;
-        const int img = r >> lgTT, rr = r & ((1 << lgTT) - 1);
-        const int oh = h0 + (rr >> lgTW), ow = w0 + (rr & (TW - 1)), b = b0 + img;
-        const bool ok = b < p.B && oh < p.H && ow < p.W;
-        v[j] = ok ? *reinterpret_cast<const f32x4*>(p.y + (long)((b * p.H + oh) * p.W + ow) * p.y_pitch + n0 + c4)
-                  : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(As + ((tid >> 4) + 16 * j) * 64 + c4) = v[j];
+    for (int j = 0; j < 8; ++j) {      // Y tile: thread -> (row tid/16 + 16 j, float4 column tid%16)
+      const int r = (tid >> 4) + 16 * j;
+      const int img = r >> lgTT, rr = r & ((1 << lgTT) - 1);
+      const int oh = h0 + (rr >> lgTW), ow = w0 + (rr & (TW - 1)), b = b0 + img;
+      const bool ok = b < p.B && oh < p.H && ow < p.W;
+      ry[j] = ok ? *reinterpret_cast<const f32x4*>(p.y + (long)((b * p.H + oh) * p.W + ow) * p.y_pitch + n0 + c4)
+                 : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // ---- X halo patch ----
-    {
-      const int c4 = (tid & 15) * 4;
-      for (int j0 = 0; j0 < NP; j0 += 16 * 6) {
-        f32x4 v[6];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          const int pos = (tid >> 4) + j0 + 16 * u;
-          bool ok = pos < NP;
-          long off = 0;
-          if (ok) {
-            const int img = pos / PP1, rem = pos - img * PP1;
-            const int py = rem / PW, px = rem - py * PW;
-            const int ih = h0 + py - 1, iw = w0 + px - 1, b = b0 + img;
-            ok = b < p.B && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            off = (long)((b * p.H + ih) * p.W + iw) * p.x_pitch + c0 + c4;
-          }
-          v[u] = ok ? *reinterpret_cast<const f32x4*>(p.x + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          const int pos = (tid >> 4) + j0 + 16 * u;
-          if (pos < NP) *reinterpret_cast<f32x4*>(Ps + pos * LDP + c4) = v[u];
-        }
+    for (int u = 0; u < NJW; ++u) {    // X halo patch
+      const int pos = (tid >> 4) + 16 * u;
+      bool ok = pos < NP;
+      long off = 0;
+      if (ok) {
+        const int img = pos / PP1, rem = pos - img * PP1;
+        const int py = rem / PW, px = rem - py * PW;
+        const int ih = h0 + py - 1, iw = w0 + px - 1, b = b0 + img;
+        ok = b < p.B && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        off = (long)((b * p.H + ih) * p.W + iw) * p.x_pitch + c0 + c4;
       }
+      rp[u] = ok ? *reinterpret_cast<const f32x4*>(p.x + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if (ts_begin < ts_end) load_tile(ts_begin);
+  for (int ts = ts_begin; ts < ts_end; ++ts) {
+    __syncthreads();   // previous tile fully consumed
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(As + ((tid >> 4) + 16 * j) * 64 + c4) = ry[j];
+#pragma unroll
+    for (int u = 0; u < NJW; ++u) {
+      const int pos = (tid >> 4) + 16 * u;
+      if (pos < NP) *reinterpret_cast<f32x4*>(Ps + pos * LDP + c4) = rp[u];
     }
     __syncthreads();
+    if (ts + 1 < ts_end) load_tile(ts + 1);
     if (do_bias) {
 #pragma unroll 8
       for (int r = 0; r < 32; ++r) bsum += As[((tid >> 6) + 4 * r) * 64 + (tid & 63)];

@@ -216,13 +216,14 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
 }
 
 // gamma/beta gradients: reduce over the batch in a fixed order
-__global__ void gn_bwd_affine_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
-                                     const float* __restrict__ ss, long ss_pitch, int B, int C,
-                                     float* __restrict__ ggamma, float* __restrict__ gbeta, float beta_acc) {
+__device__ __forceinline__ void gn_bwd_affine_body(int blk, const float* __restrict__ S1,
+                                                   const float* __restrict__ S2, const float* __restrict__ ss,
+                                                   long ss_pitch, int B, int C, float* __restrict__ ggamma,
+                                                   float* __restrict__ gbeta, float beta_acc) {
   // block = 64 channels x 4 batch lanes (fixed-order LDS combine => deterministic)
   __shared__ float sg[4][64], sb[4][64];
   const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int c = blk * 64 + cl;
   float gg = 0.f, gb = 0.f;
   if (c < C)
     for (int b = bl; b < B; b += 4) {
@@ -251,7 +252,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ P, const float* __restrict__ Qc,
                                                            const float* __restrict__ Rc, float* __restrict__ gx,
                                                            long gx_pitch, long npix, int HW, int C, int act,
-                                                           int accumulate) {
+                                                           int accumulate, int apply_blocks,
+                                                           const float* __restrict__ S1, const float* __restrict__ S2,
+                                                           const float* __restrict__ ss, long ss_pitch, int B,
+                                                           float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                           float affine_beta) {
+  if ((int)blockIdx.x >= apply_blocks) {   // trailing blocks: gamma/beta gradients, concurrent with the apply pass
+    gn_bwd_affine_body((int)blockIdx.x - apply_blocks, S1, S2, ss, ss_pitch, B, C, ggamma, gbeta, affine_beta);
+    return;
+  }
   const int c4n = C / 4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix * c4n) return;
@@ -328,11 +337,12 @@ extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int6
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * (C / cb)), dim3(256), 0, s, x, (long)x_pitch, gy, (long)gy_pitch,
                      coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss, (long)gss_pitch,
                      gss_beta, S1, S2, P, Qc, Rc);
-  hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(lgm_cdiv(C, 64)), dim3(256), 0, s, S1, S2, ss, (long)ss_pitch, B, C,
-                     ggamma, gbeta, affine_beta);
   const long npix = (long)B * HW;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(lgm_cdiv(npix * (C / 4), 256)), dim3(256), 0, s, x, (long)x_pitch, gy,
-                     (long)gy_pitch, coefA, coefB, P, Qc, Rc, gx, (long)gx_pitch, npix, HW, C, act, accumulate_gx);
+  const int apply_blocks = lgm_cdiv(npix * (C / 4), 256);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(apply_blocks + lgm_cdiv(C, 64)), dim3(256), 0, s, x, (long)x_pitch, gy,
+                     (long)gy_pitch, coefA, coefB, P, Qc, Rc, gx, (long)gx_pitch, npix, HW, C, act, accumulate_gx,
+                     apply_blocks, (const float*)S1, (const float*)S2, ss, (long)ss_pitch, B, ggamma, gbeta,
+                     affine_beta);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

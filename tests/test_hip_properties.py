@@ -1,0 +1,71 @@
+"""GPU: size-independent properties at BASELINE.json's FULL sizes (B=128, 32x32 / dim 64), where the
+CPU oracle would take minutes: linearity and adjoint identities of the convolution family, and
+bit-reproducibility (the reference trainer runs deterministic=True) of the whole training step."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize("case", [(128, 32, 64, 64, 3, 1), (128, 16, 192, 128, 3, 1), (128, 4, 512, 512, 3, 1),
+                                  (128, 32, 64, 384, 1, 0), (128, 8, 256, 128, 1, 0)])
+def test_conv_linearity_and_adjoints_full_size(dev, case):
+    from lgm_hip import ops
+    B, S, ci, co, k, pad = case
+    g = torch.Generator(device="cpu").manual_seed(sum(case))
+    geom = ops.make_geom(B, S, S, ci, co, k, k, 1, pad)
+    x1 = torch.randn(B, S, S, ci, generator=g).to(dev)
+    x2 = torch.randn(B, S, S, ci, generator=g).to(dev)
+    y1 = torch.randn(B, S, S, co, generator=g).to(dev)
+    w = (torch.randn(co, k * k, ci, generator=g) * 0.05).to(dev)
+    out = lambda: torch.empty(B, S, S, co, device=dev)  # noqa: E731
+    c1, c2, c12 = out(), out(), out()
+    ops.conv_xy(geom, x1, w.data_ptr(), None, None, c1)
+    ops.conv_xy(geom, x2, w.data_ptr(), None, None, c2)
+    ops.conv_xy(geom, (0.7 * x1 - 1.3 * x2).contiguous(), w.data_ptr(), None, None, c12)
+    ref = 0.7 * c1 - 1.3 * c2
+    assert float((c12 - ref).norm() / ref.norm()) < 1e-5                       # linearity in x
+    gx = torch.empty_like(x1)
+    ops.conv_yx(geom, y1, w.data_ptr(), None, None, gx)
+    lhs, rhs = dot(c1, y1), dot(x1, gx)                                          # <W x, y> == <x, W^T y>
+    assert abs(lhs - rhs) / max(abs(lhs), 1.0) < 1e-4
+    gw = torch.empty_like(w)
+    ops.conv_wgrad(geom, y1, x1, gw.data_ptr(), 0.0)
+    lhs2, rhs2 = dot(gw, w), dot(c1, y1)                                         # <dW(y, x), W> == <W x, y>
+    assert abs(lhs2 - rhs2) / max(abs(rhs2), 1.0) < 1e-4
+    gw2 = torch.empty_like(w)
+    ops.conv_wgrad(geom, y1, x1, gw2.data_ptr(), 0.0)
+    assert torch.equal(gw, gw2)                                                  # deterministic split-K
+
+
+def test_full_size_training_step_is_bit_reproducible(dev):
+    """Two runs of the BASELINE workload (dim 64, 32x32, B=128) from the same state and inputs give
+    bit-identical loss and gradients (fixed-order reductions, no float atomics)."""
+    from models.generative.diffusion.ddpm import GaussianDiffusion, Unet
+    torch.manual_seed(0)
+    net = Unet(dim=64, channels=3)
+    gd = GaussianDiffusion(net, img_size=32).to(dev)
+    net.prepare_hip(dev)
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(128, 3, 32, 32, generator=g).to(dev)
+    noise = torch.randn(128, 3, 32, 32, generator=g).to(dev)
+    t = torch.randint(0, 1000, (128,), generator=g).to(dev)
+    runs = []
+    for _ in range(2):
+        net._flat.zero_grad()
+        loss = gd.p_losses(img, t, noise, _normalize=True)
+        loss.backward()
+        runs.append((loss.detach().clone(), net._flat.grad.clone()))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert torch.isfinite(runs[0][1]).all() and float(runs[0][1].abs().max()) > 0
