@@ -60,8 +60,14 @@ int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch, const flo
 /* Y -> X  (Conv2d input-gradient; ConvTranspose2d.forward).
  * x = conv_transpose(y, w) + bias[c] + res   (bias, res optional; res may alias x). */
 int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
-                const float* bias, const float* res, int64_t res_pitch,
+                const float* w_t, const float* bias, const float* res, int64_t res_pitch,
                 float* x, int64_t x_pitch, void* workspace, int64_t workspace_bytes, void* stream);
+/* w_t (optional): the same weights transposed to [Cw][KH*KW][Nw]; when given, the 3x3 input-gradient
+ * kernel reads its weight fragments with the same 16-byte loads as the forward pass.
+ * lgm_transpose_weights refreshes such copies for a whole flat parameter buffer in ONE launch:
+ * table rows = (offset, Nw, T, Cw, first_block); dst uses the same offsets as src. */
+int lgm_transpose_weights(const float* src, float* dst, const int32_t* table, int n_layers,
+                          int total_blocks, void* stream);
 
 /* Optional workspace (bytes) for lgm_conv_xy (yx = 0) / lgm_conv_yx (yx = 1): small-image 3x3
  * layers split the reduction over workgroups and combine the partials in a fixed order.

@@ -23,7 +23,7 @@ constexpr int BN = 64;       // output-channel tile
 constexpr int BK = 32;       // k per weight chunk
 constexpr int LDB = BK + 4;  // weight tile row stride (XY)
 
-enum { MODE_XY = 0, MODE_YX = 1 };
+enum { MODE_XY = 0, MODE_YX = 1, MODE_YXT = 2 };   // YXT: input gradient reading TRANSPOSED weights [Cw][9][Nw]
 
 struct Args {
   const float* a;     // gathered activations, NHWC, C channels
@@ -142,12 +142,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
   // ---- weight fragments of chunk q = (cc, tap, ks): every lane fetches ITS OWN B operand values
   // straight from global memory (the weight tile is tiny and L1/L2 resident), one chunk ahead.
   // No LDS staging of weights => no barrier in the main loop: the four waves run decoupled.
-  const float* wlane = (MODE == MODE_XY) ? p.w + (long)(n0 + wn * 32 + lr) * (9 * p.C) + lh * 4
-                                         : p.w + (long)(lh * 4) * 9 * p.Wn + n0 + wn * 32 + lr;
+  constexpr bool KCONTIG = (MODE != MODE_YX);   // weight rows contiguous along the reduction index
+  constexpr bool FLIP = (MODE != MODE_XY);      // input gradient: taps are mirrored
+  const float* wlane = KCONTIG ? p.w + (long)(n0 + wn * 32 + lr) * (9 * p.C) + lh * 4
+                               : p.w + (long)(lh * 4) * 9 * p.Wn + n0 + wn * 32 + lr;
   auto load_b = [&](int q, f32x4 (&fb)[4]) {
     const int ks = q % KS, t2 = q / KS;
     const int tap = t2 % 9, cc = t2 / 9;
-    if (MODE == MODE_XY) {
+    if (KCONTIG) {
       const float* src = wlane + tap * p.C + cc * CK + ks * BK;
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) fb[kc] = *reinterpret_cast<const f32x4*>(src + kc * 8);
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
     const bool more = q + 1 < q_end;
     if (more) load_b(q + 1, nb);
 
-    const int tapoff = (MODE == MODE_XY) ? (kh * PW + kw) * LDP : ((2 - kh) * PW + (2 - kw)) * LDP;
+    const int tapoff = FLIP ? ((2 - kh) * PW + (2 - kw)) * LDP : (kh * PW + kw) * LDP;
     const float* a0 = Ps + abase[0] + tapoff + ks * BK;
     const float* a1 = Ps + abase[1] + tapoff + ks * BK;
 #pragma unroll
@@ -463,8 +465,8 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
   p.a = a; p.w = w; p.bias = bias; p.res = res; p.out = out;
   p.a_pitch = a_pitch; p.res_pitch = res_pitch; p.out_pitch = out_pitch;
   p.B = g->B; p.H = g->H; p.W = g->W;
-  p.C = mode == MODE_XY ? g->Cw : g->Nw;
-  p.N = mode == MODE_XY ? g->Nw : g->Cw;
+  p.C = mode == MODE_XY ? g->Cw : g->Nw;   // reduction (gathered) channels
+  p.N = mode == MODE_XY ? g->Nw : g->Cw;   // produced channels
   p.Wn = g->Cw;
   plan_tile(g->H, g->W, &p.TH, &p.TW, &p.NI);
   p.lgTW = ilog2(p.TW);
@@ -499,8 +501,10 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
   } while (0)
   if (mode == MODE_XY) {
     if (ck64) LGM_C3_LAUNCH(MODE_XY, 64); else LGM_C3_LAUNCH(MODE_XY, 32);
-  } else {
+  } else if (mode == MODE_YX) {
     if (ck64) LGM_C3_LAUNCH(MODE_YX, 64); else LGM_C3_LAUNCH(MODE_YX, 32);
+  } else {
+    if (ck64) LGM_C3_LAUNCH(MODE_YXT, 64); else LGM_C3_LAUNCH(MODE_YXT, 32);
   }
 #undef LGM_C3_LAUNCH
   if (p.splits > 1) {

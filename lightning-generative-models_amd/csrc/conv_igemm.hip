@@ -338,8 +338,53 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
   return dispatch_igemm<MODE_XY>(a, (hipStream_t)stream);
 }
 
+namespace {
+// Batched weight transposition: for every table row (src_off, Nw, T, Cw, first_block) rewrite
+// w[Nw][T][Cw] (at data + src_off) as wT[Cw][T][Nw] (at dst + src_off).  One 32x32 (n, c) tile of one
+// tap per block; the owning layer is found by binary search over the block prefix.
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                const int* __restrict__ table, int n_layers) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n_layers - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 5 + 4] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int* row = table + lo * 5;
+  const long off = row[0];
+  const int Nw = row[1], T = row[2], Cw = row[3];
+  int lb = bid - row[4];
+  const int tc = (Cw + 31) / 32, tn = (Nw + 31) / 32;
+  const int ct = lb % tc;
+  lb /= tc;
+  const int nt = lb % tn, tap = lb / tn;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = nt * 32 + ty + 8 * i, c = ct * 32 + tx;
+    tile[ty + 8 * i][tx] = (n < Nw && c < Cw) ? src[off + ((long)n * T + tap) * Cw + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = ct * 32 + ty + 8 * i, n = nt * 32 + tx;
+    if (n < Nw && c < Cw) dst[off + ((long)c * T + tap) * Nw + n] = tile[tx][ty + 8 * i];
+  }
+}
+}  // namespace
+
+extern "C" int lgm_transpose_weights(const float* src, float* dst, const int32_t* table, int n_layers,
+                                     int total_blocks, void* stream) {
+  LGM_REQUIRE(src && dst && table && n_layers > 0 && total_blocks > 0, "transpose_weights: bad arguments");
+  hipLaunchKernelGGL(transpose_weights_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, src, dst, table,
+                     n_layers);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
 extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
-                           const float* bias, const float* res, int64_t res_pitch, float* x,
+                           const float* w_t, const float* bias, const float* res, int64_t res_pitch, float* x,
                            int64_t x_pitch, void* workspace, int64_t workspace_bytes, void* stream) {
   if (int rc = check_geom(g)) return rc;
   LGM_REQUIRE(x && w && y, "conv_yx: null pointer");
@@ -348,8 +393,8 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
               "conv_yx: y/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(x_pitch >= g->Cw && (!res || res_pitch >= g->Cw), "conv_yx: output pitch < Cw");
   if (use_3x3() && lgm_conv3x3_supported(g, g->Nw, g->Cw))
-    return lgm_conv3x3_launch(1, g, y, y_pitch, w, bias, res, res_pitch, x, x_pitch, workspace, workspace_bytes,
-                              (hipStream_t)stream);
+    return lgm_conv3x3_launch(w_t ? 2 : 1, g, y, y_pitch, w_t ? w_t : w, bias, res, res_pitch, x, x_pitch, workspace,
+                              workspace_bytes, (hipStream_t)stream);
   IgemmArgs a{};
   a.a = y; a.w = w; a.bias = bias; a.res = res; a.out = x;
   a.a_pitch = y_pitch; a.res_pitch = res_pitch; a.out_pitch = x_pitch;

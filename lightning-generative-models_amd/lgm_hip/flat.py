@@ -85,6 +85,34 @@ class FlatParams:
             s.param._lgm_flat = self           # noqa: back-reference used by FusedAdam / EMA
             self.by_param[id(s.param)] = s
         self._grad_views_bound = False
+        self.data_t = None          # transposed copies of the weight slots (see refresh_transposed)
+        self._t_table = None
+
+    # -- transposed weights (input-gradient kernels read [Cw][T][Nw]) ---------------------------
+    def refresh_transposed(self):
+        """One launch: rewrite every conv/linear weight slot as [Cw][T][Nw] into ``data_t`` (same offsets)."""
+        from . import ops
+        if self._t_table is None:
+            rows, blk = [], 0
+            for s in self.slots:
+                if s.kind != "weight":
+                    continue
+                Np, T, Cp = s.phys_shape
+                rows.append([s.offset, Np, T, Cp, blk])
+                blk += ((Np + 31) // 32) * ((Cp + 31) // 32) * T
+            if not rows:
+                return
+            assert self.total < 2 ** 31
+            self._t_table = torch.tensor(rows, dtype=torch.int32, device=self.device).contiguous()
+            self._t_blocks = blk
+            self.data_t = torch.zeros_like(self.data)
+        ops.lib().lgm_transpose_weights(self.data.data_ptr(), self.data_t.data_ptr(), self._t_table.data_ptr(),
+                                        self._t_table.shape[0], self._t_blocks, ops.stream())
+
+    def tptr(self, p: nn.Parameter):
+        if self.data_t is None:
+            return None
+        return self.data_t.data_ptr() + 4 * self.by_param[id(p)].offset
 
     # -- pointers --------------------------------------------------------------------------
     def ptr(self, p: nn.Parameter) -> int:

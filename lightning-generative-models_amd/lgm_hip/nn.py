@@ -26,10 +26,12 @@ class GradCtx:
     """Per-backward bookkeeping: beta for the first gradient write of every parameter
     (0 = overwrite, 1 = accumulate), 1 afterwards (a parameter used twice in one pass)."""
 
-    def __init__(self, flat: FlatParams):
+    def __init__(self, flat: FlatParams, transposed: bool = True):
         self.flat = flat
         self.beta0 = flat.begin_backward()
         self.written = set()
+        if transposed:
+            flat.refresh_transposed()      # one launch per backward pass
 
     def beta(self, p: nn.Parameter) -> float:
         k = id(p)
@@ -101,7 +103,7 @@ class Conv2d(nn.Module):
         if accumulate:
             assert res is None
             res = gx
-        ops.conv_yx(g, gy, fp.ptr(self.weight), None, res, gx)
+        ops.conv_yx(g, gy, fp.ptr(self.weight), None, res, gx, fp.tptr(self.weight))
         return gx
 
 

@@ -133,11 +133,11 @@ def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
         TIMER.end()
 
 
-def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x):
+def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr: Optional[int] = None):
     if TIMER is not None:
         TIMER.begin("igemm_yx", _conv_flops(g))
     ws = _conv_ws(g, 1, y.device)
-    lib().lgm_conv_yx(ctypes.byref(g), y.data_ptr(), pitch(y), w_ptr, bias_ptr, _p(res),
+    lib().lgm_conv_yx(ctypes.byref(g), y.data_ptr(), pitch(y), w_ptr, wt_ptr, bias_ptr, _p(res),
                       pitch(res) if res is not None else 0, x.data_ptr(), pitch(x),
                       None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
     if TIMER is not None:

@@ -103,6 +103,15 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     gxd = torch.empty(B, H, W, Cp, device=dev)
     ops.conv_yx(geom, gyd, wd.data_ptr(), None, None, gxd)
     assert rel(nchw(gxd, Cin), x.grad) < RTOL
+    # input gradient again through the transposed-weight path ([Cw][T][Nw] copy made by one batched launch)
+    wt = torch.zeros_like(wd)
+    tbl = torch.tensor([[0, Np, k * k, Cp, 0]], dtype=torch.int32, device=dev)
+    ops.lib().lgm_transpose_weights(wd.data_ptr(), wt.data_ptr(), tbl.data_ptr(), 1,
+                                    ((Np + 31) // 32) * ((Cp + 31) // 32) * k * k, ops.stream())
+    assert torch.equal(wt.view(Cp, k * k, Np), wd.permute(2, 1, 0).contiguous())
+    gxt = torch.empty(B, H, W, Cp, device=dev)
+    ops.conv_yx(geom, gyd, wd.data_ptr(), None, None, gxt, wt.data_ptr())
+    assert rel(nchw(gxt, Cin), x.grad) < RTOL
     # weight gradient (+ accumulate with beta = 1) and bias gradient
     gw = torch.zeros_like(wd)
     ops.conv_wgrad(geom, gyd, xd, gw.data_ptr(), 0.0)
