@@ -28,6 +28,11 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
                         float* out, float* bias_out, float beta, long slab, int splits, int tps, int total_ts,
                         hipStream_t s);
 
+// short-reduction 1x1 convolutions with a resident activation tile (gemm_rows.hip)
+bool lgm_gemm_rows_supported(long M, int N, int K);
+int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const float* bias, const float* res,
+                         long res_pitch, float* out, long out_pitch, long M, int N, int K, hipStream_t s);
+
 static bool use_3x3() {   // LGM_NO_3X3=1 forces the generic implicit-GEMM path (A/B comparisons)
   static int v = -1;
   if (v < 0) {
@@ -329,6 +334,10 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
   if (use_3x3() && lgm_conv3x3_supported(g, g->Cw, g->Nw))
     return lgm_conv3x3_launch(0, g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, workspace, workspace_bytes,
                               (hipStream_t)stream);
+  if (use_3x3() && g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 &&
+      lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Nw, g->Cw))
+    return lgm_gemm_rows_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch, (long)g->B * g->H * g->W, g->Nw, g->Cw,
+                                (hipStream_t)stream);
   IgemmArgs a{};
   a.a = x; a.w = w; a.bias = bias; a.res = res; a.out = y;
   a.a_pitch = x_pitch; a.res_pitch = res_pitch; a.out_pitch = y_pitch;
@@ -395,6 +404,10 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
   if (use_3x3() && lgm_conv3x3_supported(g, g->Nw, g->Cw))
     return lgm_conv3x3_launch(w_t ? 2 : 1, g, y, y_pitch, w_t ? w_t : w, bias, res, res_pitch, x, x_pitch, workspace,
                               workspace_bytes, (hipStream_t)stream);
+  if (use_3x3() && w_t && g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 &&
+      lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Cw, g->Nw))
+    return lgm_gemm_rows_launch(y, y_pitch, w_t, bias, res, res_pitch, x, x_pitch, (long)g->B * g->H * g->W, g->Cw, g->Nw,
+                                (hipStream_t)stream);
   IgemmArgs a{};
   a.a = y; a.w = w; a.bias = bias; a.res = res; a.out = x;
   a.a_pitch = y_pitch; a.res_pitch = res_pitch; a.out_pitch = x_pitch;

@@ -74,6 +74,8 @@ CONV_CASES = [
     (1, 64, 64, 64, 64, 3, 1, 1),     # 3x3 patch kernel: 64x64 images (two column tiles)
     (5, 8, 8, 96, 64, 3, 1, 1),       # 3x3 patch kernel with 32-channel chunks (C % 64 != 0)
     (3, 32, 32, 128, 64, 3, 1, 1),    # 3x3 patch kernel, two channel chunks
+    (13, 32, 32, 64, 384, 1, 1, 0),   # resident-tile 1x1 kernel (to_qkv shape), 128-row tiles, ragged M
+    (50, 16, 16, 384, 128, 1, 1, 0),  # resident-tile 1x1 kernel, 64-row tiles (K = 384)
 ]
 
 
