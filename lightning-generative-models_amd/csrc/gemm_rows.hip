@@ -1,10 +1,11 @@
-// 1x1 convolution / linear layers with a short reduction (K <= 608):  Y[M,N] = X[M,K] W[N,K]^T (+bias,+res)
+// 1x1 convolution / linear layers with a short reduction (K <= 256):  Y[M,N] = X[M,K] W[N,K]^T (+bias,+res)
 //
 // With K this small a tile-per-block GEMM is all prologue and epilogue.  Here a workgroup keeps a
-// BM-row tile of X resident in LDS (loaded once, full K) and loops over ALL 64-column output tiles:
-// per tile K/32 chunks of MFMAs whose weight fragments every lane streams straight from global
-// memory (the whole weight matrix is <= a few hundred KB and L1/L2 resident), one chunk ahead,
-// across tile boundaries — no barrier after the initial one.  X is read from HBM exactly once.
+// BM-row tile of X resident in LDS (loaded once, full K) and walks over ALL output columns in
+// groups whose weight rows are staged in LDS as well.  Inside a group the loop issues NO global
+// loads — only ds_read_b128 + MFMA + the epilogue's stores — so the (in-order) vector-memory queue
+// never makes an MFMA wait for a store to drain; stores of tile t overlap the MFMAs of tile t+1.
+// X is read from HBM exactly once.  LDS is sized for two workgroups per CU where K allows it.
 // Used for to_qkv / to_out / res_conv / Downsample convs (ddpm.py:103,187,213,215,252,253) forward,
 // and for their input gradients through the transposed weight copy.
 #include "lgm_common.h"
@@ -19,13 +20,16 @@ struct RArgs {
   float* out;         // [M, N]
   long x_pitch, res_pitch, out_pitch;
   int M, N, K;
+  int wcols;          // weight rows (output columns) staged per group, multiple of 64
 };
 
 template <int TM>   // BM = 64 * TM rows per workgroup; waves 2 (m) x 2 (n), wave tile (32*TM) x 32
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const RArgs p) {
   constexpr int BM = 64 * TM;
-  extern __shared__ __align__(16) float Xs[];
-  const int LDX = p.K + 4;
+  extern __shared__ __align__(16) float smem[];
+  const int LD = p.K + 4;
+  float* Xs = smem;
+  float* Ws = smem + BM * LD;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -33,65 +37,62 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const RArgs p) {
   const int m0 = blockIdx.x * BM;
   const int k4 = p.K / 4;
 
-  // ---- stage the X tile (8 loads in flight per thread) ----
-  const int total = BM * k4;
-  for (int base = tid; base < total; base += 256 * 8) {
-    f32x4 v[8];
+  auto stage = [&](float* dst, const float* src, long src_pitch, int row0, int nrows, int row_limit) {
+    const int total = nrows * k4;
+    for (int base = tid; base < total; base += 256 * 8) {
+      f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * 256;
-      const int row = idx / k4, c4 = idx - row * k4;
-      const bool ok = idx < total && (m0 + row) < p.M;
-      v[u] = ok ? *reinterpret_cast<const f32x4*>(p.x + (long)(m0 + row) * p.x_pitch + c4 * 4)
-                : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * 256;
-      if (idx < total) {
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256;
         const int row = idx / k4, c4 = idx - row * k4;
-        *reinterpret_cast<f32x4*>(Xs + row * LDX + c4 * 4) = v[u];
+        const bool ok = idx < total && (row0 + row) < row_limit;
+        v[u] = ok ? *reinterpret_cast<const f32x4*>(src + (long)(row0 + row) * src_pitch + c4 * 4)
+                  : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256;
+        if (idx < total) {
+          const int row = idx / k4, c4 = idx - row * k4;
+          *reinterpret_cast<f32x4*>(dst + row * LD + c4 * 4) = v[u];
+        }
       }
     }
-  }
-
-  const int KQ = p.K / 32;
-  const int NT = p.N / 64;
-  const int nit = NT * KQ;
-  const float* wbase = p.w + (long)(wn * 32 + lr) * p.K + lh * 4;
-  auto load_b = [&](int it, f32x4 (&fb)[4]) {
-    const int nt = it / KQ, q = it - nt * KQ;
-    const float* src = wbase + (long)nt * 64 * p.K + q * 32;
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) fb[kc] = *reinterpret_cast<const f32x4*>(src + kc * 8);
   };
-  f32x4 cb[4], nb[4];
-  load_b(0, cb);
-  __syncthreads();
 
-  const float* a_base = Xs + (wm * 32 * TM + lr) * LDX + lh * 4;
-  f32x16 acc[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  stage(Xs, p.x, p.x_pitch, m0, BM, p.M);
+  const int KQ = p.K / 32;
+  const float* a_base = Xs + (wm * 32 * TM + lr) * LD + lh * 4;
+  const float* b_lane = Ws + (wn * 32 + lr) * LD + lh * 4;
 
-  for (int it = 0; it < nit; ++it) {
-    const int nt = it / KQ, q = it - nt * KQ;
-    if (it + 1 < nit) load_b(it + 1, nb);
+  for (int g0 = 0; g0 < p.N; g0 += p.wcols) {
+    const int gcols = min(p.wcols, p.N - g0);
+    if (g0 > 0) __syncthreads();          // previous group's weight rows fully consumed
+    stage(Ws, p.w, p.K, g0, gcols, p.N);
+    __syncthreads();
+    for (int nt = 0; nt < gcols / 64; ++nt) {
+      f32x16 acc[TM];
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      f32x4 fa[TM];
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LDX + q * 32 + kc * 8);
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      const float* bp = b_lane + nt * 64 * LD;
+      for (int q = 0; q < KQ; ++q) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int kc = 0; kc < 4; ++kc) {
+          f32x4 fa[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], cb[kc][s], acc[i], 0, 0, 0);
-    }
-    if (q == KQ - 1) {   // tile finished: epilogue, then reset the accumulators
-      const int n = nt * 64 + wn * 32 + lr;
+          for (int i = 0; i < TM; ++i)
+            fa[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LD + q * 32 + kc * 8);
+          const f32x4 fb = *reinterpret_cast<const f32x4*>(bp + q * 32 + kc * 8);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[s], acc[i], 0, 0, 0);
+        }
+      }
+      const int n = g0 + nt * 64 + wn * 32 + lr;
       const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -110,23 +111,33 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const RArgs p) {
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m < p.M) p.out[(long)m * p.out_pitch + n] = acc[i][r] + bv + rv[r];
-          acc[i][r] = 0.f;
         }
       }
     }
-    if (it + 1 < nit) {
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) cb[kc] = nb[kc];
-    }
   }
+}
+
+// LDS plan: rows per workgroup and weight columns per group
+void plan(int N, int K, int* bm, int* wcols, size_t* smem) {
+  const long row = (long)(K + 4) * 4;
+  *bm = K <= 64 ? 128 : 64;
+  const long xs = (long)*bm * row;
+  long budget = 78 * 1024;                       // two workgroups per CU
+  if (xs + 64 * row > budget) budget = 150 * 1024;
+  long cols = (budget - xs) / (64 * row) * 64;
+  if (cols > N) cols = N;
+  *wcols = (int)cols;
+  *smem = (size_t)(xs + cols * row);
 }
 
 }  // namespace
 
 bool lgm_gemm_rows_supported(long M, int N, int K) {
-  if (K % 32 != 0 || N % 64 != 0 || K > 608) return false;
-  const int bm = (long)(K + 4) * 128 * 4 <= 140 * 1024 ? 128 : 64;
-  return M / bm >= 96;   // enough row tiles to fill the chip; tiny M stays on the generic path
+  if (K % 32 != 0 || N % 64 != 0 || K > 256) return false;
+  int bm, wcols;
+  size_t smem;
+  plan(N, K, &bm, &wcols, &smem);
+  return wcols >= 64 && M / bm >= 96;   // enough row tiles to fill the chip; tiny M stays on the generic path
 }
 
 int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const float* bias, const float* res,
@@ -135,11 +146,11 @@ int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const flo
   p.x = x; p.w = w; p.bias = bias; p.res = res; p.out = out;
   p.x_pitch = x_pitch; p.res_pitch = res_pitch; p.out_pitch = out_pitch;
   p.M = (int)M; p.N = N; p.K = K;
-  const bool big = (long)(K + 4) * 128 * 4 <= 140 * 1024;
-  const int bm = big ? 128 : 64;
-  const size_t smem = (size_t)bm * (K + 4) * sizeof(float);
+  int bm;
+  size_t smem;
+  plan(N, K, &bm, &p.wcols, &smem);
   const unsigned nblocks = (unsigned)lgm_cdiv(M, bm);
-  if (big) {
+  if (bm == 128) {
     static size_t attr = 0;
     if (smem > attr) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -75,11 +75,15 @@ def main():
         y = torch.randn(B, hw, hw, co, device=dev)
         w = torch.randn(co, k * k, ci, device=dev) * 0.05
         gw = torch.zeros_like(w)
+        wt = torch.zeros_like(w)       # [Cw][T][Nw] copy, as FlatParams.refresh_transposed() maintains it
+        tbl = torch.tensor([[0, co, k * k, ci, 0]], dtype=torch.int32, device=dev)
+        ops.lib().lgm_transpose_weights(w.data_ptr(), wt.data_ptr(), tbl.data_ptr(), 1,
+                                        ((co + 31) // 32) * ((ci + 31) // 32) * k * k, ops.stream())
         gb = torch.zeros(co, device=dev)
         gx = torch.empty_like(x)
         fl = 2.0 * B * hw * hw * ci * co * k * k
         t_xy = timeit(lambda: ops.conv_xy(g, x, w.data_ptr(), gb.data_ptr(), None, y))
-        t_yx = timeit(lambda: ops.conv_yx(g, y, w.data_ptr(), None, None, gx))
+        t_yx = timeit(lambda: ops.conv_yx(g, y, w.data_ptr(), None, None, gx, wt.data_ptr()))
         t_wg = timeit(lambda: ops.conv_wgrad(g, y, x, gw.data_ptr(), 0.0, gb.data_ptr()))
         for key, t in (("xy", t_xy), ("yx", t_yx), ("wg", t_wg)):
             tot[key][0] += cnt * t
