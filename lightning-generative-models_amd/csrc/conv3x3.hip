@@ -213,43 +213,35 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
     }
   }
 
-  // ---- epilogue ----
-  const int n = n0 + wn * 32 + lr;
-  if (p.splits > 1) {   // split-K partial: plain store into this split's slab; bias/res added by the reducer
-    float* ws = p.ws + (long)split * p.ws_stride;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rt = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int img = rt >> p.lgTT, rr = rt & ((1 << p.lgTT) - 1);
-        const int oh = h0 + (rr >> p.lgTW), ow = w0 + (rr & (p.TW - 1)), b = b0 + img;
-        if (b < p.B && oh < p.H && ow < p.W) ws[(long)((b * p.H + oh) * p.W + ow) * p.N + n] = acc[i][r];
-      }
-    return;
+  // ---- epilogue: wave-private LDS transpose (the patch is dead by now), then 16-byte stores ----
+  __syncthreads();                                   // every wave has finished reading the patch
+  float* Ts = smem + wid * LGM_TS_FLOATS;
+  const int nc = n0 + wn * 32 + (lane & 7) * 4;
+  float* dst = p.out;
+  long dpitch = p.out_pitch;
+  const bool partial = p.splits > 1;                 // split-K: plain partial sums, reducer adds bias / res
+  if (partial) {
+    dst = p.ws + (long)split * p.ws_stride;
+    dpitch = p.N;
   }
-  const float bv = p.bias ? p.bias[n] : 0.f;
+  const f32x4 bv = (!partial && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    long mrow[16];
+    lgm_wave_lds_sync();
+    lgm_tile_to_lds(acc[i], Ts, lane);
+    lgm_wave_lds_sync();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rt = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    for (int j = 0; j < 4; ++j) {
+      const int rt = wm * 64 + i * 32 + (lane >> 3) + 8 * j;
       const int img = rt >> p.lgTT, rr = rt & ((1 << p.lgTT) - 1);
       const int oh = h0 + (rr >> p.lgTW), ow = w0 + (rr & (p.TW - 1)), b = b0 + img;
-      mrow[r] = (b < p.B && oh < p.H && ow < p.W) ? (long)((b * p.H + oh) * p.W + ow) : -1L;
+      if (b < p.B && oh < p.H && ow < p.W) {
+        const long m = (long)((b * p.H + oh) * p.W + ow);
+        f32x4 v = lgm_tile_row4(Ts, lane, j) + bv;
+        if (!partial && p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.res_pitch + nc);
+        *reinterpret_cast<f32x4*>(dst + m * dpitch + nc) = v;
+      }
     }
-    float rv[16];
-    if (p.res) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rv[r] = mrow[r] >= 0 ? p.res[mrow[r] * p.res_pitch + n] : 0.f;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (mrow[r] >= 0) p.out[mrow[r] * p.out_pitch + n] = acc[i][r] + bv + rv[r];
   }
 }
 

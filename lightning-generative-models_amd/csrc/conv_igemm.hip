@@ -33,6 +33,12 @@ bool lgm_gemm_rows_supported(long M, int N, int K);
 int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const float* bias, const float* res,
                          long res_pitch, float* out, long out_pitch, long M, int N, int K, hipStream_t s);
 
+// the specialised kernels store 16 bytes per lane: outputs / residual / bias must allow it
+static bool wide_ok(const float* out, long out_pitch, const float* res, long res_pitch, const float* bias) {
+  return lgm_aligned16(out) && out_pitch % 4 == 0 && (!res || (lgm_aligned16(res) && res_pitch % 4 == 0)) &&
+         (!bias || lgm_aligned16(bias));
+}
+
 static bool use_3x3() {   // LGM_NO_3X3=1 forces the generic implicit-GEMM path (A/B comparisons)
   static int v = -1;
   if (v < 0) {
@@ -331,11 +337,11 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
   LGM_REQUIRE(x_pitch % 4 == 0 && x_pitch >= g->Cw && lgm_aligned16(x) && lgm_aligned16(w),
               "conv_xy: x/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(y_pitch >= g->Nw && (!res || res_pitch >= g->Nw), "conv_xy: output pitch < Nw");
-  if (use_3x3() && lgm_conv3x3_supported(g, g->Cw, g->Nw))
+  if (use_3x3() && wide_ok(y, y_pitch, res, res_pitch, bias) && lgm_conv3x3_supported(g, g->Cw, g->Nw))
     return lgm_conv3x3_launch(0, g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, workspace, workspace_bytes,
                               (hipStream_t)stream);
-  if (use_3x3() && g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 &&
-      lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Nw, g->Cw))
+  if (use_3x3() && wide_ok(y, y_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 && g->stride == 1 &&
+      g->pad == 0 && lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Nw, g->Cw))
     return lgm_gemm_rows_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch, (long)g->B * g->H * g->W, g->Nw, g->Cw,
                                 (hipStream_t)stream);
   IgemmArgs a{};
@@ -401,11 +407,11 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
   LGM_REQUIRE(y_pitch % 4 == 0 && y_pitch >= g->Nw && lgm_aligned16(y) && lgm_aligned16(w),
               "conv_yx: y/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(x_pitch >= g->Cw && (!res || res_pitch >= g->Cw), "conv_yx: output pitch < Cw");
-  if (use_3x3() && lgm_conv3x3_supported(g, g->Nw, g->Cw))
+  if (use_3x3() && wide_ok(x, x_pitch, res, res_pitch, bias) && lgm_conv3x3_supported(g, g->Nw, g->Cw))
     return lgm_conv3x3_launch(w_t ? 2 : 1, g, y, y_pitch, w_t ? w_t : w, bias, res, res_pitch, x, x_pitch, workspace,
                               workspace_bytes, (hipStream_t)stream);
-  if (use_3x3() && w_t && g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 &&
-      lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Cw, g->Nw))
+  if (use_3x3() && w_t && wide_ok(x, x_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 && g->stride == 1 &&
+      g->pad == 0 && lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Cw, g->Nw))
     return lgm_gemm_rows_launch(y, y_pitch, w_t, bias, res, res_pitch, x, x_pitch, (long)g->B * g->H * g->W, g->Cw, g->Nw,
                                 (hipStream_t)stream);
   IgemmArgs a{};

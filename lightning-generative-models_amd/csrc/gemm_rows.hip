@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const RArgs p) {
   const int LD = p.K + 4;
   float* Xs = smem;
   float* Ws = smem + BM * LD;
+  float* Ts = smem + BM * LD + p.wcols * LD + (threadIdx.x >> 6) * LGM_TS_FLOATS;   // wave-private
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -92,25 +93,22 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const RArgs p) {
               acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[s], acc[i], 0, 0, 0);
         }
       }
-      const int n = g0 + nt * 64 + wn * 32 + lr;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+      // ---- epilogue: wave-private LDS transpose, then 16-byte stores (8 full rows per instruction)
+      const int nc = g0 + nt * 64 + wn * 32 + (lane & 7) * 4;
+      const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        float rv[16];
-        if (p.res) {
+        lgm_wave_lds_sync();                 // earlier read-back of this scratch is complete
+        lgm_tile_to_lds(acc[i], Ts, lane);
+        lgm_wave_lds_sync();
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            rv[r] = m < p.M ? p.res[(long)m * p.res_pitch + n] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const int m = m0 + wm * 32 * TM + i * 32 + (lane >> 3) + 8 * j;
+          if (m < p.M) {
+            f32x4 v = lgm_tile_row4(Ts, lane, j) + bv;
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (long)m * p.res_pitch + nc);
+            *reinterpret_cast<f32x4*>(p.out + (long)m * p.out_pitch + nc) = v;
           }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < p.M) p.out[(long)m * p.out_pitch + n] = acc[i][r] + bv + rv[r];
         }
       }
     }
@@ -121,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const RArgs p) {
 void plan(int N, int K, int* bm, int* wcols, size_t* smem) {
   const long row = (long)(K + 4) * 4;
   *bm = K <= 64 ? 128 : 64;
-  const long xs = (long)*bm * row;
+  const long xs = (long)*bm * row + 4L * LGM_TS_FLOATS * 4;   // X tile + the four epilogue scratches
   long budget = 78 * 1024;                       // two workgroups per CU
   if (xs + 64 * row > budget) budget = 150 * 1024;
   long cols = (budget - xs) / (64 * row) * 64;

@@ -46,6 +46,32 @@ __device__ __forceinline__ float lgm_wave_max(float v) {
   return v;
 }
 
+// ---- wide epilogue stores for 32x32 MFMA accumulator tiles ------------------------------------
+// The C/D layout puts one output COLUMN on a lane (16 rows in registers), so a direct epilogue is 16
+// dword stores per lane, and 4-byte stores are issue-bound (~2 TB/s chip-wide measured).  Routing the
+// tile through a wave-private LDS scratch (32 rows x LGM_TS_LD floats) lets every lane store 16
+// contiguous bytes: 4 store instructions per tile, each covering 8 full 128-byte rows.
+constexpr int LGM_TS_LD = 36;
+constexpr int LGM_TS_FLOATS = 32 * LGM_TS_LD;
+
+__device__ __forceinline__ void lgm_wave_lds_sync() {
+  // orders this wave's LDS writes before its later LDS reads (other lanes' data); no s_barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// acc -> Ts (transposed staging).  lane = threadIdx & 63.
+__device__ __forceinline__ void lgm_tile_to_lds(const f32x16& acc, float* Ts, int lane) {
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Ts[((r & 3) + 8 * (r >> 2) + 4 * lh) * LGM_TS_LD + lr] = acc[r];
+}
+// row j-th pass of the read-back: lane reads 4 consecutive columns of tile row (lane>>3) + 8*j
+__device__ __forceinline__ f32x4 lgm_tile_row4(const float* Ts, int lane, int j) {
+  return *reinterpret_cast<const f32x4*>(Ts + ((lane >> 3) + 8 * j) * LGM_TS_LD + (lane & 7) * 4);
+}
+
 // block-wide sum for blockDim.x <= 1024 (multiple of 64); `sh` needs 16 floats.
 // Deterministic: fixed shuffle tree + fixed-order combine.
 __device__ __forceinline__ float lgm_block_sum(float v, float* sh) {
