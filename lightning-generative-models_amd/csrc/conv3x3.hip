@@ -443,7 +443,7 @@ int lgm_conv3x3_splits(const LgmConvGeom* g, int gather_channels, int out_channe
   if (base >= 400) return 1;
   const int ck = gather_channels % 64 == 0 ? 64 : 32;
   const int nq = (gather_channels / ck) * 9 * (ck / BK);
-  long s = (512 + base - 1) / base;
+  long s = 512 / base;               // two workgroups per CU: stay within 512 resident workgroups
   if (s > nq / 6) s = nq / 6;        // at least 6 chunks (192 k) per split
   if (s > 8) s = 8;
   return s < 1 ? 1 : (int)s;
@@ -522,7 +522,8 @@ void lgm_wgrad3x3_plan(const LgmConvGeom* g, int* splits, int* tps, int* total_t
   plan_tile(g->H, g->W, &TH, &TW, &NI);
   const int total = lgm_cdiv(g->B, NI) * (g->H / TH) * (g->W / TW);
   const long tiles = (long)(g->Nw / 64) * (g->Cw / 64);
-  long s = (256 + tiles - 1) / tiles;     // ~one workgroup per CU (LDS allows one resident block)
+  // LDS allows ONE resident workgroup per CU: never exceed 256 workgroups (a 257th would run alone)
+  long s = 256 / tiles;
   if (s > total) s = total;
   if (s < 1) s = 1;
   const int t = lgm_cdiv(total, s);

@@ -430,7 +430,7 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
 // =====================================================================================
 namespace {
 
-constexpr int WBK = 16;  // pixels per chunk
+constexpr int WBK = 64;  // pixels per chunk (32 MFMAs per wave between barriers)
 
 struct WgradArgs {
   const float* y;  // [P, Nw] rows

@@ -131,7 +131,7 @@ void plan(int N, int K, int* bm, int* wcols, size_t* smem) {
 }  // namespace
 
 bool lgm_gemm_rows_supported(long M, int N, int K) {
-  if (K % 32 != 0 || N % 64 != 0 || K > 256) return false;
+  if (K % 32 != 0 || N % 64 != 0 || N < 128 || K > 256) return false;   // N >= 128: the X tile is reused
   int bm, wcols;
   size_t smem;
   plan(N, K, &bm, &wcols, &smem);
