@@ -443,9 +443,21 @@ int lgm_conv3x3_splits(const LgmConvGeom* g, int gather_channels, int out_channe
   if (base >= 400) return 1;
   const int ck = gather_channels % 64 == 0 ? 64 : 32;
   const int nq = (gather_channels / ck) * 9 * (ck / BK);
-  long s = 512 / base;               // two workgroups per CU: stay within 512 resident workgroups
-  if (s > nq / 6) s = nq / 6;        // at least 6 chunks (192 k) per split
-  if (s > 8) s = 8;
+  // Two workgroups fit on a CU (512 resident).  Time ~ rounds(base*s) / s: pick the split that
+  // minimises it, with a small penalty per split for the partial-sum traffic.
+  long smax = nq / 6;                 // at least 6 chunks (192 k) per split
+  if (smax > 8) smax = 8;
+  if (smax < 1) smax = 1;
+  long s = 1;
+  double best = 1e30;
+  for (long c = 1; c <= smax; ++c) {
+    const double rounds = (double)((base * c + 511) / 512);
+    const double cost = rounds / (double)c + 0.02 * (double)(c - 1);
+    if (cost < best - 1e-9) {
+      best = cost;
+      s = c;
+    }
+  }
   return s < 1 ? 1 : (int)s;
 }
 
