@@ -520,6 +520,15 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
   return LGM_OK;
 }
 
+int lgm_splitk_reduce_launch(const float* ws, long ws_stride, int splits, const float* bias, const float* res,
+                             long res_pitch, float* out, long out_pitch, long M, int N, hipStream_t s) {
+  const long items = M * (N / 4);
+  hipLaunchKernelGGL(lgm3x3::splitk_reduce_kernel, dim3((unsigned)lgm_cdiv(items, 256)), dim3(256), 0, s, ws, ws_stride,
+                     splits, bias, res, res_pitch, out, out_pitch, M, N);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
 bool lgm_wgrad3x3_supported(const LgmConvGeom* g) {
   using namespace lgm3x3;
   int TH, TW, NI;

@@ -19,6 +19,8 @@
 // specialised 3x3 / stride 1 / pad 1 kernels (conv3x3.hip)
 bool lgm_conv3x3_supported(const LgmConvGeom* g, int gather_channels, int out_channels);
 int lgm_conv3x3_splits(const LgmConvGeom* g, int gather_channels, int out_channels);
+int lgm_splitk_reduce_launch(const float* ws, long ws_stride, int splits, const float* bias, const float* res,
+                             long res_pitch, float* out, long out_pitch, long M, int N, hipStream_t s);
 int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pitch, const float* w,
                        const float* bias, const float* res, long res_pitch, float* out, long out_pitch,
                        void* workspace, long workspace_bytes, hipStream_t s);
@@ -66,6 +68,8 @@ struct IgemmArgs {
   int M, N, K;        // GEMM sizes
   int Cg;             // channels of the gathered tensor (Cw for XY, Nw for YX)
   int tiles_m, tiles_n;
+  int splits, kchunk; // split-K: `splits` partial products over K ranges of kchunk (multiple of BK) ...
+  float* ws;          // ... written to ws[split][M][N], summed in fixed order by the reducer
 };
 
 template <int MODE, int BM, int BN, int TM, int TN>
@@ -86,8 +90,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   const int lr = lane & 31, lh = lane >> 5;
 
   // tile mapping: consecutive blocks walk N first (share the A tile through L2)
-  const int tile = blockIdx.x;
+  const int split = blockIdx.x % p.splits;
+  const int tile = blockIdx.x / p.splits;
   const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+  const int k_begin = split * p.kchunk;
+  const int k_end = min(p.K, k_begin + p.kchunk);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- per-thread A-row decode (fixed over the K loop) ---------------------------
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   auto load_chunk = [&](int k0) {
     // ---- A: one tap/channel decode per thread per chunk ----
     const int k = k0 + acol * 4;
-    const bool kok = k < p.K;
+    const bool kok = k < k_end;
     const int tap = kok ? k / p.Cg : 0;
     const int c = k - tap * p.Cg;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
         const int n = n0 + arow + 32 * i;
-        const bool ok = (n < p.N) && (kb < p.K);
+        const bool ok = (n < p.N) && (kb < k_end);
         rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.w + (long)n * p.K + kb)
                    : f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
         const int kk = k0 + krow + RPP * i;
-        const bool ok = (kk < p.K) && (n0 + ncol < p.N);
+        const bool ok = (kk < k_end) && (n0 + ncol < p.N);
         const int tp = ok ? kk / p.Cg : 0;
         const int nn = kk - tp * p.Cg;
         rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.w + ((long)nn * T + tp) * p.Cw + n0 + ncol)
@@ -202,14 +209,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_chunk(0);
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  load_chunk(k_begin);
   store_chunk(0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_chunk((kt + 1) * BK);
+    if (kt + 1 < nk) load_chunk(k_begin + (kt + 1) * BK);
 
     const float* as = As + cur * A_TILE + (wm * 32 * TM + lr) * LDA + lh * 4;
     const float* bs;
@@ -249,6 +256,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   }
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (p.splits > 1) {   // partial product -> workspace slab; bias/residual are added by the reducer
+    float* slab = p.ws + (long)split * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 32 * TN + j * 32 + lr;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M) slab[(long)m * p.N + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * 32 * TN + j * 32 + lr;
@@ -289,18 +312,44 @@ int launch_igemm(IgemmArgs& a, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), smem, s, a);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
 
+// Split-K plan of the generic path: a GEMM with few output tiles and a long reduction (the fused FiLM
+// projection's input gradient: M = batch, K = 4864) would otherwise run on a handful of CUs.
+int igemm_splits(long M, int N, int K, int* kchunk) {
+  const long tiles = (long)lgm_cdiv(M, 64) * lgm_cdiv(N, 64);
+  const int nk = lgm_cdiv(K, BK);
+  *kchunk = nk * BK;
+  if (tiles > 64 || N % 4 != 0) return 1;
+  long s = 256 / tiles;
+  if (s > nk / 4) s = nk / 4;
+  if (s < 2) return 1;
+  const int per = lgm_cdiv(nk, s);
+  *kchunk = per * BK;
+  return lgm_cdiv(nk, per);
+}
+
 template <int MODE>
-int dispatch_igemm(IgemmArgs& a, hipStream_t s) {
+int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool wide, hipStream_t s) {
   const long t128 = (long)lgm_cdiv(a.M, 128);
-  const long t64 = (long)lgm_cdiv(a.M, 64);
+  a.splits = 1;
+  a.kchunk = lgm_cdiv(a.K, BK) * BK;
+  a.ws = nullptr;
   if (a.N > 64 && t128 * lgm_cdiv(a.N, 128) >= 384) return launch_igemm<MODE, 128, 128, 2, 2>(a, s);
   if (t128 * lgm_cdiv(a.N, 64) >= 384) return launch_igemm<MODE, 128, 64, 2, 1>(a, s);
-  (void)t64;
+  int kchunk;
+  const int splits = igemm_splits(a.M, a.N, a.K, &kchunk);
+  if (splits > 1 && wide && workspace && workspace_bytes >= (int64_t)splits * a.M * a.N * (int64_t)sizeof(float)) {
+    a.splits = splits;
+    a.kchunk = kchunk;
+    a.ws = (float*)workspace;
+    if (int rc = launch_igemm<MODE, 64, 64, 1, 1>(a, s)) return rc;
+    return lgm_splitk_reduce_launch(a.ws, (long)a.M * a.N, splits, a.bias, a.res, a.res_pitch, a.out, a.out_pitch, a.M,
+                                    a.N, s);
+  }
   return launch_igemm<MODE, 64, 64, 1, 1>(a, s);
 }
 
@@ -323,7 +372,12 @@ int check_geom(const LgmConvGeom* g) {
 extern "C" int64_t lgm_conv_workspace(const LgmConvGeom* g, int yx) {
   if (check_geom(g) != LGM_OK) return -1;
   const int gc = yx ? g->Nw : g->Cw, oc = yx ? g->Cw : g->Nw;
-  if (!use_3x3() || !lgm_conv3x3_supported(g, gc, oc)) return 0;
+  if (!use_3x3() || !lgm_conv3x3_supported(g, gc, oc)) {
+    const long M = yx ? (long)g->B * g->H * g->W : (long)g->B * g->Ho * g->Wo;
+    int kchunk;
+    const int s = igemm_splits(M, oc, g->KH * g->KW * gc, &kchunk);
+    return s > 1 ? (int64_t)s * M * oc * (int64_t)sizeof(float) : 0;
+  }
   const int s = lgm_conv3x3_splits(g, gc, oc);
   return s > 1 ? (int64_t)s * g->B * g->H * g->W * oc * (int64_t)sizeof(float) : 0;
 }
@@ -350,7 +404,8 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
   a.B = g->B; a.H = g->H; a.W = g->W; a.Cw = g->Cw; a.Ho = g->Ho; a.Wo = g->Wo; a.Nw = g->Nw;
   a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
   a.M = g->B * g->Ho * g->Wo; a.N = g->Nw; a.K = g->KH * g->KW * g->Cw; a.Cg = g->Cw;
-  return dispatch_igemm<MODE_XY>(a, (hipStream_t)stream);
+  return dispatch_igemm<MODE_XY>(a, workspace, workspace_bytes, wide_ok(y, y_pitch, res, res_pitch, bias),
+                                 (hipStream_t)stream);
 }
 
 namespace {
@@ -420,7 +475,8 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
   a.B = g->B; a.H = g->H; a.W = g->W; a.Cw = g->Cw; a.Ho = g->Ho; a.Wo = g->Wo; a.Nw = g->Nw;
   a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
   a.M = g->B * g->H * g->W; a.N = g->Cw; a.K = g->KH * g->KW * g->Nw; a.Cg = g->Nw;
-  return dispatch_igemm<MODE_YX>(a, (hipStream_t)stream);
+  return dispatch_igemm<MODE_YX>(a, workspace, workspace_bytes, wide_ok(x, x_pitch, res, res_pitch, bias),
+                                 (hipStream_t)stream);
 }
 
 // =====================================================================================

@@ -220,13 +220,13 @@ __device__ __forceinline__ void gn_bwd_affine_body(int blk, const float* __restr
                                                    const float* __restrict__ S2, const float* __restrict__ ss,
                                                    long ss_pitch, int B, int C, float* __restrict__ ggamma,
                                                    float* __restrict__ gbeta, float beta_acc) {
-  // block = 64 channels x 4 batch lanes (fixed-order LDS combine => deterministic)
-  __shared__ float sg[4][64], sb[4][64];
-  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
-  const int c = blk * 64 + cl;
+  // block = 16 channels x 16 batch lanes (fixed-order LDS combine => deterministic)
+  __shared__ float sg[16][17], sb[16][17];
+  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  const int c = blk * 16 + cl;
   float gg = 0.f, gb = 0.f;
   if (c < C)
-    for (int b = bl; b < B; b += 4) {
+    for (int b = bl; b < B; b += 16) {
       const float sc = ss ? ss[(long)b * ss_pitch + c] + 1.f : 1.f;
       gg += sc * S2[(long)b * C + c];
       gb += sc * S1[(long)b * C + c];
@@ -235,8 +235,13 @@ __device__ __forceinline__ void gn_bwd_affine_body(int blk, const float* __restr
   sb[bl][cl] = gb;
   __syncthreads();
   if (bl == 0 && c < C) {
-    gg = (sg[0][cl] + sg[1][cl]) + (sg[2][cl] + sg[3][cl]);
-    gb = (sb[0][cl] + sb[1][cl]) + (sb[2][cl] + sb[3][cl]);
+    gg = 0.f;
+    gb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      gg += sg[i][cl];
+      gb += sb[i][cl];
+    }
     if (beta_acc != 0.f) {
       gg += beta_acc * ggamma[c];
       gb += beta_acc * gbeta[c];
@@ -257,12 +262,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ ss, long ss_pitch, int B,
                                                            float* __restrict__ ggamma, float* __restrict__ gbeta,
                                                            float affine_beta) {
-  if ((int)blockIdx.x >= apply_blocks) {   // trailing blocks: gamma/beta gradients, concurrent with the apply pass
-    gn_bwd_affine_body((int)blockIdx.x - apply_blocks, S1, S2, ss, ss_pitch, B, C, ggamma, gbeta, affine_beta);
+  const int affine_blocks = (int)gridDim.x - apply_blocks;
+  if ((int)blockIdx.x < affine_blocks) {   // leading blocks: gamma/beta gradients, concurrent with the apply pass
+    gn_bwd_affine_body((int)blockIdx.x, S1, S2, ss, ss_pitch, B, C, ggamma, gbeta, affine_beta);
     return;
   }
   const int c4n = C / 4;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = (long)((int)blockIdx.x - affine_blocks) * blockDim.x + threadIdx.x;
   if (i >= npix * c4n) return;
   const long pix = i / c4n;
   const int c = (int)(i % c4n) * 4;
@@ -339,7 +345,7 @@ extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int6
                      gss_beta, S1, S2, P, Qc, Rc);
   const long npix = (long)B * HW;
   const int apply_blocks = lgm_cdiv(npix * (C / 4), 256);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(apply_blocks + lgm_cdiv(C, 64)), dim3(256), 0, s, x, (long)x_pitch, gy,
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(apply_blocks + lgm_cdiv(C, 16)), dim3(256), 0, s, x, (long)x_pitch, gy,
                      (long)gy_pitch, coefA, coefB, P, Qc, Rc, gx, (long)gx_pitch, npix, HW, C, act, accumulate_gx,
                      apply_blocks, (const float*)S1, (const float*)S2, ss, (long)ss_pitch, B, ggamma, gbeta,
                      affine_beta);
