@@ -38,9 +38,11 @@ struct Args {
   int Wn;             // inner dim of the weight tensor (Cw)
   int TH, TW, NI, lgTW, lgTT;   // tile: TH x TW pixels of NI images; lgTT = log2(TH*TW)
   int tiles_h, tiles_w, tiles_n, NP;
-  int splits;         // split-K over the (channel chunk, tap) sequence; > 1 => partials to ws
+  int units, per;     // work units = tiles x splits x n-tiles; units per (persistent) workgroup
+  int splits, pps;    // split-K over whole phases (pps phases per split); > 1 => partials to ws
   float* ws;          // [splits][B*H*W][N]
   long ws_stride;
+  long long* dbg;     // optional per-workgroup timestamps (experiments)
 };
 
 // out[m][n] = sum_s ws[s][m][n] + bias[n] + res[m][n]   (fixed order => deterministic)
@@ -65,13 +67,25 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
   return (nb % 8 == 0) ? (bid % 8) * (nb / 8) + bid / 8 : bid;
 }
 
-template <int MODE, int CK>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
+// Persistent, software-pipelined workgroups.  A workgroup walks a contiguous range of UNITS
+// (spatial tile, split, n-tile); a unit is a sequence of PHASES, one per CK-channel chunk of the
+// reduction, each = one halo patch in LDS + U = 9 * CK/32 MFMA steps (tap, 32 k).  While phase i
+// computes, the patch of phase i+1 (next channel chunk, or the next unit's first chunk) is
+// fetched into registers ONE 16-byte load per step, so global latency hides behind the MFMAs and
+// the only exposed load is the first patch of the workgroup.  Weight fragments run one step ahead
+// across phase and unit boundaries as well.  The step body is branch-free (clamped addresses
+// instead of predicated loads) so that the compiler's s_waitcnt placement stays exact: the only
+// wait per step is "weights of the next step have landed", after all 32 MFMAs have been issued.
+// Split-K splits on whole phases.
+template <int MODE, int CK, int VAR = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const Args p) {
   constexpr int LDP = CK + 4;            // patch row stride (floats)
   constexpr int TPP = CK / 4;            // threads per patch position
   constexpr int PPP = 256 / TPP;         // positions per pass
-  constexpr int NJ = (288 + PPP - 1) / PPP;
   constexpr int KS = CK / BK;            // weight chunks per (chunk, tap)
+  constexpr int U = 9 * KS;              // MFMA steps per phase
+  constexpr int NJ = 288 / PPP;          // patch positions per thread (LDS holds all 288 positions)
+  static_assert(NJ == U, "one prefetch load per step");
   extern __shared__ __align__(16) float smem[];
   float* Ps = smem;
 
@@ -79,54 +93,55 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int lr = lane & 31, lh = lane >> 5;
+  float* Ts = smem + 288 * LDP + wid * LGM_TS_FLOATS;   // wave-private epilogue scratch (not aliased)
 
-  const int L = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int tn = L % p.tiles_n;
-  int ts = L / p.tiles_n;
-  const int split = ts % p.splits;
-  ts /= p.splits;
-  const int twi = ts % p.tiles_w;
-  ts /= p.tiles_w;
-  const int thi = ts % p.tiles_h;
-  const int b0 = (ts / p.tiles_h) * p.NI;
-  const int h0 = thi * p.TH, w0 = twi * p.TW;
-  const int n0 = tn * BN;
+  const int Lb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int L0 = Lb * p.per;
+  const int L1 = min(p.units, L0 + p.per);
+  if (L0 >= L1) return;
+  __builtin_amdgcn_s_setprio(3);
+  int nst = 0;
+  auto stamp = [&]() { if (p.dbg && tid == 0 && nst < 30) p.dbg[blockIdx.x * 32 + 2 + nst++] = wall_clock64(); };
+  stamp();
+
   const int PW = p.TW + 2, PP1 = (p.TH + 2) * PW;
+  const int ncc_total = p.C / CK;
 
-  // ---- patch loader bookkeeping: pixel index (or -1) of every position this thread fills ----
+  auto unit = [&](int L, int& n0, int& b0, int& h0, int& w0, int& split, int& cb_, int& ce_) {
+    n0 = (L % p.tiles_n) * BN;
+    int ts = L / p.tiles_n;
+    split = ts % p.splits;
+    ts /= p.splits;
+    w0 = (ts % p.tiles_w) * p.TW;
+    ts /= p.tiles_w;
+    h0 = (ts % p.tiles_h) * p.TH;
+    b0 = (ts / p.tiles_h) * p.NI;
+    cb_ = split * p.pps;
+    ce_ = min(ncc_total, cb_ + p.pps);
+  };
+
+  // ---- patch bookkeeping: 32-bit element offset (or ~0u = zero padding) of every position ----
   const int c4 = (tid % TPP) * 4;
-  int gpix[NJ];
+  unsigned gpix[NJ];
+  auto fill_gpix = [&](int b0, int h0, int w0) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int pos = tid / TPP + PPP * j;
-    int g = -1;
-    if (pos < p.NP) {
-      const int img = pos / PP1, rem = pos - img * PP1;
-      const int py = rem / PW, px = rem - py * PW;
-      const int ih = h0 + py - 1, iw = w0 + px - 1, b = b0 + img;
-      if (b < p.B && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) g = (b * p.H + ih) * p.W + iw;
-    }
-    gpix[j] = g;
-  }
-  auto load_patch = [&](int cc) {
-    const float* src = p.a + cc * CK + c4;
-#pragma unroll
-    for (int jj = 0; jj < NJ; jj += 6) {
-      f32x4 v[6];
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int j = jj + u;
-        if (j < NJ)
-          v[u] = (gpix[j] >= 0) ? *reinterpret_cast<const f32x4*>(src + (long)gpix[j] * p.a_pitch)
-                                : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) {
+      const int pos = tid / TPP + PPP * j;
+      unsigned g = ~0u;
+      if (pos < p.NP) {
+        const int img = pos / PP1, rem = pos - img * PP1;
+        const int py = rem / PW, px = rem - py * PW;
+        const int ih = h0 + py - 1, iw = w0 + px - 1, b = b0 + img;
+        if (b < p.B && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+          g = (unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.a_pitch + (unsigned)c4;
       }
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int j = jj + u;
-        const int pos = tid / TPP + PPP * j;
-        if (j < NJ && pos < p.NP) *reinterpret_cast<f32x4*>(Ps + pos * LDP + c4) = v[u];
-      }
+      gpix[j] = g;
     }
+  };
+  f32x4 rp[NJ];
+  auto fetch = [&](int j, const float* src) {   // unconditional load (padding reads element 0, zeroed at the LDS store)
+    const unsigned off = gpix[j] == ~0u ? 0u : gpix[j];
+    rp[j] = *reinterpret_cast<const f32x4*>(src + off);
   };
 
   // ---- A fragment bases (tile-local pixel -> patch position) ----
@@ -139,22 +154,23 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
     abase[i] = ((img * (p.TH + 2) + ph) * PW + pw) * LDP + lh * 4;
   }
 
-  // ---- weight fragments of chunk q = (cc, tap, ks): every lane fetches ITS OWN B operand values
-  // straight from global memory (the weight tile is tiny and L1/L2 resident), one chunk ahead.
-  // No LDS staging of weights => no barrier in the main loop: the four waves run decoupled.
+  // ---- weight fragments: every lane fetches ITS OWN B operand values straight from global memory
+  // (the weight tile is tiny and L1/L2 resident), one step ahead.  No LDS staging of weights =>
+  // no barrier inside a phase: the four waves run decoupled.
   constexpr bool KCONTIG = (MODE != MODE_YX);   // weight rows contiguous along the reduction index
   constexpr bool FLIP = (MODE != MODE_XY);      // input gradient: taps are mirrored
-  const float* wlane = KCONTIG ? p.w + (long)(n0 + wn * 32 + lr) * (9 * p.C) + lh * 4
-                               : p.w + (long)(lh * 4) * 9 * p.Wn + n0 + wn * 32 + lr;
-  auto load_b = [&](int q, f32x4 (&fb)[4]) {
-    const int ks = q % KS, t2 = q / KS;
-    const int tap = t2 % 9, cc = t2 / 9;
+  auto wbase = [&](int n0) {
+    return KCONTIG ? p.w + (long)(n0 + wn * 32 + lr) * (9 * p.C) + lh * 4
+                   : p.w + (long)(lh * 4) * 9 * p.Wn + n0 + wn * 32 + lr;
+  };
+  auto load_b = [&](const float* wl, int cc, int u, f32x4 (&fb)[4]) {
+    const int tap = u / KS, ks = u % KS;
     if (KCONTIG) {
-      const float* src = wlane + tap * p.C + cc * CK + ks * BK;
+      const float* src = wl + tap * p.C + cc * CK + ks * BK;
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) fb[kc] = *reinterpret_cast<const f32x4*>(src + kc * 8);
     } else {
-      const float* src = wlane + ((long)(cc * CK + ks * BK) * 9 + tap) * p.Wn;
+      const float* src = wl + ((long)(cc * CK + ks * BK) * 9 + tap) * p.Wn;
       const long kstride = (long)9 * p.Wn;
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc)
@@ -169,79 +185,151 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const Args p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  const int ncc = p.C / CK;
-  const int nq = ncc * 9 * KS;
-  const int cps = (nq + p.splits - 1) / p.splits;
-  const int q_begin = split * cps;
-  const int q_end = min(nq, q_begin + cps);
-
+  // ---- first phase of the workgroup: the one exposed patch load ----
+  int L = L0, n0, b0, h0, w0, split, cc, cc_end;
+  unit(L, n0, b0, h0, w0, split, cc, cc_end);
+  const float* wl = wbase(n0);
   f32x4 cb[4], nb[4];
-  if (q_begin < q_end) {
-    load_b(q_begin, cb);
-    load_patch((q_begin / KS) / 9);
+  load_b(wl, cc, 0, cb);
+  fill_gpix(b0, h0, w0);
+  {
+    const float* src = p.a + cc * CK;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fetch(j, src);
   }
-  __syncthreads();
 
-  for (int q = q_begin; q < q_end; ++q) {
-    const int ks = q % KS, t2 = q / KS;
-    const int tap = t2 % 9, cc = t2 / 9;
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const bool more = q + 1 < q_end;
-    if (more) load_b(q + 1, nb);
-
-    const int tapoff = FLIP ? ((2 - kh) * PW + (2 - kw)) * LDP : (kh * PW + kw) * LDP;
-    const float* a0 = Ps + abase[0] + tapoff + ks * BK;
-    const float* a1 = Ps + abase[1] + tapoff + ks * BK;
-#pragma unroll
-    for (int kc = 0; kc < BK / 8; ++kc) {
-      const f32x4 fa0 = *reinterpret_cast<const f32x4*>(a0 + kc * 8);
-      const f32x4 fa1 = *reinterpret_cast<const f32x4*>(a1 + kc * 8);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], cb[kc][s], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], cb[kc][s], acc[1], 0, 0, 0);
+  for (;;) {
+    const bool last_of_unit = cc + 1 >= cc_end;
+    // ---- the phase after this one (when there is none: re-read this one, results unused) ----
+    int nL = L, nn0 = n0, nb0 = b0, nh0 = h0, nw0 = w0, nsplit = split, ncc = cc + 1, ncc_end = cc_end;
+    bool has_next = true, new_tile = false;
+    if (last_of_unit) {
+      nL = L + 1;
+      if (nL < L1) {
+        unit(nL, nn0, nb0, nh0, nw0, nsplit, ncc, ncc_end);
+        new_tile = (nb0 != b0) || (nh0 != h0) || (nw0 != w0);
+      } else {
+        has_next = false;
+        ncc = cc;
       }
     }
-    if (more) {
-      if ((ks == KS - 1) && (tap == 8)) {   // next chunk starts a new channel chunk: swap the patch
-        __syncthreads();
-        load_patch(cc + 1);
-        __syncthreads();
+    if (!(VAR & 8)) __syncthreads();                       // every wave has finished reading the previous patch
+    if (!(VAR & 16)) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int pos = tid / TPP + PPP * j;
+      *reinterpret_cast<f32x4*>(Ps + pos * LDP + c4) = (gpix[j] != ~0u) ? rp[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    }
+    if (!(VAR & 8)) __syncthreads();
+    if (new_tile) fill_gpix(nb0, nh0, nw0);
+    const float* nsrc = p.a + ncc * CK;
+    const float* nwl = (nn0 == n0) ? wl : wbase(nn0);
+
+    // A fragments are software-pipelined one k-group (8 k) ahead: the ds_reads of group g+1 are
+    // issued before the 8 MFMAs of group g, so a wave running alone on its SIMD never waits on LDS.
+    auto read_frag = [&](int gidx, f32x4 (&f)[2]) {
+      const int u = gidx / 4, kc = gidx % 4;
+      const int tap = u / KS, ks = u % KS;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int tapoff = FLIP ? ((2 - kh) * PW + (2 - kw)) * LDP : (kh * PW + kw) * LDP;
+      f[0] = *reinterpret_cast<const f32x4*>(Ps + abase[0] + tapoff + ks * BK + kc * 8);
+      f[1] = *reinterpret_cast<const f32x4*>(Ps + abase[1] + tapoff + ks * BK + kc * 8);
+    };
+    stamp();   // phase start (patch committed)
+    __builtin_amdgcn_s_setprio(0);   // MFMA stream: yield issue slots to a co-resident wave's prologue / epilogue
+    f32x4 fa[2][2];
+    read_frag(0, fa[0]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!(VAR & 1)) {
+        if (u + 1 < U) load_b(wl, cc, u + 1, nb);
+        else load_b(nwl, ncc, 0, nb);
+      } else {
+        for (int kc = 0; kc < 4; ++kc) nb[kc] = cb[kc];
+      }
+      if (!(VAR & 2)) fetch(u, nsrc);
+      __builtin_amdgcn_sched_barrier(0);   // loads are issued before this step's MFMAs, consumed after them
+#pragma unroll
+      for (int kc = 0; kc < BK / 8; ++kc) {
+        const int gidx = u * 4 + kc;
+        if (!(VAR & 4) && gidx + 1 < 4 * U) read_frag(gidx + 1, fa[(gidx + 1) & 1]);
+        if (VAR & 4) { fa[1][0] = fa[0][0]; fa[1][1] = fa[0][1]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gidx & 1][0][s], cb[kc][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gidx & 1][1][s], cb[kc][s], acc[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) cb[kc] = nb[kc];
+      __builtin_amdgcn_sched_barrier(0);
     }
-  }
 
-  // ---- epilogue: wave-private LDS transpose (the patch is dead by now), then 16-byte stores ----
-  __syncthreads();                                   // every wave has finished reading the patch
-  float* Ts = smem + wid * LGM_TS_FLOATS;
-  const int nc = n0 + wn * 32 + (lane & 7) * 4;
-  float* dst = p.out;
-  long dpitch = p.out_pitch;
-  const bool partial = p.splits > 1;                 // split-K: plain partial sums, reducer adds bias / res
-  if (partial) {
-    dst = p.ws + (long)split * p.ws_stride;
-    dpitch = p.N;
-  }
-  const f32x4 bv = (!partial && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_setprio(3);   // everything that is not MFMA runs at high priority
+    stamp();   // MFMAs issued
+    if (last_of_unit && !(VAR & 32)) {
+      // ---- epilogue: wave-private LDS transpose, then 16-byte stores ----
+      // All loads (bias, residual rows) are issued up front with clamped addresses and the stores
+      // are unconditional on the common path, so there is ONE wait and no store-to-store
+      // serialisation (a conditional store inside the row loop made the compiler insert
+      // s_waitcnt vmcnt(0) - i.e. "previous store has completed" - before every row).
+      const int nc = n0 + wn * 32 + (lane & 7) * 4;
+      float* dst = p.out;
+      long dpitch = p.out_pitch;
+      const bool partial = p.splits > 1;     // split-K: plain partial sums, the reducer adds bias / res
+      if (partial) {
+        dst = p.ws + (long)split * p.ws_stride;
+        dpitch = p.N;
+      }
+      long mrow[2][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    lgm_wave_lds_sync();
-    lgm_tile_to_lds(acc[i], Ts, lane);
-    lgm_wave_lds_sync();
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int rt = wm * 64 + i * 32 + (lane >> 3) + 8 * j;
-      const int img = rt >> p.lgTT, rr = rt & ((1 << p.lgTT) - 1);
-      const int oh = h0 + (rr >> p.lgTW), ow = w0 + (rr & (p.TW - 1)), b = b0 + img;
-      if (b < p.B && oh < p.H && ow < p.W) {
-        const long m = (long)((b * p.H + oh) * p.W + ow);
-        f32x4 v = lgm_tile_row4(Ts, lane, j) + bv;
-        if (!partial && p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.res_pitch + nc);
-        *reinterpret_cast<f32x4*>(dst + m * dpitch + nc) = v;
+        for (int j = 0; j < 4; ++j) {
+          const int rt = wm * 64 + i * 32 + (lane >> 3) + 8 * j;
+          const int img = rt >> p.lgTT, rr = rt & ((1 << p.lgTT) - 1);
+          const int oh = h0 + (rr >> p.lgTW), ow = w0 + (rr & (p.TW - 1)), b = b0 + img;
+          mrow[i][j] = (long)((b * p.H + oh) * p.W + ow);   // tiles divide B (image groups), H and W exactly
+        }
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      f32x4 rv[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!partial) {
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + nc);
+        if (p.res) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              rv[i][j] = *reinterpret_cast<const f32x4*>(p.res + mrow[i][j] * p.res_pitch + nc);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        lgm_wave_lds_sync();
+        lgm_tile_to_lds(acc[i], Ts, lane);
+        lgm_wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(dst + mrow[i][j] * dpitch + nc) = lgm_tile_row4(Ts, lane, j) + bv + rv[i][j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
       }
     }
+    if (last_of_unit) stamp();   // epilogue done
+    if (!has_next) break;
+    L = nL; n0 = nn0; b0 = nb0; h0 = nh0; w0 = nw0; split = nsplit; cc = ncc; cc_end = ncc_end;
+    wl = nwl;
+  }
+  if (p.dbg && tid == 0) {
+    p.dbg[blockIdx.x * 32 + 0] = nst;
+    p.dbg[blockIdx.x * 32 + 1] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20 /*XCC_ID*/) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4 /*HW_ID*/) << 8);
   }
 }
 
@@ -431,7 +519,8 @@ bool lgm_conv3x3_supported(const LgmConvGeom* g, int gather_channels, int out_ch
   int TH, TW, NI;
   if (!(g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1)) return false;
   if (gather_channels % 32 != 0 || out_channels % 64 != 0) return false;
-  return plan_tile(g->H, g->W, &TH, &TW, &NI);
+  if (!plan_tile(g->H, g->W, &TH, &TW, &NI)) return false;
+  return g->B % NI == 0;   // whole image groups only (the launcher also needs 32-bit element offsets)
 }
 
 // split-K factor for a given geometry (1 = none); also the workspace it needs
@@ -441,18 +530,17 @@ int lgm_conv3x3_splits(const LgmConvGeom* g, int gather_channels, int out_channe
   if (!plan_tile(g->H, g->W, &TH, &TW, &NI)) return 1;
   const long base = (long)lgm_cdiv(g->B, NI) * (g->H / TH) * (g->W / TW) * (out_channels / BN);
   if (base >= 400) return 1;
-  const int ck = gather_channels % 64 == 0 ? 64 : 32;
-  const int nq = (gather_channels / ck) * 9 * (ck / BK);
+  const int phases = gather_channels / 32;   // split on whole phases (288 k each)
   // Two workgroups fit on a CU (512 resident).  Time ~ rounds(base*s) / s: pick the split that
   // minimises it, with a small penalty per split for the partial-sum traffic.
-  long smax = nq / 6;                 // at least 6 chunks (192 k) per split
-  if (smax > 8) smax = 8;
-  if (smax < 1) smax = 1;
+  long smax = phases < 8 ? phases : 8;
   long s = 1;
   double best = 1e30;
   for (long c = 1; c <= smax; ++c) {
+    const long pps = (phases + c - 1) / c;
+    if ((phases + pps - 1) / pps != c) continue;          // would leave an empty split
     const double rounds = (double)((base * c + 511) / 512);
-    const double cost = rounds / (double)c + 0.02 * (double)(c - 1);
+    const double cost = rounds * (double)pps / (double)phases + 0.02 * (double)(c - 1);
     if (cost < best - 1e-9) {
       best = cost;
       s = c;
@@ -460,6 +548,9 @@ int lgm_conv3x3_splits(const LgmConvGeom* g, int gather_channels, int out_channe
   }
   return s < 1 ? 1 : (int)s;
 }
+
+static long long* g_c3_dbg = nullptr;
+extern "C" void lgm_debug_c3_buffer(void* p) { g_c3_dbg = (long long*)p; }
 
 int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pitch, const float* w,
                        const float* bias, const float* res, long res_pitch, float* out, long out_pitch,
@@ -490,9 +581,15 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
   }
   p.ws = (float*)workspace;
   p.ws_stride = M * p.N;
-  const unsigned nblocks = (unsigned)((long)groups * p.tiles_h * p.tiles_w * p.tiles_n * p.splits);
-  const bool ck64 = (p.C % 64 == 0);
-  const size_t smem = (size_t)p.NP * (ck64 ? 68 : 36) * sizeof(float);
+  p.dbg = g_c3_dbg;
+  const bool ck64 = false;   // 32-channel phases: the 64-wide variant needs > 256 VGPRs with the register prefetch
+  p.pps = lgm_cdiv(p.C / 32, p.splits);
+  p.splits = lgm_cdiv(p.C / 32, p.pps);
+  p.units = (int)((long)groups * p.tiles_h * p.tiles_w * p.tiles_n * p.splits);
+  static const bool one = getenv("LGM_C3_ONE") != nullptr;   // experiment: one workgroup per CU
+  p.per = lgm_cdiv(p.units, one ? 256 : 512);     // two workgroups per CU stay resident and walk their unit ranges
+  const unsigned nblocks = (unsigned)lgm_cdiv(p.units, p.per);
+  const size_t smem = one ? 100 * 1024 : ((size_t)288 * (ck64 ? 68 : 36) + 4 * LGM_TS_FLOATS) * sizeof(float);
 #define LGM_C3_LAUNCH(M, CKV)                                                                          \
   do {                                                                                                 \
     auto kern = conv3x3_kernel<M, CKV>;                                                                \
@@ -504,11 +601,22 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                    \
   } while (0)
   if (mode == MODE_XY) {
-    if (ck64) LGM_C3_LAUNCH(MODE_XY, 64); else LGM_C3_LAUNCH(MODE_XY, 32);
+    { static const int var = getenv("LGM_C3_VAR") ? atoi(getenv("LGM_C3_VAR")) : 0;
+      if (var == 0) LGM_C3_LAUNCH(MODE_XY, 32);
+      else if (var == 1) { auto kern = conv3x3_kernel<MODE_XY, 32, 1>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
+      else if (var == 2) { auto kern = conv3x3_kernel<MODE_XY, 32, 2>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
+      else if (var == 3) { auto kern = conv3x3_kernel<MODE_XY, 32, 3>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
+      else if (var == 15) { auto kern = conv3x3_kernel<MODE_XY, 32, 15>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
+      else if (var == 31) { auto kern = conv3x3_kernel<MODE_XY, 32, 31>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
+      else if (var == 63) { auto kern = conv3x3_kernel<MODE_XY, 32, 63>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
+      else if (var == 32) { auto kern = conv3x3_kernel<MODE_XY, 32, 32>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
+      else if (var == 4) { auto kern = conv3x3_kernel<MODE_XY, 32, 4>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
+      else { auto kern = conv3x3_kernel<MODE_XY, 32, 7>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
+    }
   } else if (mode == MODE_YX) {
-    if (ck64) LGM_C3_LAUNCH(MODE_YX, 64); else LGM_C3_LAUNCH(MODE_YX, 32);
+    LGM_C3_LAUNCH(MODE_YX, 32);
   } else {
-    if (ck64) LGM_C3_LAUNCH(MODE_YXT, 64); else LGM_C3_LAUNCH(MODE_YXT, 32);
+    LGM_C3_LAUNCH(MODE_YXT, 32);
   }
 #undef LGM_C3_LAUNCH
   if (p.splits > 1) {
