@@ -42,7 +42,6 @@ struct Args {
   int splits, pps;    // split-K over whole phases (pps phases per split); > 1 => partials to ws
   float* ws;          // [splits][B*H*W][N]
   long ws_stride;
-  long long* dbg;     // optional per-workgroup timestamps (experiments)
 };
 
 // out[m][n] = sum_s ws[s][m][n] + bias[n] + res[m][n]   (fixed order => deterministic)
@@ -67,81 +66,116 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
   return (nb % 8 == 0) ? (bid % 8) * (nb / 8) + bid / 8 : bid;
 }
 
-// Persistent, software-pipelined workgroups.  A workgroup walks a contiguous range of UNITS
-// (spatial tile, split, n-tile); a unit is a sequence of PHASES, one per CK-channel chunk of the
-// reduction, each = one halo patch in LDS + U = 9 * CK/32 MFMA steps (tap, 32 k).  While phase i
-// computes, the patch of phase i+1 (next channel chunk, or the next unit's first chunk) is
-// fetched into registers ONE 16-byte load per step, so global latency hides behind the MFMAs and
-// the only exposed load is the first patch of the workgroup.  Weight fragments run one step ahead
-// across phase and unit boundaries as well.  The step body is branch-free (clamped addresses
-// instead of predicated loads) so that the compiler's s_waitcnt placement stays exact: the only
-// wait per step is "weights of the next step have landed", after all 32 MFMAs have been issued.
-// Split-K splits on whole phases.
-template <int MODE, int CK, int VAR = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const Args p) {
+// One persistent workgroup per CU (one wave per SIMD), everything software-pipelined INSIDE the
+// wave.  Measured on MI355X: while a wave streams MFMAs back to back, the VALU instructions of a
+// co-resident wave on the same SIMD issue at roughly one per MFMA slot, so "let another workgroup
+// hide my prologue / epilogue" does not work for MFMA-dense code; two barrier-coupled workgroups
+// per CU ran no faster than one.  Hence:
+//   * a workgroup walks a contiguous range of UNITS (spatial tile, split, n-tile); a unit is a
+//     sequence of PHASES, one per 32-channel chunk of the reduction, each = one halo patch in LDS
+//     + 9 MFMA steps (tap, 32 k; 32 MFMAs per wave);
+//   * the LDS patch is double buffered.  During phase i the patch of phase i+1 (already in
+//     registers) is committed to the other buffer one position per step, and the patch of phase
+//     i+2 is fetched from global memory into the freed register - one 16-byte load per step;
+//   * weight fragments come straight from global memory (per-lane B operands, L2 resident), two
+//     steps ahead in a ring of three register sets, across phase and unit boundaries;
+//   * A fragments are read from LDS one k-group (8 MFMAs) ahead;
+//   * the step body is branch-free (clamped addresses, selects instead of predicated loads), which
+//     keeps the compiler's s_waitcnt placement exact;
+//   * one barrier per phase.  Split-K splits on whole phases.
+struct Phase {
+  int L, cc, cc_end;          // unit index, channel chunk, end of the unit's chunk range
+  int n0, b0, h0, w0, split;
+  bool valid;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
+  constexpr int CK = 32;                 // channels per phase
   constexpr int LDP = CK + 4;            // patch row stride (floats)
   constexpr int TPP = CK / 4;            // threads per patch position
   constexpr int PPP = 256 / TPP;         // positions per pass
-  constexpr int KS = CK / BK;            // weight chunks per (chunk, tap)
-  constexpr int U = 9 * KS;              // MFMA steps per phase
-  constexpr int NJ = 288 / PPP;          // patch positions per thread (LDS holds all 288 positions)
-  static_assert(NJ == U, "one prefetch load per step");
+  constexpr int U = 9;                   // MFMA steps per phase (one per tap)
+  constexpr int NJ = 288 / PPP;          // patch positions per thread (a buffer holds all 288 positions)
+  static_assert(NJ == U, "one patch position per step");
+  constexpr int PBUF = 288 * LDP;
   extern __shared__ __align__(16) float smem[];
-  float* Ps = smem;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int lr = lane & 31, lh = lane >> 5;
-  float* Ts = smem + 288 * LDP + wid * LGM_TS_FLOATS;   // wave-private epilogue scratch (not aliased)
+  float* Ts = smem + 2 * PBUF + wid * LGM_TS_FLOATS;   // wave-private epilogue scratch
 
   const int Lb = xcd_swizzle(blockIdx.x, gridDim.x);
   const int L0 = Lb * p.per;
   const int L1 = min(p.units, L0 + p.per);
   if (L0 >= L1) return;
-  __builtin_amdgcn_s_setprio(3);
-  int nst = 0;
-  auto stamp = [&]() { if (p.dbg && tid == 0 && nst < 30) p.dbg[blockIdx.x * 32 + 2 + nst++] = wall_clock64(); };
-  stamp();
 
   const int PW = p.TW + 2, PP1 = (p.TH + 2) * PW;
   const int ncc_total = p.C / CK;
 
-  auto unit = [&](int L, int& n0, int& b0, int& h0, int& w0, int& split, int& cb_, int& ce_) {
-    n0 = (L % p.tiles_n) * BN;
+  auto decode = [&](Phase& ph, int L) {
+    ph.L = L;
+    ph.n0 = (L % p.tiles_n) * BN;
     int ts = L / p.tiles_n;
-    split = ts % p.splits;
+    ph.split = ts % p.splits;
     ts /= p.splits;
-    w0 = (ts % p.tiles_w) * p.TW;
+    ph.w0 = (ts % p.tiles_w) * p.TW;
     ts /= p.tiles_w;
-    h0 = (ts % p.tiles_h) * p.TH;
-    b0 = (ts / p.tiles_h) * p.NI;
-    cb_ = split * p.pps;
-    ce_ = min(ncc_total, cb_ + p.pps);
+    ph.h0 = (ts % p.tiles_h) * p.TH;
+    ph.b0 = (ts / p.tiles_h) * p.NI;
+    ph.cc = ph.split * p.pps;
+    ph.cc_end = min(ncc_total, ph.cc + p.pps);
   };
-
-  // ---- patch bookkeeping: 32-bit element offset (or ~0u = zero padding) of every position ----
-  const int c4 = (tid % TPP) * 4;
-  unsigned gpix[NJ];
-  auto fill_gpix = [&](int b0, int h0, int w0) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int pos = tid / TPP + PPP * j;
-      unsigned g = ~0u;
-      if (pos < p.NP) {
-        const int img = pos / PP1, rem = pos - img * PP1;
-        const int py = rem / PW, px = rem - py * PW;
-        const int ih = h0 + py - 1, iw = w0 + px - 1, b = b0 + img;
-        if (b < p.B && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-          g = (unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.a_pitch + (unsigned)c4;
-      }
-      gpix[j] = g;
+  auto advance = [&](Phase& ph) {          // past the end: stays on the last phase (harmless re-reads)
+    if (!ph.valid) return;
+    if (ph.cc + 1 < ph.cc_end) {
+      ++ph.cc;
+    } else if (ph.L + 1 < L1) {
+      decode(ph, ph.L + 1);
+    } else {
+      ph.valid = false;
     }
   };
+
+  // ---- patch bookkeeping: the (image, row, column) of every patch position this thread owns ----
+  const int c4 = (tid % TPP) * 4;
+  int ppos[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int pos = tid / TPP + PPP * j;
+    int pk = -1;
+    if (pos < p.NP) {
+      const int img = pos / PP1, rem = pos - img * PP1;
+      const int py = rem / PW, px = rem - py * PW;
+      pk = (img << 20) | (py << 10) | px;
+    }
+    ppos[j] = pk;
+  }
   f32x4 rp[NJ];
-  auto fetch = [&](int j, const float* src) {   // unconditional load (padding reads element 0, zeroed at the LDS store)
-    const unsigned off = gpix[j] == ~0u ? 0u : gpix[j];
-    rp[j] = *reinterpret_cast<const f32x4*>(src + off);
+  // unconditional 16-byte load of position j of phase ph (zero padding reads element 0 and is
+  // masked when the value is committed to LDS); returns the validity bit
+  auto fetch_addr = [&](int j, const Phase& ph, unsigned& off) -> unsigned {
+    const int pk = ppos[j];
+    const int img = pk >> 20, py = (pk >> 10) & 1023, px = pk & 1023;
+    const int ih = ph.h0 + py - 1, iw = ph.w0 + px - 1;
+    const bool ok = pk >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+    off = ok ? (unsigned)(((ph.b0 + img) * p.H + ih) * p.W + iw) * (unsigned)p.a_pitch + (unsigned)c4 : 0u;
+    return ok ? 1u : 0u;
+  };
+  auto fetch_issue = [&](int j, const Phase& ph, unsigned off) {
+    rp[j] = *reinterpret_cast<const f32x4*>(p.a + ph.cc * CK + off);
+  };
+  auto fetch = [&](int j, const Phase& ph) -> unsigned {
+    unsigned off;
+    const unsigned ok = fetch_addr(j, ph, off);
+    fetch_issue(j, ph, off);
+    return ok;
+  };
+  auto commit = [&](int j, float* buf, unsigned mask) {
+    const int pos = tid / TPP + PPP * j;
+    *reinterpret_cast<f32x4*>(buf + pos * LDP + c4) = ((mask >> j) & 1u) ? rp[j] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
   // ---- A fragment bases (tile-local pixel -> patch position) ----
@@ -154,23 +188,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const Args p) {
     abase[i] = ((img * (p.TH + 2) + ph) * PW + pw) * LDP + lh * 4;
   }
 
-  // ---- weight fragments: every lane fetches ITS OWN B operand values straight from global memory
-  // (the weight tile is tiny and L1/L2 resident), one step ahead.  No LDS staging of weights =>
-  // no barrier inside a phase: the four waves run decoupled.
+  // ---- weight fragments: every lane fetches ITS OWN B operand values from global memory ----
   constexpr bool KCONTIG = (MODE != MODE_YX);   // weight rows contiguous along the reduction index
   constexpr bool FLIP = (MODE != MODE_XY);      // input gradient: taps are mirrored
-  auto wbase = [&](int n0) {
-    return KCONTIG ? p.w + (long)(n0 + wn * 32 + lr) * (9 * p.C) + lh * 4
-                   : p.w + (long)(lh * 4) * 9 * p.Wn + n0 + wn * 32 + lr;
-  };
-  auto load_b = [&](const float* wl, int cc, int u, f32x4 (&fb)[4]) {
-    const int tap = u / KS, ks = u % KS;
+  auto load_b = [&](const Phase& ph, int tap, f32x4 (&fb)[4]) {
     if (KCONTIG) {
-      const float* src = wl + tap * p.C + cc * CK + ks * BK;
+      const float* src = p.w + (long)(ph.n0 + wn * 32 + lr) * (9 * p.C) + lh * 4 + tap * p.C + ph.cc * CK;
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) fb[kc] = *reinterpret_cast<const f32x4*>(src + kc * 8);
     } else {
-      const float* src = wl + ((long)(cc * CK + ks * BK) * 9 + tap) * p.Wn;
+      const float* src = p.w + ((long)(lh * 4 + ph.cc * CK) * 9 + tap) * p.Wn + ph.n0 + wn * 32 + lr;
       const long kstride = (long)9 * p.Wn;
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc)
@@ -185,103 +212,93 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const Args p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  // ---- first phase of the workgroup: the one exposed patch load ----
-  int L = L0, n0, b0, h0, w0, split, cc, cc_end;
-  unit(L, n0, b0, h0, w0, split, cc, cc_end);
-  const float* wl = wbase(n0);
-  f32x4 cb[4], nb[4];
-  load_b(wl, cc, 0, cb);
-  fill_gpix(b0, h0, w0);
-  {
-    const float* src = p.a + cc * CK;
+  // ---- prologue: patch of the first phase -> buffer 0 (the one exposed load), patch of the
+  // second phase into registers, first weight fragment ----
+  Phase cur;
+  cur.valid = true;
+  decode(cur, L0);
+  Phase nx1 = cur;
+  advance(nx1);
+  Phase nx2 = nx1;
+  advance(nx2);
+  // Weight fragments run TWO steps ahead in a ring of three register sets.  vmcnt retires in
+  // order, so the wait for a weight fragment also waits for every older load - in particular the
+  // patch fetch (HBM latency) issued just before it; two steps (~2 us) of distance cover that.
+  f32x4 wq[3][4];
+  load_b(cur, 0, wq[0]);
+  load_b(cur, 1, wq[1]);
+  unsigned mrp = 0;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) fetch(j, src);
-  }
+  for (int j = 0; j < NJ; ++j) mrp |= fetch(j, cur) << j;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) commit(j, smem, mrp);
+  mrp = 0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) mrp |= fetch(j, nx1) << j;
+  __syncthreads();
 
+  int buf = 0;
   for (;;) {
-    const bool last_of_unit = cc + 1 >= cc_end;
-    // ---- the phase after this one (when there is none: re-read this one, results unused) ----
-    int nL = L, nn0 = n0, nb0 = b0, nh0 = h0, nw0 = w0, nsplit = split, ncc = cc + 1, ncc_end = cc_end;
-    bool has_next = true, new_tile = false;
-    if (last_of_unit) {
-      nL = L + 1;
-      if (nL < L1) {
-        unit(nL, nn0, nb0, nh0, nw0, nsplit, ncc, ncc_end);
-        new_tile = (nb0 != b0) || (nh0 != h0) || (nw0 != w0);
-      } else {
-        has_next = false;
-        ncc = cc;
-      }
-    }
-    if (!(VAR & 8)) __syncthreads();                       // every wave has finished reading the previous patch
-    if (!(VAR & 16)) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int pos = tid / TPP + PPP * j;
-      *reinterpret_cast<f32x4*>(Ps + pos * LDP + c4) = (gpix[j] != ~0u) ? rp[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    }
-    if (!(VAR & 8)) __syncthreads();
-    if (new_tile) fill_gpix(nb0, nh0, nw0);
-    const float* nsrc = p.a + ncc * CK;
-    const float* nwl = (nn0 == n0) ? wl : wbase(nn0);
-
-    // A fragments are software-pipelined one k-group (8 k) ahead: the ds_reads of group g+1 are
-    // issued before the 8 MFMAs of group g, so a wave running alone on its SIMD never waits on LDS.
+    const float* Pc = smem + buf * PBUF;
+    float* Pn = smem + (buf ^ 1) * PBUF;
     auto read_frag = [&](int gidx, f32x4 (&f)[2]) {
-      const int u = gidx / 4, kc = gidx % 4;
-      const int tap = u / KS, ks = u % KS;
+      const int tap = gidx / 4, kc = gidx % 4;
       const int kh = tap / 3, kw = tap - kh * 3;
       const int tapoff = FLIP ? ((2 - kh) * PW + (2 - kw)) * LDP : (kh * PW + kw) * LDP;
-      f[0] = *reinterpret_cast<const f32x4*>(Ps + abase[0] + tapoff + ks * BK + kc * 8);
-      f[1] = *reinterpret_cast<const f32x4*>(Ps + abase[1] + tapoff + ks * BK + kc * 8);
+      f[0] = *reinterpret_cast<const f32x4*>(Pc + abase[0] + tapoff + kc * 8);
+      f[1] = *reinterpret_cast<const f32x4*>(Pc + abase[1] + tapoff + kc * 8);
     };
-    stamp();   // phase start (patch committed)
-    __builtin_amdgcn_s_setprio(0);   // MFMA stream: yield issue slots to a co-resident wave's prologue / epilogue
     f32x4 fa[2][2];
     read_frag(0, fa[0]);
+    unsigned mnew = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!(VAR & 1)) {
-        if (u + 1 < U) load_b(wl, cc, u + 1, nb);
-        else load_b(nwl, ncc, 0, nb);
-      } else {
-        for (int kc = 0; kc < 4; ++kc) nb[kc] = cb[kc];
-      }
-      if (!(VAR & 2)) fetch(u, nsrc);
-      __builtin_amdgcn_sched_barrier(0);   // loads are issued before this step's MFMAs, consumed after them
+      // The step's bookkeeping is dealt out over its four k-groups so that no more than ~10
+      // non-MFMA instructions sit between two groups of 8 MFMAs: a longer clump drains the MFMA
+      // pipe (measured ~340 idle cycles per step when everything was issued up front).
+      unsigned foff = 0, fok = 0;
 #pragma unroll
-      for (int kc = 0; kc < BK / 8; ++kc) {
+      for (int kc = 0; kc < 4; ++kc) {
         const int gidx = u * 4 + kc;
-        if (!(VAR & 4) && gidx + 1 < 4 * U) read_frag(gidx + 1, fa[(gidx + 1) & 1]);
-        if (VAR & 4) { fa[1][0] = fa[0][0]; fa[1][1] = fa[0][1]; }
-        __builtin_amdgcn_sched_barrier(0);
+        if (kc == 0) {                       // weights two steps ahead
+          if (u + 2 < U) load_b(cur, u + 2, wq[(u + 2) % 3]);
+          else load_b(nx1, u + 2 - U, wq[(u + 2) % 3]);
+        } else if (kc == 1) {                // position u of the next phase's patch -> other buffer
+          commit(u, Pn, mrp);
+        } else if (kc == 2) {                // address of position u of the phase after
+          fok = fetch_addr(u, nx2, foff);
+          mnew |= fok << u;
+        } else {                             // ... and its register is refilled
+          fetch_issue(u, nx2, foff);
+        }
+        if (gidx + 1 < 4 * U) read_frag(gidx + 1, fa[(gidx + 1) & 1]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gidx & 1][0][s], cb[kc][s], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gidx & 1][1][s], cb[kc][s], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gidx & 1][0][s], wq[u % 3][kc][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gidx & 1][1][s], wq[u % 3][kc][s], acc[1], 0, 0, 0);
+        }
+        // interleave: one MFMA, then up to two of the group's other instructions (VALU / VMEM / DS)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x096, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) cb[kc] = nb[kc];
-      __builtin_amdgcn_sched_barrier(0);
     }
+    mrp = mnew;
+    __syncthreads();   // everyone is done reading Pc and writing Pn
 
-    __builtin_amdgcn_s_setprio(3);   // everything that is not MFMA runs at high priority
-    stamp();   // MFMAs issued
-    if (last_of_unit && !(VAR & 32)) {
-      // ---- epilogue: wave-private LDS transpose, then 16-byte stores ----
-      // All loads (bias, residual rows) are issued up front with clamped addresses and the stores
-      // are unconditional on the common path, so there is ONE wait and no store-to-store
-      // serialisation (a conditional store inside the row loop made the compiler insert
-      // s_waitcnt vmcnt(0) - i.e. "previous store has completed" - before every row).
-      const int nc = n0 + wn * 32 + (lane & 7) * 4;
+    if (cur.cc + 1 >= cur.cc_end) {
+      // ---- epilogue: wave-private LDS transpose, then 16-byte stores.  All loads (bias,
+      // residual rows) are issued up front and the stores are unconditional: one wait, no
+      // store-to-store serialisation.
+      const int nc = cur.n0 + wn * 32 + (lane & 7) * 4;
       float* dst = p.out;
       long dpitch = p.out_pitch;
       const bool partial = p.splits > 1;     // split-K: plain partial sums, the reducer adds bias / res
       if (partial) {
-        dst = p.ws + (long)split * p.ws_stride;
+        dst = p.ws + (long)cur.split * p.ws_stride;
         dpitch = p.N;
       }
       long mrow[2][4];
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const Args p) {
         for (int j = 0; j < 4; ++j) {
           const int rt = wm * 64 + i * 32 + (lane >> 3) + 8 * j;
           const int img = rt >> p.lgTT, rr = rt & ((1 << p.lgTT) - 1);
-          const int oh = h0 + (rr >> p.lgTW), ow = w0 + (rr & (p.TW - 1)), b = b0 + img;
+          const int oh = cur.h0 + (rr >> p.lgTW), ow = cur.w0 + (rr & (p.TW - 1)), b = cur.b0 + img;
           mrow[i][j] = (long)((b * p.H + oh) * p.W + ow);   // tiles divide B (image groups), H and W exactly
         }
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -322,14 +339,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const Args p) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
       }
     }
-    if (last_of_unit) stamp();   // epilogue done
-    if (!has_next) break;
-    L = nL; n0 = nn0; b0 = nb0; h0 = nh0; w0 = nw0; split = nsplit; cc = ncc; cc_end = ncc_end;
-    wl = nwl;
-  }
-  if (p.dbg && tid == 0) {
-    p.dbg[blockIdx.x * 32 + 0] = nst;
-    p.dbg[blockIdx.x * 32 + 1] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20 /*XCC_ID*/) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4 /*HW_ID*/) << 8);
+    if (!nx1.valid) break;
+    cur = nx1;
+    nx1 = nx2;
+    advance(nx2);
+    buf ^= 1;
   }
 }
 
@@ -529,17 +543,17 @@ int lgm_conv3x3_splits(const LgmConvGeom* g, int gather_channels, int out_channe
   int TH, TW, NI;
   if (!plan_tile(g->H, g->W, &TH, &TW, &NI)) return 1;
   const long base = (long)lgm_cdiv(g->B, NI) * (g->H / TH) * (g->W / TW) * (out_channels / BN);
-  if (base >= 400) return 1;
+  if (base >= 1024) return 1;
   const int phases = gather_channels / 32;   // split on whole phases (288 k each)
-  // Two workgroups fit on a CU (512 resident).  Time ~ rounds(base*s) / s: pick the split that
-  // minimises it, with a small penalty per split for the partial-sum traffic.
+  // One persistent workgroup per CU (256 resident).  Time ~ rounds(base*s) * phases per split: pick
+  // the split that minimises it, with a small penalty per split for the partial-sum traffic.
   long smax = phases < 8 ? phases : 8;
   long s = 1;
   double best = 1e30;
   for (long c = 1; c <= smax; ++c) {
     const long pps = (phases + c - 1) / c;
     if ((phases + pps - 1) / pps != c) continue;          // would leave an empty split
-    const double rounds = (double)((base * c + 511) / 512);
+    const double rounds = (double)((base * c + 255) / 256);
     const double cost = rounds * (double)pps / (double)phases + 0.02 * (double)(c - 1);
     if (cost < best - 1e-9) {
       best = cost;
@@ -548,9 +562,6 @@ int lgm_conv3x3_splits(const LgmConvGeom* g, int gather_channels, int out_channe
   }
   return s < 1 ? 1 : (int)s;
 }
-
-static long long* g_c3_dbg = nullptr;
-extern "C" void lgm_debug_c3_buffer(void* p) { g_c3_dbg = (long long*)p; }
 
 int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pitch, const float* w,
                        const float* bias, const float* res, long res_pitch, float* out, long out_pitch,
@@ -581,43 +592,25 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
   }
   p.ws = (float*)workspace;
   p.ws_stride = M * p.N;
-  p.dbg = g_c3_dbg;
-  const bool ck64 = false;   // 32-channel phases: the 64-wide variant needs > 256 VGPRs with the register prefetch
   p.pps = lgm_cdiv(p.C / 32, p.splits);
   p.splits = lgm_cdiv(p.C / 32, p.pps);
   p.units = (int)((long)groups * p.tiles_h * p.tiles_w * p.tiles_n * p.splits);
-  static const bool one = getenv("LGM_C3_ONE") != nullptr;   // experiment: one workgroup per CU
-  p.per = lgm_cdiv(p.units, one ? 256 : 512);     // two workgroups per CU stay resident and walk their unit ranges
+  p.per = lgm_cdiv(p.units, 256);     // one persistent workgroup per CU walks its unit range
   const unsigned nblocks = (unsigned)lgm_cdiv(p.units, p.per);
-  const size_t smem = one ? 100 * 1024 : ((size_t)288 * (ck64 ? 68 : 36) + 4 * LGM_TS_FLOATS) * sizeof(float);
-#define LGM_C3_LAUNCH(M, CKV)                                                                          \
+  const size_t smem = ((size_t)2 * 288 * 36 + 4 * LGM_TS_FLOATS) * sizeof(float);
+#define LGM_C3_LAUNCH(M)                                                                               \
   do {                                                                                                 \
-    auto kern = conv3x3_kernel<M, CKV>;                                                                \
-    static size_t attr = 0;                                                                            \
-    if (smem > attr) {                                                                                 \
+    auto kern = conv3x3_kernel<M>;                                                                     \
+    static bool attr = false;                                                                          \
+    if (!attr) {                                                                                       \
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-      attr = smem;                                                                                     \
+      attr = true;                                                                                     \
     }                                                                                                  \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                    \
   } while (0)
-  if (mode == MODE_XY) {
-    { static const int var = getenv("LGM_C3_VAR") ? atoi(getenv("LGM_C3_VAR")) : 0;
-      if (var == 0) LGM_C3_LAUNCH(MODE_XY, 32);
-      else if (var == 1) { auto kern = conv3x3_kernel<MODE_XY, 32, 1>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
-      else if (var == 2) { auto kern = conv3x3_kernel<MODE_XY, 32, 2>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
-      else if (var == 3) { auto kern = conv3x3_kernel<MODE_XY, 32, 3>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
-      else if (var == 15) { auto kern = conv3x3_kernel<MODE_XY, 32, 15>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
-      else if (var == 31) { auto kern = conv3x3_kernel<MODE_XY, 32, 31>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
-      else if (var == 63) { auto kern = conv3x3_kernel<MODE_XY, 32, 63>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
-      else if (var == 32) { auto kern = conv3x3_kernel<MODE_XY, 32, 32>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
-      else if (var == 4) { auto kern = conv3x3_kernel<MODE_XY, 32, 4>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
-      else { auto kern = conv3x3_kernel<MODE_XY, 32, 7>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p); }
-    }
-  } else if (mode == MODE_YX) {
-    LGM_C3_LAUNCH(MODE_YX, 32);
-  } else {
-    LGM_C3_LAUNCH(MODE_YXT, 32);
-  }
+  if (mode == MODE_XY) LGM_C3_LAUNCH(MODE_XY);
+  else if (mode == MODE_YX) LGM_C3_LAUNCH(MODE_YX);
+  else LGM_C3_LAUNCH(MODE_YXT);
 #undef LGM_C3_LAUNCH
   if (p.splits > 1) {
     const long items = M * (p.N / 4);
