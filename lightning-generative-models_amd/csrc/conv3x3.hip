@@ -81,11 +81,16 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
 //     steps ahead in a ring of three register sets, across phase and unit boundaries;
 //   * A fragments are read from LDS one k-group (8 MFMAs) ahead;
 //   * the step body is branch-free (clamped addresses, selects instead of predicated loads), which
-//     keeps the compiler's s_waitcnt placement exact;
+//     keeps the compiler's s_waitcnt placement exact, and cheap: per-position byte offsets and
+//     border flags are precomputed, bases are scalar - a clump of ~20 VALU instructions (64-bit
+//     multiplies, exec-mask juggling) between two MFMAs cost ~150 idle MFMA cycles per step;
 //   * one barrier per phase.  Split-K splits on whole phases.
 struct Phase {
   int L, cc, cc_end;          // unit index, channel chunk, end of the unit's chunk range
-  int n0, b0, h0, w0, split;
+  int tn, split, twi, thi, bg;   // unit coordinates (n-tile, split, tile column, tile row, image group)
+  int n0, b0, h0, w0;
+  unsigned border;            // which image borders the tile touches (+ bit 4: "never valid" positions)
+  long abase;                 // BYTE offset of patch position (image b0, row h0 - 1, column w0 - 1), channel chunk 0
   bool valid;
 };
 
@@ -115,57 +120,90 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
   const int PW = p.TW + 2, PP1 = (p.TH + 2) * PW;
   const int ncc_total = p.C / CK;
 
-  auto decode = [&](Phase& ph, int L) {
+  // unit coordinates -> tile origin, border mask, scalar base offset (all wave-uniform: SALU only)
+  auto place = [&](Phase& ph) {
+    ph.n0 = ph.tn * BN;
+    ph.w0 = ph.twi * p.TW;
+    ph.h0 = ph.thi * p.TH;
+    ph.b0 = ph.bg * p.NI;
+    ph.cc = ph.split * p.pps;
+    ph.cc_end = min(ncc_total, ph.cc + p.pps);
+    ph.border = 16u | (ph.h0 == 0 ? 1u : 0u) | (ph.h0 + p.TH == p.H ? 2u : 0u) | (ph.w0 == 0 ? 4u : 0u) |
+                (ph.w0 + p.TW == p.W ? 8u : 0u);
+    ph.abase = ((long)((ph.b0 * p.H + ph.h0 - 1) * p.W + ph.w0 - 1) * p.a_pitch) * 4;
+  };
+  auto decode = [&](Phase& ph, int L) {    // once per workgroup (integer divisions)
     ph.L = L;
-    ph.n0 = (L % p.tiles_n) * BN;
+    ph.tn = L % p.tiles_n;
     int ts = L / p.tiles_n;
     ph.split = ts % p.splits;
     ts /= p.splits;
-    ph.w0 = (ts % p.tiles_w) * p.TW;
+    ph.twi = ts % p.tiles_w;
     ts /= p.tiles_w;
-    ph.h0 = (ts % p.tiles_h) * p.TH;
-    ph.b0 = (ts / p.tiles_h) * p.NI;
-    ph.cc = ph.split * p.pps;
-    ph.cc_end = min(ncc_total, ph.cc + p.pps);
+    ph.thi = ts % p.tiles_h;
+    ph.bg = ts / p.tiles_h;
+    place(ph);
   };
   auto advance = [&](Phase& ph) {          // past the end: stays on the last phase (harmless re-reads)
     if (!ph.valid) return;
     if (ph.cc + 1 < ph.cc_end) {
       ++ph.cc;
-    } else if (ph.L + 1 < L1) {
-      decode(ph, ph.L + 1);
+    } else if (ph.L + 1 < L1) {            // next unit: odometer increment, no divisions
+      ++ph.L;
+      if (++ph.tn == p.tiles_n) {
+        ph.tn = 0;
+        if (++ph.split == p.splits) {
+          ph.split = 0;
+          if (++ph.twi == p.tiles_w) {
+            ph.twi = 0;
+            if (++ph.thi == p.tiles_h) {
+              ph.thi = 0;
+              ++ph.bg;
+            }
+          }
+        }
+      }
+      place(ph);
     } else {
       ph.valid = false;
     }
   };
 
-  // ---- patch bookkeeping: the (image, row, column) of every patch position this thread owns ----
+  // ---- patch bookkeeping.  Per owned position j: pdelta[j] = BYTE offset from the patch origin
+  // (>= 0), and a 5-bit flag group (bit 0/1: top/bottom halo row, bit 2/3: left/right halo
+  // column, bit 4: position does not exist); a position is zero padding iff flags & border != 0.
+  // The per-step cost is then 4 simple VALU instructions + one scalar-base load.
   const int c4 = (tid % TPP) * 4;
-  int ppos[NJ];
+  unsigned pdelta[NJ];
+  unsigned pflagA = 0, pflagB = 0;       // positions 0..5 / 6..8, five bits each
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int pos = tid / TPP + PPP * j;
-    int pk = -1;
+    unsigned d = 0, f = 16u;
     if (pos < p.NP) {
       const int img = pos / PP1, rem = pos - img * PP1;
       const int py = rem / PW, px = rem - py * PW;
-      pk = (img << 20) | (py << 10) | px;
+      d = (unsigned)(((img * p.H + py) * p.W + px) * (int)p.a_pitch + c4) * 4u;
+      f = (py == 0 ? 1u : 0u) | (py == p.TH + 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == p.TW + 1 ? 8u : 0u);
     }
-    ppos[j] = pk;
+    pdelta[j] = d;
+    if (j < 6) pflagA |= f << (5 * j);
+    else pflagB |= f << (5 * (j - 6));
   }
+  // a position that is certainly inside the tensor (first interior pixel of the tile's first image)
+  const unsigned safe_delta = (unsigned)((p.W + 1) * (int)p.a_pitch) * 4u;
   f32x4 rp[NJ];
-  // unconditional 16-byte load of position j of phase ph (zero padding reads element 0 and is
-  // masked when the value is committed to LDS); returns the validity bit
+  // unconditional 16-byte load of position j of phase ph (padding reads the safe position and is
+  // zeroed when the value is committed to LDS); fetch_addr returns the validity bit
   auto fetch_addr = [&](int j, const Phase& ph, unsigned& off) -> unsigned {
-    const int pk = ppos[j];
-    const int img = pk >> 20, py = (pk >> 10) & 1023, px = pk & 1023;
-    const int ih = ph.h0 + py - 1, iw = ph.w0 + px - 1;
-    const bool ok = pk >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-    off = ok ? (unsigned)(((ph.b0 + img) * p.H + ih) * p.W + iw) * (unsigned)p.a_pitch + (unsigned)c4 : 0u;
+    const unsigned fl = (j < 6 ? pflagA : pflagB) & (ph.border << (5 * (j < 6 ? j : j - 6)));
+    const bool ok = fl == 0u;
+    off = ok ? pdelta[j] : safe_delta;
     return ok ? 1u : 0u;
   };
   auto fetch_issue = [&](int j, const Phase& ph, unsigned off) {
-    rp[j] = *reinterpret_cast<const f32x4*>(p.a + ph.cc * CK + off);
+    const char* sbase = reinterpret_cast<const char*>(p.a) + ph.abase + (long)ph.cc * (CK * 4);   // wave-uniform
+    rp[j] = *reinterpret_cast<const f32x4*>(sbase + off);
   };
   auto fetch = [&](int j, const Phase& ph) -> unsigned {
     unsigned off;
@@ -191,18 +229,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
   // ---- weight fragments: every lane fetches ITS OWN B operand values from global memory ----
   constexpr bool KCONTIG = (MODE != MODE_YX);   // weight rows contiguous along the reduction index
   constexpr bool FLIP = (MODE != MODE_XY);      // input gradient: taps are mirrored
+  // (scalar base + 32-bit per-lane byte offset: no 64-bit VALU address arithmetic per step)
+  const unsigned wlane = KCONTIG ? (unsigned)((wn * 32 + lr) * 9 * p.C + lh * 4) * 4u
+                                 : (unsigned)(lh * 4 * 9 * p.Wn + wn * 32 + lr) * 4u;
   auto load_b = [&](const Phase& ph, int tap, f32x4 (&fb)[4]) {
     if (KCONTIG) {
-      const float* src = p.w + (long)(ph.n0 + wn * 32 + lr) * (9 * p.C) + lh * 4 + tap * p.C + ph.cc * CK;
+      const char* sbase = reinterpret_cast<const char*>(p.w) + ((long)ph.n0 * 9 * p.C + tap * p.C + ph.cc * CK) * 4;
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) fb[kc] = *reinterpret_cast<const f32x4*>(src + kc * 8);
+      for (int kc = 0; kc < 4; ++kc) fb[kc] = *reinterpret_cast<const f32x4*>(sbase + wlane + kc * 32);
     } else {
-      const float* src = p.w + ((long)(lh * 4 + ph.cc * CK) * 9 + tap) * p.Wn + ph.n0 + wn * 32 + lr;
-      const long kstride = (long)9 * p.Wn;
+      const char* sbase = reinterpret_cast<const char*>(p.w) + (((long)ph.cc * CK * 9 + tap) * p.Wn + ph.n0) * 4;
+      const long kstride = (long)9 * p.Wn * 4;
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) fb[kc][s] = src[(kc * 8 + s) * kstride];
+        for (int s = 0; s < 4; ++s)
+          fb[kc][s] = *reinterpret_cast<const float*>(sbase + wlane + (kc * 8 + s) * kstride);
     }
   };
 
@@ -237,6 +279,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
   for (int j = 0; j < NJ; ++j) mrp |= fetch(j, nx1) << j;
   __syncthreads();
 
+  int mrow[2][4];
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  f32x4 rv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mrow[i][j] = 0;
+      rv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   int buf = 0;
   for (;;) {
     const float* Pc = smem + buf * PBUF;
@@ -251,6 +303,32 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
     f32x4 fa[2][2];
     read_frag(0, fa[0]);
     unsigned mnew = 0;
+    // Last phase of a unit: the epilogue's bias / residual loads are issued NOW, a whole phase
+    // before they are used, so that waiting for them later does not drain the (younger) weight and
+    // patch prefetches - vmcnt retires in order.
+    const bool last_of_unit = cur.cc + 1 >= cur.cc_end;
+    if (last_of_unit) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rt = wm * 64 + i * 32 + (lane >> 3) + 8 * j;
+          const int img = rt >> p.lgTT, rr = rt & ((1 << p.lgTT) - 1);
+          const int oh = cur.h0 + (rr >> p.lgTW), ow = cur.w0 + (rr & (p.TW - 1)), b = cur.b0 + img;
+          mrow[i][j] = (b * p.H + oh) * p.W + ow;   // tiles divide B (image groups), H and W exactly
+        }
+      if (p.splits == 1) {
+        const int nc = cur.n0 + wn * 32 + (lane & 7) * 4;
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + nc);
+        if (p.res) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              rv[i][j] = *reinterpret_cast<const f32x4*>(p.res + (long)mrow[i][j] * p.res_pitch + nc);
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // The step's bookkeeping is dealt out over its four k-groups so that no more than ~10
@@ -289,43 +367,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
     mrp = mnew;
     __syncthreads();   // everyone is done reading Pc and writing Pn
 
-    if (cur.cc + 1 >= cur.cc_end) {
-      // ---- epilogue: wave-private LDS transpose, then 16-byte stores.  All loads (bias,
-      // residual rows) are issued up front and the stores are unconditional: one wait, no
-      // store-to-store serialisation.
+    if (last_of_unit) {
+      // ---- epilogue: wave-private LDS transpose, then unconditional 16-byte stores ----
       const int nc = cur.n0 + wn * 32 + (lane & 7) * 4;
       float* dst = p.out;
       long dpitch = p.out_pitch;
-      const bool partial = p.splits > 1;     // split-K: plain partial sums, the reducer adds bias / res
-      if (partial) {
+      if (p.splits > 1) {                    // split-K: plain partial sums, the reducer adds bias / res
         dst = p.ws + (long)cur.split * p.ws_stride;
         dpitch = p.N;
-      }
-      long mrow[2][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int rt = wm * 64 + i * 32 + (lane >> 3) + 8 * j;
-          const int img = rt >> p.lgTT, rr = rt & ((1 << p.lgTT) - 1);
-          const int oh = cur.h0 + (rr >> p.lgTW), ow = cur.w0 + (rr & (p.TW - 1)), b = cur.b0 + img;
-          mrow[i][j] = (long)((b * p.H + oh) * p.W + ow);   // tiles divide B (image groups), H and W exactly
-        }
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      f32x4 rv[2][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!partial) {
-        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + nc);
-        if (p.res) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              rv[i][j] = *reinterpret_cast<const f32x4*>(p.res + mrow[i][j] * p.res_pitch + nc);
-        }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -334,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
         lgm_wave_lds_sync();
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(dst + mrow[i][j] * dpitch + nc) = lgm_tile_row4(Ts, lane, j) + bv + rv[i][j];
+          *reinterpret_cast<f32x4*>(dst + (long)mrow[i][j] * dpitch + nc) = lgm_tile_row4(Ts, lane, j) + bv + rv[i][j];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
       }
