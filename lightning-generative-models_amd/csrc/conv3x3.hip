@@ -446,10 +446,36 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
   const int ts_begin = split * p.tps;
   const int ts_end = min(p.total_ts, ts_begin + p.tps);
   // Register-staged tiles: the global loads of tile t+1 are issued right after tile t has been
-  // committed to LDS, so they are in flight during tile t's 576 MFMAs per wave.
+  // committed to LDS, so they are in flight during tile t's 576 MFMAs per wave.  Everything about a
+  // thread's 8 Y rows and 18 patch positions that does not depend on the tile is computed once
+  // (byte offsets from the tile origin, border flags), so issuing a tile costs ~3 VALU
+  // instructions per load instead of two integer divisions.
   constexpr int NJW = 18;              // patch positions per thread (NP <= 288, 16 positions per pass)
   const int c4 = (tid & 15) * 4;
+  unsigned ydelta[8], xdelta[NJW];
+  unsigned xflag[3] = {0u, 0u, 0u};    // 5 flag bits per position, six positions per word
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = (tid >> 4) + 16 * j;
+    const int img = r >> lgTT, rr = r & ((1 << lgTT) - 1);
+    ydelta[j] = (unsigned)(((img * p.H + (rr >> lgTW)) * p.W + (rr & (TW - 1))) * (int)p.y_pitch + c4) * 4u;
+  }
+#pragma unroll
+  for (int u = 0; u < NJW; ++u) {
+    const int pos = (tid >> 4) + 16 * u;
+    unsigned d = 0, f = 16u;
+    if (pos < NP) {
+      const int img = pos / PP1, rem = pos - img * PP1;
+      const int py = rem / PW, px = rem - py * PW;
+      d = (unsigned)(((img * p.H + py) * p.W + px) * (int)p.x_pitch + c4) * 4u;
+      f = (py == 0 ? 1u : 0u) | (py == p.TH + 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == TW + 1 ? 8u : 0u);
+    }
+    xdelta[u] = d;
+    xflag[u / 6] |= f << (5 * (u % 6));
+  }
+  const unsigned safe_delta = (unsigned)((p.W + 1) * (int)p.x_pitch) * 4u;   // an interior pixel of the tile
   f32x4 ry[8], rp[NJW];
+  unsigned rp_ok = 0;                  // validity bits of the patch held in rp
   auto load_tile = [&](int ts) {
     int t = ts;
     const int twi = t % p.tiles_w;
@@ -457,29 +483,21 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
     const int thi = t % p.tiles_h;
     const int b0 = (t / p.tiles_h) * p.NI;
     const int h0 = thi * p.TH, w0 = twi * TW;
+    const unsigned border = 16u | (h0 == 0 ? 1u : 0u) | (h0 + p.TH == p.H ? 2u : 0u) | (w0 == 0 ? 4u : 0u) |
+                            (w0 + TW == p.W ? 8u : 0u);
+    const char* ybase = reinterpret_cast<const char*>(p.y) + ((long)((b0 * p.H + h0) * p.W + w0) * p.y_pitch + n0) * 4;
+    const char* xbase = reinterpret_cast<const char*>(p.x) +
+                        ((long)((b0 * p.H + h0 - 1) * p.W + w0 - 1) * p.x_pitch + c0) * 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {      // Y tile: thread -> (row tid/16 + 16 j, float4 column tid%16)
-      const int r = (tid >> 4) + 16 * j;
-      const int img = r >> lgTT, rr = r & ((1 << lgTT) - 1);
-      const int oh = h0 + (rr >> lgTW), ow = w0 + (rr & (TW - 1)), b = b0 + img;
-      const bool ok = b < p.B && oh < p.H && ow < p.W;
-      ry[j] = ok ? *reinterpret_cast<const f32x4*>(p.y + (long)((b * p.H + oh) * p.W + ow) * p.y_pitch + n0 + c4)
-                 : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int j = 0; j < 8; ++j) ry[j] = *reinterpret_cast<const f32x4*>(ybase + ydelta[j]);
+    unsigned okbits = 0;
 #pragma unroll
-    for (int u = 0; u < NJW; ++u) {    // X halo patch
-      const int pos = (tid >> 4) + 16 * u;
-      bool ok = pos < NP;
-      long off = 0;
-      if (ok) {
-        const int img = pos / PP1, rem = pos - img * PP1;
-        const int py = rem / PW, px = rem - py * PW;
-        const int ih = h0 + py - 1, iw = w0 + px - 1, b = b0 + img;
-        ok = b < p.B && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        off = (long)((b * p.H + ih) * p.W + iw) * p.x_pitch + c0 + c4;
-      }
-      rp[u] = ok ? *reinterpret_cast<const f32x4*>(p.x + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NJW; ++u) {
+      const bool ok = (xflag[u / 6] & (border << (5 * (u % 6)))) == 0u;
+      rp[u] = *reinterpret_cast<const f32x4*>(xbase + (ok ? xdelta[u] : safe_delta));
+      okbits |= (ok ? 1u : 0u) << u;
     }
+    rp_ok = okbits;
   };
   if (ts_begin < ts_end) load_tile(ts_begin);
   for (int ts = ts_begin; ts < ts_end; ++ts) {
@@ -489,7 +507,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
 #pragma unroll
     for (int u = 0; u < NJW; ++u) {
       const int pos = (tid >> 4) + 16 * u;
-      if (pos < NP) *reinterpret_cast<f32x4*>(Ps + pos * LDP + c4) = rp[u];
+      if (pos < 288)
+        *reinterpret_cast<f32x4*>(Ps + pos * LDP + c4) = ((rp_ok >> u) & 1u) ? rp[u] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     if (ts + 1 < ts_end) load_tile(ts + 1);
@@ -523,17 +542,29 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
     }
   }
 
+  // ---- epilogue: nine 32x32 tiles per wave through a wave-private LDS transpose, 16-byte stores
   float* out = p.out + (p.splits > 1 ? (long)split * p.slab : 0L);
-  const int c = c0 + wn * 32 + lr;
+  __syncthreads();                                   // every wave is done with As / Ps
+  float* Ts = smem + wid * LGM_TS_FLOATS;
+  const int cc = c0 + wn * 32 + (lane & 7) * 4;
+  const bool acc_out = p.splits == 1 && p.beta != 0.f;
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) {
+    f32x4 prev[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const long o = ((long)n * 9 + tp) * p.Cw + c;
-      float v = acc[tp][r];
-      if (p.splits == 1 && p.beta != 0.f) v += p.beta * out[o];
-      out[o] = v;
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wm * 32 + (lane >> 3) + 8 * j;
+      prev[j] = acc_out ? *reinterpret_cast<const f32x4*>(out + ((long)n * 9 + tp) * p.Cw + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    lgm_wave_lds_sync();
+    lgm_tile_to_lds(acc[tp], Ts, lane);
+    lgm_wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wm * 32 + (lane >> 3) + 8 * j;
+      f32x4 v = lgm_tile_row4(Ts, lane, j);
+      if (acc_out) v += p.beta * prev[j];
+      *reinterpret_cast<f32x4*>(out + ((long)n * 9 + tp) * p.Cw + cc) = v;
     }
   }
   if (do_bias) {
@@ -684,7 +715,8 @@ bool lgm_wgrad3x3_supported(const LgmConvGeom* g) {
   int TH, TW, NI;
   if (!(g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1)) return false;
   if (g->Cw % 64 != 0 || g->Nw % 64 != 0) return false;
-  return plan_tile(g->H, g->W, &TH, &TW, &NI);
+  if (!plan_tile(g->H, g->W, &TH, &TW, &NI)) return false;
+  return g->B % NI == 0;   // whole image groups only
 }
 
 void lgm_wgrad3x3_plan(const LgmConvGeom* g, int* splits, int* tps, int* total_ts) {
@@ -718,7 +750,8 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
   p.tiles_n = g->Nw / 64; p.tiles_c = g->Cw / 64;
   p.splits = splits; p.tps = tps; p.total_ts = total_ts;
   const int NP = p.NI * (p.TH + 2) * (TW + 2);
-  const size_t smem = (size_t)(128 * 64 + NP * 64) * sizeof(float);
+  (void)NP;
+  const size_t smem = (size_t)(128 * 64 + 288 * 64) * sizeof(float);   // all 288 patch positions are written
   const unsigned nblocks = (unsigned)((long)p.tiles_n * p.tiles_c * splits);
 #define LGM_W3_LAUNCH(TWV)                                                                             \
   do {                                                                                                 \

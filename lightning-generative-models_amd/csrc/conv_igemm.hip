@@ -690,11 +690,11 @@ void wgrad_plan(const LgmConvGeom* g, int* splits, int* chunk) {
 extern "C" int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g) {
   if (check_geom(g) != LGM_OK) return -1;
   int splits, chunk;
+  wgrad_plan(g, &splits, &chunk);          // the generic plan is the fallback of the 3x3 path (pitch limits)
   if (use_3x3() && lgm_wgrad3x3_supported(g)) {
-    int tps, total;
-    lgm_wgrad3x3_plan(g, &splits, &tps, &total);
-  } else {
-    wgrad_plan(g, &splits, &chunk);
+    int s3, tps, total;
+    lgm_wgrad3x3_plan(g, &s3, &tps, &total);
+    if (s3 > splits) splits = s3;
   }
   if (splits == 1) return 16;
   const int64_t slab = (int64_t)g->Nw * g->KH * g->KW * g->Cw + g->Nw;
@@ -715,7 +715,8 @@ extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pi
   a.B = g->B; a.H = g->H; a.W = g->W; a.Cw = g->Cw; a.Ho = g->Ho; a.Wo = g->Wo; a.Nw = g->Nw;
   a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
   a.P = g->B * g->Ho * g->Wo; a.Q = g->KH * g->KW * g->Cw;
-  const bool fast3 = use_3x3() && lgm_wgrad3x3_supported(g);
+  const bool fast3 = use_3x3() && lgm_wgrad3x3_supported(g) && (long)g->B * g->H * g->W * x_pitch < (1L << 30) &&
+                     (long)g->B * g->H * g->W * y_pitch < (1L << 30);   // 32-bit byte offsets
   int tps3 = 0, total3 = 0;
   if (fast3)
     lgm_wgrad3x3_plan(g, &a.splits, &tps3, &total3);
