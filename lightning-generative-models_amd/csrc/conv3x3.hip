@@ -176,19 +176,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
   const int c4 = (tid % TPP) * 4;
   unsigned pdelta[NJ];
   unsigned pflagA = 0, pflagB = 0;       // positions 0..5 / 6..8, five bits each
+  {
+    // walk pos = tid / TPP + PPP * j without divisions: (img, py, px) advance by PPP columns per j
+    int px = tid / TPP, py = 0, img = 0;
+    while (px >= PW) { px -= PW; ++py; }
+    while (py >= p.TH + 2) { py -= p.TH + 2; ++img; }
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int pos = tid / TPP + PPP * j;
-    unsigned d = 0, f = 16u;
-    if (pos < p.NP) {
-      const int img = pos / PP1, rem = pos - img * PP1;
-      const int py = rem / PW, px = rem - py * PW;
-      d = (unsigned)(((img * p.H + py) * p.W + px) * (int)p.a_pitch + c4) * 4u;
-      f = (py == 0 ? 1u : 0u) | (py == p.TH + 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == p.TW + 1 ? 8u : 0u);
+    for (int j = 0; j < NJ; ++j) {
+      unsigned d = 0, f = 16u;
+      if (img < p.NI) {
+        d = (unsigned)(((img * p.H + py) * p.W + px) * (int)p.a_pitch + c4) * 4u;
+        f = (py == 0 ? 1u : 0u) | (py == p.TH + 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == p.TW + 1 ? 8u : 0u);
+      }
+      pdelta[j] = d;
+      if (j < 6) pflagA |= f << (5 * j);
+      else pflagB |= f << (5 * (j - 6));
+      px += PPP;
+      while (px >= PW) { px -= PW; ++py; }
+      while (py >= p.TH + 2) { py -= p.TH + 2; ++img; }
     }
-    pdelta[j] = d;
-    if (j < 6) pflagA |= f << (5 * j);
-    else pflagB |= f << (5 * (j - 6));
   }
   // a position that is certainly inside the tensor (first interior pixel of the tile's first image)
   const unsigned safe_delta = (unsigned)((p.W + 1) * (int)p.a_pitch) * 4u;
@@ -410,6 +416,7 @@ struct WArgs {
   long slab, y_pitch, x_pitch;
   int B, H, W, Nw, Cw;
   int TH, lgTH, NI, tiles_h, tiles_w, tiles_n, tiles_c, splits, tps, total_ts;
+  int gsplit;        // sub-blocks per spatial tile along its eight 16-pixel groups (small problems)
 };
 
 template <int TW>
@@ -429,7 +436,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
   const int lr = lane & 31, lh = lane >> 5;
 
   int bid = blockIdx.x;
-  const int split = bid % p.splits;
+  const int slab_id = bid % p.splits;      // slab = (tile split, group split)
+  const int gs = slab_id % p.gsplit, split = slab_id / p.gsplit;
+  const int g_lo = gs * (8 / p.gsplit), g_hi = g_lo + 8 / p.gsplit;
   bid /= p.splits;
   const int tc = bid % p.tiles_c, tn = bid / p.tiles_c;
   const int n0 = tn * 64, c0 = tc * 64;
@@ -460,18 +469,23 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
     const int img = r >> lgTT, rr = r & ((1 << lgTT) - 1);
     ydelta[j] = (unsigned)(((img * p.H + (rr >> lgTW)) * p.W + (rr & (TW - 1))) * (int)p.y_pitch + c4) * 4u;
   }
+  {
+    int px = tid >> 4, py = 0, img = 0;  // walk pos = tid / 16 + 16 u without divisions
+    while (px >= PW) { px -= PW; ++py; }
+    while (py >= p.TH + 2) { py -= p.TH + 2; ++img; }
 #pragma unroll
-  for (int u = 0; u < NJW; ++u) {
-    const int pos = (tid >> 4) + 16 * u;
-    unsigned d = 0, f = 16u;
-    if (pos < NP) {
-      const int img = pos / PP1, rem = pos - img * PP1;
-      const int py = rem / PW, px = rem - py * PW;
-      d = (unsigned)(((img * p.H + py) * p.W + px) * (int)p.x_pitch + c4) * 4u;
-      f = (py == 0 ? 1u : 0u) | (py == p.TH + 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == TW + 1 ? 8u : 0u);
+    for (int u = 0; u < NJW; ++u) {
+      unsigned d = 0, f = 16u;
+      if (img < p.NI) {
+        d = (unsigned)(((img * p.H + py) * p.W + px) * (int)p.x_pitch + c4) * 4u;
+        f = (py == 0 ? 1u : 0u) | (py == p.TH + 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == TW + 1 ? 8u : 0u);
+      }
+      xdelta[u] = d;
+      xflag[u / 6] |= f << (5 * (u % 6));
+      px += 16;
+      while (px >= PW) { px -= PW; ++py; }
+      while (py >= p.TH + 2) { py -= p.TH + 2; ++img; }
     }
-    xdelta[u] = d;
-    xflag[u / 6] |= f << (5 * (u % 6));
   }
   const unsigned safe_delta = (unsigned)((p.W + 1) * (int)p.x_pitch) * 4u;   // an interior pixel of the tile
   f32x4 ry[8], rp[NJW];
@@ -514,12 +528,15 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
     if (ts + 1 < ts_end) load_tile(ts + 1);
     if (do_bias) {
 #pragma unroll 8
-      for (int r = 0; r < 32; ++r) bsum += As[((tid >> 6) + 4 * r) * 64 + (tid & 63)];
+      for (int r = 0; r < 32; ++r) {
+        const int row = (tid >> 6) + 4 * r;
+        if (row >= g_lo * 16 && row < g_hi * 16) bsum += As[row * 64 + (tid & 63)];
+      }
     }
     // ---- MFMAs: k = pixel.  16-pixel groups; inside a group all patch offsets are constants ----
     const float* ap = As + lh * 64 + wm * 32 + lr;
     const float* bp = Ps + wn * 32 + lr;
-    for (int g = 0; g < 8; ++g) {
+    for (int g = g_lo; g < g_hi; ++g) {
       const int pix0 = g * 16;
       const int img = pix0 >> lgTT, rr = pix0 & ((1 << lgTT) - 1);
       const int pos0 = (img * (p.TH + 2) + (rr >> lgTW)) * PW + (rr & (TW - 1));
@@ -543,7 +560,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
   }
 
   // ---- epilogue: nine 32x32 tiles per wave through a wave-private LDS transpose, 16-byte stores
-  float* out = p.out + (p.splits > 1 ? (long)split * p.slab : 0L);
+  float* out = p.out + (p.splits > 1 ? (long)slab_id * p.slab : 0L);
   __syncthreads();                                   // every wave is done with As / Ps
   float* Ts = smem + wid * LGM_TS_FLOATS;
   const int cc = c0 + wn * 32 + (lane & 7) * 4;
@@ -573,7 +590,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
     __syncthreads();
     if (tid < 64) {
       float v = (As[tid] + As[64 + tid]) + (As[128 + tid] + As[192 + tid]);
-      float* bo = p.bias_out + (p.splits > 1 ? (long)split * p.slab : 0L) + n0 + tid;
+      float* bo = p.bias_out + (p.splits > 1 ? (long)slab_id * p.slab : 0L) + n0 + tid;
       if (p.splits == 1 && p.beta != 0.f) v += p.beta * bo[0];
       bo[0] = v;
     }
@@ -731,7 +748,13 @@ void lgm_wgrad3x3_plan(const LgmConvGeom* g, int* splits, int* tps, int* total_t
   if (s < 1) s = 1;
   const int t = lgm_cdiv(total, s);
   *tps = t;
-  *splits = lgm_cdiv(total, t);
+  const int tsplits = lgm_cdiv(total, t);
+  // few workgroups (small batch / small maps): also split each tile's eight 16-pixel groups, so
+  // that a workgroup's MFMA chain (576 per tile and wave) is shorter and more CUs take part
+  const long wgs = tiles * tsplits;
+  static const bool no_gsplit = getenv("LGM_NO_GSPLIT") != nullptr;   // A/B switch
+  const int gsplit = no_gsplit ? 1 : wgs <= 64 ? 4 : wgs <= 128 ? 2 : 1;
+  *splits = tsplits * gsplit;
   *total_ts = total;
 }
 
@@ -749,6 +772,7 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
   p.tiles_h = g->H / p.TH; p.tiles_w = g->W / TW;
   p.tiles_n = g->Nw / 64; p.tiles_c = g->Cw / 64;
   p.splits = splits; p.tps = tps; p.total_ts = total_ts;
+  p.gsplit = splits / lgm_cdiv(total_ts, tps);
   const int NP = p.NI * (p.TH + 2) * (TW + 2);
   (void)NP;
   const size_t smem = (size_t)(128 * 64 + 288 * 64) * sizeof(float);   // all 288 patch positions are written
