@@ -4,6 +4,8 @@
 //
 // Reference arithmetic: Block.forward ddpm.py:164-173 (GroupNorm(8, C, eps=1e-5) -> x*(scale+1)+shift
 // -> SiLU), RMSNorm ddpm.py:107-113 (F.normalize(x, dim=1) * g * sqrt(C)).
+#include <stdlib.h>
+
 #include "lgm_common.h"
 
 namespace {
@@ -18,13 +20,14 @@ __device__ __forceinline__ float silu_grad(float z) {
 // GN statistics: one block per (image, channel block of CB channels); two in-kernel passes
 // (mean, then centred second moment) so the variance does not suffer cancellation.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long pitch, int HW,
+template <int NT>   // threads per block: 1024 on large maps (more loads in flight for an HBM-bound pass)
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ x, long pitch, int HW,
                                                        int C, int G, int CB, float eps,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ ss, long ss_pitch,
                                                        float* __restrict__ mean, float* __restrict__ rstd,
                                                        float* __restrict__ A, float* __restrict__ Bc) {
-  __shared__ float sh[256 * 4];
+  __shared__ float sh[NT * 4];
   __shared__ float chs[256];
   __shared__ float gmean[64], grstd[64];
   const int nb = C / CB;
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   const int c0 = cb * CB;
   const int Cg = C / G;
   const int tq = CB / 4;              // threads per pixel
-  const int ppb = 256 / tq;           // pixel lanes
+  const int ppb = NT / tq;            // pixel lanes
   const int tid = threadIdx.x;
   const int q = tid % tq, pl = tid / tq;
   const bool active = pl < ppb;
@@ -59,19 +62,37 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   };
 
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (active)
-    for (int p = pl; p < HW; p += ppb) s += *reinterpret_cast<const f32x4*>(xb + (long)p * pitch);
+  if (active) {
+    int p = pl;
+    for (; p + 3 * ppb < HW; p += 4 * ppb) {     // four independent loads in flight
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long)p * pitch);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + (long)(p + ppb) * pitch);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(xb + (long)(p + 2 * ppb) * pitch);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(xb + (long)(p + 3 * ppb) * pitch);
+      s += (v0 + v1) + (v2 + v3);
+    }
+    for (; p < HW; p += ppb) s += *reinterpret_cast<const f32x4*>(xb + (long)p * pitch);
+  }
   *reinterpret_cast<f32x4*>(&sh[tid * 4]) = s;
   group_reduce(gmean, false);
   f32x4 mu;
 #pragma unroll
   for (int k = 0; k < 4; ++k) mu[k] = gmean[(q * 4 + k) / Cg];
   f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
-  if (active)
-    for (int p = pl; p < HW; p += ppb) {
-      f32x4 d = *reinterpret_cast<const f32x4*>(xb + (long)p * pitch) - mu;
+  if (active) {
+    int p = pl;
+    for (; p + 3 * ppb < HW; p += 4 * ppb) {
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(xb + (long)p * pitch) - mu;
+      const f32x4 d1 = *reinterpret_cast<const f32x4*>(xb + (long)(p + ppb) * pitch) - mu;
+      const f32x4 d2 = *reinterpret_cast<const f32x4*>(xb + (long)(p + 2 * ppb) * pitch) - mu;
+      const f32x4 d3 = *reinterpret_cast<const f32x4*>(xb + (long)(p + 3 * ppb) * pitch) - mu;
+      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    for (; p < HW; p += ppb) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(xb + (long)p * pitch) - mu;
       s2 += d * d;
     }
+  }
   *reinterpret_cast<f32x4*>(&sh[tid * 4]) = s2;
   group_reduce(grstd, true);
   if (tid < ngl) {
@@ -120,7 +141,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 }
 
 // backward pass 1: S1[b,c] = sum_hw gz, S2[b,c] = sum_hw gz * xhat
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, long x_pitch,
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const float* __restrict__ x, long x_pitch,
                                                             const float* __restrict__ gy, long gy_pitch,
                                                             const float* __restrict__ A, const float* __restrict__ Bc,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -131,12 +153,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
                                                             float* __restrict__ S1, float* __restrict__ S2,
                                                             float* __restrict__ P, float* __restrict__ Qc,
                                                             float* __restrict__ Rc) {
-  __shared__ float sh[256 * 8];
+  __shared__ float sh[NT * 8];
   const int nb = C / CB;
   const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
   const int c0 = cb * CB;
   const int Cg = C / G;
-  const int tq = CB / 4, ppb = 256 / tq;
+  const int tq = CB / 4, ppb = NT / tq;
   const int tid = threadIdx.x;
   const int q = tid % tq, pl = tid / tq;
   const bool active = pl < ppb;
@@ -313,8 +335,13 @@ extern "C" int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C,
   LGM_REQUIRE(x_pitch % 4 == 0 && y_pitch % 4 == 0 && (!res || res_pitch % 4 == 0), "gn_fwd: pitch %% 4 != 0");
   hipStream_t s = (hipStream_t)stream;
   const int cb = gn_cb(C, G);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(B * (C / cb)), dim3(256), 0, s, x, (long)x_pitch, HW, C, G, cb, eps, gamma,
-                     beta, ss, (long)ss_pitch, mean, rstd, coefA, coefB);
+  static const bool small_only = getenv("LGM_GN_256") != nullptr;   // A/B switch
+  if (!small_only && (long)HW * cb >= 16384)
+    hipLaunchKernelGGL(gn_stats_kernel<1024>, dim3(B * (C / cb)), dim3(1024), 0, s, x, (long)x_pitch, HW, C, G, cb, eps,
+                       gamma, beta, ss, (long)ss_pitch, mean, rstd, coefA, coefB);
+  else
+    hipLaunchKernelGGL(gn_stats_kernel<256>, dim3(B * (C / cb)), dim3(256), 0, s, x, (long)x_pitch, HW, C, G, cb, eps,
+                       gamma, beta, ss, (long)ss_pitch, mean, rstd, coefA, coefB);
   const long npix = (long)B * HW;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(lgm_cdiv(npix * (C / 4), 256)), dim3(256), 0, s, x, (long)x_pitch, coefA,
                      coefB, res, (long)res_pitch, y, (long)y_pitch, npix, HW, C, act);
@@ -340,9 +367,15 @@ extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int6
   float* Qc = P + bc;
   float* Rc = Qc + bc;
   const int cb = gn_cb(C, G);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * (C / cb)), dim3(256), 0, s, x, (long)x_pitch, gy, (long)gy_pitch,
-                     coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss, (long)gss_pitch,
-                     gss_beta, S1, S2, P, Qc, Rc);
+  static const bool small_only = getenv("LGM_GN_256") != nullptr;
+  if (!small_only && (long)HW * cb >= 16384)
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<1024>, dim3(B * (C / cb)), dim3(1024), 0, s, x, (long)x_pitch, gy,
+                       (long)gy_pitch, coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss,
+                       (long)gss_pitch, gss_beta, S1, S2, P, Qc, Rc);
+  else
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<256>, dim3(B * (C / cb)), dim3(256), 0, s, x, (long)x_pitch, gy,
+                       (long)gy_pitch, coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss,
+                       (long)gss_pitch, gss_beta, S1, S2, P, Qc, Rc);
   const long npix = (long)B * HW;
   const int apply_blocks = lgm_cdiv(npix * (C / 4), 256);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(apply_blocks + lgm_cdiv(C, 16)), dim3(256), 0, s, x, (long)x_pitch, gy,
