@@ -263,6 +263,11 @@ int lgm_lerp_rows(const float* x, const float* y, const float* alpha, float* out
 int64_t lgm_gp_penalty_workspace(int64_t npix);
 int lgm_gp_penalty(const float* g, int64_t npix, int C, float lambda, const float* gscale,
                    float* loss_out, float* gbar, void* workspace, void* stream);
+/* R1 regulariser on real data (r1gan.py:74-77): loss_out = 0.5 * mean_b sum_{chw} g^2 (the caller
+ * applies hparams.r1_penalty); gbar = d(gscale*loss)/dg = gscale/B * g.  g, gbar dense NHWC4 with a
+ * zero padding lane; workspace as lgm_gp_penalty_workspace(npix). */
+int lgm_r1_penalty(const float* g, int64_t npix, int64_t B, const float* gscale, float* loss_out,
+                   float* gbar, void* workspace, void* stream);
 /* out = scale * mean_i v[i*pitch]  (critic score means, wgan.py:85-87) */
 int lgm_mean_col(const float* v, int64_t pitch, int64_t n, float scale, float* out, void* stream);
 /* out[r][c] = (c == col) ? scale * (vptr ? *vptr : 1) : 0 */
@@ -279,6 +284,12 @@ int lgm_wgan_dloss(float* vals4, void* stream);
 int lgm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                   float b2, float eps, float weight_decay, float step, const float* step_dev,
                   float grad_scale, int decoupled, void* stream);
+/* torch.optim.RMSprop with its defaults (momentum 0, not centred) - the critic / generator optimiser
+ * of the weight-clipping WGAN (wgan.py:171-181): sq = alpha*sq + (1-alpha)*g^2; p -= lr*g/(sqrt(sq)+eps) */
+int lgm_rmsprop_step(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps,
+                     float weight_decay, float grad_scale, void* stream);
+/* WGAN weight clipping, param.data.clamp_(-c, c) over the critic's flat parameter buffer (wgan.py:158-168) */
+int lgm_clamp(float* x, int64_t n, float lo, float hi, void* stream);
 /* ema_pytorch.EMA.update (ddpm.py:1047-1048): shadow += (online - shadow) * w   (w = 1 copies) */
 int lgm_ema_lerp(float* shadow, const float* online, int64_t n, float w, void* stream);
 int lgm_add_scalar(float* x, float a, void* stream);

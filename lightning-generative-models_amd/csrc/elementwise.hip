@@ -593,6 +593,22 @@ __global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict
   if (threadIdx.x == 0) partial[blockIdx.x] = pen;
 }
 
+// R1 penalty (r1gan.py:77): partial[block] = sum_p sum_c g[p,c]^2;  gbar = gscale / B * g.
+__global__ __launch_bounds__(256) void r1_penalty_kernel(const float* __restrict__ g, long npix, float inv_b,
+                                                         const float* __restrict__ gscale, float* __restrict__ partial,
+                                                         float* __restrict__ gbar) {
+  __shared__ float sh[16];
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float pen = 0.f;
+  if (p < npix) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + p * 4);
+    pen = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);   // the padding lane carries zeros
+    if (gbar) *reinterpret_cast<f32x4*>(gbar + p * 4) = v * (gscale[0] * inv_b);
+  }
+  pen = lgm_block_sum(pen, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = pen;
+}
+
 // vals[slot] = scale * sum_i partial[i]   (single block, fixed order)
 __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ partial, long n, long stride,
                                                         float scale, float* __restrict__ out) {
@@ -639,6 +655,20 @@ extern "C" int lgm_gp_penalty(const float* g, int64_t npix, int C, float lambda,
                      gbar);
   hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, (long)nb, 1L,
                      lambda / (float)npix, loss_out);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_r1_penalty(const float* g, int64_t npix, int64_t B, const float* gscale, float* loss_out,
+                              float* gbar, void* workspace, void* stream) {
+  LGM_REQUIRE(g && loss_out && workspace && npix > 0 && B > 0 && (!gbar || gscale) && lgm_aligned16(g),
+              "r1_penalty: bad arguments (dense NHWC4 gradient expected)");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = lgm_cdiv(npix, 256);
+  hipLaunchKernelGGL(r1_penalty_kernel, dim3(nb), dim3(256), 0, s, g, (long)npix, 1.f / (float)B, gscale,
+                     (float*)workspace, gbar);
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, (long)nb, 1L, 0.5f / (float)B,
+                     loss_out);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

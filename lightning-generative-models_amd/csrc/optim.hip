@@ -93,6 +93,51 @@ extern "C" int lgm_adam_step(float* p, const float* g, float* m, float* v, int64
   return LGM_OK;
 }
 
+namespace {
+// torch.optim.RMSprop defaults (momentum = 0, centered = False): sq = alpha*sq + (1-alpha)*g^2;
+// p -= lr * g / (sqrt(sq) + eps).  Coupled weight decay like torch (g += wd * p).
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ sq, long n, float lr, float alpha,
+                                                      float eps, float wd, float grad_scale) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const int cnt = (i + 3 < n) ? 4 : (int)(n - i);
+  for (int k = 0; k < cnt; ++k) {
+    float pv = p[i + k], gv = g[i + k] * grad_scale, sv = sq[i + k];
+    if (wd != 0.f) gv += pv * wd;
+    sv = sv * alpha + gv * gv * (1.f - alpha);
+    pv -= lr * (gv / (sqrtf(sv) + eps));
+    p[i + k] = pv;
+    sq[i + k] = sv;
+  }
+}
+
+__global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ x, long n, float lo, float hi) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const int cnt = (i + 3 < n) ? 4 : (int)(n - i);
+  for (int k = 0; k < cnt; ++k) x[i + k] = fminf(fmaxf(x[i + k], lo), hi);
+}
+}  // namespace
+
+extern "C" int lgm_rmsprop_step(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps,
+                                float weight_decay, float grad_scale, void* stream) {
+  LGM_REQUIRE(p && g && sq && n > 0, "rmsprop_step: bad arguments");
+  const long nthreads = (n + 3) / 4;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(lgm_cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, p, g, sq, (long)n,
+                     lr, alpha, eps, weight_decay, grad_scale);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_clamp(float* x, int64_t n, float lo, float hi, void* stream) {
+  LGM_REQUIRE(x && n > 0 && lo <= hi, "clamp: bad arguments");
+  const long nthreads = (n + 3) / 4;
+  hipLaunchKernelGGL(clamp_kernel, dim3(lgm_cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)n, lo, hi);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
 extern "C" int lgm_ema_lerp(float* shadow, const float* online, int64_t n, float w, void* stream) {
   LGM_REQUIRE(shadow && online && n > 0 && lgm_aligned16(shadow) && lgm_aligned16(online), "ema_lerp: bad arguments");
   const long nthreads = (n + 3) / 4;

@@ -305,6 +305,14 @@ def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, step_dev=None, grad_scal
                         float(step), _p(step_dev), grad_scale, 1 if decoupled else 0, stream())
 
 
+def rmsprop_step(p, g, sq, n, lr, alpha, eps, wd, grad_scale=1.0):
+    lib().lgm_rmsprop_step(p.data_ptr(), g.data_ptr(), sq.data_ptr(), n, lr, alpha, eps, wd, grad_scale, stream())
+
+
+def clamp_(x, lo, hi):
+    lib().lgm_clamp(x.data_ptr(), x.numel(), lo, hi, stream())
+
+
 def ema_lerp(shadow, online, w):
     lib().lgm_ema_lerp(shadow.data_ptr(), online.data_ptr(), shadow.numel(), w, stream())
 

@@ -60,6 +60,30 @@ class FusedAdam(torch.optim.Optimizer):
                 fp.zero_grad()
 
 
+class FusedRMSprop(FusedAdam):
+    """torch.optim.RMSprop with its defaults (alpha 0.99, eps 1e-8, momentum 0, not centred) — the
+    optimiser of the weight-clipping WGAN (reference wgan.py:171-181) — one kernel per flat buffer."""
+
+    def __init__(self, params: Iterable[nn.Parameter], lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0):
+        torch.optim.Optimizer.__init__(self, params, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay))
+        self._flat_state = {}
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            for fp in self._flats(group):
+                st = self._flat_state.get(id(fp))
+                if st is None:
+                    st = dict(sq=torch.zeros_like(fp.data), step=0, flat=fp)
+                    self._flat_state[id(fp)] = st
+                st["step"] += 1
+                ops.rmsprop_step(fp.data, fp.grad, st["sq"], fp.total, group["lr"], group["alpha"], group["eps"],
+                                 group["weight_decay"], self.grad_scale)
+        return loss
+
+
 class EMA(nn.Module):
     """Shadow copy of a network updated every ``update_every`` calls of update()."""
 

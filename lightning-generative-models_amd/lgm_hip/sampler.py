@@ -82,7 +82,7 @@ class _Chain:
 def p_sample_step(chain: _Chain, t: int, noise: Optional[torch.Tensor]):
     """One ancestral step (p_sample :748-757): clip x0, posterior mean + sigma * noise (t > 0)."""
     hs = _host_schedule(chain.gd)
-    sigma = _f32(torch.tensor(0.5 * hs["posterior_log_variance_clipped"][t]).exp()) if t > 0 else 0.0
+    sigma = _f32(torch.as_tensor(0.5 * hs["posterior_log_variance_clipped"][t]).exp()) if t > 0 else 0.0
     chain.step(t, noise if t > 0 else None, True, _f32(hs["posterior_mean_coef1"][t]),
                _f32(hs["posterior_mean_coef2"][t]), 0.0, sigma)
 

@@ -207,8 +207,10 @@ class Discriminator(_Net):
         return g
 
     # ---- engine: gradient penalty with its second-order backward (wgan.py:117-156) ---------------
-    def gradient_penalty(self, x4, lam: float):
-        """Forward on interpolates + first backward (dD/dx, grad_outputs = 1).
+    def gradient_penalty(self, x4, lam: float, kind: str = "wgan"):
+        """Forward on ``x4`` + first backward (dD/dx, grad_outputs = 1), then the penalty functional:
+        kind "wgan": lam * mean_p (||g_p||_channels - 1)^2  (reference wgan.py:153-156, interpolates);
+        kind "r1":   0.5 * mean_b sum_chw g^2               (reference r1gan.py:74-77, real data).
         Returns (penalty scalar tensor [1], state for gp_backward)."""
         L = ops.lib()
         scores, tape = self.fwd(x4, True)
@@ -236,22 +238,29 @@ class Discriminator(_Net):
         Bx, H, W, Cp = x4.shape
         pen = ops.new((1,), x4)
         ws = ops.workspace(L.lgm_gp_penalty_workspace(Bx * H * W), x4.device)
-        L.lgm_gp_penalty(g.data_ptr(), Bx * H * W, self.img_channels, lam, None, pen.data_ptr(), None, ws.data_ptr(),
-                         ops.stream())
-        return pen, (tape, first, g, lam)
+        if kind == "r1":
+            L.lgm_r1_penalty(g.data_ptr(), Bx * H * W, Bx, None, pen.data_ptr(), None, ws.data_ptr(), ops.stream())
+        else:
+            L.lgm_gp_penalty(g.data_ptr(), Bx * H * W, self.img_channels, lam, None, pen.data_ptr(), None,
+                             ws.data_ptr(), ops.stream())
+        return pen, (tape, first, g, lam, kind)
 
     def gp_backward(self, gc: GradCtx, state, gscale):
         """d(gscale * penalty)/d(theta_D): reverse sweep over the first-backward nodes, then over the
         forward nodes (LeakyReLU'' = 0, convolutions are linear, BatchNorm via adjoint_T)."""
-        tape, first, gx, lam = state
+        tape, first, gx, lam, kind = state
         L = ops.lib()
         n = len(self.model)
         B, H, W, Cp = gx.shape
         u = ops.new(gx.shape, gx)
         pen = ops.new((1,), gx)
         ws = ops.workspace(L.lgm_gp_penalty_workspace(B * H * W), gx.device)
-        L.lgm_gp_penalty(gx.data_ptr(), B * H * W, self.img_channels, lam, gscale.data_ptr(), pen.data_ptr(),
-                         u.data_ptr(), ws.data_ptr(), ops.stream())
+        if kind == "r1":
+            L.lgm_r1_penalty(gx.data_ptr(), B * H * W, B, gscale.data_ptr(), pen.data_ptr(), u.data_ptr(),
+                             ws.data_ptr(), ops.stream())
+        else:
+            L.lgm_gp_penalty(gx.data_ptr(), B * H * W, self.img_channels, lam, gscale.data_ptr(), pen.data_ptr(),
+                             u.data_ptr(), ws.data_ptr(), ops.stream())
         a_extra = [None] * n
         # ---- sweep 1: nodes of the first backward pass, in forward order --------------------------
         for i in range(n):

@@ -15,7 +15,7 @@ import torch
 
 from lgm_hip import ops
 from lgm_hip.nn import GradCtx
-from lgm_hip.optim import FusedAdam
+from lgm_hip.optim import FusedAdam, FusedRMSprop
 from models.generative.gan.dcgan import DCGAN, _to_nhwc
 
 
@@ -29,8 +29,6 @@ class WGAN(DCGAN):
                          summary=summary)
         assert constraint_method in ["gp", "clip"], \
             "Either gradient penalty (gp) or weight clipping (clip) to enforce 1-Lipschitz constraint."
-        if constraint_method == "clip":
-            raise NotImplementedError("weight-clipping / RMSprop branch is outside this round's hot path (SURVEY §8f)")
         self.clip_value = clip_value
         self.grad_penalty = grad_penalty
         self.constraint_method = constraint_method
@@ -55,20 +53,33 @@ class WGAN(DCGAN):
 
     def _calculate_d_loss(self, x, x_hat, alpha=None):
         """reference :84-110.  ``alpha`` may be injected (parity tests); default U[0,1) per sample."""
-        if alpha is None and self.training:
+        with_gp = self.training and self.hparams.constraint_method == "gp"
+        if alpha is None and with_gp:
             alpha = torch.rand(x.size(0), 1, 1, 1, device=x.device)
         d_loss, real, fake, gp = _CriticLossFn.apply(self.D._anchor(x.device), self.D, x, x_hat.detach(), alpha,
-                                                     float(self.hparams.grad_penalty), self.training)
+                                                     float(self.hparams.grad_penalty), with_gp)
         out = {"d_loss": d_loss, "d_loss_real": real, "d_loss_fake": fake}
-        if self.training:
+        if with_gp:
             out["gradient_penalty"] = gp
+        elif self.training:
+            self._weight_clipping()          # reference :101-102 (after the loss, before its backward)
         return out
+
+    def _weight_clipping(self):
+        """reference :158-168: every critic parameter clamped to [-clip_value, clip_value] — one
+        launch over the critic's flat parameter buffer (its padding lanes are zero and stay zero)."""
+        self.D.prepare_hip(next(self.D.parameters()).device)
+        ops.clamp_(self.D._flat.data, -float(self.hparams.clip_value), float(self.hparams.clip_value))
 
     def _calculate_g_loss(self, x_hat):
         """reference :112-115: g_loss = -D(x_hat).mean()"""
         return {"g_loss": _GenLossFn.apply(self.D, x_hat)}
 
     def configure_optimizers(self):
+        """reference :170-197: RMSprop(lr) for the weight-clipping variant, Adam for gradient penalty"""
+        if self.hparams.constraint_method == "clip":
+            return [FusedRMSprop(self.D.parameters(), lr=self.hparams.lr),
+                    FusedRMSprop(self.G.parameters(), lr=self.hparams.lr)], []
         kw = dict(lr=self.hparams.lr, betas=(self.hparams.b1, self.hparams.b2), weight_decay=self.hparams.weight_decay)
         return [FusedAdam(self.D.parameters(), **kw), FusedAdam(self.G.parameters(), **kw)], []
 

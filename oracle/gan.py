@@ -6,7 +6,11 @@ Reference anchors:
   models/generative/gan/dcgan.py  Generator :35-104, Discriminator :107-164,
                                    initialize_weights :23-32
   models/generative/gan/wgan.py   _calculate_d_loss :84-110, _calculate_g_loss :112-115,
-                                   _calculate_gradient_penalty :117-156 (norm over dim=1 only)
+                                   _calculate_gradient_penalty :117-156 (norm over dim=1 only),
+                                   _weight_clipping :158-168
+  models/generative/gan/dcgan.py  DCGAN._calculate_d_loss / _calculate_g_loss :223-245 (BCE with logits)
+  models/generative/gan/lsgan.py  _calculate_d_loss :53-79, _calculate_g_loss :81-97
+  models/generative/gan/r1gan.py  _calculate_d_loss :62-94 (R1 = 0.5 * mean_b ||dD(x)/dx||^2, flattened)
 
 State-dict keys follow the reference modules: ``model.{i}.0.weight`` (conv / convT),
 ``model.{i}.1.{weight,bias,running_mean,running_var,num_batches_tracked}`` (BatchNorm2d).
@@ -112,3 +116,65 @@ def wgan_d_loss(D: Params, x, x_hat, alpha, lam=10.0, img_size=64):
 
 def wgan_g_loss(D: Params, x_hat, img_size=64):
     return -discriminator(D, x_hat, img_size).mean()
+
+
+# ---- the other heads on the same generator / critic -------------------------------
+def dcgan_d_loss(D: Params, x, x_hat, img_size=64):
+    """dcgan.py:223-239"""
+    lr_ = discriminator(D, x, img_size)
+    lf = discriminator(D, x_hat, img_size)
+    real = F.binary_cross_entropy_with_logits(lr_, torch.ones_like(lr_))
+    fake = F.binary_cross_entropy_with_logits(lf, torch.zeros_like(lf))
+    return dict(d_loss=(real + fake) / 2, d_loss_real=real, d_loss_fake=fake, logits_real=lr_.mean(),
+                logits_fake=lf.mean())
+
+
+def dcgan_g_loss(D: Params, x_hat, img_size=64):
+    """dcgan.py:241-245"""
+    lf = discriminator(D, x_hat, img_size)
+    return F.binary_cross_entropy_with_logits(lf, torch.ones_like(lf))
+
+
+def lsgan_d_loss(D: Params, x, x_hat, img_size=64):
+    """lsgan.py:53-79"""
+    lr_ = discriminator(D, x, img_size)
+    lf = discriminator(D, x_hat, img_size)
+    real = 0.5 * torch.mean((lr_ - 1) ** 2)
+    fake = 0.5 * torch.mean(lf ** 2)
+    return dict(d_loss=real + fake, d_loss_real=real, d_loss_fake=fake, logits_real=lr_.mean(), logits_fake=lf.mean())
+
+
+def lsgan_g_loss(D: Params, x_hat, img_size=64):
+    """lsgan.py:81-97"""
+    lf = discriminator(D, x_hat, img_size)
+    return 0.5 * torch.mean((lf - 1) ** 2)
+
+
+def r1_penalty(D: Params, x, img_size=64):
+    """r1gan.py:72-77: 0.5 * mean_b sum_{chw} (d sum(D(x)) / dx)^2"""
+    xr = x.detach().clone().requires_grad_(True)
+    score = discriminator(D, xr, img_size)
+    grad = torch.autograd.grad(score.sum(), xr, create_graph=True)[0]
+    return 0.5 * grad.pow(2).reshape(grad.shape[0], -1).sum(1).mean()
+
+
+def r1gan_d_loss(D: Params, x, x_hat, lam=10.0, img_size=64):
+    """r1gan.py:62-94"""
+    out = dcgan_d_loss(D, x, x_hat, img_size)
+    r1 = r1_penalty(D, x, img_size)
+    out["d_loss"] = out["d_loss"] + lam * r1
+    out["r1_penalty"] = r1
+    return out
+
+
+def wgan_clip_d_loss(D: Params, x, x_hat, img_size=64):
+    """wgan.py:84-93 with constraint_method = "clip": no penalty term (the weights are clamped as a
+    side effect, see weight_clip)."""
+    real = discriminator(D, x, img_size).mean()
+    fake = discriminator(D, x_hat, img_size).mean()
+    return dict(d_loss=fake - real, d_loss_real=real, d_loss_fake=fake)
+
+
+def weight_clip(D: Params, c: float) -> Params:
+    """wgan.py:158-168"""
+    return {k: v.clamp(-c, c) for k, v in D.items()}

@@ -317,14 +317,79 @@ def gen_gan():
     np.savez_compressed(os.path.join(OUT, "wgan.npz"), **to_np(fx))
 
 
+def gen_gan_heads():
+    """DCGAN (BCE), LSGAN, R1GAN heads and the weight-clipping WGAN + RMSprop, from the
+    reference classes on CPU, same injected weights / inputs as gen_gan."""
+    from models.generative.gan import dcgan as RD, lsgan as RL, r1gan as RR, wgan as RW
+    from oracle import gan as O
+
+    fx = {}
+
+    def grads(prefix, module):
+        for n, p in module.named_parameters():
+            fx[f"{prefix}:{n}"] = (p.grad.numpy().copy() if p.numel() < 20000
+                                   else p.grad.reshape(-1)[:: p.numel() // 256][:256].numpy().copy())
+            fx[f"{prefix}norm:{n}"] = np.float64(p.grad.double().norm().item())
+
+    for img_size, ch, latent, B in ((64, 3, 100, 4), (28, 1, 128, 4)):
+        tag = f"{img_size}"
+        kw = dict(img_channels=ch, img_size=img_size, latent_dim=latent, lr=2e-4, b1=0.5, b2=0.999, weight_decay=1e-5)
+        models = {"dcgan": RD.DCGAN(summary=False, **kw), "lsgan": RL.LSGAN(summary=False, **kw),
+                  "r1gan": RR.R1GAN(r1_penalty=10.0, **kw)}
+        G, D = O.gan_init(img_size, ch, latent, seed=21)
+        g = torch.Generator().manual_seed(22)
+        x = torch.rand(B, ch, img_size, img_size, generator=g) * 2 - 1
+        z = torch.randn(B, latent, 1, 1, generator=g)
+        for name, m in models.items():
+            gsd = m.G.state_dict(); gsd.update(G); m.G.load_state_dict(gsd, strict=True)
+            dsd = m.D.state_dict(); dsd.update(D); m.D.load_state_dict(dsd, strict=True)
+            m.train()
+            x_hat = m.G(z)
+            ld = m._calculate_d_loss(x.clone(), x_hat)
+            m.D.zero_grad()
+            ld["d_loss"].backward()
+            for k, v in ld.items():
+                fx[f"{name}_{k}_{tag}"] = v.detach().numpy()
+            grads(f"{name}_dgrad_{tag}", m.D)
+            m.G.zero_grad(); m.D.zero_grad()
+            gl = m._calculate_g_loss(m.G(z))["g_loss"]
+            gl.backward()
+            fx[f"{name}_g_loss_{tag}"] = gl.detach().numpy()
+            for n, p in m.G.named_parameters():
+                fx[f"{name}_ggradnorm_{tag}:{n}"] = np.float64(p.grad.double().norm().item())
+            print(name, tag, {k: float(v) for k, v in ld.items()}, float(gl))
+        # ---- weight-clipping WGAN: loss, clipped weights, one RMSprop step of the critic ----
+        m = RW.WGAN(img_channels=ch, img_size=img_size, latent_dim=latent, lr=5e-5, n_critic=5, clip_value=0.01,
+                    constraint_method="clip", summary=False)
+        gsd = m.G.state_dict(); gsd.update(G); m.G.load_state_dict(gsd, strict=True)
+        dsd = m.D.state_dict(); dsd.update(D); m.D.load_state_dict(dsd, strict=True)
+        m.train()
+        d_optim, g_optim = m.configure_optimizers()[0]
+        x_hat = m.G(z)
+        ld = m._calculate_d_loss(x, x_hat)          # clamps the critic's weights as a side effect
+        d_optim.zero_grad()
+        ld["d_loss"].backward()
+        for k, v in ld.items():
+            fx[f"wgancp_{k}_{tag}"] = v.detach().numpy()
+        grads(f"wgancp_dgrad_{tag}", m.D)
+        d_optim.step()
+        for n, p in m.D.named_parameters():
+            fx[f"wgancp_after_{tag}:{n}"] = (p.detach().numpy().copy() if p.numel() < 20000
+                                             else p.detach().reshape(-1)[:: p.numel() // 256][:256].numpy().copy())
+        print("wgan_cp", tag, {k: float(v) for k, v in ld.items()})
+    np.savez_compressed(os.path.join(OUT, "gan_heads.npz"), **to_np(fx))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["diffusion", "vq", "gan"]
+    which = sys.argv[1:] or ["diffusion", "vq", "gan", "gan_heads"]
     if "diffusion" in which:
         gen_diffusion()
     if "vq" in which:
         gen_vq()
     if "gan" in which:
         gen_gan()
+    if "gan_heads" in which:
+        gen_gan_heads()

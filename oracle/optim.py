@@ -37,6 +37,15 @@ def adam_step(p, g, m, v, step: int, lr: float, b1: float, b2: float,
     return p - step_size * (m / denom), m, v
 
 
+def rmsprop_step(p, g, sq, lr: float, alpha: float = 0.99, eps: float = 1e-8, weight_decay: float = 0.0):
+    """torch.optim.RMSprop with its defaults (momentum 0, not centred) - reference wgan.py:171-181.
+    Returns (p', sq')."""
+    if weight_decay != 0.0:
+        g = g + weight_decay * p
+    sq = sq * alpha + (1 - alpha) * g * g
+    return p - lr * g / (sq.sqrt() + eps), sq
+
+
 def ema_decay(step: int, beta: float, update_after_step: int = 100,
               inv_gamma: float = 1.0, power: float = 2.0 / 3.0, min_value: float = 0.0) -> float:
     epoch = max(step - update_after_step - 1, 0)

@@ -31,7 +31,8 @@ def test_load_config_checks_and_registry(tmp_path):
     with pytest.raises(ValueError, match="Failed to import"):
         load_model({"name": "NoSuchModel", "args": {}})
     for rel in ("gan/wgan_gp.json", "gan/wgan_gp_celeba.json", "vae/vqvae.json", "vae/vqvae_ema.json", "vae/vae.json",
-                "diffusion/ddim.json"):
+                "diffusion/ddim.json", "gan/dcgan.json", "gan/dcgan_mnist.json", "gan/lsgan.json", "gan/r1gan.json",
+                "gan/wgan_cp.json"):
         c = load_config(os.path.join(PKG, "configs", rel))
         m = load_model(c["model"])          # constructs on CPU without touching the GPU
         assert type(m).__name__ == c["model"]["name"]

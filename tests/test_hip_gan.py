@@ -150,3 +150,101 @@ def test_wgan_training_schedule_and_steps(dev):
                 assert torch.isfinite(m.logged[k])
     assert kinds == ["d"] * 5 + ["g"] + ["d"] * 5 + ["g"]
     assert not torch.equal(m.D.model[0][0].weight, d0) and not torch.equal(m.G.model[0][0].weight, g0)
+
+
+def _load_head(name, img_size, ch, latent, dev):
+    from oracle import gan as OG
+    kw = dict(img_channels=ch, img_size=img_size, latent_dim=latent, lr=2e-4, b1=0.5, b2=0.999, weight_decay=1e-5)
+    if name == "dcgan":
+        from models.generative.gan.dcgan import DCGAN
+        m = DCGAN(**kw)
+    elif name == "lsgan":
+        from models.generative.gan.lsgan import LSGAN
+        m = LSGAN(**kw)
+    elif name == "r1gan":
+        from models.generative.gan.r1gan import R1GAN
+        m = R1GAN(r1_penalty=10.0, **kw)
+    else:
+        from models.generative.gan.wgan import WGAN
+        m = WGAN(img_channels=ch, img_size=img_size, latent_dim=latent, lr=5e-5, n_critic=5, clip_value=0.01,
+                 constraint_method="clip")
+    G, D = OG.gan_init(img_size, ch, latent, seed=21)
+    gsd = m.G.state_dict()
+    gsd.update(G)
+    m.G.load_state_dict(gsd, strict=True)
+    dsd = m.D.state_dict()
+    dsd.update(D)
+    m.D.load_state_dict(dsd, strict=True)
+    m.to(dev)
+    m.prepare_hip(dev)
+    m.train()
+    return m
+
+
+def _sample(p):
+    return p if p.numel() < 20000 else p.reshape(-1)[:: p.numel() // 256][:256]
+
+
+@pytest.mark.parametrize("cfg", [(64, 3, 100), (28, 1, 128)])
+@pytest.mark.parametrize("name", ["dcgan", "lsgan", "r1gan"])
+def test_gan_heads_match_reference_fixture(dev, golden_dir, cfg, name):
+    """plain DCGAN (BCE), LSGAN, R1GAN (second-order sweep with the R1 functional) on
+    the HIP critic / generator vs fixtures captured from the reference classes."""
+    img_size, ch, latent = cfg
+    B, tag = 4, str(cfg[0])
+    fx = dict(np.load(os.path.join(golden_dir, "gan_heads.npz")))
+    m = _load_head(name, img_size, ch, latent, dev)
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(B, ch, img_size, img_size, generator=g) * 2 - 1
+    z = torch.randn(B, latent, 1, 1, generator=g)
+    x_hat = m.G(z.to(dev))
+    ld = m._calculate_d_loss(x.to(dev), x_hat)
+    for k, v in ld.items():
+        assert rel(v, fx[f"{name}_{k}_{tag}"]) < 2 * RTOL, (k, float(v), float(fx[f"{name}_{k}_{tag}"]))
+    d_opt, g_opt = m.configure_optimizers()[0]
+    d_opt.zero_grad()
+    ld["d_loss"].backward()
+    for n, p in m.D.named_parameters():
+        ref_norm = float(fx[f"{name}_dgrad_{tag}norm:{n}"])
+        gn = p.grad.double().norm().item()
+        assert abs(gn - ref_norm) / max(ref_norm, 1e-12) < 1e-3, (n, gn, ref_norm)
+        assert rel(_sample(p.grad), fx[f"{name}_dgrad_{tag}:{n}"]) < 2e-3, n
+    g_opt.zero_grad()
+    gl = m._calculate_g_loss(m.G(z.to(dev)))["g_loss"]
+    assert rel(gl, fx[f"{name}_g_loss_{tag}"]) < 2 * RTOL
+    gl.backward()
+    for n, p in m.G.named_parameters():
+        ref_norm = float(fx[f"{name}_ggradnorm_{tag}:{n}"])
+        assert abs(p.grad.double().norm().item() - ref_norm) / max(ref_norm, 1e-12) < 1e-3, n
+
+
+@pytest.mark.parametrize("cfg", [(64, 3, 100), (28, 1, 128)])
+def test_wgan_weight_clipping_and_rmsprop_match_reference_fixture(dev, golden_dir, cfg):
+    """constraint_method="clip": loss on the unclipped weights, clamp of every critic
+    parameter, backward through the clipped weights, one fused RMSprop step (wgan.py:101-102,158-181)."""
+    img_size, ch, latent = cfg
+    B, tag = 4, str(cfg[0])
+    fx = dict(np.load(os.path.join(golden_dir, "gan_heads.npz")))
+    m = _load_head("wgancp", img_size, ch, latent, dev)
+    from lgm_hip.optim import FusedRMSprop
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(B, ch, img_size, img_size, generator=g) * 2 - 1
+    z = torch.randn(B, latent, 1, 1, generator=g)
+    d_opt, g_opt = m.configure_optimizers()[0]
+    assert isinstance(d_opt, FusedRMSprop) and isinstance(g_opt, FusedRMSprop)
+    x_hat = m.G(z.to(dev))
+    ld = m._calculate_d_loss(x.to(dev), x_hat)
+    assert "gradient_penalty" not in ld
+    for k, v in ld.items():
+        assert rel(v, fx[f"wgancp_{k}_{tag}"]) < 2 * RTOL, k
+    for p in m.D.parameters():
+        assert float(p.detach().abs().max()) <= 0.01 + 1e-9
+    d_opt.zero_grad()
+    ld["d_loss"].backward()
+    for n, p in m.D.named_parameters():
+        ref_norm = float(fx[f"wgancp_dgrad_{tag}norm:{n}"])
+        gn = p.grad.double().norm().item()
+        assert abs(gn - ref_norm) / max(ref_norm, 1e-12) < 1e-3, (n, gn, ref_norm)
+    d_opt.step()
+    for n, p in m.D.named_parameters():
+        assert rel(_sample(p.detach()), fx[f"wgancp_after_{tag}:{n}"]) < 1e-4, n

@@ -199,6 +199,57 @@ def test_wgan_gp_losses(golden_dir):
             assert abs(p.grad.double().norm().item() - ref) / max(ref, 1e-12) < 5 * RTOL, n
 
 
+def test_gan_heads_losses(golden_dir):
+    """DCGAN (BCE), LSGAN, R1GAN, weight-clipping WGAN + RMSprop against the reference fixture."""
+    from oracle import optim as OO
+    fx = load(golden_dir, "gan_heads.npz")
+    heads = {"dcgan": (OG.dcgan_d_loss, OG.dcgan_g_loss), "lsgan": (OG.lsgan_d_loss, OG.lsgan_g_loss),
+             "r1gan": (lambda D, x, xh, s: OG.r1gan_d_loss(D, x, xh, 10.0, s), OG.dcgan_g_loss)}
+    for img_size, ch, latent, B in ((64, 3, 100, 4), (28, 1, 128, 4)):
+        tag = str(img_size)
+        g = torch.Generator().manual_seed(22)
+        x = torch.rand(B, ch, img_size, img_size, generator=g) * 2 - 1
+        z = torch.randn(B, latent, 1, 1, generator=g)
+        for name, (dl, gl_fn) in heads.items():
+            G, D = OG.gan_init(img_size, ch, latent, seed=21)
+            for p in list(G.values()) + list(D.values()):
+                p.requires_grad_(True)
+            x_hat = OG.generator(G, z, img_size, ch)
+            ld = dl(D, x, x_hat.detach(), img_size)
+            for k, v in ld.items():
+                assert rel_err(v, fx[f"{name}_{k}_{tag}"]) < RTOL, (name, k)
+            ld["d_loss"].backward()
+            for n, p in D.items():
+                ref = float(fx[f"{name}_dgrad_{tag}norm:{n}"])
+                assert abs(p.grad.double().norm().item() - ref) / max(ref, 1e-12) < 5 * RTOL, (name, n)
+            gl = gl_fn(D, OG.generator(G, z, img_size, ch), img_size)
+            assert rel_err(gl, fx[f"{name}_g_loss_{tag}"]) < RTOL, name
+            for p in G.values():
+                p.grad = None
+            gl.backward()
+            for n, p in G.items():
+                ref = float(fx[f"{name}_ggradnorm_{tag}:{n}"])
+                assert abs(p.grad.double().norm().item() - ref) / max(ref, 1e-12) < 5 * RTOL, (name, n)
+        # weight clipping + one RMSprop step of the critic (wgan.py:101-102,158-181)
+        G, D = OG.gan_init(img_size, ch, latent, seed=21)
+        x_hat = OG.generator(G, z, img_size, ch).detach()
+        ld = OG.wgan_clip_d_loss(D, x, x_hat, img_size)          # loss on the UNclipped weights
+        for k, v in ld.items():
+            assert rel_err(v, fx[f"wgancp_{k}_{tag}"]) < RTOL, k
+        Dc = {k: v.clone().requires_grad_(True) for k, v in OG.weight_clip(D, 0.01).items()}
+        # the reference clamps .data in place after the forward: the backward sees the clipped weights
+        # in every weight-dependent node but the activations of the unclipped forward.  Reproduce with
+        # autograd on the unclipped graph is impossible; the fixture's gradients are checked on the
+        # GPU path (which has the same "late weights" semantics); here only RMSprop is pinned.
+        for n in D:
+            got_key = f"wgancp_after_{tag}:{n}"
+            gkey = f"wgancp_dgrad_{tag}:{n}"
+            if D[n].numel() < 20000:
+                gref = torch.as_tensor(fx[gkey]).reshape(D[n].shape)
+                p1, _ = OO.rmsprop_step(Dc[n].detach(), gref, torch.zeros_like(gref), lr=5e-5)
+                assert rel_err(p1, fx[got_key]) < 1e-6, n
+
+
 def test_adam_matches_torch():
     torch.manual_seed(0)
     for wd in (0.0, 1e-5):
