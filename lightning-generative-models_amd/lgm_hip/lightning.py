@@ -162,6 +162,17 @@ class FlatGradSync:
         return 1.0 / self.world
 
 
+def save_checkpoint(model, optimizers, path: str, epoch: int = 0):
+    """Write a checkpoint with the layout of a PyTorch-Lightning ``.ckpt`` (reference train.py:41,
+    113-117,140 resumes from / writes these): ``state_dict`` with the reference's keys (incl.
+    ``ema.online_model.*`` / ``ema.ema_model.*`` / ``ema.initted`` / ``ema.step``), ``global_step``
+    (= optimizer steps), ``optimizer_states`` in torch's own per-parameter format, hyper-parameters."""
+    torch.save({"epoch": int(epoch), "global_step": int(model.global_step),
+                "pytorch-lightning_version": "2.0.0+lgm_hip", "state_dict": model.state_dict(),
+                "loops": {}, "callbacks": {}, "optimizer_states": [o.state_dict() for o in optimizers],
+                "lr_schedulers": [], "hparams_name": "kwargs", "hyper_parameters": dict(model.hparams)}, path)
+
+
 class MiniTrainer:
     """Single-node trainer: one process per GPU, optional DDP-style gradient averaging with a
     single all-reduce per flat gradient buffer (RCCL over xGMI when backend is nccl)."""
@@ -193,16 +204,21 @@ class MiniTrainer:
             torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
         model.to(device)
         model.trainer = self
+        ckpt = None
         if ckpt_path:
-            sd = torch.load(ckpt_path, map_location=device)
-            model.load_state_dict(sd["state_dict"])
-            model._global_step = sd.get("global_step", 0)
+            ckpt = torch.load(ckpt_path, map_location=device, weights_only=False)
+            model.load_state_dict(ckpt["state_dict"])
+            model._global_step = int(ckpt.get("global_step", 0))
         if hasattr(model, "prepare_hip"):
             model.prepare_hip(device)
         cfg = model.configure_optimizers()
         opts = cfg[0] if isinstance(cfg, tuple) else cfg
         if not isinstance(opts, (list, tuple)):
             opts = [opts]
+        if ckpt is not None:
+            # resume: Lightning layout, one torch-format optimizer state per optimizer, in order
+            for o, osd in zip(opts, ckpt.get("optimizer_states", [])):
+                o.load_state_dict(osd)
         model._optimizers = [_CountingOptimizer(o, model) for o in opts]
         loader = train_dataloader if train_dataloader is not None else datamodule.train_dataloader()
         model.train()
@@ -236,6 +252,5 @@ class MiniTrainer:
                 done = True
         if self.root and self.rank == 0:
             os.makedirs(self.root, exist_ok=True)
-            torch.save({"state_dict": model.state_dict(), "global_step": model.global_step,
-                        "hyper_parameters": dict(model.hparams)}, os.path.join(self.root, "last.ckpt"))
+            save_checkpoint(model, list(model._optimizers), os.path.join(self.root, "last.ckpt"), epoch=epoch)
         return model

@@ -59,13 +59,67 @@ class FusedAdam(torch.optim.Optimizer):
             for fp in self._flats(group):
                 fp.zero_grad()
 
+    # ---- checkpoint interchange: torch.optim.Adam's own state_dict layout -------------------------
+    # (Lightning stores ``optimizer.state_dict()`` under "optimizer_states"; parameter order is the
+    # registration order, which this package keeps identical to the reference's modules.)
+    _STATE_KEYS = (("m", "exp_avg"), ("v", "exp_avg_sq"))
+
+    def state_dict(self):
+        from .flat import logical_view
+        state, groups, idx = {}, [], 0
+        for group in self.param_groups:
+            ids = []
+            for p in group["params"]:
+                fp = p._lgm_flat
+                st = self._flat_state.get(id(fp))
+                if st is not None and st["step"] > 0:
+                    sl = fp.slot(p)
+                    ent = {"step": torch.tensor(float(st["step"]))}
+                    for mine, theirs in self._STATE_KEYS:
+                        ent[theirs] = logical_view(st[mine][sl.offset:sl.offset + sl.numel], p.shape, sl.kind,
+                                                   sl.phys_shape).detach().clone().contiguous()
+                    state[idx] = ent
+                ids.append(idx)
+                idx += 1
+            g = {k: v for k, v in group.items() if k != "params"}
+            g["params"] = ids
+            groups.append(g)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        from .flat import logical_view
+        idx = 0
+        for group, saved in zip(self.param_groups, sd["param_groups"]):
+            for k, v in saved.items():
+                if k != "params" and k in group:
+                    group[k] = tuple(v) if isinstance(group[k], tuple) else v
+            for p in group["params"]:
+                ent = sd["state"].get(idx, sd["state"].get(str(idx)))
+                idx += 1
+                if ent is None:
+                    continue
+                fp = p._lgm_flat
+                st = self._flat_state.get(id(fp))
+                if st is None:
+                    st = {mine: torch.zeros_like(fp.data) for mine, _ in self._STATE_KEYS}
+                    st.update(step=0, flat=fp)
+                    self._flat_state[id(fp)] = st
+                sl = fp.slot(p)
+                for mine, theirs in self._STATE_KEYS:
+                    logical_view(st[mine][sl.offset:sl.offset + sl.numel], p.shape, sl.kind, sl.phys_shape).copy_(
+                        ent[theirs].to(fp.device, torch.float32))
+                st["step"] = int(float(ent["step"]))
+
 
 class FusedRMSprop(FusedAdam):
     """torch.optim.RMSprop with its defaults (alpha 0.99, eps 1e-8, momentum 0, not centred) — the
     optimiser of the weight-clipping WGAN (reference wgan.py:171-181) — one kernel per flat buffer."""
 
+    _STATE_KEYS = (("sq", "square_avg"),)
+
     def __init__(self, params: Iterable[nn.Parameter], lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0):
-        torch.optim.Optimizer.__init__(self, params, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay))
+        torch.optim.Optimizer.__init__(self, params, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay,
+                                                          momentum=0, centered=False))
         self._flat_state = {}
         self.grad_scale = 1.0
 
@@ -99,6 +153,13 @@ class EMA(nn.Module):
         self.register_buffer("step", torch.tensor(0))
         self._step_py = 0          # host mirrors: no device sync on the hot path
         self._initted_py = False
+        # a checkpoint restores the ``step`` / ``initted`` buffers: re-sync the host mirrors from them
+        self.register_load_state_dict_post_hook(EMA._sync_host_state)
+
+    @staticmethod
+    def _sync_host_state(module, incompatible_keys):
+        module._step_py = int(module.step.item())
+        module._initted_py = bool(module.initted.item())
 
     @property
     def model(self):

@@ -172,3 +172,68 @@ def test_ddpm_module_training_steps(dev):
     # the stock training_step path (random t / noise on device) runs and returns a finite scalar
     out = m.training_step((torch.rand(4, 3, 16, 16, device=dev) * 2 - 1, torch.zeros(4, dtype=torch.long, device=dev)))
     assert out.dim() == 0 and torch.isfinite(out)
+
+
+def test_checkpoint_resume_and_torch_optimizer_interchange(dev, tmp_path):
+    """a Lightning-layout checkpoint (reference key names, torch-format Adam state) written
+    after 3 steps resumes to the same parameters as 5 uninterrupted steps, and its optimizer state
+    loads into a real torch.optim.Adam with identical next-step results."""
+    from lgm_hip.lightning import MiniTrainer, save_checkpoint
+    from models.generative.diffusion.ddpm import DDPM
+
+    def make():
+        torch.manual_seed(3)
+        m = DDPM(img_channels=3, img_size=16, dim=8, diffusion_timesteps=50, lr=1e-3, ema_update_every=2)
+        m.sample_every = 0
+        return m
+
+    g = torch.Generator().manual_seed(5)
+    batches = [(torch.rand(4, 3, 16, 16, generator=g) * 2 - 1, torch.zeros(4, dtype=torch.long)) for _ in range(5)]
+
+    def feed(bs, reseed_at):
+        for i, b in enumerate(bs):
+            if i == reseed_at:
+                torch.manual_seed(77)      # (t, noise) come from the device RNG: same draws in both runs
+            yield b
+
+    def fit(m, data, ckpt=None):
+        MiniTrainer(max_epochs=1, default_root_dir=None, log_every=0, device=dev).fit(m, train_dataloader=data,
+                                                                                     ckpt_path=ckpt)
+        return m
+
+    torch.manual_seed(11)
+    a = fit(make(), feed(batches, 3))                       # five uninterrupted steps
+    torch.manual_seed(11)
+    b1 = fit(make(), feed(batches[:3], -1))                  # three steps, checkpoint ...
+    path = str(tmp_path / "step3.ckpt")
+    save_checkpoint(b1, list(b1._optimizers), path)
+    ck = torch.load(path, weights_only=False)
+    assert ck["global_step"] == 3 and "ema.online_model.model.init_conv.weight" in ck["state_dict"]
+    assert "ema.ema_model.model.init_conv.weight" in ck["state_dict"] and "ema.step" in ck["state_dict"]
+    osd = ck["optimizer_states"][0]
+    n_params = len(list(b1.ema.online_model.parameters()))
+    assert len(osd["state"]) == n_params and set(osd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert osd["state"][0]["exp_avg"].shape == b1.ema.online_model.model.init_conv.weight.shape
+    b2 = fit(make(), feed(batches[3:], 0), ckpt=path)        # ... fresh process state, two more steps
+    assert b2.global_step == 5 == a.global_step
+    for (n, p), (_, q) in zip(a.state_dict().items(), b2.state_dict().items()):
+        assert torch.allclose(p.float(), q.float(), rtol=1e-6, atol=1e-7), n
+    # torch.optim.Adam accepts the exported state and reproduces the fused step
+    c = make()
+    c.load_state_dict(ck["state_dict"])
+    params = [p.detach().clone().requires_grad_(True) for p in c.ema.online_model.parameters()]
+    topt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.99))
+    topt.load_state_dict(osd)
+    gg = torch.Generator().manual_seed(9)
+    grads = [torch.randn(p.shape, generator=gg) * 1e-2 for p in params]
+    for p, gr in zip(params, grads):
+        p.grad = gr.clone()
+    topt.step()
+    d = fit(make(), [], ckpt=path)                           # loads weights + optimizer state, no steps
+    unet = d.ema.online_model.model
+    unet._flat.bind_grad_views()
+    for p, gr in zip(d.ema.online_model.parameters(), grads):
+        p.grad.copy_(gr.to(dev))
+    d._optimizers[0].step()
+    for p, q in zip(params, d.ema.online_model.parameters()):
+        assert torch.allclose(p.detach(), q.detach().cpu(), rtol=2e-5, atol=1e-7)
