@@ -176,8 +176,22 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         conv_ms = sum(v["ms"] for v in summ.values())
         conv_fl = sum(v["flops"] for v in summ.values())
+        # HBM-side bytes per launch of the dominant family: PMC counters cannot be read from inside this
+        # process, so the figure comes from the committed rocprofv3 --pmc summary of this same command
+        # (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and args.batch == GLOBAL_BATCH and world == 1:
+            with open(pmc) as fh:
+                t = json.load(fh).get(name)
+            if t:
+                traffic, traffic_src = t["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+        bytes_per_img = 69.6e6 + 1.472e9 / per_gpu        # algorithmic HBM bytes per image
         roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(d.get("bytes", 0) / max(d["launches"], 1)) or None,
+                "hbm_frac_of_8TBps": round(value / world * bytes_per_img / 8.0e12, 4),
                 "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
                 "family": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()},

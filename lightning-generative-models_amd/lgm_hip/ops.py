@@ -82,10 +82,10 @@ class KernelTimer:
     def __init__(self):
         self.records = []   # (name, flops, start_event, end_event)
 
-    def begin(self, name, flops):
+    def begin(self, name, flops, nbytes=0.0):
         s = torch.cuda.Event(enable_timing=True)
         s.record()
-        self._cur = (name, flops, s)
+        self._cur = (name, flops, nbytes, s)
 
     def end(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -95,10 +95,11 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, s, e in self.records:
-            d = out.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
+        for name, flops, nbytes, s, e in self.records:
+            d = out.setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += s.elapsed_time(e)
         return out
 
@@ -108,6 +109,11 @@ TIMER: Optional[KernelTimer] = None
 
 def _conv_flops(g: ConvGeom) -> float:
     return 2.0 * g.B * g.Ho * g.Wo * g.Nw * g.KH * g.KW * g.Cw
+
+
+def _conv_bytes(g: ConvGeom) -> float:
+    """algorithmic bytes of one conv-family launch: X side + Y side + weights, each touched once"""
+    return 4.0 * (g.B * g.H * g.W * g.Cw + g.B * g.Ho * g.Wo * g.Nw + g.Nw * g.KH * g.KW * g.Cw)
 
 
 _CONV_WS_BYTES = {}
@@ -124,7 +130,7 @@ def _conv_ws(g: ConvGeom, yx: int, device):
 
 def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
     if TIMER is not None:
-        TIMER.begin("igemm_xy", _conv_flops(g))
+        TIMER.begin("igemm_xy", _conv_flops(g), _conv_bytes(g))
     ws = _conv_ws(g, 0, x.device)
     lib().lgm_conv_xy(ctypes.byref(g), x.data_ptr(), pitch(x), w_ptr, bias_ptr, _p(res),
                       pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
@@ -135,7 +141,7 @@ def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
 
 def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr: Optional[int] = None):
     if TIMER is not None:
-        TIMER.begin("igemm_yx", _conv_flops(g))
+        TIMER.begin("igemm_yx", _conv_flops(g), _conv_bytes(g))
     ws = _conv_ws(g, 1, y.device)
     lib().lgm_conv_yx(ctypes.byref(g), y.data_ptr(), pitch(y), w_ptr, wt_ptr, bias_ptr, _p(res),
                       pitch(res) if res is not None else 0, x.data_ptr(), pitch(x),
@@ -149,7 +155,7 @@ def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[
     nbytes = L.lgm_conv_wgrad_workspace(ctypes.byref(g))
     ws = workspace(nbytes, y.device)
     if TIMER is not None:
-        TIMER.begin("wgrad", _conv_flops(g))
+        TIMER.begin("wgrad", _conv_flops(g), _conv_bytes(g))
     L.lgm_conv_wgrad(ctypes.byref(g), y.data_ptr(), pitch(y), x.data_ptr(), pitch(x), gw_ptr, gbias_ptr, beta,
                      ws.data_ptr(), ws.numel() * 4, stream())
     if TIMER is not None:
