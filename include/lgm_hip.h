@@ -255,6 +255,11 @@ int lgm_bn_affine3(const float* v1, int64_t v1_pitch, const float* v2, int64_t v
                    const float* A1, const float* A2, const float* A3, const float* A4, float* out,
                    int64_t out_pitch, int accumulate, int act, float slope, int64_t rows, int C,
                    void* stream);
+/* Input pipeline of the reference DataModule on the device (data/datamodule.py:41-53, data/utils.py:7-35):
+ * src u8 [B,H,W,C] (decoded images) -> dst fp32 NCHW [B,C,S,S] = Normalize(ToTensor(.)), centre-cropped to
+ * min(H,W), resized to SxS (bilinear, antialias=True), flipped horizontally where flip[b] != 0 (NULL: none). */
+int lgm_image_transform(const unsigned char* src, int64_t B, int H, int W, int C, const unsigned char* flip,
+                        float* dst, int S, void* stream);
 /* interpolated_images = alpha*x + (1-alpha)*x_hat (wgan.py:137), alpha [B] */
 int lgm_lerp_rows(const float* x, const float* y, const float* alpha, float* out, int64_t B,
                   int64_t rowlen, void* stream);

@@ -632,7 +632,58 @@ __global__ void fill_col_kernel(float* __restrict__ out, long pitch, long n, int
 // vals = (real, fake, gp, d_loss): d_loss = fake - real + gp
 __global__ void wgan_dloss_kernel(float* __restrict__ vals) { vals[3] = vals[1] - vals[0] + vals[2]; }
 
+
+// Device-side input pipeline of the reference DataModule (data/datamodule.py:41-53): ToTensor (u8 -> [0,1]),
+// Normalize(0.5, 0.5), CenterCropMinXY (data/utils.py:7-35), Resize(S, bilinear, antialias=True),
+// RandomHorizontalFlip (flags drawn by the caller).  The antialiased resize is the separable triangle
+// filter of torch's _upsample_bilinear2d_aa: support = max(scale, 1), window [int(c - support + .5),
+// int(c + support + .5)), weights max(0, 1 - |(j + .5 - c) / max(scale, 1)|) normalised to 1.
+// One thread per output pixel, all (<= 4) channels; u8 HWC in, fp32 NCHW out.
+__global__ __launch_bounds__(256) void image_transform_kernel(const unsigned char* __restrict__ src, int H, int W, int C,
+                                                              const unsigned char* __restrict__ flip,
+                                                              float* __restrict__ dst, int S, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ox = (int)(i % S), oy = (int)((i / S) % S);
+  const long b = i / ((long)S * S);
+  const int D = H < W ? H : W, top = (H - D) / 2, left = (W - D) / 2;
+  const float scale = (float)D / (float)S;
+  const float support = scale >= 1.f ? scale : 1.f;
+  const float inv = 1.f / support;
+  const int sx = (flip && flip[b]) ? S - 1 - ox : ox;     // flip after the resize == mirrored source column
+  const float cy = scale * (oy + 0.5f), cx = scale * (sx + 0.5f);
+  const int ymin = max(0, (int)(cy - support + 0.5f)), ymax = min(D, (int)(cy + support + 0.5f));
+  const int xmin = max(0, (int)(cx - support + 0.5f)), xmax = min(D, (int)(cx + support + 0.5f));
+  float wys = 0.f, wxs = 0.f;
+  for (int y = ymin; y < ymax; ++y) wys += fmaxf(0.f, 1.f - fabsf((y - cy + 0.5f) * inv));
+  for (int x = xmin; x < xmax; ++x) wxs += fmaxf(0.f, 1.f - fabsf((x - cx + 0.5f) * inv));
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const unsigned char* img = src + b * (long)H * W * C;
+  for (int y = ymin; y < ymax; ++y) {
+    const float wy = fmaxf(0.f, 1.f - fabsf((y - cy + 0.5f) * inv)) / wys;
+    float row[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int x = xmin; x < xmax; ++x) {
+      const float wx = fmaxf(0.f, 1.f - fabsf((x - cx + 0.5f) * inv)) / wxs;
+      const unsigned char* px = img + ((long)(top + y) * W + left + x) * C;
+      for (int c = 0; c < C; ++c) row[c] += wx * (float)px[c];
+    }
+    for (int c = 0; c < C; ++c) acc[c] += wy * row[c];
+  }
+  for (int c = 0; c < C; ++c)
+    dst[((b * C + c) * S + oy) * (long)S + ox] = acc[c] * (2.f / 255.f) - 1.f;   // /255, (x - .5) / .5
+}
+
 }  // namespace
+
+extern "C" int lgm_image_transform(const unsigned char* src, int64_t B, int H, int W, int C, const unsigned char* flip,
+                                   float* dst, int S, void* stream) {
+  LGM_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C >= 1 && C <= 4 && S > 0, "image_transform: bad arguments");
+  const long total = (long)B * S * S;
+  hipLaunchKernelGGL(image_transform_kernel, dim3(lgm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src, H, W, C,
+                     flip, dst, S, total);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
 
 extern "C" int lgm_lerp_rows(const float* x, const float* y, const float* alpha, float* out, int64_t B,
                              int64_t rowlen, void* stream) {

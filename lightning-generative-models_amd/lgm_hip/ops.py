@@ -311,6 +311,18 @@ def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, step_dev=None, grad_scal
                         float(step), _p(step_dev), grad_scale, 1 if decoupled else 0, stream())
 
 
+def image_transform(src_u8: torch.Tensor, size: int, flip: Optional[torch.Tensor] = None, out=None):
+    """u8 [B,H,W,C] decoded images -> fp32 NCHW [B,C,size,size] in [-1,1] (reference DataModule transforms)."""
+    assert src_u8.dtype == torch.uint8 and src_u8.dim() == 4 and src_u8.is_contiguous()
+    B, H, W, C = src_u8.shape
+    if out is None:
+        out = torch.empty((B, C, size, size), dtype=torch.float32, device=src_u8.device)
+    if flip is not None:
+        assert flip.dtype == torch.uint8 and flip.numel() == B
+    lib().lgm_image_transform(src_u8.data_ptr(), B, H, W, C, _p(flip), out.data_ptr(), size, stream())
+    return out
+
+
 def rmsprop_step(p, g, sq, n, lr, alpha, eps, wd, grad_scale=1.0):
     lib().lgm_rmsprop_step(p.data_ptr(), g.data_ptr(), sq.data_ptr(), n, lr, alpha, eps, wd, grad_scale, stream())
 

@@ -396,3 +396,22 @@ def test_qsample_loss_and_adam(dev):
     shd, ond = sh.to(dev), on.to(dev)
     ops.ema_lerp(shd, ond, 0.25)
     assert rel(shd, OO.ema_apply(sh, on, "lerp", 0.25)) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(28, 28, 1, 28), (32, 32, 3, 32), (218, 178, 3, 64), (100, 160, 3, 64), (40, 40, 3, 64)])
+def test_device_image_transforms_match_reference_stack(dev, shape):
+    """ToTensor + Normalize + CenterCropMinXY + antialiased Resize + flip in one kernel vs the
+    torch restatement of the reference transform stack (identity, down- and up-scaling cases)."""
+    from data.transforms import DeviceTransforms
+    from oracle import data as OD
+    H, W, C, S = shape
+    g = torch.Generator().manual_seed(H * 7 + W)
+    imgs = torch.randint(0, 256, (5, H, W, C), dtype=torch.uint8, generator=g)
+    flip = torch.tensor([0, 1, 0, 1, 1], dtype=torch.uint8)
+    out = DeviceTransforms(S, train=True)(imgs.to(dev), flip.to(dev)).cpu()
+    ref = torch.stack([OD.transform(imgs[i], S, bool(flip[i])) for i in range(5)])
+    assert out.shape == ref.shape == (5, C, S, S)
+    assert float((out - ref).abs().max()) < 2e-5
+    ev = DeviceTransforms(S, train=False)(imgs.to(dev)).cpu()
+    ref0 = torch.stack([OD.transform(imgs[i], S, False) for i in range(5)])
+    assert float((ev - ref0).abs().max()) < 2e-5
