@@ -70,6 +70,11 @@ struct IgemmArgs {
   int tiles_m, tiles_n;
   int splits, kchunk; // split-K: `splits` partial products over K ranges of kchunk (multiple of BK) ...
   float* ws;          // ... written to ws[split][M][N], summed in fixed order by the reducer
+  // Strided input gradient / transposed convolution (MODE_YX, stride s > 1) by PHASE decomposition: the
+  // output pixels of one residue class (ih % s, iw % s) only ever meet the KH/s x KW/s taps of matching
+  // parity, so each class is a dense GEMM with K = (KH/s)(KW/s)Nw instead of KH*KW*Nw with (1 - 1/s^2) of
+  // the products multiplied by zero.  phases = s*s (or 1 = off); then M, K, tiles_m describe ONE class.
+  int phases, KHs, KWs;
 };
 
 template <int MODE, int BM, int BN, int TM, int TN>
@@ -91,7 +96,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
   // tile mapping: consecutive blocks walk N first (share the A tile through L2)
   const int split = blockIdx.x % p.splits;
-  const int tile = blockIdx.x / p.splits;
+  int tile = blockIdx.x / p.splits;
+  const int per_phase = p.tiles_m * p.tiles_n;
+  const int pc = tile / per_phase;               // residue class (0 when the decomposition is off)
+  tile -= pc * per_phase;
+  const int ph = pc / p.stride, pw = pc - ph * p.stride;
+  const int kh0 = (ph + p.pad) % p.stride, kw0 = (pw + p.pad) % p.stride;
+  const int Hq = p.H / p.stride, Wq = p.W / p.stride;
   const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
   const int k_begin = split * p.kchunk;
   const int k_end = min(p.K, k_begin + p.kchunk);
@@ -113,6 +124,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
       r_pix[i] = b * p.H * p.W;
       r_h[i] = oh * p.stride - p.pad;
       r_w[i] = ow * p.stride - p.pad;
+    } else if (p.phases > 1) {
+      const int iwq = mm % Wq, t = mm / Wq;
+      const int ihq = t % Hq, b = t / Hq;
+      r_pix[i] = b * p.Ho * p.Wo;
+      r_h[i] = ihq * p.stride + ph + p.pad;
+      r_w[i] = iwq * p.stride + pw + p.pad;
     } else {
       const int iw = mm % p.W, t = mm / p.W;
       const int ih = t % p.H, b = t / p.H;
@@ -130,7 +147,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const bool kok = k < k_end;
     const int tap = kok ? k / p.Cg : 0;
     const int c = k - tap * p.Cg;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    int kh, kw;
+    if (MODE == MODE_YX && p.phases > 1) {
+      const int ta = tap / p.KWs;
+      kh = kh0 + ta * p.stride;
+      kw = kw0 + (tap - ta * p.KWs) * p.stride;
+    } else {
+      kh = tap / p.KW;
+      kw = tap - kh * p.KW;
+    }
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       bool ok = kok && r_ok[i];
@@ -143,8 +168,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         int th = r_h[i] - kh, tw = r_w[i] - kw;
         ok = ok && th >= 0 && tw >= 0;
         if (p.stride != 1) {
-          ok = ok && (th % p.stride == 0) && (tw % p.stride == 0);
-          th /= p.stride;
+          if (p.phases == 1) ok = ok && (th % p.stride == 0) && (tw % p.stride == 0);
+          th /= p.stride;         // exact inside a residue class
           tw /= p.stride;
         }
         ok = ok && th < p.Ho && tw < p.Wo;
@@ -172,8 +197,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
       for (int i = 0; i < B_PER; ++i) {
         const int kk = k0 + krow + RPP * i;
         const bool ok = (kk < k_end) && (n0 + ncol < p.N);
-        const int tp = ok ? kk / p.Cg : 0;
+        int tp = ok ? kk / p.Cg : 0;
         const int nn = kk - tp * p.Cg;
+        if (p.phases > 1) {
+          const int ta = tp / p.KWs;
+          tp = (kh0 + ta * p.stride) * p.KW + kw0 + (tp - ta * p.KWs) * p.stride;
+        }
         rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.w + ((long)nn * T + tp) * p.Cw + n0 + ncol)
                    : f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -255,6 +284,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     __syncthreads();
   }
 
+  // GEMM row -> output pixel (identity unless the rows enumerate one residue class)
+  auto out_row = [&](int m) -> long {
+    if (MODE == MODE_YX && p.phases > 1) {
+      const int iwq = m % Wq, t = m / Wq;
+      const int ihq = t % Hq, b = t / Hq;
+      return (long)(b * p.H + ihq * p.stride + ph) * p.W + iwq * p.stride + pw;
+    }
+    return (long)m;
+  };
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   if (p.splits > 1) {   // partial product -> workspace slab; bias/residual are added by the reducer
     float* slab = p.ws + (long)split * p.M * p.N;
@@ -284,7 +322,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          rv[r] = m < p.M ? p.res[(long)m * p.res_pitch + n] : 0.f;
+          rv[r] = m < p.M ? p.res[out_row(m) * p.res_pitch + n] : 0.f;
         }
       } else {
 #pragma unroll
@@ -293,7 +331,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.M) p.out[(long)m * p.out_pitch + n] = acc[i][j][r] + bv + rv[r];
+        if (m < p.M) p.out[out_row(m) * p.out_pitch + n] = acc[i][j][r] + bv + rv[r];
       }
     }
   }
@@ -312,7 +350,7 @@ int launch_igemm(IgemmArgs& a, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits * a.phases)), dim3(256), smem, s, a);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
@@ -334,14 +372,25 @@ int igemm_splits(long M, int N, int K, int* kchunk) {
 
 template <int MODE>
 int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool wide, hipStream_t s) {
-  const long t128 = (long)lgm_cdiv(a.M, 128);
+  a.phases = 1;
+  a.KHs = a.KH;
+  a.KWs = a.KW;
+  if (MODE == MODE_YX && a.stride > 1 && a.KH % a.stride == 0 && a.KW % a.stride == 0 && a.H % a.stride == 0 &&
+      a.W % a.stride == 0) {
+    a.phases = a.stride * a.stride;
+    a.KHs = a.KH / a.stride;
+    a.KWs = a.KW / a.stride;
+    a.M = a.B * (a.H / a.stride) * (a.W / a.stride);       // rows of ONE residue class
+    a.K = a.KHs * a.KWs * a.Cg;
+  }
+  const long t128 = (long)lgm_cdiv(a.M, 128) * a.phases;
   a.splits = 1;
   a.kchunk = lgm_cdiv(a.K, BK) * BK;
   a.ws = nullptr;
   if (a.N > 64 && t128 * lgm_cdiv(a.N, 128) >= 384) return launch_igemm<MODE, 128, 128, 2, 2>(a, s);
   if (t128 * lgm_cdiv(a.N, 64) >= 384) return launch_igemm<MODE, 128, 64, 2, 1>(a, s);
   int kchunk;
-  const int splits = igemm_splits(a.M, a.N, a.K, &kchunk);
+  const int splits = a.phases > 1 ? 1 : igemm_splits(a.M, a.N, a.K, &kchunk);
   if (splits > 1 && wide && workspace && workspace_bytes >= (int64_t)splits * a.M * a.N * (int64_t)sizeof(float)) {
     a.splits = splits;
     a.kchunk = kchunk;
