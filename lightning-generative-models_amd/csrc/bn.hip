@@ -37,19 +37,29 @@ __global__ __launch_bounds__(256) void bn_reduce_stage1(const float* __restrict_
   if (c < C) {
     const float mu = (mode != 1 && mean) ? mean[c] : 0.f;
     const float rs = (mode == 0 && rstd) ? rstd[c] : 0.f;
-    for (long r = r0 + rl; r < r1; r += 4) {
-      if (mode == 0) {
-        const float x = v1[r * v1_pitch + c];
-        s1 += x;
-        if (a) s2 += x * ((a[r * a_pitch + c] - mu) * rs);
-        if (v2) s3 += x * v2[r * v2_pitch + c];
-      } else if (mode == 1) {
-        s1 += a[r * a_pitch + c];
-      } else {
-        const float d = a[r * a_pitch + c] - mu;
-        s1 += d * d;
+    // four independent row streams per thread (rows r, r+4, r+8, r+12): four loads in flight, fixed order
+    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f}, t3[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long rb = r0 + rl; rb < r1; rb += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long r = rb + 4 * u;
+        if (r >= r1) continue;
+        if (mode == 0) {
+          const float x = v1[r * v1_pitch + c];
+          t1[u] += x;
+          if (a) t2[u] += x * ((a[r * a_pitch + c] - mu) * rs);
+          if (v2) t3[u] += x * v2[r * v2_pitch + c];
+        } else if (mode == 1) {
+          t1[u] += a[r * a_pitch + c];
+        } else {
+          const float d = a[r * a_pitch + c] - mu;
+          t1[u] += d * d;
+        }
       }
     }
+    s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]);
+    s2 = (t2[0] + t2[1]) + (t2[2] + t2[3]);
+    s3 = (t3[0] + t3[1]) + (t3[2] + t3[3]);
   }
   sh[0][rl][cl] = s1;
   sh[1][rl][cl] = s2;
@@ -61,13 +71,29 @@ __global__ __launch_bounds__(256) void bn_reduce_stage1(const float* __restrict_
   }
 }
 
-__global__ void bn_reduce_stage2(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ out3) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // i in [0, 3C)
-  if (i >= 3 * C) return;
-  const int k = i / C, c = i % C;
-  float s = 0.f;
-  for (int j = 0; j < nsplit; ++j) s += partial[((long)j * 3 + k) * C + c];
-  out3[i] = s;
+// stage 2: block = 64 of the 3C sums x 4 split lanes; lane l adds splits l, l+4, ... (two at a time,
+// unconditionally - rows past nsplit are clamped and weighted 0), fixed-order LDS combine
+__global__ __launch_bounds__(256) void bn_reduce_stage2(const float* __restrict__ partial, int nsplit, int C,
+                                                        float* __restrict__ out3) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, jl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cl;   // i in [0, 3C)
+  float s0 = 0.f, s1 = 0.f;
+  if (i < 3 * C) {
+    const int k = i / C, c = i - k * C;
+    const float* base = partial + (long)k * C + c;
+    const long stride = 3L * C;
+    for (int j = jl; j < nsplit; j += 8) {
+      const int j2 = j + 4;
+      const float a = base[(long)j * stride];
+      const float b = base[(long)(j2 < nsplit ? j2 : j) * stride];
+      s0 += a;
+      s1 += j2 < nsplit ? b : 0.f;
+    }
+  }
+  sh[jl][cl] = s0 + s1;
+  __syncthreads();
+  if (jl == 0 && i < 3 * C) out3[i] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 
 // finalize batch statistics: mode 1 result -> mean; mode 2 result -> rstd (+ running stats, torch semantics:
@@ -177,7 +203,7 @@ int reduce3(int mode, const float* v1, long v1_pitch, const float* v2, long v2_p
   const int ns = lgm_cdiv(rows, rpb);
   hipLaunchKernelGGL(bn_reduce_stage1, dim3(lgm_cdiv(C, 64), ns), dim3(256), 0, s, v1, v1_pitch, v2, v2_pitch, a,
                      a_pitch, mean, rstd, mode, rows, C, rpb, ws);
-  hipLaunchKernelGGL(bn_reduce_stage2, dim3(lgm_cdiv(3 * C, 256)), dim3(256), 0, s, (const float*)ws, ns, C, out3);
+  hipLaunchKernelGGL(bn_reduce_stage2, dim3(lgm_cdiv(3 * C, 64)), dim3(256), 0, s, (const float*)ws, ns, C, out3);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
