@@ -503,6 +503,88 @@ extern "C" int lgm_transpose_weights(const float* src, float* dst, const int32_t
   return LGM_OK;
 }
 
+namespace {
+// Input gradient / transposed convolution with <= 4 produced channels (the image end of the DCGAN
+// critic and generator: dD/dx for the gradient penalty, the generator's last layer).  As a GEMM this has
+// N = 4 and would idle 15/16 of a 64-wide MFMA tile; it is a memory-bound dot product instead: one wave
+// per output pixel, lane l owns gathered channels 4l..4l+3, the (tap, out-channel) weight vectors sit in
+// LDS, four accumulators are combined with a fixed shuffle tree.  Only taps of the pixel's stride
+// residue class are visited.
+struct SmallNArgs {
+  const float* y;     // gathered tensor [B,Ho,Wo,Nw] (pitch y_pitch)
+  const float* w;     // [Nw][T][4]
+  const float* bias;
+  const float* res;
+  float* x;           // [B,H,W,4]
+  long y_pitch, res_pitch, x_pitch;
+  int B, H, W, Ho, Wo, Nw, KH, KW, stride, pad;
+  long npix;
+};
+
+// KHS x KWS = taps per residue class (KH/stride x KW/stride); LPP = Nw/4 lanes share one output pixel,
+// 64/LPP pixels per wave; all tap loads of a pixel are issued before they are consumed.
+template <int KHS, int KWS>
+__global__ __launch_bounds__(256) void smalln_yx_kernel(const SmallNArgs p) {
+  extern __shared__ __align__(16) float wsm[];   // [T][4][Nw]
+  const int T = p.KH * p.KW;
+  for (int i = threadIdx.x; i < T * 4 * p.Nw; i += 256) {
+    const int n = i % p.Nw, c = (i / p.Nw) % 4, t = i / (4 * p.Nw);
+    wsm[i] = p.w[((long)n * T + t) * 4 + c];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int LPP = p.Nw / 4;                       // power of two, <= 64
+  const int ppw = 64 / LPP;
+  const int sub = lane / LPP, cl = lane % LPP;   // pixel slot inside the wave, channel chunk
+  const long per_iter = (long)gridDim.x * 4 * ppw;
+  for (long base = ((long)blockIdx.x * 4 + wid) * ppw; base < p.npix; base += per_iter) {
+    const long pix = base + sub;
+    const bool live = pix < p.npix;
+    const long pp = live ? pix : 0;
+    const int iw = (int)(pp % p.W);
+    const long t0 = pp / p.W;
+    const int ih = (int)(t0 % p.H), b = (int)(t0 / p.H);
+    const int kh0 = (ih + p.pad) % p.stride, kw0 = (iw + p.pad) % p.stride;
+    f32x4 yv[KHS * KWS];
+    bool ok[KHS * KWS];
+#pragma unroll
+    for (int ta = 0; ta < KHS; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < KWS; ++tb) {
+        const int dh = ih + p.pad - (kh0 + ta * p.stride), dw = iw + p.pad - (kw0 + tb * p.stride);
+        const int th = dh / p.stride, tw = dw / p.stride;
+        const bool v = live && dh >= 0 && dw >= 0 && th < p.Ho && tw < p.Wo;
+        ok[ta * KWS + tb] = v;
+        const long off = v ? ((long)(b * p.Ho + th) * p.Wo + tw) * p.y_pitch + cl * 4 : 0L;
+        yv[ta * KWS + tb] = *reinterpret_cast<const f32x4*>(p.y + off);     // unconditional (clamped) load
+      }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ta = 0; ta < KHS; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < KWS; ++tb) {
+        const int tap = (kh0 + ta * p.stride) * p.KW + kw0 + tb * p.stride;
+        const float* wt = wsm + (long)tap * 4 * p.Nw + cl * 4;
+        const f32x4 y4 = ok[ta * KWS + tb] ? yv[ta * KWS + tb] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + c * p.Nw);
+          acc[c] += (y4[0] * wv[0] + y4[1] * wv[1]) + (y4[2] * wv[2] + y4[3] * wv[3]);
+        }
+      }
+    for (int off = LPP >> 1; off > 0; off >>= 1) {   // fixed tree inside the pixel's lane group
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+    }
+    if (cl == 0 && live) {
+      if (p.bias) acc += *reinterpret_cast<const f32x4*>(p.bias);
+      if (p.res) acc += *reinterpret_cast<const f32x4*>(p.res + pix * p.res_pitch);
+      *reinterpret_cast<f32x4*>(p.x + pix * p.x_pitch) = acc;
+    }
+  }
+}
+}  // namespace
+
 extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
                            const float* w_t, const float* bias, const float* res, int64_t res_pitch, float* x,
                            int64_t x_pitch, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -520,6 +602,29 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
       g->pad == 0 && lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Cw, g->Nw))
     return lgm_gemm_rows_launch(y, y_pitch, w_t, bias, res, res_pitch, x, x_pitch, (long)g->B * g->H * g->W, g->Cw, g->Nw,
                                 (hipStream_t)stream);
+  const int lpp = g->Nw / 4;
+  if (use_3x3() && g->Cw == 4 && g->Nw % 4 == 0 && lpp <= 64 && (lpp & (lpp - 1)) == 0 && g->stride == 2 &&
+      g->KH == 4 && g->KW == 4 && wide_ok(x, x_pitch, res, res_pitch, bias) &&
+      (long)g->KH * g->KW * 4 * g->Nw * 4 <= 64 * 1024) {
+    SmallNArgs q{};
+    q.y = y; q.w = w; q.bias = bias; q.res = res; q.x = x;
+    q.y_pitch = y_pitch; q.res_pitch = res_pitch; q.x_pitch = x_pitch;
+    q.B = g->B; q.H = g->H; q.W = g->W; q.Ho = g->Ho; q.Wo = g->Wo; q.Nw = g->Nw;
+    q.KH = g->KH; q.KW = g->KW; q.stride = g->stride; q.pad = g->pad;
+    q.npix = (long)g->B * g->H * g->W;
+    const size_t smem = (size_t)g->KH * g->KW * 4 * g->Nw * sizeof(float);
+    static size_t attr = 0;
+    if (smem > attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(smalln_yx_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)smem);
+      attr = smem;
+    }
+    const long want = (q.npix + 4 * (64 / lpp) - 1) / (4 * (64 / lpp));
+    const unsigned nb = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL((smalln_yx_kernel<2, 2>), dim3(nb), dim3(256), smem, (hipStream_t)stream, q);
+    LGM_LAUNCH_CHECK();
+    return LGM_OK;
+  }
   IgemmArgs a{};
   a.a = y; a.w = w; a.bias = bias; a.res = res; a.out = x;
   a.a_pitch = y_pitch; a.res_pitch = res_pitch; a.out_pitch = x_pitch;
