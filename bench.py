@@ -67,6 +67,38 @@ def cpu_baseline(batch=16, warmup=1, steps=3):
             "sample": f"oracle fwd+bwd+Adam, B={batch}, 3x{IMG}x{IMG}, median of {steps} steps after {warmup} warm-up"}
 
 
+def torch_gpu_baseline(dev, batch=GLOBAL_BATCH, warmup=5, steps=10):
+    """Baseline leg, optional (--torch-gpu-baseline): the same oracle (the reference's arithmetic as plain
+    torch ops, i.e. what the reference's modules execute) with its tensors on the MI355X — PyTorch-ROCm eager
+    kernels (MIOpen / rocBLAS / ATen) + torch.optim.Adam.  A reported comparison point, not the target."""
+    from oracle import diffusion as OD
+    torch.manual_seed(10)
+    P = {k: v.to(dev).requires_grad_(True) for k, v in OD.unet_init(dim=DIM, channels=3, seed=0).items()}
+    bufs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in OD.diffusion_buffers(1000).items()}
+    opt = torch.optim.Adam(list(P.values()), lr=2e-5, betas=(0.9, 0.99))
+    x = (torch.rand(batch, 3, IMG, IMG) * 2 - 1).to(dev)
+
+    def one():
+        t = torch.randint(0, 1000, (batch,), device=dev)
+        noise = torch.randn_like(x)
+        loss = OD.diffusion_forward(P, bufs, x, t, noise, dim=DIM)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    for i in range(warmup):
+        print(f"[bench] torch_gpu_baseline warm-up {i}", file=sys.stderr, flush=True)
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(batch / dt, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "kind": "port",
+            "sample": f"oracle (torch eager ops on the GPU) fwd+bwd+Adam, B={batch}, mean of {steps} steps after {warmup}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +107,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python (no HIP-graph replay)")
     ap.add_argument("--batch", type=int, default=GLOBAL_BATCH, help="global batch (default 128 = the metric)")
+    ap.add_argument("--torch-gpu-baseline", action="store_true",
+                    help="also time the oracle's plain torch ops on the GPU (PyTorch-ROCm eager) as a comparison point")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,6 +249,8 @@ def main():
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and args.torch_gpu_baseline:
+            line["torch_gpu_baseline"] = torch_gpu_baseline(dev, args.batch)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -811,8 +811,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const long i = ((long)blockIdx.x * 64 + col) * 4;
   const long n = n_w + n_b;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (i < n)
-    for (int k = lane; k < splits; k += 4) s += *reinterpret_cast<const f32x4*>(ws + (long)k * slab + i);
+  if (i < n) {
+    // four independent slab streams per thread (k, k+4, k+8, k+12): four 16-byte loads in flight;
+    // slabs past `splits` are clamped and weighted 0 so the loop body has no branches
+    f32x4 t0 = s, t1 = s, t2 = s, t3 = s;
+    for (int k = lane; k < splits; k += 16) {
+      const int k1 = k + 4, k2 = k + 8, k3 = k + 12;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(ws + (long)k * slab + i);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(ws + (long)(k1 < splits ? k1 : k) * slab + i);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(ws + (long)(k2 < splits ? k2 : k) * slab + i);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(ws + (long)(k3 < splits ? k3 : k) * slab + i);
+      t0 += v0;
+      t1 += v1 * (k1 < splits ? 1.f : 0.f);
+      t2 += v2 * (k2 < splits ? 1.f : 0.f);
+      t3 += v3 * (k3 < splits ? 1.f : 0.f);
+    }
+    s = (t0 + t1) + (t2 + t3);
+  }
   *reinterpret_cast<f32x4*>(&sh[lane][col * 4]) = s;
   __syncthreads();
   if (lane == 0 && i < n) {
