@@ -241,11 +241,13 @@ def main():
         line = {"metric": "training images/sec (DDPM UNet 32x32, bs=128)", "value": round(value, 2),
                 "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
+                "dtype": "f32" if not ops.B3 else "f32 (3x3 conv fwd/dgrad: opt-in bf16x3 split MFMA, fp32-level error)",
+                "data": "synthetic",
                 "config": {"workload": "configs/diffusion/ddpm.json UNet dim=64, 3x32x32 synthetic NCHW fp32, "
                                        "training_step+backward+Adam+EMA", "global_batch": args.batch,
                            "per_gpu_batch": per_gpu, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),
-                           "launch": "hipGraph replay (2 graphs/step)" if graphed is not None else "eager"},
+                           "launch": "hipGraph replay (2 graphs/step)" if graphed is not None else "eager",
+                           "conv_mode": "bf16x3 (LGM_CONV_MODE)" if ops.B3 else "fp32 MFMA"},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -282,6 +282,26 @@ int lgm_fill_col(float* out, int64_t pitch, int64_t n, int ncols, int col, float
 int lgm_wgan_dloss(float* vals4, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * OPT-IN split-precision 3x3 convolution (SURVEY.md "bf16x3 ... behind a flag, only if it holds 1e-4";
+ * never used unless the caller asks for it): each fp32 operand is split exactly into three bf16 pieces
+ * and the product evaluated with six bf16 MFMAs and fp32 accumulation (fp32-level error, measured in
+ * tests/test_hip_bf16x3.py).  Same contract as lgm_conv_xy / lgm_conv_yx for 3x3 / stride 1 / pad 1
+ * (Block.proj ddpm.py:160-171 and its input gradient), except that the weights are passed as the three
+ * planes produced by lgm_split_bf16x3 from the fp32 weights [Nw][9][Cw] (mode 0, forward) or from their
+ * transposed copy [Cw][9][Nw] (mode 1, input gradient); plane p starts at w_planes + p*plane_elems.
+ * ------------------------------------------------------------------------------------- */
+int64_t lgm_conv3x3_bf16x3_supported(const LgmConvGeom* g, int mode, int64_t a_pitch);   /* 1 / 0 */
+/* table rows (int32 x 5): element offset of the slot (same in src and in every dst plane), rows, taps, K,
+ * first chunk; rows %% 32 == 0, K %% 16 == 0; total_chunks = sum rows*taps*K/8.  The planes are written in the
+ * MFMA fragment order the kernel reads (one contiguous 1 KB read per wave and fragment). */
+int lgm_split_bf16x3(const float* src, uint16_t* dst, const int32_t* table, int n_slots, int64_t total_chunks,
+                     int64_t plane_elems, void* stream);
+int lgm_conv3x3_bf16x3(int mode, const LgmConvGeom* g, const float* a, int64_t a_pitch,
+                       const uint16_t* w_planes, int64_t plane_elems, const float* bias, const float* res,
+                       int64_t res_pitch, float* out, int64_t out_pitch, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimiser kernels on flat storage.
  * torch.optim.Adam (coupled L2; decoupled=1 gives AdamW) — ddpm.py:1053-1059, vqvae.py:207-214,
  * wgan.py:183-195.  step: 1-based count (host value, or read from step_dev when non-NULL).

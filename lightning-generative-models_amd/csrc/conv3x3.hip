@@ -42,6 +42,8 @@ struct Args {
   int splits, pps;    // split-K over whole phases (pps phases per split); > 1 => partials to ws
   float* ws;          // [splits][B*H*W][N]
   long ws_stride;
+  const unsigned short* wb;   // split-precision path: bf16 planes [3][w_plane] of the (k-contiguous) weights
+  long w_plane;
 };
 
 // out[m][n] = sum_s ws[s][m][n] + bias[n] + res[m][n]   (fixed order => deterministic)
@@ -403,6 +405,372 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
 }
 
 // =====================================================================================
+// Split-precision variant (opt-in, SURVEY.md "bf16x3"): every fp32 operand is split EXACTLY into three
+// bf16 pieces x = h + m + l (truncation splits of the 24-bit significand) and the product is evaluated as
+// hh' + hm' + mh' + hl' + lh' + mm' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped terms
+// are <= 2^-24 relative: the result carries fp32-level error), at 6 x 32-cycle MFMAs per 16 k instead of
+// 8 x 64-cycle fp32 MFMAs.  Same work decomposition, pipelining and epilogue as conv3x3_kernel; the LDS
+// patch holds three bf16 planes per position (row = 3 x 64 B + 16 B pad = 208 B, conflict-free
+// ds_read_b128), activations are split while being committed to LDS, weights are pre-split per step by
+// lgm_split_bf16x3.  FLIP = input gradient (mirrored taps) on the transposed weight copy.
+// =====================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3(const f32x4& v, u32x2& H, u32x2& M, u32x2& L) {
+  unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned xb = __float_as_uint(v[i]);
+    hb[i] = xb & 0xFFFF0000u;
+    const float r1 = v[i] - __uint_as_float(hb[i]);
+    mb[i] = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mb[i]);
+    lb[i] = __float_as_uint(r2) & 0xFFFF0000u;
+  }
+  H[0] = (hb[0] >> 16) | hb[1]; H[1] = (hb[2] >> 16) | hb[3];
+  M[0] = (mb[0] >> 16) | mb[1]; M[1] = (mb[2] >> 16) | mb[3];
+  L[0] = (lb[0] >> 16) | lb[1]; L[1] = (lb[2] >> 16) | lb[3];
+}
+
+template <bool FLIP>
+__global__ __launch_bounds__(256, 1) void conv3x3_b3_kernel(const Args p) {
+  constexpr int CK = 32;
+  constexpr int ROWB = 208;              // bytes per patch position: planes h | m | l (64 B each) + pad
+  constexpr int U = 9, NJ = 9, TPP = 8, PPP = 32;
+  constexpr int PBUFB = 288 * ROWB;
+  extern __shared__ __align__(16) float smem[];
+  char* smemb = reinterpret_cast<char*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  float* Ts = reinterpret_cast<float*>(smemb + 2 * PBUFB) + wid * LGM_TS_FLOATS;
+
+  const int Lb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int L0 = Lb * p.per;
+  const int L1 = min(p.units, L0 + p.per);
+  if (L0 >= L1) return;
+
+  const int PW = p.TW + 2;
+  const int ncc_total = p.C / CK;
+
+  auto place = [&](Phase& ph) {
+    ph.n0 = ph.tn * BN;
+    ph.w0 = ph.twi * p.TW;
+    ph.h0 = ph.thi * p.TH;
+    ph.b0 = ph.bg * p.NI;
+    ph.cc = ph.split * p.pps;
+    ph.cc_end = min(ncc_total, ph.cc + p.pps);
+    ph.border = 16u | (ph.h0 == 0 ? 1u : 0u) | (ph.h0 + p.TH == p.H ? 2u : 0u) | (ph.w0 == 0 ? 4u : 0u) |
+                (ph.w0 + p.TW == p.W ? 8u : 0u);
+    ph.abase = ((long)((ph.b0 * p.H + ph.h0 - 1) * p.W + ph.w0 - 1) * p.a_pitch) * 4;
+  };
+  auto decode = [&](Phase& ph, int L) {
+    ph.L = L;
+    ph.tn = L % p.tiles_n;
+    int ts = L / p.tiles_n;
+    ph.split = ts % p.splits;
+    ts /= p.splits;
+    ph.twi = ts % p.tiles_w;
+    ts /= p.tiles_w;
+    ph.thi = ts % p.tiles_h;
+    ph.bg = ts / p.tiles_h;
+    place(ph);
+  };
+  auto advance = [&](Phase& ph) {
+    if (!ph.valid) return;
+    if (ph.cc + 1 < ph.cc_end) {
+      ++ph.cc;
+    } else if (ph.L + 1 < L1) {
+      ++ph.L;
+      if (++ph.tn == p.tiles_n) {
+        ph.tn = 0;
+        if (++ph.split == p.splits) {
+          ph.split = 0;
+          if (++ph.twi == p.tiles_w) {
+            ph.twi = 0;
+            if (++ph.thi == p.tiles_h) {
+              ph.thi = 0;
+              ++ph.bg;
+            }
+          }
+        }
+      }
+      place(ph);
+    } else {
+      ph.valid = false;
+    }
+  };
+
+  const int c4 = (tid % TPP) * 4;
+  unsigned pdelta[NJ];
+  unsigned pflagA = 0, pflagB = 0;
+  {
+    int px = tid / TPP, py = 0, img = 0;
+    while (px >= PW) { px -= PW; ++py; }
+    while (py >= p.TH + 2) { py -= p.TH + 2; ++img; }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      unsigned d = 0, f = 16u;
+      if (img < p.NI) {
+        d = (unsigned)(((img * p.H + py) * p.W + px) * (int)p.a_pitch + c4) * 4u;
+        f = (py == 0 ? 1u : 0u) | (py == p.TH + 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == p.TW + 1 ? 8u : 0u);
+      }
+      pdelta[j] = d;
+      if (j < 6) pflagA |= f << (5 * j);
+      else pflagB |= f << (5 * (j - 6));
+      px += PPP;
+      while (px >= PW) { px -= PW; ++py; }
+      while (py >= p.TH + 2) { py -= p.TH + 2; ++img; }
+    }
+  }
+  const unsigned safe_delta = (unsigned)((p.W + 1) * (int)p.a_pitch) * 4u;
+  f32x4 rp[NJ];
+  auto fetch_addr = [&](int j, const Phase& ph, unsigned& off) -> unsigned {
+    const unsigned fl = (j < 6 ? pflagA : pflagB) & (ph.border << (5 * (j < 6 ? j : j - 6)));
+    const bool ok = fl == 0u;
+    off = ok ? pdelta[j] : safe_delta;
+    return ok ? 1u : 0u;
+  };
+  auto fetch_issue = [&](int j, const Phase& ph, unsigned off) {
+    const char* sbase = reinterpret_cast<const char*>(p.a) + ph.abase + (long)ph.cc * (CK * 4);
+    rp[j] = *reinterpret_cast<const f32x4*>(sbase + off);
+  };
+  auto fetch = [&](int j, const Phase& ph) -> unsigned {
+    unsigned off;
+    const unsigned ok = fetch_addr(j, ph, off);
+    fetch_issue(j, ph, off);
+    return ok;
+  };
+  // split the fp32 patch value into its three bf16 planes while committing it
+  auto commit = [&](int j, char* buf, unsigned mask) {
+    const int pos = tid / TPP + PPP * j;
+    const f32x4 v = ((mask >> j) & 1u) ? rp[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x2 H, M, L;
+    split3(v, H, M, L);
+    char* row = buf + pos * ROWB + c4 * 2;
+    *reinterpret_cast<u32x2*>(row) = H;
+    *reinterpret_cast<u32x2*>(row + 64) = M;
+    *reinterpret_cast<u32x2*>(row + 128) = L;
+  };
+
+  int apos[2];                            // patch position of the lane's two pixels (tile rows i = 0, 1)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wm * 64 + i * 32 + lr;
+    const int img = r >> p.lgTT, rr = r & ((1 << p.lgTT) - 1);
+    const int ph = rr >> p.lgTW, pw = rr & (p.TW - 1);
+    apos[i] = (img * (p.TH + 2) + ph) * PW + pw;
+  }
+
+  // weight fragments in FRAGMENT-MAJOR order (written by lgm_split_bf16x3): per plane
+  // [n/32][tap][k/16][lane][8], lane = n%32 + 32*((k%16)/8) - a wave's B operand of one (tap, 16 k) is
+  // one contiguous 1 KB read (the row-major layout made every load touch 32 cache lines and the
+  // texture-address path became the limiter)
+  auto load_b = [&](const Phase& ph, int tap, bf16x8 (&fb)[2][3]) {
+    const long frag = (((long)(ph.n0 / 32 + wn) * 9 + tap) * (p.C / 16) + ph.cc * 2) * 64 + lane;
+    const char* sbase = reinterpret_cast<const char*>(p.wb) + frag * 16;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        fb[q][pl] = *reinterpret_cast<const bf16x8*>(sbase + (long)pl * p.w_plane * 2 + q * 1024);
+  };
+
+  f32x16 acc[2], accs[2];      // large-term and small-term partial sums per pixel tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[i][r] = 0.f;
+      accs[i][r] = 0.f;
+    }
+
+  Phase cur;
+  cur.valid = true;
+  decode(cur, L0);
+  Phase nx1 = cur;
+  advance(nx1);
+  Phase nx2 = nx1;
+  advance(nx2);
+  bf16x8 wq[3][2][3];
+  load_b(cur, 0, wq[0]);
+  load_b(cur, 1, wq[1]);
+  unsigned mrp = 0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) mrp |= fetch(j, cur) << j;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) commit(j, smemb, mrp);
+  mrp = 0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) mrp |= fetch(j, nx1) << j;
+  __syncthreads();
+
+  int mrow[2][4];
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  f32x4 rv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mrow[i][j] = 0;
+      rv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  int buf = 0;
+  for (;;) {
+    const char* Pc = smemb + buf * PBUFB;
+    char* Pn = smemb + (buf ^ 1) * PBUFB;
+    // group g = (tap, q): fragments of the two pixel tiles, three planes each
+    auto read_frag = [&](int gidx, bf16x8 (&f)[2][3]) {
+      const int tap = gidx / 2, q = gidx % 2;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int tapoff = FLIP ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          f[i][pl] = *reinterpret_cast<const bf16x8*>(Pc + (apos[i] + tapoff) * ROWB + pl * 64 + q * 32 + lh * 16);
+    };
+    bf16x8 fa[2][2][3];
+    read_frag(0, fa[0]);
+    unsigned mnew = 0;
+    const bool last_of_unit = cur.cc + 1 >= cur.cc_end;
+    if (last_of_unit) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rt = wm * 64 + i * 32 + (lane >> 3) + 8 * j;
+          const int img = rt >> p.lgTT, rr = rt & ((1 << p.lgTT) - 1);
+          const int oh = cur.h0 + (rr >> p.lgTW), ow = cur.w0 + (rr & (p.TW - 1)), b = cur.b0 + img;
+          mrow[i][j] = (b * p.H + oh) * p.W + ow;
+        }
+      if (p.splits == 1) {
+        const int nc = cur.n0 + wn * 32 + (lane & 7) * 4;
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + nc);
+        if (p.res) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              rv[i][j] = *reinterpret_cast<const f32x4*>(p.res + (long)mrow[i][j] * p.res_pitch + nc);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      unsigned foff = 0, fok = 0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int gidx = u * 2 + q;
+        if (q == 0) {
+          if (u + 2 < U) load_b(cur, u + 2, wq[(u + 2) % 3]);
+          else load_b(nx1, u + 2 - U, wq[(u + 2) % 3]);
+          fok = fetch_addr(u, nx2, foff);
+          mnew |= fok << u;
+        } else {
+          commit(u, Pn, mrp);
+          fetch_issue(u, nx2, foff);
+        }
+        if (gidx + 1 < 2 * U) read_frag(gidx + 1, fa[(gidx + 1) & 1]);
+        {
+          // four independent accumulator chains (tile 0/1 x small/large terms): consecutive MFMAs never
+          // depend on each other (a dependent 8-pass MFMA cannot issue back to back)
+          const bf16x8 Bh = wq[u % 3][q][0], Bm = wq[u % 3][q][1], Bl = wq[u % 3][q][2];
+          const bf16x8 A0h = fa[gidx & 1][0][0], A0m = fa[gidx & 1][0][1], A0l = fa[gidx & 1][0][2];
+          const bf16x8 A1h = fa[gidx & 1][1][0], A1m = fa[gidx & 1][1][1], A1l = fa[gidx & 1][1][2];
+          accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0l, Bh, accs[0], 0, 0, 0);
+          accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1l, Bh, accs[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0m, Bh, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1m, Bh, acc[1], 0, 0, 0);
+          accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0h, Bl, accs[0], 0, 0, 0);
+          accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1h, Bl, accs[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0h, Bm, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1h, Bm, acc[1], 0, 0, 0);
+          accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0m, Bm, accs[0], 0, 0, 0);
+          accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1m, Bm, accs[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0h, Bh, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1h, Bh, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x296, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    mrp = mnew;
+    __syncthreads();
+
+    if (last_of_unit) {
+      const int nc = cur.n0 + wn * 32 + (lane & 7) * 4;
+      float* dst = p.out;
+      long dpitch = p.out_pitch;
+      if (p.splits > 1) {
+        dst = p.ws + (long)cur.split * p.ws_stride;
+        dpitch = p.N;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        lgm_wave_lds_sync();
+        acc[i] += accs[i];
+        lgm_tile_to_lds(acc[i], Ts, lane);
+        lgm_wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(dst + (long)mrow[i][j] * dpitch + nc) = lgm_tile_row4(Ts, lane, j) + bv + rv[i][j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[i][r] = 0.f;
+          accs[i][r] = 0.f;
+        }
+      }
+    }
+    if (!nx1.valid) break;
+    cur = nx1;
+    nx1 = nx2;
+    advance(nx2);
+    buf ^= 1;
+  }
+}
+
+// fp32 weights [rows][T][K] -> three bf16 planes in fragment-major order (see conv3x3_b3_kernel::load_b).
+// Table rows: (offset, rows, T, K, first_chunk); one thread per 8-element chunk; rows % 32 == 0, K % 16 == 0.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                           const int* __restrict__ table, int n_slots, long total_chunks,
+                                                           long plane) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total_chunks) return;
+  int lo = 0, hi = n_slots - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((long)table[mid * 5 + 4] <= gid) lo = mid; else hi = mid - 1;
+  }
+  const int* row = table + lo * 5;
+  const long off = row[0];
+  const int T = row[2], K = row[3];
+  long ch = gid - row[4];                 // chunk inside the slot: (((nt * T + tap) * (K/16) + kq) * 64 + lane)
+  const int lane = (int)(ch % 64);
+  long t = ch / 64;
+  const int kq = (int)(t % (K / 16));
+  t /= K / 16;
+  const int tap = (int)(t % T), nt = (int)(t / T);
+  const int n = nt * 32 + (lane & 31), c = kq * 16 + (lane >> 5) * 8;
+  const float* sp = src + off + ((long)n * T + tap) * K + c;
+  u32x2 H0, M0, L0, H1, M1, L1;
+  split3(*reinterpret_cast<const f32x4*>(sp), H0, M0, L0);
+  split3(*reinterpret_cast<const f32x4*>(sp + 4), H1, M1, L1);
+  unsigned short* dp = dst + off + ch * 8;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<u32x4*>(dp) = u32x4{H0[0], H0[1], H1[0], H1[1]};
+  *reinterpret_cast<u32x4*>(dp + plane) = u32x4{M0[0], M0[1], M1[0], M1[1]};
+  *reinterpret_cast<u32x4*>(dp + 2 * plane) = u32x4{L0[0], L0[1], L1[0], L1[1]};
+}
+
+// =====================================================================================
 // wgrad: block = (pixel range, 64 n, 64 c); per spatial tile the Y tile [128 pix][64 n] and the X
 // halo patch are staged once, then 9 taps x 64 pixel-pairs of MFMAs (k = pixel) accumulate into
 // nine 32x32 accumulators per wave.
@@ -713,6 +1081,91 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
     const long items = M * (p.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)lgm_cdiv(items, 256)), dim3(256), 0, s,
                        (const float*)p.ws, p.ws_stride, p.splits, bias, res, res_pitch, out, out_pitch, M, p.N);
+  }
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// ---- split-precision (bf16x3) path: same planning as the fp32 launcher, other kernel and LDS footprint
+extern "C" int64_t lgm_conv3x3_bf16x3_supported(const LgmConvGeom* g, int mode, int64_t a_pitch) {
+  if (!g) return 0;
+  const int gc = mode == 0 ? g->Cw : g->Nw, oc = mode == 0 ? g->Nw : g->Cw;
+  return lgm_conv3x3_supported(g, gc, oc) && (long)g->B * g->H * g->W * a_pitch < (1L << 30) ? 1 : 0;
+}
+
+extern "C" int lgm_split_bf16x3(const float* src, uint16_t* dst, const int32_t* table, int n_slots, int64_t total_chunks,
+                                int64_t plane_elems, void* stream) {
+  LGM_REQUIRE(src && dst && table && n_slots > 0 && total_chunks > 0 && plane_elems % 8 == 0 && lgm_aligned16(src) &&
+                  lgm_aligned16(dst),
+              "split_bf16x3: bad arguments");
+  hipLaunchKernelGGL(lgm3x3::split_bf16x3_kernel, dim3((unsigned)lgm_cdiv(total_chunks, 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, table, n_slots, (long)total_chunks, (long)plane_elems);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_conv3x3_bf16x3(int mode, const LgmConvGeom* g, const float* a, int64_t a_pitch,
+                                  const uint16_t* w_planes, int64_t plane_elems, const float* bias, const float* res,
+                                  int64_t res_pitch, float* out, int64_t out_pitch, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  using namespace lgm3x3;
+  LGM_REQUIRE(g && a && w_planes && out && (mode == 0 || mode == 1), "conv3x3_bf16x3: bad arguments");
+  LGM_REQUIRE(lgm_conv3x3_bf16x3_supported(g, mode, a_pitch), "conv3x3_bf16x3: unsupported geometry");
+  LGM_REQUIRE(lgm_aligned16(a) && lgm_aligned16(out) && a_pitch % 4 == 0 && out_pitch % 4 == 0 &&
+                  (((uintptr_t)w_planes) & 15u) == 0 && plane_elems % 8 == 0 &&
+                  (!res || (lgm_aligned16(res) && res_pitch % 4 == 0)) && (!bias || lgm_aligned16(bias)),
+              "conv3x3_bf16x3: 16-byte aligned tensors with pitch %% 4 == 0 required");
+  hipStream_t s = (hipStream_t)stream;
+  Args p{};
+  p.a = a; p.w = nullptr; p.wb = w_planes; p.w_plane = plane_elems; p.bias = bias; p.res = res; p.out = out;
+  p.a_pitch = a_pitch; p.res_pitch = res_pitch; p.out_pitch = out_pitch;
+  p.B = g->B; p.H = g->H; p.W = g->W;
+  p.C = mode == 0 ? g->Cw : g->Nw;
+  p.N = mode == 0 ? g->Nw : g->Cw;
+  p.Wn = g->Cw;
+  plan_tile(g->H, g->W, &p.TH, &p.TW, &p.NI);
+  p.lgTW = ilog2(p.TW);
+  p.lgTT = ilog2(p.TH * p.TW);
+  p.tiles_h = g->H / p.TH;
+  p.tiles_w = g->W / p.TW;
+  p.tiles_n = p.N / BN;
+  p.NP = p.NI * (p.TH + 2) * (p.TW + 2);
+  const int groups = lgm_cdiv(g->B, p.NI);
+  const long M = (long)g->B * g->H * g->W;
+  p.splits = lgm_conv3x3_splits(g, p.C, p.N);
+  if (p.splits > 1) {
+    const long need = (long)p.splits * M * p.N * (long)sizeof(float);
+    if (!workspace || workspace_bytes < need || !lgm_aligned16(workspace)) p.splits = 1;
+  }
+  p.ws = (float*)workspace;
+  p.ws_stride = M * p.N;
+  p.pps = lgm_cdiv(p.C / 32, p.splits);
+  p.splits = lgm_cdiv(p.C / 32, p.pps);
+  p.units = (int)((long)groups * p.tiles_h * p.tiles_w * p.tiles_n * p.splits);
+  p.per = lgm_cdiv(p.units, 256);
+  const unsigned nblocks = (unsigned)lgm_cdiv(p.units, p.per);
+  const size_t smem = (size_t)2 * 288 * 208 + 4 * LGM_TS_FLOATS * sizeof(float);
+  if (mode == 0) {
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_b3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)smem);
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv3x3_b3_kernel<false>, dim3(nblocks), dim3(256), smem, s, p);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_b3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)smem);
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv3x3_b3_kernel<true>, dim3(nblocks), dim3(256), smem, s, p);
+  }
+  if (p.splits > 1) {
+    const long items = M * (p.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)lgm_cdiv(items, 256)), dim3(256), 0, s, (const float*)p.ws,
+                       p.ws_stride, p.splits, bias, res, res_pitch, out, out_pitch, M, p.N);
   }
   LGM_LAUNCH_CHECK();
   return LGM_OK;

@@ -87,6 +87,12 @@ class FlatParams:
         self._grad_views_bound = False
         self.data_t = None          # transposed copies of the weight slots (see refresh_transposed)
         self._t_table = None
+        # opt-in split-precision convolutions (LGM_CONV_MODE=bf16x3): three bf16 planes of the weights
+        # (forward layout) and of their transposed copies, in MFMA fragment order
+        self.b3 = False
+        self.planes = None
+        self.planes_t = None
+        self._b3_tables = None
 
     # -- transposed weights (input-gradient kernels read [Cw][T][Nw]) ---------------------------
     def refresh_transposed(self):
@@ -108,6 +114,50 @@ class FlatParams:
             self.data_t = torch.zeros_like(self.data)
         ops.lib().lgm_transpose_weights(self.data.data_ptr(), self.data_t.data_ptr(), self._t_table.data_ptr(),
                                         self._t_table.shape[0], self._t_blocks, ops.stream())
+        if self.b3:
+            self._refresh_split_t()
+
+    # -- split-precision planes ---------------------------------------------------------------
+    def enable_b3(self):
+        """Allocate the bf16 planes; ``refresh_split`` / ``refresh_transposed`` keep them current."""
+        from . import ops
+        if self.b3:
+            return
+        rows_f, rows_t, cf, ct = [], [], 0, 0
+        for s in self.slots:
+            if s.kind != "weight":
+                continue
+            Np, T, Cp = s.phys_shape
+            if T == 9 and Np % 32 == 0 and Cp % 16 == 0:      # forward operand [Np][9][Cp]
+                rows_f.append([s.offset, Np, T, Cp, cf])
+                cf += Np * T * Cp // 8
+            if T == 9 and Cp % 32 == 0 and Np % 16 == 0:      # transposed operand [Cp][9][Np]
+                rows_t.append([s.offset, Cp, T, Np, ct])
+                ct += Np * T * Cp // 8
+        assert self.total < 2 ** 31
+        mk = lambda r: torch.tensor(r, dtype=torch.int32, device=self.device).contiguous() if r else None  # noqa: E731
+        self._b3_tables = (mk(rows_f), cf, mk(rows_t), ct)
+        self._b3_slots = ({r[0] for r in rows_f}, {r[0] for r in rows_t})
+        self.pstride = (self.total + 7) // 8 * 8       # elements per plane (16-byte aligned planes)
+        self.planes = torch.zeros(3 * self.pstride, dtype=torch.int16, device=self.device)
+        self.planes_t = torch.zeros(3 * self.pstride, dtype=torch.int16, device=self.device)
+        self.b3 = True
+        ops.register_b3_flat(self)
+
+    def refresh_split(self):
+        """bf16 planes of the CURRENT weights (call once per forward pass: the optimizer moved them)."""
+        from . import ops
+        tab, chunks, _, _ = self._b3_tables
+        if tab is not None:
+            ops.lib().lgm_split_bf16x3(self.data.data_ptr(), self.planes.data_ptr(), tab.data_ptr(), tab.shape[0], chunks,
+                                       self.pstride, ops.stream())
+
+    def _refresh_split_t(self):
+        from . import ops
+        _, _, tab, chunks = self._b3_tables
+        if tab is not None:
+            ops.lib().lgm_split_bf16x3(self.data_t.data_ptr(), self.planes_t.data_ptr(), tab.data_ptr(), tab.shape[0],
+                                       chunks, self.pstride, ops.stream())
 
     def tptr(self, p: nn.Parameter):
         if self.data_t is None:

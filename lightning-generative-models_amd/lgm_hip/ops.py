@@ -118,6 +118,44 @@ def _conv_bytes(g: ConvGeom) -> float:
 
 _CONV_WS_BYTES = {}
 
+# OPT-IN split-precision 3x3 convolutions ("bf16x3 ... behind a flag"): LGM_CONV_MODE=bf16x3.
+# Only flats that called enable_b3() take part; everything else, and the default, is exact fp32 MFMA.
+import os as _os
+
+B3 = _os.environ.get("LGM_CONV_MODE", "fp32") == "bf16x3"
+_B3_FLATS = []
+_B3_OK = {}
+
+
+def register_b3_flat(fp):
+    _B3_FLATS.append(fp)
+
+
+def _b3_planes(ptr: Optional[int], transposed: bool):
+    """-> (address of the slot's plane 0, plane stride in elements) when ``ptr`` is a 3x3 weight slot of a
+    registered flat buffer, else None"""
+    if ptr is None:
+        return None
+    for fp in _B3_FLATS:
+        base = (fp.data_t if transposed else fp.data)
+        if base is None:
+            continue
+        off = ptr - base.data_ptr()
+        if 0 <= off < 4 * fp.total and (off // 4) in fp._b3_slots[1 if transposed else 0]:
+            pl = fp.planes_t if transposed else fp.planes
+            addr = pl.data_ptr() + (off // 4) * 2
+            return (addr, fp.pstride) if addr % 16 == 0 else None     # fragment loads are 16 bytes wide
+    return None
+
+
+def _b3_supported(g: ConvGeom, mode: int, a_pitch: int) -> bool:
+    key = (g.B, g.H, g.W, g.Cw, g.Nw, g.KH, g.stride, g.pad, mode, a_pitch)
+    v = _B3_OK.get(key)
+    if v is None:
+        v = bool(g.KH == 3 and g.KW == 3 and lib().lgm_conv3x3_bf16x3_supported(ctypes.byref(g), mode, a_pitch))
+        _B3_OK[key] = v
+    return v
+
 
 def _conv_ws(g: ConvGeom, yx: int, device):
     key = (g.B, g.H, g.W, g.Cw, g.Nw, g.KH, g.stride, g.pad, yx)
@@ -132,9 +170,15 @@ def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
     if TIMER is not None:
         TIMER.begin("igemm_xy", _conv_flops(g), _conv_bytes(g))
     ws = _conv_ws(g, 0, x.device)
-    lib().lgm_conv_xy(ctypes.byref(g), x.data_ptr(), pitch(x), w_ptr, bias_ptr, _p(res),
-                      pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
-                      None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
+    pl = _b3_planes(w_ptr, False) if (B3 and _b3_supported(g, 0, pitch(x))) else None
+    if pl is not None:
+        lib().lgm_conv3x3_bf16x3(0, ctypes.byref(g), x.data_ptr(), pitch(x), pl[0], pl[1], bias_ptr, _p(res),
+                                 pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
+                                 None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
+    else:
+        lib().lgm_conv_xy(ctypes.byref(g), x.data_ptr(), pitch(x), w_ptr, bias_ptr, _p(res),
+                          pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
+                          None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
     if TIMER is not None:
         TIMER.end()
 
@@ -143,6 +187,14 @@ def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr:
     if TIMER is not None:
         TIMER.begin("igemm_yx", _conv_flops(g), _conv_bytes(g))
     ws = _conv_ws(g, 1, y.device)
+    pl = _b3_planes(wt_ptr, True) if (B3 and wt_ptr is not None and _b3_supported(g, 1, pitch(y))) else None
+    if pl is not None:
+        lib().lgm_conv3x3_bf16x3(1, ctypes.byref(g), y.data_ptr(), pitch(y), pl[0], pl[1], bias_ptr, _p(res),
+                                 pitch(res) if res is not None else 0, x.data_ptr(), pitch(x),
+                                 None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
+        if TIMER is not None:
+            TIMER.end()
+        return
     lib().lgm_conv_yx(ctypes.byref(g), y.data_ptr(), pitch(y), w_ptr, wt_ptr, bias_ptr, _p(res),
                       pitch(res) if res is not None else 0, x.data_ptr(), pitch(x),
                       None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
