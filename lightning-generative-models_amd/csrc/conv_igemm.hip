@@ -75,6 +75,7 @@ struct IgemmArgs {
   // parity, so each class is a dense GEMM with K = (KH/s)(KW/s)Nw instead of KH*KW*Nw with (1 - 1/s^2) of
   // the products multiplied by zero.  phases = s*s (or 1 = off); then M, K, tiles_m describe ONE class.
   int phases, KHs, KWs;
+  int wide;           // output / residual / bias are 16-byte aligned with pitches % 4 == 0 (wide epilogue allowed)
 };
 
 template <int MODE, int BM, int BN, int TM, int TN>
@@ -310,6 +311,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
     return;
   }
+  if (p.wide && m0 + BM <= p.M && n0 + BN <= p.N) {
+    // full tile, 16-byte aligned output: wave-private LDS transpose (the A/B tiles are dead), residual
+    // rows loaded up front, unconditional 16-byte stores (see lgm_common.h; a conditional dword store per
+    // element serialises on s_waitcnt vmcnt(0) and is issue-bound)
+    __syncthreads();
+    float* Ts = smem + wid * LGM_TS_FLOATS;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nc = n0 + wn * 32 * TN + j * 32 + (lane & 7) * 4;
+      const f32x4 bv4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        long orow[4];
+        f32x4 rv4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          orow[q] = out_row(m0 + wm * 32 * TM + i * 32 + (lane >> 3) + 8 * q);
+          rv4[q] = p.res ? *reinterpret_cast<const f32x4*>(p.res + orow[q] * p.res_pitch + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        lgm_wave_lds_sync();
+        lgm_tile_to_lds(acc[i][j], Ts, lane);
+        lgm_wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(p.out + orow[q] * p.out_pitch + nc) = lgm_tile_row4(Ts, lane, q) + bv4 + rv4[q];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * 32 * TN + j * 32 + lr;
@@ -372,6 +402,7 @@ int igemm_splits(long M, int N, int K, int* kchunk) {
 
 template <int MODE>
 int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool wide, hipStream_t s) {
+  a.wide = wide && a.N % 4 == 0 ? 1 : 0;
   a.phases = 1;
   a.KHs = a.KH;
   a.KWs = a.KW;

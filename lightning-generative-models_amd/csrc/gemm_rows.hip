@@ -93,9 +93,26 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const RArgs p) {
               acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[s], acc[i], 0, 0, 0);
         }
       }
-      // ---- epilogue: wave-private LDS transpose, then 16-byte stores (8 full rows per instruction)
+      // ---- epilogue: wave-private LDS transpose, then 16-byte stores (8 full rows per instruction).
+      // Residual rows are loaded up front and the stores are unconditional (M is a multiple of the
+      // row tile): a conditional store inside the row loop makes the compiler wait for the previous
+      // store to complete (s_waitcnt vmcnt(0)) before every row.
       const int nc = g0 + nt * 64 + wn * 32 + (lane & 7) * 4;
       const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 rv[TM][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.res) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const long m = m0 + wm * 32 * TM + i * 32 + (lane >> 3) + 8 * j;
+            rv[i][j] = *reinterpret_cast<const f32x4*>(p.res + m * p.res_pitch + nc);
+          }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         lgm_wave_lds_sync();                 // earlier read-back of this scratch is complete
@@ -103,12 +120,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const RArgs p) {
         lgm_wave_lds_sync();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int m = m0 + wm * 32 * TM + i * 32 + (lane >> 3) + 8 * j;
-          if (m < p.M) {
-            f32x4 v = lgm_tile_row4(Ts, lane, j) + bv;
-            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (long)m * p.res_pitch + nc);
-            *reinterpret_cast<f32x4*>(p.out + (long)m * p.out_pitch + nc) = v;
-          }
+          const long m = m0 + wm * 32 * TM + i * 32 + (lane >> 3) + 8 * j;
+          *reinterpret_cast<f32x4*>(p.out + m * p.out_pitch + nc) = lgm_tile_row4(Ts, lane, j) + bv + rv[i][j];
         }
       }
     }
@@ -135,7 +148,7 @@ bool lgm_gemm_rows_supported(long M, int N, int K) {
   int bm, wcols;
   size_t smem;
   plan(N, K, &bm, &wcols, &smem);
-  return wcols >= 64 && M / bm >= 96;   // enough row tiles to fill the chip; tiny M stays on the generic path
+  return wcols >= 64 && M % bm == 0 && M / bm >= 96;   // whole row tiles, enough of them to fill the chip
 }
 
 int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const float* bias, const float* res,
