@@ -799,6 +799,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
   }
 
   float* out = p.out + (p.splits > 1 ? (long)split * p.slab : 0L);
+  const bool acc_out = p.splits == 1 && p.beta != 0.f;
+  if (m0 + BM <= p.Nw && q0 + BN <= p.Q && p.Q % 4 == 0 && lgm_aligned16_dev(out)) {
+    // full tile: wave-private LDS transpose (the K loop ended with a barrier: As is free), previous values
+    // loaded up front, unconditional 16-byte stores - the per-element conditional dword stores below made
+    // the compiler wait for every previous store (s_waitcnt vmcnt(0) x 16 per tile)
+    float* Ts = &As[0][0] + wid * LGM_TS_FLOATS;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int qc = q0 + wn * 32 * TN + j * 32 + (lane & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        long o[4];
+        f32x4 prev[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o[q] = (long)(m0 + wm * 32 * TM + i * 32 + (lane >> 3) + 8 * q) * p.Q + qc;
+          prev[q] = acc_out ? *reinterpret_cast<const f32x4*>(out + o[q]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        lgm_wave_lds_sync();
+        lgm_tile_to_lds(acc[i][j], Ts, lane);
+        lgm_wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = lgm_tile_row4(Ts, lane, q);
+          if (acc_out) v += prev[q] * p.beta;
+          *reinterpret_cast<f32x4*>(out + o[q]) = v;
+        }
+      }
+    }
+    __syncthreads();     // the bias reduction below reuses As
+  } else
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int qq = q0 + wn * 32 * TN + j * 32 + lr;

@@ -33,6 +33,7 @@ void lgm_set_error(const char* fmt, ...);
 static inline int lgm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 static inline bool lgm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+__device__ __forceinline__ bool lgm_aligned16_dev(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // ---- device helpers -------------------------------------------------------------
 __device__ __forceinline__ float lgm_wave_sum(float v) {
