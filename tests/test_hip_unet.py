@@ -98,6 +98,29 @@ def test_unet_matches_oracle_fresh_inputs(dev):
     assert rel(p0.grad, 2 * Pr[n0].grad) < 2 * RTOL
 
 
+@pytest.mark.parametrize("B", [1, 5])
+def test_full_width_unet_ragged_batches_match_oracle(dev, B):
+    """dim 64 (the benchmark network), batches that do not fill the 3x3 kernels' image groups (8 images
+    per tile at 4x4, 2 at 8x8): those layers must take the generic path and still match the oracle."""
+    from oracle import diffusion as OD
+    dim, S = 64, 32
+    P = OD.unet_init(dim=dim, channels=3, seed=11)
+    bufs = OD.diffusion_buffers(1000)
+    g = torch.Generator().manual_seed(100 + B)
+    img = torch.rand(B, 3, S, S, generator=g)
+    noise = torch.randn(B, 3, S, S, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss_ref = OD.diffusion_forward(Pr, bufs, img, t, noise, dim=dim)
+    loss_ref.backward()
+    net, gd = build(dim, S, P, dev)
+    loss = gd.p_losses(img.to(dev), t.to(dev), noise.to(dev), _normalize=True)
+    assert abs(loss.item() - loss_ref.item()) / loss_ref.item() < RTOL
+    loss.backward()
+    worst = max(rel(p.grad, Pr[n].grad) for n, p in net.named_parameters())
+    assert worst < 3 * RTOL, worst
+
+
 def test_sampling_steps_match_reference_fixture(dev, golden_dir):
     from lgm_hip import sampler
     fx, dim, S, P, img, noise, t = case(golden_dir, "small")
