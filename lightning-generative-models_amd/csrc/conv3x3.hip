@@ -1,27 +1,28 @@
 // Specialised 3x3 / stride 1 / pad 1 convolution kernels (98 % of the DDPM UNet's FLOPs,
-// SURVEY.md §8a) on v_mfma_f32_32x32x2_f32.
+// SURVEY.md §8a): reference Block.proj ddpm.py:160-171 and everything autograd derives from it.
 //
-// Idea: a workgroup owns a spatial tile of 128 output pixels (TH x TW pixels of NI images) and
-// stages the (TH+2) x (TW+2) halo patch of the gathered tensor in LDS ONCE per 64-channel chunk.
-// All nine filter taps then read their A fragments straight from that patch at a wave-uniform
-// offset ((kh*(TW+2)+kw) positions): no per-chunk gather, no bounds checks and no address
-// arithmetic in the MFMA loop, and the activation bytes cross L2 once instead of nine times.
-// Only the weight tile (64 x 32 floats per chunk) is streamed global -> registers -> LDS (double
-// buffered, one barrier per chunk).
+//   conv3x3_kernel<MODE>   exact fp32, v_mfma_f32_32x32x2_f32
+//       MODE_XY  : y[pix][n] = sum_{tap,c} x[pix + tap - 1][c] * w[n][tap][c]
+//       MODE_YXT : x[pix][c] = sum_{tap,n} y[pix + 1 - tap][n] * wT[c][tap][n]   (input gradient, transposed
+//                  weight copy); MODE_YX the same from the untransposed weights
+//   conv3x3_b3_kernel      the same two products in split precision (opt-in, see below)
+//   wgrad3x3_kernel<TW>    gw[n][tap][c] = sum_pix y[pix][n] * x[pix + tap - 1][c]   (+ fused bias gradient)
 //
-//   conv3x3  MODE_XY : y[pix][n] = sum_{tap,c} x[pix + tap - 1][c] * w[n][tap][c]
-//            MODE_YX : x[pix][c] = sum_{tap,n} y[pix + 1 - tap][n] * w[n][tap][c]   (input gradient)
-//   wgrad3x3         : gw[n][tap][c] = sum_pix y[pix][n] * x[pix + tap - 1][c]      (+ fused bias grad)
+// A workgroup owns spatial tiles of 128 output pixels (TH x TW pixels of NI images) and stages the
+// (TH+2) x (TW+2) halo patch of the gathered tensor in LDS once per 32-channel chunk; all nine taps read
+// their A fragments from that patch at a wave-uniform offset, so the MFMA loop has no gather, no bounds
+// checks and no address arithmetic, and the activation bytes cross L2 once instead of nine times.  The
+// pipelining around that idea is described at each kernel.
 //
-// Supported: H, W powers of two >= 4 (W <= 32 or W % 32 == 0), gathered channels % 32 == 0,
-// output channels % 64 == 0.  Everything else takes the generic implicit-GEMM path.
+// Supported: H, W powers of two >= 4 (W <= 32 or W % 32 == 0), gathered channels % 32 == 0, produced
+// channels % 64 == 0, batch a multiple of the images per tile, tensors < 2^30 elements.  Everything else
+// takes the generic implicit-GEMM path (conv_igemm.hip).
 #include "lgm_common.h"
 
 namespace lgm3x3 {
 
 constexpr int BN = 64;       // output-channel tile
 constexpr int BK = 32;       // k per weight chunk
-constexpr int LDB = BK + 4;  // weight tile row stride (XY)
 
 enum { MODE_XY = 0, MODE_YX = 1, MODE_YXT = 2 };   // YXT: input gradient reading TRANSPOSED weights [Cw][9][Nw]
 
