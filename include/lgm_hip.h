@@ -84,6 +84,15 @@ int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g);
 int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
                    int64_t x_pitch, float* gw, float* gbias, float beta, void* workspace,
                    int64_t workspace_bytes, void* stream);
+/* Deferred form (same arithmetic): writes only the per-split partial slabs into `workspace` (which must then
+ * stay untouched until the reduction) and fills desc[8] = {workspace, slab stride, gw, n_w, gbias, n_b, splits,
+ * beta bits}; lgm_wgrad_reduce_batch then performs the fixed-order slab reductions of MANY layers in one
+ * launch (table rows = desc + first block, blocks per row = ceil((n_w + n_b) / 256); rows with splits == 1
+ * must be left out: their result is already in gw).  Replaces ~75 tiny reduce launches per DDPM step. */
+int lgm_conv_wgrad_deferred(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
+                            int64_t x_pitch, float* gw, float* gbias, float beta, void* workspace,
+                            int64_t workspace_bytes, int64_t* desc, void* stream);
+int lgm_wgrad_reduce_batch(const int64_t* table, int n_entries, int64_t total_blocks, void* stream);
 
 /* Column sums of a [rows, cols] matrix with row pitch: out[c] = beta*out[c] + sum_r a[r,c].
  * Used for conv/linear bias gradients.  Deterministic two-stage; workspace >=

@@ -932,9 +932,9 @@ extern "C" int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g) {
   return (int64_t)splits * slab * (int64_t)sizeof(float);
 }
 
-extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
-                              int64_t x_pitch, float* gw, float* gbias, float beta, void* workspace,
-                              int64_t workspace_bytes, void* stream) {
+static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x, int64_t x_pitch,
+                           float* gw, float* gbias, float beta, void* workspace, int64_t workspace_bytes,
+                           int64_t* desc, void* stream) {
   if (int rc = check_geom(g)) return rc;
   LGM_REQUIRE(y && x && gw, "conv_wgrad: null pointer");
   LGM_REQUIRE(g->Cw % 4 == 0 && g->Nw % 4 == 0, "conv_wgrad: Cw=%d, Nw=%d must be multiples of 4", g->Cw, g->Nw);
@@ -975,12 +975,94 @@ extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pi
     hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
     LGM_LAUNCH_CHECK();
   }
+  const long n_b = gbias ? a.Nw : 0;
+  if (desc) {            // deferred: the caller reduces many layers' slabs with ONE lgm_wgrad_reduce_batch launch
+    union { float f; int64_t i; } bb;
+    bb.i = 0;
+    bb.f = beta;
+    desc[0] = (int64_t)(uintptr_t)workspace; desc[1] = a.slab; desc[2] = (int64_t)(uintptr_t)gw; desc[3] = n_w;
+    desc[4] = (int64_t)(uintptr_t)gbias; desc[5] = n_b; desc[6] = a.splits; desc[7] = bb.i;
+    return LGM_OK;
+  }
   if (a.splits > 1) {
-    const long n_b = gbias ? a.Nw : 0;
     const long groups = (n_w + n_b + 3) / 4;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lgm_cdiv(groups, 64)), dim3(256), 0, s,
                        (const float*)workspace, a.slab, gw, n_w, gbias, n_b, a.splits, beta);
     LGM_LAUNCH_CHECK();
   }
+  return LGM_OK;
+}
+
+extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
+                              int64_t x_pitch, float* gw, float* gbias, float beta, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+  return conv_wgrad_impl(g, y, y_pitch, x, x_pitch, gw, gbias, beta, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int lgm_conv_wgrad_deferred(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
+                                       int64_t x_pitch, float* gw, float* gbias, float beta, void* workspace,
+                                       int64_t workspace_bytes, int64_t* desc, void* stream) {
+  LGM_REQUIRE(desc, "conv_wgrad_deferred: null descriptor");
+  return conv_wgrad_impl(g, y, y_pitch, x, x_pitch, gw, gbias, beta, workspace, workspace_bytes, desc, stream);
+}
+
+namespace {
+// One launch for the slab reductions of many layers.  Table rows (int64 x 9): slab base, slab stride (floats),
+// gw, n_w, gbias, n_b, splits, beta (float bits), first block; the owning row is found by binary search.
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const long long* __restrict__ table, int n_entries) {
+  __shared__ __align__(16) float sh[4][64 * 4];
+  int lo = 0, hi = n_entries - 1;
+  const long long bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 9 + 8] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const long long* row = table + lo * 9;
+  const float* ws = reinterpret_cast<const float*>(row[0]);
+  const long slab = row[1];
+  float* gw = reinterpret_cast<float*>(row[2]);
+  const long n_w = row[3];
+  float* gb = reinterpret_cast<float*>(row[4]);
+  const long n_b = row[5];
+  const int splits = (int)row[6];
+  union { float f; long long i; } bb;
+  bb.i = row[7];
+  const float beta = bb.f;
+  const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;
+  const long i = ((long)(bid - row[8]) * 64 + col) * 4;
+  const long n = n_w + n_b;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    f32x4 t0 = s, t1 = s, t2 = s, t3 = s;
+    for (int k = lane; k < splits; k += 16) {
+      const int k1 = k + 4, k2 = k + 8, k3 = k + 12;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(ws + (long)k * slab + i);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(ws + (long)(k1 < splits ? k1 : k) * slab + i);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(ws + (long)(k2 < splits ? k2 : k) * slab + i);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(ws + (long)(k3 < splits ? k3 : k) * slab + i);
+      t0 += v0;
+      t1 += v1 * (k1 < splits ? 1.f : 0.f);
+      t2 += v2 * (k2 < splits ? 1.f : 0.f);
+      t3 += v3 * (k3 < splits ? 1.f : 0.f);
+    }
+    s = (t0 + t1) + (t2 + t3);
+  }
+  *reinterpret_cast<f32x4*>(&sh[lane][col * 4]) = s;
+  __syncthreads();
+  if (lane == 0 && i < n) {
+    f32x4 t = (*reinterpret_cast<const f32x4*>(&sh[0][col * 4]) + *reinterpret_cast<const f32x4*>(&sh[1][col * 4])) +
+              (*reinterpret_cast<const f32x4*>(&sh[2][col * 4]) + *reinterpret_cast<const f32x4*>(&sh[3][col * 4]));
+    float* dst = i < n_w ? gw + i : gb + (i - n_w);
+    if (beta != 0.f) t += *reinterpret_cast<const f32x4*>(dst) * beta;
+    *reinterpret_cast<f32x4*>(dst) = t;
+  }
+}
+}  // namespace
+
+extern "C" int lgm_wgrad_reduce_batch(const int64_t* table, int n_entries, int64_t total_blocks, void* stream) {
+  LGM_REQUIRE(table && n_entries > 0 && total_blocks > 0, "wgrad_reduce_batch: bad arguments");
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(table), n_entries);
+  LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

@@ -26,12 +26,19 @@ class GradCtx:
     """Per-backward bookkeeping: beta for the first gradient write of every parameter
     (0 = overwrite, 1 = accumulate), 1 afterwards (a parameter used twice in one pass)."""
 
-    def __init__(self, flat: FlatParams, transposed: bool = True):
+    def __init__(self, flat: FlatParams, transposed: bool = True, defer: bool = False):
         self.flat = flat
         self.beta0 = flat.begin_backward()
         self.written = set()
+        # defer=True: conv weight-gradient slabs are reduced by ONE batched launch per flush() instead of
+        # one launch per layer; the owner of the context MUST call flush() before the gradients are read
+        self.deferred = [] if defer else None
         if transposed:
             flat.refresh_transposed()      # one launch per backward pass
+
+    def flush(self):
+        if self.deferred:
+            ops.wgrad_reduce_batch(self.deferred, self.flat.device)
 
     def beta(self, p: nn.Parameter) -> float:
         k = id(p)
@@ -94,7 +101,7 @@ class Conv2d(nn.Module):
                 gb = fp.gptr(self.bias)              # bias gradient fused into the wgrad kernel
             else:
                 ops.colsum(gy, fp.gptr(self.bias), bb)
-        ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb)
+        ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=gc.deferred)
         if not need_gx:
             return None
         if gx is None:

@@ -202,16 +202,55 @@ def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr:
         TIMER.end()
 
 
-def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[int] = None):
+_WGRAD_WS = {}        # deferred mode: one persistent slab workspace per weight (keyed by its gradient address)
+_WGRAD_TABLES = {}    # tuple of descriptor rows -> (device table, blocks)
+
+
+def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[int] = None, defer=None):
+    """``defer``: a list collecting slab descriptors; the caller must call ``wgrad_reduce_batch(defer)`` before
+    the gradients are used (one reduce launch for many layers instead of one per layer)."""
     L = lib()
     nbytes = L.lgm_conv_wgrad_workspace(ctypes.byref(g))
-    ws = workspace(nbytes, y.device)
     if TIMER is not None:
         TIMER.begin("wgrad", _conv_flops(g), _conv_bytes(g))
-    L.lgm_conv_wgrad(ctypes.byref(g), y.data_ptr(), pitch(y), x.data_ptr(), pitch(x), gw_ptr, gbias_ptr, beta,
-                     ws.data_ptr(), ws.numel() * 4, stream())
+    if defer is None:
+        ws = workspace(nbytes, y.device)
+        L.lgm_conv_wgrad(ctypes.byref(g), y.data_ptr(), pitch(y), x.data_ptr(), pitch(x), gw_ptr, gbias_ptr, beta,
+                         ws.data_ptr(), ws.numel() * 4, stream())
+    else:
+        key = (gw_ptr, nbytes)
+        ws = _WGRAD_WS.get(key)
+        if ws is None:
+            ws = torch.empty(max(nbytes // 4 + 4, 16), dtype=torch.float32, device=y.device)
+            _WGRAD_WS[key] = ws
+        desc = (ctypes.c_int64 * 8)()
+        L.lgm_conv_wgrad_deferred(ctypes.byref(g), y.data_ptr(), pitch(y), x.data_ptr(), pitch(x), gw_ptr, gbias_ptr,
+                                  beta, ws.data_ptr(), ws.numel() * 4, ctypes.addressof(desc), stream())
+        if desc[6] > 1:
+            defer.append(tuple(desc))
     if TIMER is not None:
         TIMER.end()
+
+
+def wgrad_reduce_batch(rows, device):
+    """One launch: fixed-order reduction of the partial slabs of every deferred weight gradient in ``rows``."""
+    if not rows:
+        return
+    key = tuple(rows)
+    ent = _WGRAD_TABLES.get(key)
+    if ent is None:
+        tab, blk = [], 0
+        for r in rows:
+            tab.append(list(r) + [blk])
+            blk += (r[3] + r[5] + 255) // 256
+        ent = (torch.tensor(tab, dtype=torch.int64, device=device).contiguous(), blk)
+        _WGRAD_TABLES[key] = ent
+    if TIMER is not None:
+        TIMER.begin("wgrad", 0.0, 0.0)
+    lib().lgm_wgrad_reduce_batch(ent[0].data_ptr(), len(rows), ent[1], stream())
+    if TIMER is not None:
+        TIMER.end()
+    rows.clear()
 
 
 def colsum(a, out_ptr: int, beta: float):

@@ -470,7 +470,7 @@ class Unet(nn.Module):
         [_ups_start, total) of the flat buffer is final (first exchange bucket)."""
         time_saved, tape, sm1, sm2, sm3, ups_tape, sf, fin, x_in, cat_shapes = tape_all
         fp = self._flat
-        gc = GradCtx(fp)
+        gc = GradCtx(fp, defer=True)     # weight-gradient slabs: one batched reduce per exchange bucket
         B, S = x_in.shape[0], x_in.shape[1]
         dim = self.dim
         n = len(self.in_out)
@@ -514,6 +514,7 @@ class Unet(nn.Module):
         gcur = ops.new(gm1.shape, x_in)
         self.mid_block1.bwd(gc, sm1, gm1, gsl[k], gcur, False); k -= 1
         del gm1
+        gc.flush()
         sync = getattr(self, "grad_sync", None)
         if sync is not None:
             sync.ready(self._ups_start, fp.total)
@@ -553,9 +554,11 @@ class Unet(nn.Module):
                 gcur = gprev
         assert k == -1
         self.init_conv.bwd(gc, x_in, gcur, need_gx=False)
+        gc.flush()
         if sync is not None:
             sync.ready(self._head_end, self._ups_start)
         self._time_bwd(gc, st["time_saved"], st["gss_all"])
+        gc.flush()
         if sync is not None:
             sync.ready(0, self._head_end)
         fp.bind_grad_views()
