@@ -530,9 +530,9 @@ extern "C" int64_t lgm_rmsnorm_bwd_workspace(int64_t npix, int C) {
   return (int64_t)rms_blocks(npix, L) * C * (int64_t)sizeof(float) + lgm_colsum_workspace(rms_blocks(npix, L), C);
 }
 
-extern "C" int lgm_rmsnorm_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch,
-                               const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, float* gg,
-                               float gg_beta, int64_t npix, int C, void* workspace, void* stream) {
+static int rmsnorm_bwd_impl(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, const float* g,
+                            float* gx, int64_t gx_pitch, int accumulate_gx, float* gg, float gg_beta, int64_t npix,
+                            int C, void* workspace, int64_t* desc, void* stream) {
   int L, Q;
   if (int rc = rms_plan(C, &L, &Q)) return rc;
   LGM_REQUIRE(x && gy && g && gx && gg && workspace && npix > 0, "rmsnorm_bwd: null pointer / empty");
@@ -546,5 +546,29 @@ extern "C" int lgm_rmsnorm_bwd(const float* x, int64_t x_pitch, const float* gy,
   if (Q == 1) RMS_BWD(1); else if (Q == 2) RMS_BWD(2); else RMS_BWD(4);
 #undef RMS_BWD
   LGM_LAUNCH_CHECK();
+  if (desc) {   // deferred: the per-block partial rows are summed later by lgm_wgrad_reduce_batch (rows = "splits")
+    union { float f; int64_t i; } bb;
+    bb.i = 0;
+    bb.f = gg_beta;
+    desc[0] = (int64_t)(uintptr_t)partial; desc[1] = C; desc[2] = (int64_t)(uintptr_t)gg; desc[3] = C;
+    desc[4] = 0; desc[5] = 0; desc[6] = nb; desc[7] = bb.i;
+    return LGM_OK;
+  }
   return lgm_colsum(partial, C, nb, C, gg, gg_beta, partial + (long)nb * C, stream);
+}
+
+extern "C" int lgm_rmsnorm_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch,
+                               const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, float* gg,
+                               float gg_beta, int64_t npix, int C, void* workspace, void* stream) {
+  return rmsnorm_bwd_impl(x, x_pitch, gy, gy_pitch, g, gx, gx_pitch, accumulate_gx, gg, gg_beta, npix, C, workspace, nullptr,
+                          stream);
+}
+
+extern "C" int lgm_rmsnorm_bwd_deferred(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch,
+                                        const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, float* gg,
+                                        float gg_beta, int64_t npix, int C, void* workspace, int64_t* desc,
+                                        void* stream) {
+  LGM_REQUIRE(desc && C % 4 == 0 && lgm_aligned16(gg) && lgm_aligned16(workspace), "rmsnorm_bwd_deferred: bad arguments");
+  return rmsnorm_bwd_impl(x, x_pitch, gy, gy_pitch, g, gx, gx_pitch, accumulate_gx, gg, gg_beta, npix, C, workspace, desc,
+                          stream);
 }

@@ -270,7 +270,8 @@ class RMSNorm(nn.Module):
         if gx is None:
             gx = ops.new(x.shape, x)
             accumulate = False
-        ops.rmsnorm_bwd(x, gy, gc.flat.ptr(self.g), gx, accumulate, gc.flat.gptr(self.g), gc.beta(self.g))
+        ops.rmsnorm_bwd(x, gy, gc.flat.ptr(self.g), gx, accumulate, gc.flat.gptr(self.g), gc.beta(self.g),
+                        defer=gc.deferred)
         return gx
 
 

@@ -297,12 +297,25 @@ def rmsnorm_fwd(x, g_ptr, res, y):
                           y.data_ptr(), pitch(y), rows(x), x.shape[-1], stream())
 
 
-def rmsnorm_bwd(x, gy, g_ptr, gx, accumulate: bool, gg_ptr, gg_beta: float):
+def rmsnorm_bwd(x, gy, g_ptr, gx, accumulate: bool, gg_ptr, gg_beta: float, defer=None):
     L = lib()
     n, C = rows(x), x.shape[-1]
-    ws = workspace(L.lgm_rmsnorm_bwd_workspace(n, C), x.device)
-    L.lgm_rmsnorm_bwd(x.data_ptr(), pitch(x), gy.data_ptr(), pitch(gy), g_ptr, gx.data_ptr(), pitch(gx),
-                      1 if accumulate else 0, gg_ptr, gg_beta, n, C, ws.data_ptr(), stream())
+    nbytes = L.lgm_rmsnorm_bwd_workspace(n, C)
+    if defer is None or gg_ptr % 16 != 0:
+        ws = workspace(nbytes, x.device)
+        L.lgm_rmsnorm_bwd(x.data_ptr(), pitch(x), gy.data_ptr(), pitch(gy), g_ptr, gx.data_ptr(), pitch(gx),
+                          1 if accumulate else 0, gg_ptr, gg_beta, n, C, ws.data_ptr(), stream())
+        return
+    key = (gg_ptr, nbytes)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = torch.empty(max(nbytes // 4 + 4, 16), dtype=torch.float32, device=x.device)
+        _WGRAD_WS[key] = ws
+    desc = (ctypes.c_int64 * 8)()
+    L.lgm_rmsnorm_bwd_deferred(x.data_ptr(), pitch(x), gy.data_ptr(), pitch(gy), g_ptr, gx.data_ptr(), pitch(gx),
+                               1 if accumulate else 0, gg_ptr, gg_beta, n, C, ws.data_ptr(), ctypes.addressof(desc),
+                               stream())
+    defer.append(tuple(desc))
 
 
 # ----------------------------------------------------------------------------------------
