@@ -12,6 +12,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Tuple
 
 import torch
+import torch.distributed as dist
 from torch import nn
 
 from lgm_hip import ops
@@ -144,6 +145,10 @@ class _Embedding(nn.Module):
             -1 / num_embeddings, 1 / num_embeddings))          # vector_quantizer.py:39-43
 
 
+def _world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 class VectorQuantizer(nn.Module):
     """reference vector_quantizer.py:8-93 (state: ``embedding.weight``)."""
 
@@ -168,8 +173,17 @@ class VectorQuantizer(nn.Module):
         counts = ops.new((K,), lat)
         L.lgm_vq_segment_sum(lat.data_ptr(), D, idx.data_ptr(), N, K, D, dw.data_ptr(), counts.data_ptr(), st)
         if self.use_ema and training:      # codebook is replaced BEFORE the lookup (:168-177)
+            cnt_u, dw_u = counts, dw
+            if _world_size() > 1:
+                # Deliberate deviation: upstream updates the codebook Parameter from per-rank
+                # statistics while DDP only re-broadcasts the EMA buffers, so ranks drift.  Here the batch
+                # statistics (count[K], dw[K,D]: 133 KB) are summed over ranks first; every rank then applies
+                # the identical update.  Single-GPU arithmetic is unchanged.
+                stat = torch.cat([counts.reshape(-1), dw.reshape(-1)])
+                dist.all_reduce(stat)
+                cnt_u, dw_u = stat[:K], stat[K:].view(K, D)
             L.lgm_vq_ema_update(self._ema_cluster_size.data_ptr(), self._ema_embedding.data_ptr(), cb,
-                                counts.data_ptr(), dw.data_ptr(), K, D, self.decay, self.epsilon, st)
+                                cnt_u.data_ptr(), dw_u.data_ptr(), K, D, self.decay, self.epsilon, st)
         q = ops.new(lat.shape, lat)
         out3 = ops.new((3,), lat)
         ws = ops.workspace(L.lgm_vq_gather_workspace(N, D), lat.device)

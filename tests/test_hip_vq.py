@@ -113,3 +113,57 @@ def test_vqvae_training_step_matches_reference_fixture(dev, golden_dir, tag):
     opt.step()
     xh, vq_loss, ppl = m(x.to(dev))
     assert xh.shape == (4, 3, 32, 32) and torch.isfinite(vq_loss) and ppl.item() >= 1.0
+
+
+_EMA_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from models.generative.vae.vqvae import VectorQuantizerEMA
+from lgm_hip.flat import FlatParams
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda", 0)
+torch.manual_seed(4)
+def make():
+    torch.manual_seed(4)
+    vq = VectorQuantizerEMA(64, 16, 0.25, 0.99, 1e-5).to(dev)
+    FlatParams([("embedding.weight", vq.embedding.weight, "vector")], dev)
+    return vq
+g = torch.Generator().manual_seed(9)
+lat = torch.randn(8, 4, 4, 16, generator=g)
+vq = make()
+n = 8 // world
+vq.fwd(lat[rank * n:(rank + 1) * n].contiguous().to(dev), True)      # this rank's shard
+torch.cuda.synchronize()
+mine = torch.cat([vq._ema_cluster_size.flatten(), vq._ema_embedding.flatten(), vq.embedding.weight.detach().flatten()]).cpu()
+gathered = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(gathered, mine)
+same = all(torch.equal(gathered[0], t) for t in gathered)
+ok_ref = True
+if rank == 0:
+    dist.destroy_process_group()
+    ref = make()
+    ref.fwd(lat.contiguous().to(dev), True)                             # one process, whole batch
+    torch.cuda.synchronize()
+    r = torch.cat([ref._ema_cluster_size.flatten(), ref._ema_embedding.flatten(), ref.embedding.weight.detach().flatten()]).cpu()
+    ok_ref = bool(torch.allclose(r, mine, rtol=1e-5, atol=1e-7))
+    print(f"EMA_SYNC same={same} ref={ok_ref}", flush=True)
+else:
+    dist.destroy_process_group()
+'''
+
+
+def test_vq_ema_statistics_are_summed_over_ranks(dev, tmp_path):
+    """SURVEY §8(e) deviation: with >1 rank the EMA batch statistics are all-reduced before the codebook
+    update, so every rank holds the codebook a single process would compute on the concatenated batch."""
+    import subprocess
+    import sys
+    script = tmp_path / "ema_worker.py"
+    script.write_text(_EMA_WORKER)
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lightning-generative-models_amd")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script), pkg],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "EMA_SYNC same=True ref=True" in r.stdout, r.stdout + r.stderr[-1500:]
