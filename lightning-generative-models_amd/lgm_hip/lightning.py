@@ -104,7 +104,19 @@ class MiniLightningModule(nn.Module):
         return self._optimizers
 
     def manual_backward(self, loss, *a, **k):
+        """Lightning semantics under DDP: gradients are averaged over ranks as part of the backward.  Only the
+        flat buffers this backward actually wrote (a GAN's critic OR generator) are exchanged."""
         loss.backward(*a, **k)
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world > 1:
+            for fp in _flat_grads_of(self):
+                if not fp.fresh:
+                    dist.all_reduce(fp.grad)
+                    fp.grad.div_(world)
+            for p in self.parameters():
+                if getattr(p, "_lgm_flat", None) is None and p.grad is not None:
+                    dist.all_reduce(p.grad)
+                    p.grad.div_(world)
 
     # hooks (no-ops by default)
     def on_train_batch_end(self, outputs, batch, batch_idx):
