@@ -17,9 +17,11 @@
 // Supported: H, W powers of two >= 4 (W <= 32 or W % 32 == 0), gathered channels % 32 == 0, produced
 // channels % 64 == 0, batch a multiple of the images per tile, tensors < 2^30 elements.  Everything else
 // takes the generic implicit-GEMM path (conv_igemm.hip).
+#include <type_traits>
 #include "lgm_common.h"
 
 namespace lgm3x3 {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BN = 64;       // output-channel tile
 constexpr int BK = 32;       // k per weight chunk
@@ -765,7 +767,6 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
   split3(*reinterpret_cast<const f32x4*>(sp), H0, M0, L0);
   split3(*reinterpret_cast<const f32x4*>(sp + 4), H1, M1, L1);
   unsigned short* dp = dst + off + ch * 8;
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   *reinterpret_cast<u32x4*>(dp) = u32x4{H0[0], H0[1], H1[0], H1[1]};
   *reinterpret_cast<u32x4*>(dp + plane) = u32x4{M0[0], M0[1], M1[0], M1[1]};
   *reinterpret_cast<u32x4*>(dp + 2 * plane) = u32x4{L0[0], L0[1], L1[0], L1[1]};
@@ -788,8 +789,9 @@ struct WArgs {
   int gsplit;        // sub-blocks per spatial tile along its eight 16-pixel groups (small problems)
 };
 
-template <int TW>
+template <int TW, int GS>
 __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
+  constexpr int NG = 8 / GS;       // 16-pixel groups this block runs per tile
   constexpr int LDP = 64;
   constexpr int PW = TW + 2;
   constexpr int lgTW = TW == 32 ? 5 : TW == 16 ? 4 : TW == 8 ? 3 : 2;
@@ -806,8 +808,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
 
   int bid = blockIdx.x;
   const int slab_id = bid % p.splits;      // slab = (tile split, group split)
-  const int gs = slab_id % p.gsplit, split = slab_id / p.gsplit;
-  const int g_lo = gs * (8 / p.gsplit), g_hi = g_lo + 8 / p.gsplit;
+  const int gs = slab_id % GS, split = slab_id / GS;
+  const int g_lo = gs * NG, g_hi = g_lo + NG;
   bid /= p.splits;
   const int tc = bid % p.tiles_c, tn = bid / p.tiles_c;
   const int n0 = tn * 64, c0 = tc * 64;
@@ -838,12 +840,63 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
     const int img = r >> lgTT, rr = r & ((1 << lgTT) - 1);
     ydelta[j] = (unsigned)(((img * p.H + (rr >> lgTW)) * p.W + (rr & (TW - 1))) * (int)p.y_pitch + c4) * 4u;
   }
+  // Tiles are fetched with raw buffer loads: 32-bit per-lane offset (the precomputed deltas) plus a
+  // scalar tile offset, and a position outside the image is given an offset past the descriptor's
+  // range, for which the hardware returns zeros -- no 64-bit address arithmetic, no zero-fill selects.
+  // The X descriptor starts one row and one column before the tensor so the halo origin is >= 0.
+  const long pixels = (long)p.B * p.H * p.W;
+  const unsigned nrec_y = (unsigned)((pixels * p.y_pitch - n0) * 4);
+  const unsigned nrec_x = (unsigned)(((pixels + p.W + 1) * p.x_pitch - c0) * 4);
+  auto make_rsrc = [](const float* base, unsigned nrec) {   // descriptor pinned to scalar registers
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(p.y + n0, nrec_y);
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(p.x + c0 - (long)(p.W + 1) * p.x_pitch, nrec_x);
+  u32x4 ry[8], rp[NJW];
+  unsigned soff_y = 0, soff_x = 0, border = 16u;
+  auto tile_base = [&](int ts, bool exists) {
+    int t = ts;
+    const int twi = t % p.tiles_w;
+    t /= p.tiles_w;
+    const int thi = t % p.tiles_h;
+    const int b0 = (t / p.tiles_h) * p.NI;
+    const int h0 = thi * p.TH, w0 = twi * TW;
+    border = 16u | (h0 == 0 ? 1u : 0u) | (h0 + p.TH == p.H ? 2u : 0u) | (w0 == 0 ? 4u : 0u) |
+             (w0 + TW == p.W ? 8u : 0u);
+    const unsigned pix = (unsigned)((b0 * p.H + h0) * p.W + w0);
+    // a tile past this block's range: offsets beyond both descriptors, every load returns zeros
+    soff_y = exists ? pix * (unsigned)p.y_pitch * 4u : 0x80000000u;
+    soff_x = exists ? pix * (unsigned)p.x_pitch * 4u : 0x80000000u;
+  };
+  auto load_one = [&](int idx) {   // idx is a constant after unrolling: 0..7 Y rows, 8..25 patch positions
+    if (idx < 8) {
+      ry[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, ydelta[idx], soff_y, 0);
+    } else {
+      const int u = idx - 8;
+      const bool ok = (xflag[u / 6] & (border << (5 * (u % 6)))) == 0u;
+      rp[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? xdelta[u] : nrec_x, soff_x, 0);
+    }
+  };
+  // first tile: the Y loads go out before the patch offsets are worked out
+  if (ts_begin < ts_end) {
+    tile_base(ts_begin, true);
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) load_one(idx);
+  }
   {
-    int px = tid >> 4, py = 0, img = 0;  // walk pos = tid / 16 + 16 u without divisions
-    while (px >= PW) { px -= PW; ++py; }
-    while (py >= p.TH + 2) { py -= p.TH + 2; ++img; }
+    // pos = tid / 16 + 16 u  ->  (image, patch row, patch column); positions are < 512, so the
+    // quotient by the runtime patch size is exact in fp32 with a half-unit bias
+    const float inv_pp1 = 1.0f / (float)PP1;
 #pragma unroll
     for (int u = 0; u < NJW; ++u) {
+      const int pos = (tid >> 4) + 16 * u;
+      const int img = (int)(((float)pos + 0.5f) * inv_pp1);
+      const int rem = pos - img * PP1;
+      const int py = rem / PW, px = rem - py * PW;   // PW is a compile-time constant
       unsigned d = 0, f = 16u;
       if (img < p.NI) {
         d = (unsigned)(((img * p.H + py) * p.W + px) * (int)p.x_pitch + c4) * 4u;
@@ -851,80 +904,103 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
       }
       xdelta[u] = d;
       xflag[u / 6] |= f << (5 * (u % 6));
-      px += 16;
-      while (px >= PW) { px -= PW; ++py; }
-      while (py >= p.TH + 2) { py -= p.TH + 2; ++img; }
     }
   }
-  const unsigned safe_delta = (unsigned)((p.W + 1) * (int)p.x_pitch) * 4u;   // an interior pixel of the tile
-  f32x4 ry[8], rp[NJW];
-  unsigned rp_ok = 0;                  // validity bits of the patch held in rp
-  auto load_tile = [&](int ts) {
-    int t = ts;
-    const int twi = t % p.tiles_w;
-    t /= p.tiles_w;
-    const int thi = t % p.tiles_h;
-    const int b0 = (t / p.tiles_h) * p.NI;
-    const int h0 = thi * p.TH, w0 = twi * TW;
-    const unsigned border = 16u | (h0 == 0 ? 1u : 0u) | (h0 + p.TH == p.H ? 2u : 0u) | (w0 == 0 ? 4u : 0u) |
-                            (w0 + TW == p.W ? 8u : 0u);
-    const char* ybase = reinterpret_cast<const char*>(p.y) + ((long)((b0 * p.H + h0) * p.W + w0) * p.y_pitch + n0) * 4;
-    const char* xbase = reinterpret_cast<const char*>(p.x) +
-                        ((long)((b0 * p.H + h0 - 1) * p.W + w0 - 1) * p.x_pitch + c0) * 4;
+  if (ts_begin < ts_end) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ry[j] = *reinterpret_cast<const f32x4*>(ybase + ydelta[j]);
-    unsigned okbits = 0;
-#pragma unroll
-    for (int u = 0; u < NJW; ++u) {
-      const bool ok = (xflag[u / 6] & (border << (5 * (u % 6)))) == 0u;
-      rp[u] = *reinterpret_cast<const f32x4*>(xbase + (ok ? xdelta[u] : safe_delta));
-      okbits |= (ok ? 1u : 0u) << u;
-    }
-    rp_ok = okbits;
-  };
-  if (ts_begin < ts_end) load_tile(ts_begin);
+    for (int idx = 8; idx < 8 + NJW; ++idx) load_one(idx);
+  }
   for (int ts = ts_begin; ts < ts_end; ++ts) {
     __syncthreads();   // previous tile fully consumed
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(As + ((tid >> 4) + 16 * j) * 64 + c4) = ry[j];
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(As + ((tid >> 4) + 16 * j) * 64 + c4) = ry[j];
 #pragma unroll
     for (int u = 0; u < NJW; ++u) {
       const int pos = (tid >> 4) + 16 * u;
       if (pos < 288)
-        *reinterpret_cast<f32x4*>(Ps + pos * LDP + c4) = ((rp_ok >> u) & 1u) ? rp[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<u32x4*>(Ps + pos * LDP + c4) = rp[u];
     }
     __syncthreads();
-    if (ts + 1 < ts_end) load_tile(ts + 1);
-    if (do_bias) {
-#pragma unroll 8
-      for (int r = 0; r < 32; ++r) {
-        const int row = (tid >> 6) + 4 * r;
-        if (row >= g_lo * 16 && row < g_hi * 16) bsum += As[row * 64 + (tid & 63)];
+    // The next tile's 26 loads ride inside the MFMA steps (a burst here would be TA-rate bound,
+    // ~2k cycles per tile); after the last tile they all fall out of range and fetch nothing.
+    tile_base(ts + 1 < ts_end ? ts + 1 : ts, ts + 1 < ts_end);
+    if (do_bias) {   // column sums of this block's Y rows: branch-free, four reads in flight
+      const float* col = As + (g_lo * 16 + (tid >> 6)) * 64 + (tid & 63);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int r = 0; r < g_hi - g_lo; ++r) {
+        s0 += col[(16 * r) * 64];
+        s1 += col[(16 * r + 4) * 64];
+        s2 += col[(16 * r + 8) * 64];
+        s3 += col[(16 * r + 12) * 64];
       }
+      bsum += (s0 + s1) + (s2 + s3);
     }
     // ---- MFMAs: k = pixel.  16-pixel groups; inside a group all patch offsets are constants ----
     const float* ap = As + lh * 64 + wm * 32 + lr;
     const float* bp = Ps + wn * 32 + lr;
-    for (int g = g_lo; g < g_hi; ++g) {
+    // Operands one step ahead: step (g, s) issues the ten LDS reads of step (g, s + 1) -- or of
+    // (g + 1, 0) -- before its own nine MFMAs, so no LDS latency is exposed inside a tile.
+    auto group_base = [&](int g) {
       const int pix0 = g * 16;
       const int img = pix0 >> lgTT, rr = pix0 & ((1 << lgTT) - 1);
       const int pos0 = (img * (p.TH + 2) + (rr >> lgTW)) * PW + (rr & (TW - 1));
-      const float* bg = bp + pos0 * LDP;
+      return pos0;
+    };
+    float a_cur, b_cur[9], a_nxt, b_nxt[9];
+    auto read_step = [&](const float* ag, const float* bg, int s, float& a, float (&b)[9]) {
+      const int j0 = 2 * s;
+      const int rowoff = (j0 / TW) * PW + (j0 % TW);   // lh adds +1 column (TW is even)
+      a = ag[j0 * 64];
+      const float* bb = bg + (rowoff + lh) * LDP;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) b[tp] = bb[((tp / 3) * PW + (tp % 3)) * LDP];
+    };
+    const float* ag = ap + g_lo * 16 * 64;
+    const float* bg = bp + group_base(g_lo) * LDP;
+    read_step(ag, bg, 0, a_cur, b_cur);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int gn = g_lo + (gi + 1 < NG ? gi + 1 : gi);
+      const float* ag_n = ap + gn * 16 * 64;
+      const float* bg_n = bp + group_base(gn) * LDP;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        // pixel j = 2 s + lh inside the group -> (row j / TW, col j % TW)
-        const float a = ap[(pix0 + 2 * s) * 64];
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int j0 = 2 * s;
-        const int rowoff = (j0 / TW) * PW + (j0 % TW);   // lh adds +1 column (TW is even)
-        const float* bb = bg + (rowoff + lh) * LDP;
+        // loads of this step: 26 spread over the block's 8 NG steps
+        const int q = gi * 8 + s;
+        const int first = GS == 1 ? q / 2 : q * (GS / 2);
+        const int cnt = GS == 1 ? ((q & 1) == 0 ? 1 : 0) : GS / 2;
+        int issued = 0;
+        if (s < 7) read_step(ag, bg, s + 1, a_nxt, b_nxt);
+        else read_step(ag_n, bg_n, 0, a_nxt, b_nxt);
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-          const float b = bb[((tp / 3) * PW + (tp % 3)) * LDP];
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tp], 0, 0, 0);
+        for (int i = 0; i < cnt; ++i)
+          if (first + i < 8 + NJW) {
+            load_one(first + i);
+            ++issued;
+          }
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[tp], acc[tp], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);   // next step's LDS reads first ...
+        if (issued == 0) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);  // ... then this step's MFMAs
+        } else if (issued == 1) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
         }
+        a_cur = a_nxt;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) b_cur[tp] = b_nxt[tp];
       }
+      ag = ag_n;
+      bg = bg_n;
+      __builtin_amdgcn_sched_barrier(0);   // keep the scheduler's read-ahead inside one group
     }
   }
 
@@ -1231,9 +1307,9 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
   (void)NP;
   const size_t smem = (size_t)(128 * 64 + 288 * 64) * sizeof(float);   // all 288 patch positions are written
   const unsigned nblocks = (unsigned)((long)p.tiles_n * p.tiles_c * splits);
-#define LGM_W3_LAUNCH(TWV)                                                                             \
+#define LGM_W3_LAUNCH1(TWV, GSV)                                                                       \
   do {                                                                                                 \
-    auto kern = wgrad3x3_kernel<TWV>;                                                                  \
+    auto kern = wgrad3x3_kernel<TWV, GSV>;                                                             \
     static size_t attr = 0;                                                                            \
     if (smem > attr) {                                                                                 \
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
@@ -1241,6 +1317,16 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
     }                                                                                                  \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                    \
   } while (0)
+#define LGM_W3_LAUNCH(TWV)                                                                             \
+  do {                                                                                                 \
+    if (p.gsplit == 4) LGM_W3_LAUNCH1(TWV, 4);                                                         \
+    else if (p.gsplit == 2) LGM_W3_LAUNCH1(TWV, 2);                                                    \
+    else LGM_W3_LAUNCH1(TWV, 1);                                                                       \
+  } while (0)
+  if (p.gsplit != 1 && p.gsplit != 2 && p.gsplit != 4) {
+    lgm_set_error("wgrad3x3: unsupported group split %d", p.gsplit);
+    return LGM_ERR_UNSUPPORTED;
+  }
   switch (TW) {
     case 32: LGM_W3_LAUNCH(32); break;
     case 16: LGM_W3_LAUNCH(16); break;
@@ -1249,6 +1335,7 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
     default: lgm_set_error("wgrad3x3: unsupported tile width %d", TW); return LGM_ERR_UNSUPPORTED;
   }
 #undef LGM_W3_LAUNCH
+#undef LGM_W3_LAUNCH1
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

@@ -946,8 +946,10 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
   a.B = g->B; a.H = g->H; a.W = g->W; a.Cw = g->Cw; a.Ho = g->Ho; a.Wo = g->Wo; a.Nw = g->Nw;
   a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
   a.P = g->B * g->Ho * g->Wo; a.Q = g->KH * g->KW * g->Cw;
-  const bool fast3 = use_3x3() && lgm_wgrad3x3_supported(g) && (long)g->B * g->H * g->W * x_pitch < (1L << 30) &&
-                     (long)g->B * g->H * g->W * y_pitch < (1L << 30);   // 32-bit byte offsets
+  // 32-bit buffer offsets: bytes (+ the one-row halo shift of the X descriptor) stay below 2^31
+  const bool fast3 = use_3x3() && lgm_wgrad3x3_supported(g) &&
+                     ((long)g->B * g->H * g->W + g->W + 1) * x_pitch < (1L << 29) &&
+                     (long)g->B * g->H * g->W * y_pitch < (1L << 29);
   int tps3 = 0, total3 = 0;
   if (fast3)
     lgm_wgrad3x3_plan(g, &a.splits, &tps3, &total3);
