@@ -26,6 +26,10 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
                        void* workspace, long workspace_bytes, hipStream_t s);
 bool lgm_wgrad3x3_supported(const LgmConvGeom* g);
 void lgm_wgrad3x3_plan(const LgmConvGeom* g, int* splits, int* tps, int* total_ts);
+bool lgm_wgrad1x1_supported(const LgmConvGeom* g, long y_pitch, long x_pitch);
+void lgm_wgrad1x1_plan(const LgmConvGeom* g, int* splits, int* chunks_per_split);
+int lgm_wgrad1x1_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch, float* out,
+                        float* bias_out, float beta, long slab, int splits, int chunks_per_split, hipStream_t s);
 int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch,
                         float* out, float* bias_out, float beta, long slab, int splits, int tps, int total_ts,
                         hipStream_t s);
@@ -927,6 +931,11 @@ extern "C" int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g) {
     lgm_wgrad3x3_plan(g, &s3, &tps, &total);
     if (s3 > splits) splits = s3;
   }
+  if (g->KH == 1 && g->KW == 1 && g->Nw % 64 == 0 && g->Cw % 64 == 0) {
+    int s1, per;
+    lgm_wgrad1x1_plan(g, &s1, &per);
+    if (s1 > splits) splits = s1;
+  }
   if (splits == 1) return 16;
   const int64_t slab = (int64_t)g->Nw * g->KH * g->KW * g->Cw + g->Nw;
   return (int64_t)splits * slab * (int64_t)sizeof(float);
@@ -950,9 +959,13 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
   const bool fast3 = use_3x3() && lgm_wgrad3x3_supported(g) &&
                      ((long)g->B * g->H * g->W + g->W + 1) * x_pitch < (1L << 29) &&
                      (long)g->B * g->H * g->W * y_pitch < (1L << 29);
-  int tps3 = 0, total3 = 0;
+  static const bool no_w1x1 = getenv("LGM_NO_W1X1") != nullptr;   // A/B switch
+  const bool fast1 = !fast3 && !no_w1x1 && lgm_wgrad1x1_supported(g, y_pitch, x_pitch);
+  int tps3 = 0, total3 = 0, per1 = 0;
   if (fast3)
     lgm_wgrad3x3_plan(g, &a.splits, &tps3, &total3);
+  else if (fast1)
+    lgm_wgrad1x1_plan(g, &a.splits, &per1);
   else
     wgrad_plan(g, &a.splits, &a.chunk);
   const long n_w = (long)a.Nw * a.Q;
@@ -972,6 +985,9 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
   if (fast3) {
     if (int rc = lgm_wgrad3x3_launch(g, y, y_pitch, x, x_pitch, a.out, a.bias_out, beta, a.slab, a.splits, tps3,
                                      total3, s))
+      return rc;
+  } else if (fast1) {
+    if (int rc = lgm_wgrad1x1_launch(g, y, y_pitch, x, x_pitch, a.out, a.bias_out, beta, a.slab, a.splits, per1, s))
       return rc;
   } else {
     hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);

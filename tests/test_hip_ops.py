@@ -76,6 +76,10 @@ CONV_CASES = [
     (3, 32, 32, 128, 64, 3, 1, 1),    # 3x3 patch kernel, two channel chunks
     (13, 32, 32, 64, 384, 1, 1, 0),   # resident-tile 1x1 kernel (to_qkv shape), 128-row tiles, ragged M
     (50, 16, 16, 384, 128, 1, 1, 0),  # resident-tile 1x1 kernel, 64-row tiles (K = 384)
+    (16, 32, 32, 64, 384, 1, 1, 0),   # streaming 1x1 weight gradient, 128x64 block of gw, three n-tiles
+    (20, 32, 32, 128, 64, 1, 1, 0),   # streaming 1x1 weight gradient, 64x128 block, ragged split
+    (64, 16, 16, 128, 128, 1, 1, 0),  # streaming 1x1 weight gradient, 128x128 block
+    (72, 16, 16, 192, 64, 1, 1, 0),   # streaming 1x1 weight gradient, 64x64 blocks, three k-tiles
 ]
 
 
