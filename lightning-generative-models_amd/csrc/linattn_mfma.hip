@@ -20,9 +20,9 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
                                                         float* __restrict__ kmax_out, float* __restrict__ ksum_out,
                                                         float* __restrict__ r_out) {
   __shared__ float Ws[TP * LDW];
-  __shared__ float Us[TP * DH];
+  __shared__ __align__(16) float Us[TP * DH];
   __shared__ __align__(16) float Red[4][DH][DH];
-  __shared__ float red8[8][DH];
+  __shared__ __align__(16) float red32[32][DH];
   __shared__ float kmax_s[DH];
   const int bh = blockIdx.x;
   const int b = bh / heads, h = bh % heads;
@@ -30,21 +30,34 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int d_l = tid % DH, pl = tid / DH;   // staging map: 8 pixel lanes x 32 channels
+  // staging map: a pixel's 32 channels are eight 16-byte loads; 32 pixels per pass of the block
+  const int c4 = (tid & 7) * 4, prow = tid >> 3;
   const float* base = qkv + (long)b * n * pitch + h * DH;
   const float* memk = mem_kv + ((long)(0 * heads + h) * DH) * M;  // [d][j]
   const float* memv = mem_kv + ((long)(1 * heads + h) * DH) * M;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   if (MODE == 0) {
-    float mx = -INFINITY;
-    for (int i = pl; i < n; i += 8) mx = fmaxf(mx, base[(long)i * pitch + hidden + d_l]);
-    if (pl == 0)
-      for (int j = 0; j < M; ++j) mx = fmaxf(mx, memk[d_l * M + j]);
-    red8[pl][d_l] = mx;
+    // max over the pixels of every key channel: eight independent 16-byte loads in flight
+    f32x4 m4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int i0 = 0; i0 < n; i0 += 256) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + prow + 32 * u;
+        v[u] = i < n ? *reinterpret_cast<const f32x4*>(base + (long)i * pitch + hidden + c4) : m4;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m4[k] = fmaxf(m4[k], v[u][k]);
+    }
+    *reinterpret_cast<f32x4*>(&red32[prow][c4]) = m4;
     __syncthreads();
     if (tid < DH) {
-      float m = red8[0][tid];
-      for (int k = 1; k < 8; ++k) m = fmaxf(m, red8[k][tid]);
+      float m = red32[0][tid];
+      for (int k = 1; k < 32; ++k) m = fmaxf(m, red32[k][tid]);
+      for (int j = 0; j < M; ++j) m = fmaxf(m, memk[tid * M + j]);
       kmax_s[tid] = m;
     }
     __syncthreads();
@@ -53,32 +66,54 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float wsum = 0.f;
+  f32x4 wsum4 = zero4;
   const int total = n + (MODE == 0 ? M : 0);
-  for (int i0 = 0; i0 < total; i0 += TP) {
-    __syncthreads();
-#pragma unroll 4
-    for (int j = 0; j < TP / 8; ++j) {
-      const int r = pl + 8 * j;
-      const int i = i0 + r;
-      float wv = 0.f, uv = 0.f;
+  // register-staged tiles: tile t+1 is fetched while tile t is normalised and multiplied
+  f32x4 w4[4], u4[4];
+  auto fetch = [&](int i0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + prow + 32 * u;
+      f32x4 wv = zero4, uv = zero4;
       if (i < n) {
         if (MODE == 0) {
-          wv = __expf(base[(long)i * pitch + hidden + d_l] - kmax_s[d_l]);
-          uv = base[(long)i * pitch + 2 * hidden + d_l];
+          wv = *reinterpret_cast<const f32x4*>(base + (long)i * pitch + hidden + c4);
+          uv = *reinterpret_cast<const f32x4*>(base + (long)i * pitch + 2 * hidden + c4);
         } else {
-          wv = base[(long)i * pitch + d_l];
-          uv = gout[((long)b * n + i) * gout_pitch + h * DH + d_l];
+          wv = *reinterpret_cast<const f32x4*>(base + (long)i * pitch + c4);
+          uv = *reinterpret_cast<const f32x4*>(gout + ((long)b * n + i) * gout_pitch + h * DH + c4);
         }
       } else if (i < total) {
         const int jm = i - n;
-        wv = __expf(memk[d_l * M + jm] - kmax_s[d_l]);
-        uv = memv[d_l * M + jm];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          wv[k] = memk[(c4 + k) * M + jm];
+          uv[k] = memv[(c4 + k) * M + jm];
+        }
       }
-      Ws[r * LDW + d_l] = wv;
-      Us[r * DH + d_l] = uv;
+      w4[u] = wv;
+      u4[u] = uv;
+    }
+  };
+  fetch(0);
+  for (int i0 = 0; i0 < total; i0 += TP) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = prow + 32 * u;
+      f32x4 wv = w4[u];
+      if (MODE == 0) {
+        const bool live = i0 + r < total;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wv[k] = live ? __expf(wv[k] - kmax_s[c4 + k]) : 0.f;
+        wsum4 += wv;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) Ws[r * LDW + c4 + k] = wv[k];
+      *reinterpret_cast<f32x4*>(&Us[r * DH + c4]) = u4[u];
     }
     __syncthreads();
+    if (i0 + TP < total) fetch(i0 + TP);
     if (MODE == 1) {
       // softmax over d for every pixel row: 4 threads per row, 8 channels each, two passes of 64 rows
 #pragma unroll
@@ -106,10 +141,6 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
       }
       __syncthreads();
     }
-    if (MODE == 0) {
-#pragma unroll 4
-      for (int j = 0; j < TP / 8; ++j) wsum += Ws[(pl + 8 * j) * LDW + d_l];
-    }
     // MFMA: k = pixel; wave w owns pixels [32 w, 32 w + 32) of the tile.  A[i = d][k], B[k][j = e]
     const float* ap = Ws + (32 * wid + lh) * LDW + lr;
     const float* bp = Us + (32 * wid + lh) * DH + lr;
@@ -120,7 +151,7 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
   // cross-wave reduction in a fixed order
 #pragma unroll
   for (int r = 0; r < 16; ++r) Red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
-  if (MODE == 0) red8[pl][d_l] = wsum;
+  if (MODE == 0) *reinterpret_cast<f32x4*>(&red32[prow][c4]) = wsum4;
   __syncthreads();
   const int d_c = tid / 8, e0 = (tid % 8) * 4;
   f32x4 cv = (*reinterpret_cast<const f32x4*>(&Red[0][d_c][e0]) + *reinterpret_cast<const f32x4*>(&Red[1][d_c][e0])) +
@@ -128,7 +159,7 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
   float* co = ctx_out + ((long)bh * DH + d_c) * DH + e0;
   if (MODE == 0) {
     float ws = 0.f;
-    for (int k = 0; k < 8; ++k) ws += red8[k][d_c];
+    for (int k = 0; k < 32; ++k) ws += red32[k][d_c];
     *reinterpret_cast<f32x4*>(co) = cv * (1.f / ws);
     if ((tid % 8) == 0) {
       kmax_out[bh * DH + d_c] = kmax_s[d_c];
@@ -298,6 +329,8 @@ __global__ __launch_bounds__(256) void linattn_bwd_mfma(
 int lgm_linattn_ctx_launch(int mode, const float* qkv, long pitch, const float* mem_kv, const float* gout,
                            long gout_pitch, const float* ctx_in, int B, int n, int heads, int M, float scale,
                            float* ctx_out, float* kmax, float* ksum, float* r_out, hipStream_t s) {
+  LGM_REQUIRE(pitch % 4 == 0 && lgm_aligned16(qkv) && (mode == 0 || (gout_pitch % 4 == 0 && lgm_aligned16(gout))),
+              "linattn_ctx: 16-byte aligned rows required");
   if (mode == 0)
     hipLaunchKernelGGL(linattn_ctx_mfma<0>, dim3(B * heads), dim3(256), 0, s, qkv, pitch, mem_kv, gout, gout_pitch,
                        ctx_in, n, heads, M, scale, ctx_out, kmax, ksum, r_out);
