@@ -215,26 +215,45 @@ __global__ __launch_bounds__(256) void linattn_bwd_mfma(
   }
   __syncthreads();
   const int rows = is_mem ? M : min(TP, n - i0);
+  if (is_mem) {
 #pragma unroll 4
-  for (int j = 0; j < TP / 8; ++j) {
-    const int r = pl + 8 * j;
-    float qv = 0.f, kv = 0.f, vv = 0.f, gv = 0.f;
-    if (r < rows) {
-      if (is_mem) {
+    for (int j = 0; j < TP / 8; ++j) {
+      const int r = pl + 8 * j;
+      float kv = 0.f, vv = 0.f;
+      if (r < rows) {
         kv = __expf(memk[d_l * M + r] - kmx[d_l]) * kinv[d_l];
         vv = memv[d_l * M + r];
-      } else {
-        const long row = (long)b * n + i0 + r;
-        qv = qkv[row * pitch + h * DH + d_l];
-        kv = __expf(qkv[row * pitch + hidden + h * DH + d_l] - kmx[d_l]) * kinv[d_l];
-        vv = qkv[row * pitch + 2 * hidden + h * DH + d_l];
-        gv = gout[row * gout_pitch + h * DH + d_l];
+      }
+      Qs[r * LDW + d_l] = 0.f;
+      Ks[r * LDW + d_l] = kv;
+      Vs[r * LDW + d_l] = vv;
+      Gs[r * LDW + d_l] = 0.f;
+    }
+  } else {
+    // a pixel's 32 channels are eight 16-byte loads; 32 pixels per pass, all sixteen loads in flight
+    const int c4 = (tid & 7) * 4, prow = tid >> 3;
+    f32x4 q4[4], k4[4], v4[4], g4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = prow + 32 * u;
+      const long row = (long)b * n + i0 + (r < rows ? r : 0);
+      q4[u] = *reinterpret_cast<const f32x4*>(qkv + row * pitch + h * DH + c4);
+      k4[u] = *reinterpret_cast<const f32x4*>(qkv + row * pitch + hidden + h * DH + c4);
+      v4[u] = *reinterpret_cast<const f32x4*>(qkv + row * pitch + 2 * hidden + h * DH + c4);
+      g4[u] = *reinterpret_cast<const f32x4*>(gout + row * gout_pitch + h * DH + c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = prow + 32 * u;
+      const bool live = r < rows;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        Qs[r * LDW + c4 + k] = live ? q4[u][k] : 0.f;
+        Ks[r * LDW + c4 + k] = live ? __expf(k4[u][k] - kmx[c4 + k]) * kinv[c4 + k] : 0.f;
+        Vs[r * LDW + c4 + k] = live ? v4[u][k] : 0.f;
+        Gs[r * LDW + c4 + k] = live ? g4[u][k] : 0.f;
       }
     }
-    Qs[r * LDW + d_l] = qv;
-    Ks[r * LDW + d_l] = kv;
-    Vs[r * LDW + d_l] = vv;
-    Gs[r * LDW + d_l] = gv;
   }
   __syncthreads();
   // ---- phase A: s = softmax_d(q) in place ----
@@ -314,11 +333,16 @@ __global__ __launch_bounds__(256) void linattn_bwd_mfma(
         for (int k = 0; k < 8; ++k) gm[((long)(0 * heads + h) * DH + c0 + k) * M + r] = gk[k];
       } else {
         float* o = gqkv + ((long)b * n + i0 + r) * gq_pitch + h * DH + c0;
+        f32x4 oq[2], ok[2];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          o[k] = s[k] * (g1[k] - dot);
-          o[hidden + k] = gk[k];
+          oq[k >> 2][k & 3] = s[k] * (g1[k] - dot);
+          ok[k >> 2][k & 3] = gk[k];
         }
+        *reinterpret_cast<f32x4*>(o) = oq[0];
+        *reinterpret_cast<f32x4*>(o + 4) = oq[1];
+        *reinterpret_cast<f32x4*>(o + hidden) = ok[0];
+        *reinterpret_cast<f32x4*>(o + hidden + 4) = ok[1];
       }
     }
   }
@@ -345,6 +369,9 @@ int lgm_linattn_bwd_launch(const float* qkv, long pitch, const float* mem_kv, co
                            const float* ctx, const float* gctx, const float* kmax, const float* ksum,
                            const float* rvec, int B, int n, int heads, int M, float scale, float* gqkv,
                            long gq_pitch, float* gmem_partial, hipStream_t s) {
+  LGM_REQUIRE(pitch % 4 == 0 && gout_pitch % 4 == 0 && gq_pitch % 4 == 0 && lgm_aligned16(qkv) && lgm_aligned16(gout) &&
+                  lgm_aligned16(gqkv),
+              "linattn_bwd: 16-byte aligned rows required");
   const size_t smem = ((size_t)4 * TP * LDW + 2 * DH * LDW + 3 * DH) * sizeof(float);
   static bool attr = false;
   if (!attr) {
