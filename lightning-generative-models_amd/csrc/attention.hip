@@ -39,9 +39,20 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restric
   const int tid = threadIdx.x;
   const int d_l = tid % DH, pl = tid / DH;
   for (int k = tid; k < DH * DH; k += 256) Cs[k / DH][k % DH] = ctx[(long)bh * DH * DH + k];
-  for (int r = pl; r < TI; r += 8) {
-    const int i = i0 + r;
-    Qs[r][d_l] = i < n ? qkv[((long)b * n + i) * pitch + h * DH + d_l] : 0.f;
+  {
+    // a pixel's 32 query channels are eight 16-byte loads; 32 pixels per pass
+    const int c4 = (tid & 7) * 4, prow = tid >> 3;
+    f32x4 q4[TI / 32];
+#pragma unroll
+    for (int u = 0; u < TI / 32; ++u) {
+      const int i = i0 + prow + 32 * u;
+      q4[u] = i < n ? *reinterpret_cast<const f32x4*>(qkv + ((long)b * n + i) * pitch + h * DH + c4)
+                    : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < TI / 32; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) Qs[prow + 32 * u][c4 + k] = q4[u][k];
   }
   __syncthreads();
   const int r = tid / 4, part = tid % 4;

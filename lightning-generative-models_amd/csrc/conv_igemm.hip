@@ -34,6 +34,14 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
                         float* out, float* bias_out, float beta, long slab, int splits, int tps, int total_ts,
                         hipStream_t s);
 
+// 1x1 convolutions with a resident weight slice, X streamed (gemm_stream.hip)
+bool lgm_gemm_stream_supported(long M, int N, int K, long x_pitch, long out_pitch, long res_pitch);
+int lgm_gemm_stream_launch(const float* x, long x_pitch, const float* w, const float* bias, const float* res,
+                           long res_pitch, float* out, long out_pitch, long M, int N, int K, hipStream_t s);
+static bool use_gstream() {
+  static const bool off = getenv("LGM_NO_GSTREAM") != nullptr;   // A/B switch
+  return !off;
+}
 // short-reduction 1x1 convolutions with a resident activation tile (gemm_rows.hip)
 bool lgm_gemm_rows_supported(long M, int N, int K);
 int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const float* bias, const float* res,
@@ -479,6 +487,10 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
       (long)g->B * g->H * g->W * x_pitch < (1L << 30))   // 32-bit BYTE offsets in the patch prefetch
     return lgm_conv3x3_launch(0, g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, workspace, workspace_bytes,
                               (hipStream_t)stream);
+  if (use_3x3() && use_gstream() && wide_ok(y, y_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 &&
+      g->stride == 1 && g->pad == 0 && lgm_gemm_stream_supported((long)g->B * g->H * g->W, g->Nw, g->Cw, x_pitch, y_pitch, res ? res_pitch : 0))
+    return lgm_gemm_stream_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch, (long)g->B * g->H * g->W, g->Nw,
+                                  g->Cw, (hipStream_t)stream);
   if (use_3x3() && wide_ok(y, y_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 && g->stride == 1 &&
       g->pad == 0 && lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Nw, g->Cw))
     return lgm_gemm_rows_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch, (long)g->B * g->H * g->W, g->Nw, g->Cw,
@@ -633,6 +645,10 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
       (long)g->B * g->H * g->W * y_pitch < (1L << 30))
     return lgm_conv3x3_launch(w_t ? 2 : 1, g, y, y_pitch, w_t ? w_t : w, bias, res, res_pitch, x, x_pitch, workspace,
                               workspace_bytes, (hipStream_t)stream);
+  if (use_3x3() && use_gstream() && w_t && wide_ok(x, x_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 &&
+      g->stride == 1 && g->pad == 0 && lgm_gemm_stream_supported((long)g->B * g->H * g->W, g->Cw, g->Nw, y_pitch, x_pitch, res ? res_pitch : 0))
+    return lgm_gemm_stream_launch(y, y_pitch, w_t, bias, res, res_pitch, x, x_pitch, (long)g->B * g->H * g->W, g->Cw,
+                                  g->Nw, (hipStream_t)stream);
   if (use_3x3() && w_t && wide_ok(x, x_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 && g->stride == 1 &&
       g->pad == 0 && lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Cw, g->Nw))
     return lgm_gemm_rows_launch(y, y_pitch, w_t, bias, res, res_pitch, x, x_pitch, (long)g->B * g->H * g->W, g->Cw, g->Nw,

@@ -133,7 +133,7 @@ void plan(int N, int K, int* bm, int* wcols, size_t* smem) {
   const long row = (long)(K + 4) * 4;
   *bm = K <= 64 ? 128 : 64;
   const long xs = (long)*bm * row + 4L * LGM_TS_FLOATS * 4;   // X tile + the four epilogue scratches
-  long budget = 78 * 1024;                       // two workgroups per CU
+  long budget = (getenv("LGM_GR_KB") ? atoi(getenv("LGM_GR_KB")) : 78) * 1024L;   // two workgroups per CU
   if (xs + 64 * row > budget) budget = 150 * 1024;
   long cols = (budget - xs) / (64 * row) * 64;
   if (cols > N) cols = N;

@@ -80,6 +80,9 @@ CONV_CASES = [
     (20, 32, 32, 128, 64, 1, 1, 0),   # streaming 1x1 weight gradient, 64x128 block, ragged split
     (64, 16, 16, 128, 128, 1, 1, 0),  # streaming 1x1 weight gradient, 128x128 block
     (72, 16, 16, 192, 64, 1, 1, 0),   # streaming 1x1 weight gradient, 64x64 blocks, three k-tiles
+    (64, 32, 32, 128, 128, 1, 1, 0),  # resident-weight streaming 1x1 conv, K = 128 (forward and input gradient)
+    (48, 32, 32, 192, 128, 1, 1, 0),  # resident-weight streaming 1x1 conv, K = 192
+    (64, 32, 32, 256, 64, 1, 1, 0),   # resident-weight streaming 1x1 conv, K = 256 forward, K = 64 input gradient
 ]
 
 
