@@ -1010,23 +1010,38 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
   float* Ts = smem + wid * LGM_TS_FLOATS;
   const int cc = c0 + wn * 32 + (lane & 7) * 4;
   const bool acc_out = p.splits == 1 && p.beta != 0.f;
+  // Two copies of the loop: with the (rare) read-modify-write of gw inside it, every tap would wait
+  // for its loads and with them -- the vector-memory queue retires in order -- for the previous
+  // tap's stores.
+  if (acc_out) {
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp) {
-    f32x4 prev[4];
+    for (int tp = 0; tp < 9; ++tp) {
+      f32x4 prev[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wm * 32 + (lane >> 3) + 8 * j;
-      prev[j] = acc_out ? *reinterpret_cast<const f32x4*>(out + ((long)n * 9 + tp) * p.Cw + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wm * 32 + (lane >> 3) + 8 * j;
+        prev[j] = *reinterpret_cast<const f32x4*>(out + ((long)n * 9 + tp) * p.Cw + cc);
+      }
+      lgm_wave_lds_sync();
+      lgm_tile_to_lds(acc[tp], Ts, lane);
+      lgm_wave_lds_sync();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wm * 32 + (lane >> 3) + 8 * j;
+        *reinterpret_cast<f32x4*>(out + ((long)n * 9 + tp) * p.Cw + cc) = lgm_tile_row4(Ts, lane, j) + p.beta * prev[j];
+      }
     }
-    lgm_wave_lds_sync();
-    lgm_tile_to_lds(acc[tp], Ts, lane);
-    lgm_wave_lds_sync();
+  } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wm * 32 + (lane >> 3) + 8 * j;
-      f32x4 v = lgm_tile_row4(Ts, lane, j);
-      if (acc_out) v += p.beta * prev[j];
-      *reinterpret_cast<f32x4*>(out + ((long)n * 9 + tp) * p.Cw + cc) = v;
+    for (int tp = 0; tp < 9; ++tp) {
+      lgm_wave_lds_sync();
+      lgm_tile_to_lds(acc[tp], Ts, lane);
+      lgm_wave_lds_sync();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wm * 32 + (lane >> 3) + 8 * j;
+        *reinterpret_cast<f32x4*>(out + ((long)n * 9 + tp) * p.Cw + cc) = lgm_tile_row4(Ts, lane, j);
+      }
     }
   }
   if (do_bias) {

@@ -163,28 +163,45 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const PArgs p) {
   float* out = p.out + (p.splits > 1 ? (long)split * p.slab : 0L);
   float* Ts = smem + wid * LGM_TS_FLOATS;          // the operand buffers are dead (barrier above)
   const bool acc_out = p.splits == 1 && p.beta != 0.f;
+  // (two copies of the loop: a read-modify-write of gw inside it would make every tile wait for its
+  // loads and, the vector-memory queue retiring in order, for the previous tile's stores)
+  if (acc_out) {
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < TK; ++j) {
-      const int cc = c0 + wk * 32 * TK + j * 32 + (lane & 7) * 4;
-      f32x4 prev[4];
+      for (int j = 0; j < TK; ++j) {
+        const int cc = c0 + wk * 32 * TK + j * 32 + (lane & 7) * 4;
+        f32x4 prev[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 32 * TN + i * 32 + (lane >> 3) + 8 * q;
-        prev[q] = acc_out ? *reinterpret_cast<const f32x4*>(out + (long)n * p.Cw + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 32 * TN + i * 32 + (lane >> 3) + 8 * q;
+          prev[q] = *reinterpret_cast<const f32x4*>(out + (long)n * p.Cw + cc);
+        }
+        lgm_wave_lds_sync();
+        lgm_tile_to_lds(acc[i][j], Ts, lane);
+        lgm_wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 32 * TN + i * 32 + (lane >> 3) + 8 * q;
+          *reinterpret_cast<f32x4*>(out + (long)n * p.Cw + cc) = lgm_tile_row4(Ts, lane, q) + p.beta * prev[q];
+        }
       }
-      lgm_wave_lds_sync();
-      lgm_tile_to_lds(acc[i][j], Ts, lane);
-      lgm_wave_lds_sync();
+  } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 32 * TN + i * 32 + (lane >> 3) + 8 * q;
-        f32x4 v = lgm_tile_row4(Ts, lane, q);
-        if (acc_out) v += p.beta * prev[q];
-        *reinterpret_cast<f32x4*>(out + (long)n * p.Cw + cc) = v;
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TK; ++j) {
+        const int cc = c0 + wk * 32 * TK + j * 32 + (lane & 7) * 4;
+        lgm_wave_lds_sync();
+        lgm_tile_to_lds(acc[i][j], Ts, lane);
+        lgm_wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 32 * TN + i * 32 + (lane >> 3) + 8 * q;
+          *reinterpret_cast<f32x4*>(out + (long)n * p.Cw + cc) = lgm_tile_row4(Ts, lane, q);
+        }
       }
-    }
+  }
   if (do_bias) {
     constexpr int LANES = 256 / NB;
     __syncthreads();                 // every wave is done with its transpose scratch
