@@ -121,19 +121,22 @@ int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitc
                float* gbeta, float affine_beta, float* gss, int64_t gss_pitch, float gss_beta,
                float* workspace, void* stream);
 
-/* RMSNorm over channels — ddpm.py:107-113: y = x / max(||x||_2, 1e-12) * g * sqrt(C) (+ res). */
+/* RMSNorm over channels — ddpm.py:107-113: y = x / max(||x||_2, 1e-12) * g * sqrt(C) (+ res).
+ * Backward: gx = [gx +] d/dx (+ res): `res` (or null) is the gradient arriving over the residual branch
+ * around the PreNorm'd attention block (ddpm.py:187-193), added in the same pass. */
 int lgm_rmsnorm_fwd(const float* x, int64_t x_pitch, const float* g, const float* res,
                     int64_t res_pitch, float* y, int64_t y_pitch, int64_t npix, int C, void* stream);
 int64_t lgm_rmsnorm_bwd_workspace(int64_t npix, int C);
 int lgm_rmsnorm_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch,
-                    const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, float* gg,
-                    float gg_beta, int64_t npix, int C, void* workspace, void* stream);
+                    const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, const float* res,
+                    int64_t res_pitch, float* gg, float gg_beta, int64_t npix, int C, void* workspace, void* stream);
 /* Deferred form: leaves the per-block partial rows of the g gradient in `workspace` and fills a descriptor in
  * the format of lgm_conv_wgrad_deferred (rows play the role of splits), so that lgm_wgrad_reduce_batch sums
  * the g gradients of all RMSNorm layers together with the weight-gradient slabs in one launch. */
 int lgm_rmsnorm_bwd_deferred(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch,
-                             const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, float* gg,
-                             float gg_beta, int64_t npix, int C, void* workspace, int64_t* desc, void* stream);
+                             const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, const float* res,
+                             int64_t res_pitch, float* gg, float gg_beta, int64_t npix, int C, void* workspace,
+                             int64_t* desc, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Attention cores on qkv [B, n, 3*heads*32] (channel = which*hidden + head*32 + d).

@@ -430,7 +430,8 @@ template <int Q>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, long x_pitch,
                                                           const float* __restrict__ gy, long gy_pitch,
                                                           const float* __restrict__ g, float* __restrict__ gx,
-                                                          long gx_pitch, int accumulate, long npix, int C, int L,
+                                                          long gx_pitch, int accumulate, const float* __restrict__ res,
+                                                          long res_pitch, long npix, int C, int L,
                                                           float* __restrict__ gg_partial) {
   __shared__ float sh[256 * 4 * Q];
   const int ppb = 256 / L;
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       f32x4 o = (gxh[k] - xh[k] * dot) * invn;
       float* dst = gx + pix * gx_pitch + (l + k * L) * 4;
       if (accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+      if (res) o += *reinterpret_cast<const f32x4*>(res + pix * res_pitch + (l + k * L) * 4);
       *reinterpret_cast<f32x4*>(dst) = o;
     }
   }
@@ -531,18 +533,20 @@ extern "C" int64_t lgm_rmsnorm_bwd_workspace(int64_t npix, int C) {
 }
 
 static int rmsnorm_bwd_impl(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, const float* g,
-                            float* gx, int64_t gx_pitch, int accumulate_gx, float* gg, float gg_beta, int64_t npix,
-                            int C, void* workspace, int64_t* desc, void* stream) {
+                            float* gx, int64_t gx_pitch, int accumulate_gx, const float* res, int64_t res_pitch,
+                            float* gg, float gg_beta, int64_t npix, int C, void* workspace, int64_t* desc,
+                            void* stream) {
   int L, Q;
   if (int rc = rms_plan(C, &L, &Q)) return rc;
   LGM_REQUIRE(x && gy && g && gx && gg && workspace && npix > 0, "rmsnorm_bwd: null pointer / empty");
-  LGM_REQUIRE(x_pitch % 4 == 0 && gy_pitch % 4 == 0 && gx_pitch % 4 == 0, "rmsnorm_bwd: pitch %% 4 != 0");
+  LGM_REQUIRE(x_pitch % 4 == 0 && gy_pitch % 4 == 0 && gx_pitch % 4 == 0 && (!res || (res_pitch % 4 == 0 && lgm_aligned16(res))),
+              "rmsnorm_bwd: pitch %% 4 != 0");
   hipStream_t s = (hipStream_t)stream;
   const int nb = rms_blocks(npix, L);
   float* partial = (float*)workspace;
 #define RMS_BWD(QQ)                                                                                              \
   hipLaunchKernelGGL(rmsnorm_bwd_kernel<QQ>, dim3(nb), dim3(256), 0, s, x, (long)x_pitch, gy, (long)gy_pitch, g, gx, \
-                     (long)gx_pitch, accumulate_gx, (long)npix, C, L, partial)
+                     (long)gx_pitch, accumulate_gx, res, (long)res_pitch, (long)npix, C, L, partial)
   if (Q == 1) RMS_BWD(1); else if (Q == 2) RMS_BWD(2); else RMS_BWD(4);
 #undef RMS_BWD
   LGM_LAUNCH_CHECK();
@@ -558,17 +562,18 @@ static int rmsnorm_bwd_impl(const float* x, int64_t x_pitch, const float* gy, in
 }
 
 extern "C" int lgm_rmsnorm_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch,
-                               const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, float* gg,
-                               float gg_beta, int64_t npix, int C, void* workspace, void* stream) {
-  return rmsnorm_bwd_impl(x, x_pitch, gy, gy_pitch, g, gx, gx_pitch, accumulate_gx, gg, gg_beta, npix, C, workspace, nullptr,
-                          stream);
+                               const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, const float* res,
+                               int64_t res_pitch, float* gg, float gg_beta, int64_t npix, int C, void* workspace,
+                               void* stream) {
+  return rmsnorm_bwd_impl(x, x_pitch, gy, gy_pitch, g, gx, gx_pitch, accumulate_gx, res, res_pitch, gg, gg_beta, npix, C,
+                          workspace, nullptr, stream);
 }
 
 extern "C" int lgm_rmsnorm_bwd_deferred(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch,
-                                        const float* g, float* gx, int64_t gx_pitch, int accumulate_gx, float* gg,
-                                        float gg_beta, int64_t npix, int C, void* workspace, int64_t* desc,
-                                        void* stream) {
+                                        const float* g, float* gx, int64_t gx_pitch, int accumulate_gx,
+                                        const float* res, int64_t res_pitch, float* gg, float gg_beta, int64_t npix,
+                                        int C, void* workspace, int64_t* desc, void* stream) {
   LGM_REQUIRE(desc && C % 4 == 0 && lgm_aligned16(gg) && lgm_aligned16(workspace), "rmsnorm_bwd_deferred: bad arguments");
-  return rmsnorm_bwd_impl(x, x_pitch, gy, gy_pitch, g, gx, gx_pitch, accumulate_gx, gg, gg_beta, npix, C, workspace, desc,
-                          stream);
+  return rmsnorm_bwd_impl(x, x_pitch, gy, gy_pitch, g, gx, gx_pitch, accumulate_gx, res, res_pitch, gg, gg_beta, npix, C,
+                          workspace, desc, stream);
 }

@@ -266,12 +266,12 @@ class RMSNorm(nn.Module):
         ops.rmsnorm_fwd(x, _flat(self.g).ptr(self.g), res, y)
         return y
 
-    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False):
+    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, res=None):
         if gx is None:
             gx = ops.new(x.shape, x)
             accumulate = False
         ops.rmsnorm_bwd(x, gy, gc.flat.ptr(self.g), gx, accumulate, gc.flat.gptr(self.g), gc.beta(self.g),
-                        defer=gc.deferred)
+                        defer=gc.deferred, res=res)
         return gx
 
 

@@ -297,14 +297,15 @@ def rmsnorm_fwd(x, g_ptr, res, y):
                           y.data_ptr(), pitch(y), rows(x), x.shape[-1], stream())
 
 
-def rmsnorm_bwd(x, gy, g_ptr, gx, accumulate: bool, gg_ptr, gg_beta: float, defer=None):
+def rmsnorm_bwd(x, gy, g_ptr, gx, accumulate: bool, gg_ptr, gg_beta: float, defer=None, res=None):
     L = lib()
+    rp, rpitch = (res.data_ptr(), pitch(res)) if res is not None else (None, 0)
     n, C = rows(x), x.shape[-1]
     nbytes = L.lgm_rmsnorm_bwd_workspace(n, C)
     if defer is None or gg_ptr % 16 != 0:
         ws = workspace(nbytes, x.device)
         L.lgm_rmsnorm_bwd(x.data_ptr(), pitch(x), gy.data_ptr(), pitch(gy), g_ptr, gx.data_ptr(), pitch(gx),
-                          1 if accumulate else 0, gg_ptr, gg_beta, n, C, ws.data_ptr(), stream())
+                          1 if accumulate else 0, rp, rpitch, gg_ptr, gg_beta, n, C, ws.data_ptr(), stream())
         return
     key = (gg_ptr, nbytes)
     ws = _WGRAD_WS.get(key)
@@ -313,7 +314,8 @@ def rmsnorm_bwd(x, gy, g_ptr, gx, accumulate: bool, gg_ptr, gg_beta: float, defe
         _WGRAD_WS[key] = ws
     desc = (ctypes.c_int64 * 8)()
     L.lgm_rmsnorm_bwd_deferred(x.data_ptr(), pitch(x), gy.data_ptr(), pitch(gy), g_ptr, gx.data_ptr(), pitch(gx),
-                               1 if accumulate else 0, gg_ptr, gg_beta, n, C, ws.data_ptr(), ctypes.addressof(desc),
+                               1 if accumulate else 0, rp, rpitch, gg_ptr, gg_beta, n, C, ws.data_ptr(),
+                               ctypes.addressof(desc),
                                stream())
     defer.append(tuple(desc))
 

@@ -113,11 +113,8 @@ class LinearAttention(nn.Module):
                         fp.gptr(self.mem_kv), gc.beta(self.mem_kv))
         gxn = self.to_qkv.bwd(gc, xn, gqkv)
         del gqkv, gao
-        if accumulate:
-            ops.axpby(gx, 1.0, gy, 1.0, gx)
-        else:
-            ops.axpby(gy, 1.0, None, 0.0, gx)
-        self.norm.bwd(gc, x, gxn, gx, True)
+        # gx (+)= d norm / dx + gy: the residual branch's gradient rides in the RMSNorm backward pass
+        self.norm.bwd(gc, x, gxn, gx, accumulate, res=gy)
         return gx
 
 
@@ -152,11 +149,8 @@ class Attention(nn.Module):
                      fp.gptr(self.mem_kv), gc.beta(self.mem_kv))
         gxn = self.to_qkv.bwd(gc, xn, gqkv)
         del gqkv, gao
-        if accumulate:
-            ops.axpby(gx, 1.0, gy, 1.0, gx)
-        else:
-            ops.axpby(gy, 1.0, None, 0.0, gx)
-        self.norm.bwd(gc, x, gxn, gx, True)
+        # gx (+)= d norm / dx + gy: the residual branch's gradient rides in the RMSNorm backward pass
+        self.norm.bwd(gc, x, gxn, gx, accumulate, res=gy)
         return gx
 
 
