@@ -140,6 +140,114 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   *reinterpret_cast<f32x4*>(y + pix * y_pitch + c) = z;
 }
 
+// ---------------------------------------------------------------------------------------
+// One-pass forward: statistics AND normalisation in one kernel.  A block owns the (image, CB
+// channels) slice as above but keeps it in registers -- NV 16-byte loads per thread, all in flight
+// at once -- so x is read from memory once instead of three times (mean pass, centred-moment pass,
+// apply pass) and the second launch disappears.  Same thread -> (pixel lane, channel quad) map and
+// the same fixed-order reductions as gn_stats_kernel.
+// ---------------------------------------------------------------------------------------
+template <int NT, int NV>
+__global__ __launch_bounds__(NT) void gn_fused_fwd_kernel(const float* __restrict__ x, long pitch, int HW, int C, int G,
+                                                           int CB, float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ ss,
+                                                           long ss_pitch, int act, const float* __restrict__ res,
+                                                           long res_pitch, float* __restrict__ y, long y_pitch,
+                                                           float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ A, float* __restrict__ Bc) {
+  __shared__ float sh[NT * 4];
+  __shared__ float chs[256];
+  __shared__ float gmean[64], grstd[64];
+  __shared__ __align__(16) float cA[256], cB[256];
+  const int nb = C / CB;
+  const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
+  const int c0 = cb * CB;
+  const int Cg = C / G;
+  const int tq = CB / 4;              // threads per pixel
+  const int ppb = NT / tq;            // pixel lanes (HW == NV * ppb, checked by the host)
+  const int tid = threadIdx.x;
+  const int q = tid % tq, pl = tid / tq;
+  const float* xb = x + (long)b * HW * pitch + c0 + q * 4;
+  const int ngl = CB / Cg;
+  const float inv_n = 1.f / ((float)Cg * (float)HW);
+
+  auto group_reduce = [&](float* dst, bool second) {
+    __syncthreads();
+    if (tid < CB) {
+      float acc = 0.f;
+      for (int pp = 0; pp < ppb; ++pp) acc += sh[pp * CB + tid];
+      chs[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < ngl) {
+      float acc = 0.f;
+      for (int c = 0; c < Cg; ++c) acc += chs[tid * Cg + c];
+      dst[tid] = second ? rsqrtf(acc * inv_n + eps) : acc * inv_n;
+    }
+    __syncthreads();
+  };
+
+  f32x4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(xb + (long)(pl + k * ppb) * pitch);
+  f32x4 s = v[0];
+#pragma unroll
+  for (int k = 1; k < NV; ++k) s += v[k];
+  *reinterpret_cast<f32x4*>(&sh[tid * 4]) = s;
+  group_reduce(gmean, false);
+  f32x4 mu;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) mu[k] = gmean[(q * 4 + k) / Cg];
+  f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const f32x4 d = v[k] - mu;
+    s2 += d * d;
+  }
+  *reinterpret_cast<f32x4*>(&sh[tid * 4]) = s2;
+  group_reduce(grstd, true);
+  if (tid < ngl) {
+    const int g = c0 / Cg + tid;
+    mean[b * G + g] = gmean[tid];
+    rstd[b * G + g] = grstd[tid];
+  }
+  if (tid < CB) {      // z = x * A[b,c] + Bc[b,c]  (also kept for the backward pass)
+    const int c = c0 + tid;
+    const float m = gmean[tid / Cg], rs = grstd[tid / Cg];
+    float a = rs * gamma[c];
+    float bb = beta[c] - m * a;
+    if (ss) {
+      const float sc = ss[(long)b * ss_pitch + c] + 1.f;
+      const float shf = ss[(long)b * ss_pitch + C + c];
+      a *= sc;
+      bb = bb * sc + shf;
+    }
+    A[(long)b * C + c] = a;
+    Bc[(long)b * C + c] = bb;
+    cA[tid] = a;
+    cB[tid] = bb;
+  }
+  __syncthreads();
+  const f32x4 a4 = *reinterpret_cast<const f32x4*>(&cA[q * 4]);
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(&cB[q * 4]);
+  f32x4 r[NV];
+  if (res) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      r[k] = *reinterpret_cast<const f32x4*>(res + ((long)b * HW + pl + k * ppb) * res_pitch + c0 + q * 4);
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    f32x4 z = v[k] * a4 + b4;
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[e] = silu_f(z[e]);
+    }
+    if (res) z += r[k];
+    *reinterpret_cast<f32x4*>(y + ((long)b * HW + pl + k * ppb) * y_pitch + c0 + q * 4) = z;
+  }
+}
+
 // backward pass 1: S1[b,c] = sum_hw gz, S2[b,c] = sum_hw gz * xhat
 template <int NT>
 __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const float* __restrict__ x, long x_pitch,
@@ -336,6 +444,28 @@ extern "C" int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C,
   hipStream_t s = (hipStream_t)stream;
   const int cb = gn_cb(C, G);
   static const bool small_only = getenv("LGM_GN_256") != nullptr;   // A/B switch
+  static const bool no_fused = getenv("LGM_GN_TWO_PASS") != nullptr;   // A/B switch
+  {   // one-pass kernel when the block's slice fits its registers (NV 16-byte values per thread)
+    const int nt = (long)HW * cb >= 16384 ? 1024 : 256;
+    const int ppb = nt / (cb / 4);
+    const int nv = HW % ppb == 0 ? HW / ppb : 0;
+    if (!no_fused && (nv == 1 || nv == 2 || nv == 4 || nv == 8 || nv == 16)) {
+#define GN_FUSED(NTV, NVV)                                                                                            \
+  hipLaunchKernelGGL((gn_fused_fwd_kernel<NTV, NVV>), dim3(B * (C / cb)), dim3(NTV), 0, s, x, (long)x_pitch, HW, C, G, \
+                     cb, eps, gamma, beta, ss, (long)ss_pitch, act, res, (long)res_pitch, y, (long)y_pitch, mean,    \
+                     rstd, coefA, coefB)
+      if (nt == 1024) {
+        if (nv == 1) GN_FUSED(1024, 1); else if (nv == 2) GN_FUSED(1024, 2); else if (nv == 4) GN_FUSED(1024, 4);
+        else if (nv == 8) GN_FUSED(1024, 8); else GN_FUSED(1024, 16);
+      } else {
+        if (nv == 1) GN_FUSED(256, 1); else if (nv == 2) GN_FUSED(256, 2); else if (nv == 4) GN_FUSED(256, 4);
+        else if (nv == 8) GN_FUSED(256, 8); else GN_FUSED(256, 16);
+      }
+#undef GN_FUSED
+      LGM_LAUNCH_CHECK();
+      return LGM_OK;
+    }
+  }
   if (!small_only && (long)HW * cb >= 16384)
     hipLaunchKernelGGL(gn_stats_kernel<1024>, dim3(B * (C / cb)), dim3(1024), 0, s, x, (long)x_pitch, HW, C, G, cb, eps,
                        gamma, beta, ss, (long)ss_pitch, mean, rstd, coefA, coefB);
