@@ -417,6 +417,126 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(o) = r;
 }
 
+// One-pass backward: the block's x and gy slices stay in registers (2 NV 16-byte values per thread),
+// so both are read once instead of twice (reduce pass + apply pass).  Same maps, same fixed-order
+// reductions and the same coefficient algebra as gn_bwd_reduce_kernel + gn_bwd_apply_kernel; the
+// gamma/beta reduction over the batch (needs every block's S1/S2) is the small kernel below.
+template <int NT, int NV>
+__global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restrict__ x, long x_pitch,
+                                                           const float* __restrict__ gy, long gy_pitch,
+                                                           const float* __restrict__ A, const float* __restrict__ Bc,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           int HW, int C, int G, int CB, int act,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ ss, long ss_pitch,
+                                                           float* __restrict__ gss, long gss_pitch, float gss_beta,
+                                                           float* __restrict__ S1, float* __restrict__ S2,
+                                                           float* __restrict__ gx, long gx_pitch, int accumulate) {
+  __shared__ float sh[NT * 8];
+  __shared__ float wa1[256], wa2[256];
+  __shared__ __align__(16) float cP[256], cQ[256], cR[256];
+  const int nb = C / CB;
+  const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
+  const int c0 = cb * CB;
+  const int Cg = C / G;
+  const int tq = CB / 4, ppb = NT / tq;     // HW == NV * ppb (checked by the host)
+  const int tid = threadIdx.x;
+  const int q = tid % tq, pl = tid / tq;
+  const int c = c0 + q * 4;
+  const float* xb = x + (long)b * HW * x_pitch + c;
+  const float* gb = gy + (long)b * HW * gy_pitch + c;
+  f32x4 xv[NV], g[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    xv[k] = *reinterpret_cast<const f32x4*>(xb + (long)(pl + k * ppb) * x_pitch);
+    g[k] = *reinterpret_cast<const f32x4*>(gb + (long)(pl + k * ppb) * gy_pitch);
+  }
+  const f32x4 a = *reinterpret_cast<const f32x4*>(A + (long)b * C + c);
+  const f32x4 bc = *reinterpret_cast<const f32x4*>(Bc + (long)b * C + c);
+  f32x4 mu, rs;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    mu[k] = mean[b * G + (c + k) / Cg];
+    rs[k] = rstd[b * G + (c + k) / Cg];
+  }
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (act) {
+      const f32x4 z = xv[k] * a + bc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[k][e] *= silu_grad(z[e]);
+    }
+    s1 += g[k];
+    s2 += g[k] * ((xv[k] - mu) * rs);
+  }
+  *reinterpret_cast<f32x4*>(&sh[tid * 8]) = s1;
+  *reinterpret_cast<f32x4*>(&sh[tid * 8 + 4]) = s2;
+  __syncthreads();
+  float a1 = 0.f, a2 = 0.f, scv = 1.f;
+  if (tid < CB) {  // one thread per channel, fixed-order sum over pixel lanes
+    const int qq = tid / 4, k = tid % 4;
+    for (int pp = 0; pp < ppb; ++pp) {
+      a1 += sh[(pp * tq + qq) * 8 + k];
+      a2 += sh[(pp * tq + qq) * 8 + 4 + k];
+    }
+    const int cc = c0 + tid;
+    S1[(long)b * C + cc] = a1;
+    S2[(long)b * C + cc] = a2;
+    scv = ss ? ss[(long)b * ss_pitch + cc] + 1.f : 1.f;
+    const float w = gamma[cc] * scv;
+    wa1[tid] = w * a1;
+    wa2[tid] = w * a2;
+  }
+  __syncthreads();
+  if (tid < CB) {  // coefficients of gx = P*gz + Qc + x*Rc, and the FiLM scale/shift gradients
+    const int cc = c0 + tid;
+    const int g0 = (tid / Cg) * Cg;
+    float m1 = 0.f, m2 = 0.f;
+    for (int j = 0; j < Cg; ++j) {
+      m1 += wa1[g0 + j];
+      m2 += wa2[g0 + j];
+    }
+    const float inv_n = 1.f / ((float)Cg * (float)HW);
+    m1 *= inv_n;
+    m2 *= inv_n;
+    const float m = mean[b * G + cc / Cg], r = rstd[b * G + cc / Cg];
+    cP[tid] = r * gamma[cc] * scv;
+    const float R = -r * m2;          // multiplies xhat
+    cR[tid] = R * r;                  // multiplies x
+    cQ[tid] = -r * m1 - m * r * R;
+    if (gss) {
+      float gsc = gamma[cc] * a2 + beta[cc] * a1;
+      float gsh = a1;
+      if (gss_beta != 0.f) {
+        gsc += gss_beta * gss[(long)b * gss_pitch + cc];
+        gsh += gss_beta * gss[(long)b * gss_pitch + C + cc];
+      }
+      gss[(long)b * gss_pitch + cc] = gsc;
+      gss[(long)b * gss_pitch + C + cc] = gsh;
+    }
+  }
+  __syncthreads();
+  const f32x4 P4 = *reinterpret_cast<const f32x4*>(&cP[q * 4]);
+  const f32x4 Q4 = *reinterpret_cast<const f32x4*>(&cQ[q * 4]);
+  const f32x4 R4 = *reinterpret_cast<const f32x4*>(&cR[q * 4]);
+  float* ob = gx + (long)b * HW * gx_pitch + c;
+  // (the previous gx values are read next to their use: holding NV more quads would spill at NV = 8)
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    f32x4 r = g[k] * P4 + Q4 + xv[k] * R4;
+    if (accumulate) r += *reinterpret_cast<const f32x4*>(ob + (long)(pl + k * ppb) * gx_pitch);
+    *reinterpret_cast<f32x4*>(ob + (long)(pl + k * ppb) * gx_pitch) = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_affine_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+                                                            const float* __restrict__ ss, long ss_pitch, int B, int C,
+                                                            float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                            float affine_beta) {
+  gn_bwd_affine_body((int)blockIdx.x, S1, S2, ss, ss_pitch, B, C, ggamma, gbeta, affine_beta);
+}
+
 int gn_cb(int C, int G) {
   const int Cg = C / G;
   int cb = Cg * ((32 + Cg - 1) / Cg);
@@ -449,14 +569,14 @@ extern "C" int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C,
     const int nt = (long)HW * cb >= 16384 ? 1024 : 256;
     const int ppb = nt / (cb / 4);
     const int nv = HW % ppb == 0 ? HW / ppb : 0;
-    if (!no_fused && (nv == 1 || nv == 2 || nv == 4 || nv == 8 || nv == 16)) {
+    if (!no_fused && (nv == 1 || nv == 2 || nv == 4 || nv == 8 || (nv == 16 && nt == 256))) {
 #define GN_FUSED(NTV, NVV)                                                                                            \
   hipLaunchKernelGGL((gn_fused_fwd_kernel<NTV, NVV>), dim3(B * (C / cb)), dim3(NTV), 0, s, x, (long)x_pitch, HW, C, G, \
                      cb, eps, gamma, beta, ss, (long)ss_pitch, act, res, (long)res_pitch, y, (long)y_pitch, mean,    \
                      rstd, coefA, coefB)
       if (nt == 1024) {
         if (nv == 1) GN_FUSED(1024, 1); else if (nv == 2) GN_FUSED(1024, 2); else if (nv == 4) GN_FUSED(1024, 4);
-        else if (nv == 8) GN_FUSED(1024, 8); else GN_FUSED(1024, 16);
+        else GN_FUSED(1024, 8);
       } else {
         if (nv == 1) GN_FUSED(256, 1); else if (nv == 2) GN_FUSED(256, 2); else if (nv == 4) GN_FUSED(256, 4);
         else if (nv == 8) GN_FUSED(256, 8); else GN_FUSED(256, 16);
@@ -498,6 +618,30 @@ extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int6
   float* Rc = Qc + bc;
   const int cb = gn_cb(C, G);
   static const bool small_only = getenv("LGM_GN_256") != nullptr;
+  static const bool no_fused = getenv("LGM_GN_TWO_PASS") != nullptr;   // A/B switch
+  {   // one-pass kernel when the block's x and gy slices fit its registers
+    const int nt = (long)HW * cb >= 16384 ? 1024 : 256;
+    const int ppb = nt / (cb / 4);
+    const int nv = HW % ppb == 0 ? HW / ppb : 0;
+    if (!no_fused && (nv == 1 || nv == 2 || nv == 4 || nv == 8)) {
+#define GN_FUSED(NTV, NVV)                                                                                             \
+  hipLaunchKernelGGL((gn_fused_bwd_kernel<NTV, NVV>), dim3(B * (C / cb)), dim3(NTV), 0, s, x, (long)x_pitch, gy,        \
+                     (long)gy_pitch, coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss, \
+                     (long)gss_pitch, gss_beta, S1, S2, gx, (long)gx_pitch, accumulate_gx)
+      if (nt == 1024) {
+        if (nv == 1) GN_FUSED(1024, 1); else if (nv == 2) GN_FUSED(1024, 2); else if (nv == 4) GN_FUSED(1024, 4);
+        else GN_FUSED(1024, 8);
+      } else {
+        if (nv == 1) GN_FUSED(256, 1); else if (nv == 2) GN_FUSED(256, 2); else if (nv == 4) GN_FUSED(256, 4);
+        else GN_FUSED(256, 8);
+      }
+#undef GN_FUSED
+      hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(lgm_cdiv(C, 16)), dim3(256), 0, s, (const float*)S1, (const float*)S2,
+                         ss, (long)ss_pitch, B, C, ggamma, gbeta, affine_beta);
+      LGM_LAUNCH_CHECK();
+      return LGM_OK;
+    }
+  }
   if (!small_only && (long)HW * cb >= 16384)
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<1024>, dim3(B * (C / cb)), dim3(1024), 0, s, x, (long)x_pitch, gy,
                        (long)gy_pitch, coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss,
