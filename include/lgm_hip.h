@@ -120,6 +120,16 @@ int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitc
                const float* coefB, float* gx, int64_t gx_pitch, int accumulate_gx, float* ggamma,
                float* gbeta, float affine_beta, float* gss, int64_t gss_pitch, float gss_beta,
                float* workspace, void* stream);
+/* Deferred form: when the one-pass kernel applies, the per-image rows [sc*S2 | sc*S1] (B x 2C floats) are left in
+ * `rows` and `desc` is filled in the format of lgm_conv_wgrad_deferred (images play the role of splits), so that
+ * lgm_wgrad_reduce_batch produces ggamma / gbeta of many layers in one launch; otherwise the gradients are
+ * complete on return and desc[6] == 0. */
+int lgm_gn_bwd_deferred(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
+                        int C, int G, const float* gamma, const float* beta, const float* ss,
+                        int64_t ss_pitch, int act, const float* mean, const float* rstd, const float* coefA,
+                        const float* coefB, float* gx, int64_t gx_pitch, int accumulate_gx, float* ggamma,
+                        float* gbeta, float affine_beta, float* gss, int64_t gss_pitch, float gss_beta,
+                        float* workspace, float* rows, int64_t* desc, void* stream);
 
 /* RMSNorm over channels — ddpm.py:107-113: y = x / max(||x||_2, 1e-12) * g * sqrt(C) (+ res).
  * Backward: gx = [gx +] d/dx (+ res): `res` (or null) is the gradient arriving over the residual branch

@@ -431,7 +431,8 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
                                                            const float* __restrict__ ss, long ss_pitch,
                                                            float* __restrict__ gss, long gss_pitch, float gss_beta,
                                                            float* __restrict__ S1, float* __restrict__ S2,
-                                                           float* __restrict__ gx, long gx_pitch, int accumulate) {
+                                                           float* __restrict__ gx, long gx_pitch, int accumulate,
+                                                           float* __restrict__ T) {
   __shared__ float sh[NT * 8];
   __shared__ float wa1[256], wa2[256];
   __shared__ __align__(16) float cP[256], cQ[256], cR[256];
@@ -487,6 +488,10 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
     const float w = gamma[cc] * scv;
     wa1[tid] = w * a1;
     wa2[tid] = w * a2;
+    if (T) {   // deferred gamma/beta reduction: this image's row [sc*S2 | sc*S1] for lgm_wgrad_reduce_batch
+      T[(long)b * 2 * C + cc] = scv * a2;
+      T[(long)b * 2 * C + C + cc] = scv * a1;
+    }
   }
   __syncthreads();
   if (tid < CB) {  // coefficients of gx = P*gz + Qc + x*Rc, and the FiLM scale/shift gradients
@@ -599,12 +604,14 @@ extern "C" int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C,
   return LGM_OK;
 }
 
-extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
-                          int C, int G, const float* gamma, const float* beta, const float* ss,
-                          int64_t ss_pitch, int act, const float* mean, const float* rstd,
-                          const float* coefA, const float* coefB, float* gx, int64_t gx_pitch,
-                          int accumulate_gx, float* ggamma, float* gbeta, float affine_beta, float* gss,
-                          int64_t gss_pitch, float gss_beta, float* workspace, void* stream) {
+static int gn_bwd_impl(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
+                       int C, int G, const float* gamma, const float* beta, const float* ss,
+                       int64_t ss_pitch, int act, const float* mean, const float* rstd,
+                       const float* coefA, const float* coefB, float* gx, int64_t gx_pitch,
+                       int accumulate_gx, float* ggamma, float* gbeta, float affine_beta, float* gss,
+                       int64_t gss_pitch, float gss_beta, float* workspace, float* rows, int64_t* desc,
+                       void* stream) {
+  if (desc) desc[6] = 0;      // nothing deferred unless the one-pass kernel below takes it
   if (int rc = gn_check(B, HW, C, G)) return rc;
   LGM_REQUIRE(x && gy && gamma && beta && mean && rstd && coefA && coefB && gx && ggamma && gbeta && workspace,
               "gn_bwd: null pointer");
@@ -627,7 +634,7 @@ extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int6
 #define GN_FUSED(NTV, NVV)                                                                                             \
   hipLaunchKernelGGL((gn_fused_bwd_kernel<NTV, NVV>), dim3(B * (C / cb)), dim3(NTV), 0, s, x, (long)x_pitch, gy,        \
                      (long)gy_pitch, coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss, \
-                     (long)gss_pitch, gss_beta, S1, S2, gx, (long)gx_pitch, accumulate_gx)
+                     (long)gss_pitch, gss_beta, S1, S2, gx, (long)gx_pitch, accumulate_gx, rows)
       if (nt == 1024) {
         if (nv == 1) GN_FUSED(1024, 1); else if (nv == 2) GN_FUSED(1024, 2); else if (nv == 4) GN_FUSED(1024, 4);
         else GN_FUSED(1024, 8);
@@ -636,8 +643,16 @@ extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int6
         else GN_FUSED(256, 8);
       }
 #undef GN_FUSED
-      hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(lgm_cdiv(C, 16)), dim3(256), 0, s, (const float*)S1, (const float*)S2,
-                         ss, (long)ss_pitch, B, C, ggamma, gbeta, affine_beta);
+      if (rows && desc) {   // the caller sums the per-image rows of many layers with ONE lgm_wgrad_reduce_batch launch
+        union { float f; int64_t i; } bb;
+        bb.i = 0;
+        bb.f = affine_beta;
+        desc[0] = (int64_t)(uintptr_t)rows; desc[1] = 2L * C; desc[2] = (int64_t)(uintptr_t)ggamma; desc[3] = C;
+        desc[4] = (int64_t)(uintptr_t)gbeta; desc[5] = C; desc[6] = B; desc[7] = bb.i;
+      } else {
+        hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(lgm_cdiv(C, 16)), dim3(256), 0, s, (const float*)S1,
+                           (const float*)S2, ss, (long)ss_pitch, B, C, ggamma, gbeta, affine_beta);
+      }
       LGM_LAUNCH_CHECK();
       return LGM_OK;
     }
@@ -658,6 +673,31 @@ extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int6
                      affine_beta);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
+}
+
+extern "C" int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
+                          int C, int G, const float* gamma, const float* beta, const float* ss,
+                          int64_t ss_pitch, int act, const float* mean, const float* rstd,
+                          const float* coefA, const float* coefB, float* gx, int64_t gx_pitch,
+                          int accumulate_gx, float* ggamma, float* gbeta, float affine_beta, float* gss,
+                          int64_t gss_pitch, float gss_beta, float* workspace, void* stream) {
+  return gn_bwd_impl(x, x_pitch, gy, gy_pitch, B, HW, C, G, gamma, beta, ss, ss_pitch, act, mean, rstd, coefA, coefB, gx,
+                     gx_pitch, accumulate_gx, ggamma, gbeta, affine_beta, gss, gss_pitch, gss_beta, workspace, nullptr,
+                     nullptr, stream);
+}
+
+extern "C" int lgm_gn_bwd_deferred(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
+                                   int C, int G, const float* gamma, const float* beta, const float* ss,
+                                   int64_t ss_pitch, int act, const float* mean, const float* rstd,
+                                   const float* coefA, const float* coefB, float* gx, int64_t gx_pitch,
+                                   int accumulate_gx, float* ggamma, float* gbeta, float affine_beta, float* gss,
+                                   int64_t gss_pitch, float gss_beta, float* workspace, float* rows, int64_t* desc,
+                                   void* stream) {
+  LGM_REQUIRE(rows && desc && lgm_aligned16(rows) && lgm_aligned16(ggamma) && lgm_aligned16(gbeta),
+              "gn_bwd_deferred: rows / descriptor missing or gradients not 16-byte aligned");
+  return gn_bwd_impl(x, x_pitch, gy, gy_pitch, B, HW, C, G, gamma, beta, ss, ss_pitch, act, mean, rstd, coefA, coefB, gx,
+                     gx_pitch, accumulate_gx, ggamma, gbeta, affine_beta, gss, gss_pitch, gss_beta, workspace, rows, desc,
+                     stream);
 }
 
 // =====================================================================================

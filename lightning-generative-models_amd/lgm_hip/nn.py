@@ -251,7 +251,7 @@ class GroupNorm(nn.Module):
             gx = ops.new(x.shape, x)
             accumulate = False
         ops.gn_bwd(x, gy, self.groups, fp.ptr(self.weight), fp.ptr(self.bias), ss, act, sv, gx, accumulate,
-                   fp.gptr(self.weight), fp.gptr(self.bias), gc.beta(self.weight), gss, 0.0)
+                   fp.gptr(self.weight), fp.gptr(self.bias), gc.beta(self.weight), gss, 0.0, defer=gc.deferred)
         gc.beta(self.bias)
         return gx
 

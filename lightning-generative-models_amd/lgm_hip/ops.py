@@ -282,9 +282,25 @@ def gn_fwd(x, G, eps, gamma_ptr, beta_ptr, ss, act: bool, res, y) -> GNSaved:
 
 
 def gn_bwd(x, gy, G, gamma_ptr, beta_ptr, ss, act: bool, sv: GNSaved, gx, accumulate: bool,
-           ggamma_ptr, gbeta_ptr, affine_beta: float, gss, gss_beta: float):
+           ggamma_ptr, gbeta_ptr, affine_beta: float, gss, gss_beta: float, defer=None):
     B, H, W, C = x.shape
     ws = workspace(5 * B * C * 4, x.device)
+    if defer is not None and ggamma_ptr % 16 == 0 and gbeta_ptr % 16 == 0:
+        key = (ggamma_ptr, B * 2 * C)
+        rws = _WGRAD_WS.get(key)
+        if rws is None:
+            rws = torch.empty(B * 2 * C + 4, dtype=torch.float32, device=x.device)
+            _WGRAD_WS[key] = rws
+        desc = (ctypes.c_int64 * 8)()
+        lib().lgm_gn_bwd_deferred(x.data_ptr(), pitch(x), gy.data_ptr(), pitch(gy), B, H * W, C, G, gamma_ptr, beta_ptr,
+                                  _p(ss), pitch(ss) if ss is not None else 0, 1 if act else 0, sv.mean.data_ptr(),
+                                  sv.rstd.data_ptr(), sv.A.data_ptr(), sv.Bc.data_ptr(), gx.data_ptr(), pitch(gx),
+                                  1 if accumulate else 0, ggamma_ptr, gbeta_ptr, affine_beta, _p(gss),
+                                  pitch(gss) if gss is not None else 0, gss_beta, ws.data_ptr(), rws.data_ptr(),
+                                  ctypes.addressof(desc), stream())
+        if desc[6] > 0:
+            defer.append(tuple(desc))
+        return
     lib().lgm_gn_bwd(x.data_ptr(), pitch(x), gy.data_ptr(), pitch(gy), B, H * W, C, G, gamma_ptr, beta_ptr,
                      _p(ss), pitch(ss) if ss is not None else 0, 1 if act else 0, sv.mean.data_ptr(),
                      sv.rstd.data_ptr(), sv.A.data_ptr(), sv.Bc.data_ptr(), gx.data_ptr(), pitch(gx),
