@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
     ph.cc_end = min(ncc_total, ph.cc + p.pps);
     ph.border = 16u | (ph.h0 == 0 ? 1u : 0u) | (ph.h0 + p.TH == p.H ? 2u : 0u) | (ph.w0 == 0 ? 4u : 0u) |
                 (ph.w0 + p.TW == p.W ? 8u : 0u);
-    ph.abase = ((long)((ph.b0 * p.H + ph.h0 - 1) * p.W + ph.w0 - 1) * p.a_pitch) * 4;
+    ph.abase = ((long)((ph.b0 * p.H + ph.h0) * p.W + ph.w0) * p.a_pitch) * 4;   // relative to the shifted descriptor
   };
   auto decode = [&](Phase& ph, int L) {    // once per workgroup (integer divisions)
     ph.L = L;
@@ -201,20 +201,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
       while (py >= p.TH + 2) { py -= p.TH + 2; ++img; }
     }
   }
-  // a position that is certainly inside the tensor (first interior pixel of the tile's first image)
-  const unsigned safe_delta = (unsigned)((p.W + 1) * (int)p.a_pitch) * 4u;
-  f32x4 rp[NJ];
-  // unconditional 16-byte load of position j of phase ph (padding reads the safe position and is
-  // zeroed when the value is committed to LDS); fetch_addr returns the validity bit
+  // The patch is fetched with raw buffer loads through a descriptor that starts one row and one
+  // column BEFORE the tensor (so the halo origin of every tile is a non-negative offset): per-lane
+  // 32-bit offset + scalar (tile, channel chunk) offset, and a padding position gets an offset past
+  // the descriptor's range, for which the hardware returns zeros -- no select when the value is
+  // committed to LDS, no 64-bit address arithmetic.  (The host keeps all offsets below 2^31.)
+  const unsigned nrec_a = (unsigned)(((long)p.B * p.H * p.W + p.W + 1) * p.a_pitch * 4);
+  __amdgpu_buffer_rsrc_t rsrc_a;
+  {
+    const unsigned long long ab = reinterpret_cast<unsigned long long>(p.a - (long)(p.W + 1) * p.a_pitch);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ab);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ab >> 32));
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                               __builtin_amdgcn_readfirstlane(nrec_a), 0x00020000);
+  }
+  u32x4 rp[NJ];
   auto fetch_addr = [&](int j, const Phase& ph, unsigned& off) -> unsigned {
     const unsigned fl = (j < 6 ? pflagA : pflagB) & (ph.border << (5 * (j < 6 ? j : j - 6)));
-    const bool ok = fl == 0u;
-    off = ok ? pdelta[j] : safe_delta;
-    return ok ? 1u : 0u;
+    off = fl == 0u ? pdelta[j] : nrec_a;
+    return 0u;
   };
   auto fetch_issue = [&](int j, const Phase& ph, unsigned off) {
-    const char* sbase = reinterpret_cast<const char*>(p.a) + ph.abase + (long)ph.cc * (CK * 4);   // wave-uniform
-    rp[j] = *reinterpret_cast<const f32x4*>(sbase + off);
+    const unsigned soff = (unsigned)(ph.abase + (long)ph.cc * (CK * 4));   // wave-uniform
+    rp[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, soff, 0);
   };
   auto fetch = [&](int j, const Phase& ph) -> unsigned {
     unsigned off;
@@ -224,7 +233,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const Args p) {
   };
   auto commit = [&](int j, float* buf, unsigned mask) {
     const int pos = tid / TPP + PPP * j;
-    *reinterpret_cast<f32x4*>(buf + pos * LDP + c4) = ((mask >> j) & 1u) ? rp[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    (void)mask;
+    *reinterpret_cast<u32x4*>(buf + pos * LDP + c4) = rp[j];
   };
 
   // ---- A fragment bases (tile-local pixel -> patch position) ----

@@ -484,7 +484,7 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
               "conv_xy: x/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(y_pitch >= g->Nw && (!res || res_pitch >= g->Nw), "conv_xy: output pitch < Nw");
   if (use_3x3() && wide_ok(y, y_pitch, res, res_pitch, bias) && lgm_conv3x3_supported(g, g->Cw, g->Nw) &&
-      (long)g->B * g->H * g->W * x_pitch < (1L << 30))   // 32-bit BYTE offsets in the patch prefetch
+      ((long)g->B * g->H * g->W + g->W + 1) * x_pitch < (1L << 29))   // buffer offsets (bytes) below 2^31
     return lgm_conv3x3_launch(0, g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, workspace, workspace_bytes,
                               (hipStream_t)stream);
   if (use_3x3() && use_gstream() && wide_ok(y, y_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 &&
@@ -642,7 +642,7 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
               "conv_yx: y/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(x_pitch >= g->Cw && (!res || res_pitch >= g->Cw), "conv_yx: output pitch < Cw");
   if (use_3x3() && wide_ok(x, x_pitch, res, res_pitch, bias) && lgm_conv3x3_supported(g, g->Nw, g->Cw) &&
-      (long)g->B * g->H * g->W * y_pitch < (1L << 30))
+      ((long)g->B * g->H * g->W + g->W + 1) * y_pitch < (1L << 29))
     return lgm_conv3x3_launch(w_t ? 2 : 1, g, y, y_pitch, w_t ? w_t : w, bias, res, res_pitch, x, x_pitch, workspace,
                               workspace_bytes, (hipStream_t)stream);
   if (use_3x3() && use_gstream() && w_t && wide_ok(x, x_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 &&
