@@ -204,7 +204,7 @@ struct Plan {
 bool make_plan(long M, int N, int K, Plan* pl) {
   if (!(K == 64 || K == 128 || K == 192 || K == 256)) return false;
   if (M < 64 || M % 64 != 0 || M > (1L << 30)) return false;
-  const int nb = K <= 128 ? 128 : 64;
+  const int nb = (K <= 128 && N % 128 == 0) ? 128 : 64;   // 128-column slices where they divide N and fit
   if (N % nb != 0) return false;
   pl->kq = K / 32;
   pl->tn = nb / 64;
@@ -261,8 +261,14 @@ int lgm_gemm_stream_launch(const float* x, long x_pitch, const float* w, const f
     else LGM_GS_LAUNCH1(KQV, TNV, false);          \
   } while (0)
   switch (pl.kq) {
-    case 2: LGM_GS_LAUNCH(2, 2); break;
-    case 4: LGM_GS_LAUNCH(4, 2); break;
+    case 2:
+      if (pl.tn == 2) LGM_GS_LAUNCH(2, 2);
+      else LGM_GS_LAUNCH(2, 1);
+      break;
+    case 4:
+      if (pl.tn == 2) LGM_GS_LAUNCH(4, 2);
+      else LGM_GS_LAUNCH(4, 1);
+      break;
     case 6: LGM_GS_LAUNCH(6, 1); break;
     default: LGM_GS_LAUNCH(8, 1); break;
   }

@@ -83,6 +83,8 @@ CONV_CASES = [
     (64, 32, 32, 128, 128, 1, 1, 0),  # resident-weight streaming 1x1 conv, K = 128 (forward and input gradient)
     (48, 32, 32, 192, 128, 1, 1, 0),  # resident-weight streaming 1x1 conv, K = 192
     (64, 32, 32, 256, 64, 1, 1, 0),   # resident-weight streaming 1x1 conv, K = 256 forward, K = 64 input gradient
+    (64, 32, 32, 128, 64, 1, 1, 0),   # resident-weight streaming 1x1 conv, 64-column slice (N = 64), K = 128
+    (64, 32, 32, 64, 64, 1, 1, 0),    # resident-weight streaming 1x1 conv, 64-column slice, K = 64
 ]
 
 
