@@ -1042,17 +1042,31 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const WArgs p) {
       }
     }
   } else {
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      lgm_wave_lds_sync();
-      lgm_tile_to_lds(acc[tp], Ts, lane);
-      lgm_wave_lds_sync();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wm * 32 + (lane >> 3) + 8 * j;
-        *reinterpret_cast<f32x4*>(out + ((long)n * 9 + tp) * p.Cw + cc) = lgm_tile_row4(Ts, lane, j);
-      }
+    // Straight from the accumulator layout: register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 lh
+    // (n), column lr (c), so one dword store writes two full 128-byte segments of the slab -- no LDS
+    // transpose, no dependent write -> read -> store chain per tap; lane offset + scalar (row, tap)
+    // offset through a buffer descriptor over this block's slab.
+    __amdgpu_buffer_rsrc_t rsrc_o;
+    {
+      const unsigned long long ob = reinterpret_cast<unsigned long long>(out);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ob);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ob >> 32));
+      rsrc_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane((unsigned)(p.Nw * 9 * p.Cw) * 4u),
+                                                 0x00020000);
     }
+    const unsigned row_bytes = (unsigned)(9 * p.Cw) * 4u;
+    const unsigned vo = (unsigned)(n0 + wm * 32 + 4 * lh) * row_bytes + (unsigned)(c0 + wn * 32 + lr) * 4u;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[tp][r];
+        asm volatile("" : "+v"(v));   // (a direct bit_cast of the accumulator element stored element 0 sixteen times)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_o, vo,
+                                              (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes + (unsigned)(tp * p.Cw) * 4u,
+                                              0);
+      }
   }
   if (do_bias) {
     __syncthreads();
