@@ -40,6 +40,12 @@ class GradCtx:
         if self.deferred:
             ops.wgrad_reduce_batch(self.deferred, self.flat.device)
 
+    def defer_for(self, p: nn.Parameter):
+        """The deferred-reduction list for the FIRST gradient contribution of ``p`` in this pass, else None: the
+        per-parameter slab / row workspaces hold one contribution at a time, so a parameter used twice
+        (a shared module) reduces its later contributions immediately.  Call before ``beta(p)``."""
+        return self.deferred if id(p) not in self.written else None
+
     def beta(self, p: nn.Parameter) -> float:
         k = id(p)
         if k in self.written:
@@ -93,6 +99,7 @@ class Conv2d(nn.Module):
         B, H, W, _ = x.shape
         g = self.geom(B, H, W)
         fp = gc.flat
+        dfr = gc.defer_for(self.weight)
         bw = gc.beta(self.weight)
         gb = None
         if self.bias is not None:
@@ -101,7 +108,7 @@ class Conv2d(nn.Module):
                 gb = fp.gptr(self.bias)              # bias gradient fused into the wgrad kernel
             else:
                 ops.colsum(gy, fp.gptr(self.bias), bb)
-        ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=gc.deferred)
+        ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=dfr)
         if not need_gx:
             return None
         if gx is None:
@@ -250,8 +257,9 @@ class GroupNorm(nn.Module):
         if gx is None:
             gx = ops.new(x.shape, x)
             accumulate = False
+        dfr = gc.defer_for(self.weight)
         ops.gn_bwd(x, gy, self.groups, fp.ptr(self.weight), fp.ptr(self.bias), ss, act, sv, gx, accumulate,
-                   fp.gptr(self.weight), fp.gptr(self.bias), gc.beta(self.weight), gss, 0.0, defer=gc.deferred)
+                   fp.gptr(self.weight), fp.gptr(self.bias), gc.beta(self.weight), gss, 0.0, defer=dfr)
         gc.beta(self.bias)
         return gx
 
@@ -270,8 +278,9 @@ class RMSNorm(nn.Module):
         if gx is None:
             gx = ops.new(x.shape, x)
             accumulate = False
+        dfr = gc.defer_for(self.g)
         ops.rmsnorm_bwd(x, gy, gc.flat.ptr(self.g), gx, accumulate, gc.flat.gptr(self.g), gc.beta(self.g),
-                        defer=gc.deferred, res=res)
+                        defer=dfr, res=res)
         return gx
 
 

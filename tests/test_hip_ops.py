@@ -175,7 +175,9 @@ def test_conv_transpose(dev, case):
     assert rel(gw, phys_weight(w.grad, dev)) < RTOL
 
 
-@pytest.mark.parametrize("shape", [(3, 64, 16, 16, 8), (2, 128, 8, 8, 8), (2, 512, 4, 4, 8), (2, 16, 8, 8, 8), (5, 256, 4, 4, 8)])
+@pytest.mark.parametrize("shape", [(3, 64, 16, 16, 8), (2, 128, 8, 8, 8), (2, 512, 4, 4, 8), (2, 16, 8, 8, 8), (5, 256, 4, 4, 8),
+                                   (2, 64, 32, 32, 8),     # one-pass kernels, 1024-thread blocks
+                                   (1, 64, 64, 64, 8)])    # slice too large for the registers: two-pass kernels
 @pytest.mark.parametrize("film", [True, False])
 def test_groupnorm_film_silu(dev, shape, film):
     from lgm_hip import ops
@@ -213,6 +215,15 @@ def test_groupnorm_film_silu(dev, shape, film):
     ops.gn_bwd(xd, gyd, G, gd.data_ptr(), bd.data_ptr(), ssd if film else None, True, sv, gxd, True,
                gg.data_ptr(), gb.data_ptr(), 1.0, None, 0.0)
     assert rel(nchw(gxd), 2 * x.grad) < RTOL and rel(gg, 2 * gamma.grad) < RTOL
+    # deferred form: gamma/beta gradients through the batched slab reducer (or complete at once when the
+    # two-pass kernels ran and nothing was deferred)
+    rows = []
+    gx2 = torch.zeros(B, H, W, C, device=dev)
+    gg2, gb2 = torch.full((C,), 3.0, device=dev), torch.full((C,), -2.0, device=dev)
+    ops.gn_bwd(xd, gyd, G, gd.data_ptr(), bd.data_ptr(), ssd if film else None, True, sv, gx2, False,
+               gg2.data_ptr(), gb2.data_ptr(), 0.0, None, 0.0, defer=rows)
+    ops.wgrad_reduce_batch(rows, dev)
+    assert rel(nchw(gx2), x.grad) < RTOL and rel(gg2, gamma.grad) < RTOL and rel(gb2, beta.grad) < RTOL
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 128, 8, 8), (2, 512, 4, 4), (2, 16, 8, 8), (130, 256, 4, 4)])
@@ -236,6 +247,10 @@ def test_rmsnorm(dev, shape):
     ops.rmsnorm_bwd(xd, gyd, gpd.data_ptr(), gxd, False, gg.data_ptr(), 0.0)
     assert rel(nchw(gxd), x.grad) < RTOL
     assert rel(gg, gp.grad.reshape(-1)) < RTOL
+    # residual-branch gradient added in the same pass (+ accumulate into gx)
+    rg = torch.randn(B, C, H, W, generator=g)
+    ops.rmsnorm_bwd(xd, gyd, gpd.data_ptr(), gxd, True, gg.data_ptr(), 1.0, res=nhwc(rg, dev, extra=4))
+    assert rel(nchw(gxd), 2 * x.grad + rg) < RTOL and rel(gg, 2 * gp.grad.reshape(-1)) < RTOL
 
 
 def _lin_attn_core(q, k, v, mem, scale):
