@@ -53,10 +53,12 @@ class GraphedDDPMStep:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self.g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1):
+        # thread_local: only THIS thread is held to the capture rules -- the RCCL watchdog thread of a
+        # multi-GPU job keeps polling its events while the step is being captured
+        with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
             self.loss, st = part1()
         self.g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+        with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode="thread_local"):
             self.net.backward_phase2(st)
         self._st = st                                # keeps the captured buffers alive
 
