@@ -35,8 +35,9 @@ IMG = 32
 DIM = 64
 
 
-def cpu_baseline(batch=16, warmup=1, steps=3):
-    """The CPU oracle (validated against the reference by tests/golden) on this host's cores."""
+def cpu_baseline(batch=32, warmup=1, min_seconds=12.0, max_steps=200):
+    """The CPU oracle (validated against the reference by tests/golden) on this host's cores: whole
+    training steps (forward + backward + Adam) until ``min_seconds`` of timed work have accumulated."""
     from oracle import diffusion as OD
     torch.manual_seed(10)
     try:
@@ -50,8 +51,11 @@ def cpu_baseline(batch=16, warmup=1, steps=3):
     opt = torch.optim.Adam(list(P.values()), lr=2e-5, betas=(0.9, 0.99))
     x = torch.rand(batch, 3, IMG, IMG) * 2 - 1
     times = []
-    for i in range(warmup + steps):
-        print(f"[bench] cpu_baseline step {i} ({nthreads} threads)", file=sys.stderr, flush=True)
+    i = 0
+    while i < warmup or (sum(times) < min_seconds and len(times) < max_steps):
+        if i < warmup or len(times) % 10 == 0:
+            print(f"[bench] cpu_baseline step {i} ({nthreads} threads, {sum(times):.1f}s timed)", file=sys.stderr,
+                  flush=True)
         t0 = time.perf_counter()
         t = torch.randint(0, 1000, (batch,))
         noise = torch.randn_like(x)
@@ -61,10 +65,11 @@ def cpu_baseline(batch=16, warmup=1, steps=3):
         opt.step()
         if i >= warmup:
             times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(batch / med, 2), "unit": "images/s", "cores": nthreads, "kind": "port",
-            "sample": f"oracle fwd+bwd+Adam, B={batch}, 3x{IMG}x{IMG}, median of {steps} steps after {warmup} warm-up"}
+        i += 1
+    total = sum(times)
+    return {"value": round(batch * len(times) / total, 2), "unit": "images/s", "cores": nthreads, "kind": "port",
+            "sample": f"oracle fwd+bwd+Adam, B={batch}, 3x{IMG}x{IMG}: {len(times)} steps = {total:.1f} s of CPU work "
+                      f"after {warmup} warm-up"}
 
 
 def torch_gpu_baseline(dev, batch=GLOBAL_BATCH, warmup=5, steps=10):
