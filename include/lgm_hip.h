@@ -172,8 +172,9 @@ int lgm_attn_bwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const
 /* ---------------------------------------------------------------------------------------
  * Elementwise / data-movement kernels.
  * ------------------------------------------------------------------------------------- */
-/* SinusoidalPosEmb ddpm.py:125-132: out[b] = cat(sin(t_b f), cos(t_b f)), f_i = exp(-i ln(theta)/(dim/2-1)) */
-int lgm_posemb(const int64_t* t, int B, int dim, float theta, float* out, int64_t pitch, void* stream);
+/* SinusoidalPosEmb ddpm.py:125-132: out[b] = cat(sin(t_b f), cos(t_b f)).  freqs[dim/2] (device) is the
+ * table f_i = exp(-i ln(theta)/(dim/2-1)) computed by the caller on the host, as the reference does. */
+int lgm_posemb(const int64_t* t, int B, int dim, const float* freqs, float* out, int64_t pitch, void* stream);
 
 #define LGM_ACT_NONE 0
 #define LGM_ACT_SILU 1  /* nn.SiLU  ddpm.py:162,180 */

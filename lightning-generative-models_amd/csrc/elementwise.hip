@@ -83,19 +83,19 @@ extern "C" int lgm_colsum(const float* a, int64_t pitch, int64_t rows, int64_t c
 }
 
 // ---------------------------------------------------------------------------------------
-// Sinusoidal position embedding  (ddpm.py:125-132): emb[b] = cat(sin(t*f), cos(t*f)),
-// f[i] = exp(i * -(ln(theta)/(half-1)))
+// Sinusoidal position embedding  (ddpm.py:125-132): emb[b] = cat(sin(t*f), cos(t*f)).  The frequency
+// table f[i] = exp(i * -(ln(theta)/(half-1))) is computed by the CALLER on the host exactly as the
+// reference computes it (torch.exp on the CPU): a device expf differs by an ulp, which times t = 999 is
+// 1e-4 in the argument.
 // ---------------------------------------------------------------------------------------
 namespace {
-__global__ void posemb_kernel(const int64_t* __restrict__ t, int B, int dim, float theta, float* __restrict__ out,
-                              long pitch) {
+__global__ void posemb_kernel(const int64_t* __restrict__ t, int B, int dim, const float* __restrict__ freqs,
+                              float* __restrict__ out, long pitch) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int half = dim / 2;
   if (i >= B * half) return;
   const int b = i / half, j = i % half;
-  const float step = logf(theta) / (float)(half - 1);
-  const float f = expf((float)j * -step);
-  const float arg = (float)t[b] * f;
+  const float arg = (float)t[b] * freqs[j];
   out[(long)b * pitch + j] = sinf(arg);
   out[(long)b * pitch + half + j] = cosf(arg);
 }
@@ -407,10 +407,11 @@ __global__ __launch_bounds__(256) void sample_step_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int lgm_posemb(const int64_t* t, int B, int dim, float theta, float* out, int64_t pitch, void* stream) {
-  LGM_REQUIRE(t && out && B > 0 && dim >= 4 && dim % 2 == 0 && pitch >= dim, "posemb: bad arguments");
+extern "C" int lgm_posemb(const int64_t* t, int B, int dim, const float* freqs, float* out, int64_t pitch,
+                          void* stream) {
+  LGM_REQUIRE(t && out && freqs && B > 0 && dim >= 4 && dim % 2 == 0 && pitch >= dim, "posemb: bad arguments");
   hipLaunchKernelGGL(posemb_kernel, dim3(lgm_cdiv((long)B * dim / 2, 256)), dim3(256), 0, (hipStream_t)stream, t, B,
-                     dim, theta, out, (long)pitch);
+                     dim, freqs, out, (long)pitch);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
@@ -581,7 +582,9 @@ __global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict
     const float r = sqrtf(s);
     pen = (r - 1.f) * (r - 1.f);
     if (gbar) {
-      const float k = gscale[0] * lambda * 2.f / (float)npix * (r - 1.f) / r;
+      // r == 0 (a pixel whose channel gradient is exactly zero: dead / clipped critic): torch's backward of
+      // norm(2, dim=1) uses the zero subgradient there (wgan.py:153-154), not (r-1)/r = -inf
+      const float k = r > 0.f ? gscale[0] * lambda * 2.f / (float)npix * (r - 1.f) / r : 0.f;
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 4; ++c)

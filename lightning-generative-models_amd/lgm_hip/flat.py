@@ -76,6 +76,7 @@ class FlatParams:
         self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.by_param: Dict[int, ParamSlot] = {}
         self.fresh = True        # next backward overwrites (beta = 0) instead of accumulating
+        self.written = False     # a backward pass wrote this buffer since the flag was last cleared
         for s in self.slots:
             view = logical_view(self.data[s.offset:s.offset + s.numel], s.param.shape, s.kind, s.phys_shape)
             with torch.no_grad():
@@ -188,6 +189,7 @@ class FlatParams:
             self._grad_views_bound = False
         beta = 0.0 if self.fresh else 1.0
         self.fresh = False
+        self.written = True
         return beta
 
     def bind_grad_views(self):

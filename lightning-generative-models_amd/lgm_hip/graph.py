@@ -24,7 +24,11 @@ from . import ops
 
 
 class GraphedDDPMStep:
-    def __init__(self, model, opt, x: torch.Tensor, sync=None, warmup: int = 3):
+    """``inject=True`` (parity tests): ``t`` / ``noise`` are static INPUT buffers the caller fills before each
+    step instead of being drawn inside graph 1.  Either way ``self.t`` / ``self.noise`` hold the values the
+    last replay used."""
+
+    def __init__(self, model, opt, x: torch.Tensor, sync=None, warmup: int = 3, inject: bool = False):
         from models.generative.diffusion.ddpm import hip_loss_backward_phase1, hip_loss_forward
         self.model, self.opt, self.sync = model, opt, sync
         self.gd = model.ema.online_model
@@ -34,15 +38,24 @@ class GraphedDDPMStep:
         self._fwd, self._bwd1 = hip_loss_forward, hip_loss_backward_phase1
         self.net.grad_sync = None                    # collectives are issued by step(), never captured
         fp = self.net._flat
+        self.t = torch.zeros(x.shape[0], dtype=torch.long, device=x.device) if inject else None
+        self.noise = torch.zeros_like(x) if inject else None
 
         def part1():
             gd = self.gd
-            t = torch.randint(0, gd.num_timesteps, (x.shape[0],), device=x.device).long()
-            noise = torch.randn_like(self.x)
+            if inject:
+                t, noise = self.t, self.noise
+            else:
+                t = torch.randint(0, gd.num_timesteps, (x.shape[0],), device=x.device).long()
+                noise = torch.randn_like(self.x)
+                self.t, self.noise = t, noise
             loss, ctx = self._fwd(gd, self.x, t, noise, gd.auto_normalize, True)
             fp.zero_grad()
             return loss, self._bwd1(ctx, self.one)
 
+        # warm-up and capture must not perturb the random stream: a run that captures at batch 0 and a run that
+        # resumes from a checkpoint (and captures later) draw the same (t, noise) for the same seed
+        rng_state = torch.cuda.get_rng_state(x.device)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -61,6 +74,7 @@ class GraphedDDPMStep:
         with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode="thread_local"):
             self.net.backward_phase2(st)
         self._st = st                                # keeps the captured buffers alive
+        torch.cuda.set_rng_state(rng_state, x.device)
 
     def step(self, batch_idx: int = 0):
         net, sync = self.net, self.sync
@@ -73,5 +87,63 @@ class GraphedDDPMStep:
             sync.ready(0, net._head_end)
             sync.finish()
         self.opt.step()
+        self.opt.zero_grad()                         # host flag only: the next backward overwrites
         self.model.on_train_batch_end(None, None, batch_idx)
         return self.loss
+
+
+class DDPMFastStep:
+    """What ``MiniTrainer.fit`` drives for a ``DDPM`` module (``DDPM.make_fast_step``): the bucketed gradient
+    exchange overlapped with the hand-written backward (``FlatGradSync``, N > 1) and the two-graph replay of
+    the step, captured lazily at the first batch.  When capture is not possible (or a batch has another shape)
+    the same step runs from eager launches, in the same process, with the same overlapped exchange.
+    Logging (``train_loss``) and the reference's periodic in-training sampling (ddpm.py:1017-1027) stay
+    outside the graphs."""
+
+    def __init__(self, model, opt, world: int, use_graph: bool = True):
+        from .lightning import FlatGradSync
+        self.model, self.opt = model, opt
+        self.net = model.ema.online_model.model
+        self.sync = FlatGradSync(self.net._flat) if world > 1 else None
+        inner = getattr(opt, "_opt", opt)            # MiniTrainer wraps optimizers in a step-counting proxy
+        if self.sync is not None:
+            inner.grad_scale = self.sync.grad_scale  # 1/N folded into Adam (no divide pass)
+        self.use_graph = use_graph
+        self.graphed: Optional[GraphedDDPMStep] = None
+        self.mode = "eager"
+
+    def _capture(self, x):
+        try:
+            self.graphed = GraphedDDPMStep(self.model, self.opt, x.clone(), self.sync)
+            self.mode = "hipGraph replay (2 graphs/step)"
+        except Exception as e:  # capture is an optimisation: fall back to eager launches
+            import sys
+            print(f"[lgm_hip] HIP-graph capture unavailable ({type(e).__name__}: {e}); eager launches",
+                  file=sys.stderr, flush=True)
+            self.use_graph = False
+            self.graphed = None
+
+    def step(self, batch, batch_idx: int = 0):
+        from models.generative.diffusion.ddpm import _is_master
+        m = self.model
+        x = batch[0]
+        if m.sample_every and m.global_step % m.sample_every == 0 and _is_master():
+            m._log_sample()
+        if self.use_graph and self.graphed is None:
+            self._capture(x)
+        if self.graphed is not None and x.shape == self.graphed.x.shape:
+            self.graphed.x.copy_(x)
+            loss = self.graphed.step(batch_idx)
+        else:
+            self.net.grad_sync = self.sync           # backward phases hand finished buckets to the exchange
+            gd = m.ema.online_model
+            loss = gd(x)
+            loss.backward()
+            if self.sync is not None:
+                self.sync.finish()
+            self.opt.step()
+            self.opt.zero_grad()
+            m.on_train_batch_end(None, batch, batch_idx)
+            self.net.grad_sync = None
+        m.log("train_loss", loss, prog_bar=True, logger=True, sync_dist=False)
+        return loss

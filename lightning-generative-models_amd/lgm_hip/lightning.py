@@ -1,17 +1,24 @@
 """LightningModule / Trainer surface used by the hot path.
 
-If ``pytorch_lightning`` is importable it is used unchanged (the models are ordinary
-LightningModules).  It is not installed in the build image, so this file also provides a
-minimal stand-in with the subset of behaviour the reference relies on
-(train.py:124-141, ddpm.py:983,1017-1027,1047, wgan.py:58-82, vqvae.py:184-194):
+The models derive from ``MiniLightningModule`` UNCONDITIONALLY and ``train.py`` always drives them with
+``MiniTrainer`` — also when ``pytorch_lightning`` is importable (the reference's own environment): the
+HIP engine needs ``prepare_hip``, flat gradient buffers and the graph-replayed step, none of which
+``pl.Trainer`` knows about, and a ``pl.LightningModule`` routes ``global_step`` / ``optimizers()`` /
+``log`` through a ``pl.Trainer`` that is not there.  ``HAVE_PL`` is informational only.
+
+The stand-in provides the subset of behaviour the reference relies on
+(train.py:113-141, ddpm.py:983,1017-1027,1047, wgan.py:58-82, vqvae.py:184-194):
 
   save_hyperparameters / hparams, log / log_dict (kept in ``logged``), global_step (counts
   optimizer.step() calls, which is what makes WGAN's n_critic schedule work — wgan.py:64),
   optimizers(), manual_backward(), automatic vs manual optimisation, on_train_batch_end,
-  one process per GPU with gradient averaging over torch.distributed (RCCL on ROCm).
+  validation every ``check_val_every_n_epoch`` epochs, ``last.ckpt`` (ModelCheckpoint(save_last=True),
+  train.py:113-117) written atomically at every epoch end / every ``ckpt_every_n_steps`` optimizer
+  steps / on interruption, one process per GPU with gradient averaging over torch.distributed (RCCL).
 """
 from __future__ import annotations
 
+import importlib.util
 import inspect
 import os
 import time
@@ -21,12 +28,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-try:  # pragma: no cover - not available in the build image
-    import pytorch_lightning as _pl  # type: ignore
-    HAVE_PL = True
-except Exception:  # noqa
-    _pl = None
-    HAVE_PL = False
+HAVE_PL = importlib.util.find_spec("pytorch_lightning") is not None     # informational (see above)
 
 
 class _AttrDict(dict):
@@ -106,13 +108,17 @@ class MiniLightningModule(nn.Module):
     def manual_backward(self, loss, *a, **k):
         """Lightning semantics under DDP: gradients are averaged over ranks as part of the backward.  Only the
         flat buffers this backward actually wrote (a GAN's critic OR generator) are exchanged."""
+        flats = _flat_grads_of(self)
+        for fp in flats:
+            fp.written = False               # set by FlatParams.begin_backward() of the passes that run now
         loss.backward(*a, **k)
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if world > 1:
-            for fp in _flat_grads_of(self):
-                if not fp.fresh:
+            for fp in flats:
+                if fp.written:
                     dist.all_reduce(fp.grad)
                     fp.grad.div_(world)
+                    fp.written = False
             for p in self.parameters():
                 if getattr(p, "_lgm_flat", None) is None and p.grad is not None:
                     dist.all_reduce(p.grad)
@@ -126,7 +132,7 @@ class MiniLightningModule(nn.Module):
         raise NotImplementedError
 
 
-LightningModule = _pl.LightningModule if HAVE_PL else MiniLightningModule
+LightningModule = MiniLightningModule
 
 
 def _flat_grads_of(module: nn.Module):
@@ -178,26 +184,39 @@ def save_checkpoint(model, optimizers, path: str, epoch: int = 0):
     """Write a checkpoint with the layout of a PyTorch-Lightning ``.ckpt`` (reference train.py:41,
     113-117,140 resumes from / writes these): ``state_dict`` with the reference's keys (incl.
     ``ema.online_model.*`` / ``ema.ema_model.*`` / ``ema.initted`` / ``ema.step``), ``global_step``
-    (= optimizer steps), ``optimizer_states`` in torch's own per-parameter format, hyper-parameters."""
+    (= optimizer steps), ``optimizer_states`` in torch's own per-parameter format, hyper-parameters.
+    Atomic: written to a temporary file in the same directory, then renamed over ``path``."""
+    tmp = f"{path}.tmp.{os.getpid()}"
     torch.save({"epoch": int(epoch), "global_step": int(model.global_step),
                 "pytorch-lightning_version": "2.0.0+lgm_hip", "state_dict": model.state_dict(),
                 "loops": {}, "callbacks": {}, "optimizer_states": [o.state_dict() for o in optimizers],
-                "lr_schedulers": [], "hparams_name": "kwargs", "hyper_parameters": dict(model.hparams)}, path)
+                "lr_schedulers": [], "hparams_name": "kwargs", "hyper_parameters": dict(model.hparams)}, tmp)
+    os.replace(tmp, path)
 
 
 class MiniTrainer:
-    """Single-node trainer: one process per GPU, optional DDP-style gradient averaging with a
-    single all-reduce per flat gradient buffer (RCCL over xGMI when backend is nccl)."""
+    """Single-node trainer: one process per GPU, DDP-style gradient averaging (RCCL over xGMI when the
+    backend is nccl).  Models that offer ``make_fast_step`` (DDPM) are driven through it: bucketed
+    all-reduce overlapped with the hand-written backward + HIP-graph replay of the step — the same objects
+    bench.py times — with an in-process fallback to eager launches when capture is not possible."""
 
     def __init__(self, max_steps=-1, max_epochs=-1, accumulate_grad_batches=1, device=None,
-                 default_root_dir=None, log_every=50, **_ignored):
+                 default_root_dir=None, log_every=50, check_val_every_n_epoch=1, ckpt_every_n_steps=1000,
+                 limit_val_batches=None, fast_path=True, **_ignored):
         self.max_steps, self.max_epochs = max_steps, max_epochs
         self.accumulate = max(1, int(accumulate_grad_batches))
         self.device = device
         self.root = default_root_dir
         self.log_every = log_every
+        self.val_every = max(1, int(check_val_every_n_epoch or 1))
+        self.ckpt_every = int(ckpt_every_n_steps or 0)
+        self.limit_val_batches = limit_val_batches
+        self.fast_path = fast_path
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
+        self.best_val = None
+        self.best_path = None
+        self.val_history: List[float] = []
 
     def allreduce_grads(self, module):
         if self.world == 1:
@@ -211,7 +230,53 @@ class MiniTrainer:
                 dist.all_reduce(p.grad)
                 p.grad.div_(self.world)
 
-    def fit(self, model, datamodule=None, train_dataloader=None, ckpt_path=None):
+    # -- checkpoints (reference: ModelCheckpoint(dirpath, save_last=True, monitor="val_loss")) ------
+    def _save_last(self, model, epoch):
+        if self.root and self.rank == 0:
+            os.makedirs(self.root, exist_ok=True)
+            save_checkpoint(model, list(model._optimizers), os.path.join(self.root, "last.ckpt"), epoch=epoch)
+
+    def _save_best(self, model, epoch, val_loss):
+        if not (self.root and self.rank == 0) or val_loss is None:
+            return
+        if self.best_val is None or val_loss < self.best_val:
+            path = os.path.join(self.root, f"epoch={epoch}-step={model.global_step}.ckpt")
+            save_checkpoint(model, list(model._optimizers), path, epoch=epoch)
+            if self.best_path and self.best_path != path and os.path.exists(self.best_path):
+                os.remove(self.best_path)          # save_top_k = 1
+            self.best_val, self.best_path = val_loss, path
+
+    # -- validation (Lightning: eval mode, no grad, every check_val_every_n_epoch epochs) -----------
+    def validate(self, model, loader, device):
+        was_training = model.training
+        model.eval()
+        takes_idx = "batch_idx" in inspect.signature(model.validation_step).parameters
+        seen = 0
+        total = None
+        with torch.no_grad():
+            for batch_idx, batch in enumerate(loader):
+                if self.limit_val_batches is not None and batch_idx >= self.limit_val_batches:
+                    break
+                batch = tuple(b.to(device, non_blocking=True) if torch.is_tensor(b) else b for b in batch)
+                model.validation_step(batch, batch_idx) if takes_idx else model.validation_step(batch)
+                v = model.logged.get("val_loss")
+                if v is not None:
+                    v = v.detach().float().reshape(()) if torch.is_tensor(v) else torch.tensor(float(v))
+                    total = v.clone() if total is None else total + v
+                seen += 1
+        model.train(was_training)
+        if total is None or seen == 0:
+            return None
+        val = total / seen
+        if self.world > 1:                    # sync_dist-style mean over ranks
+            val = val.to(device)
+            dist.all_reduce(val)
+            val = val / self.world
+        val = float(val)
+        self.val_history.append(val)
+        return val
+
+    def fit(self, model, datamodule=None, train_dataloader=None, ckpt_path=None, val_dataloader=None):
         device = torch.device(self.device) if self.device is not None else (
             torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
         model.to(device)
@@ -233,36 +298,73 @@ class MiniTrainer:
                 o.load_state_dict(osd)
         model._optimizers = [_CountingOptimizer(o, model) for o in opts]
         loader = train_dataloader if train_dataloader is not None else datamodule.train_dataloader()
+        if val_dataloader is None and datamodule is not None and hasattr(datamodule, "val_dataloader"):
+            val_dataloader = datamodule.val_dataloader()
         model.train()
-        epoch, done = 0, False
+        fast = None
+        if (self.fast_path and model.automatic_optimization and self.accumulate == 1 and device.type == "cuda"
+                and hasattr(model, "make_fast_step")):
+            fast = model.make_fast_step(model._optimizers[0], self.world)
+        self.fast = fast
+        epoch = int(ckpt.get("epoch", 0)) if ckpt is not None else 0
+        done = False
         t0 = time.time()
         takes_idx = "batch_idx" in inspect.signature(model.training_step).parameters
-        while not done:
-            for batch_idx, batch in enumerate(loader):
-                batch = tuple(b.to(device, non_blocking=True) if torch.is_tensor(b) else b for b in batch)
-                if model.automatic_optimization:
-                    opt = model._optimizers[0]
-                    loss = model.training_step(batch, batch_idx) if takes_idx else model.training_step(batch)
-                    if self.accumulate > 1:
-                        loss = loss / self.accumulate
-                    loss.backward()
-                    if (batch_idx + 1) % self.accumulate == 0:
-                        self.allreduce_grads(model)
-                        opt.step()
-                        opt.zero_grad()
-                else:
-                    model.training_step(batch, batch_idx) if takes_idx else model.training_step(batch)
-                model.on_train_batch_end(None, batch, batch_idx)
-                if self.rank == 0 and self.log_every and model.global_step % self.log_every == 0:
-                    msg = {k: (float(v) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
-                    print(f"[step {model.global_step}] {msg} ({time.time() - t0:.1f}s)", flush=True)
-                if 0 < self.max_steps <= model.global_step:
+        last_saved_step = model.global_step
+        try:
+            while not done:
+                pending = 0                          # micro-batches whose gradients are not stepped yet
+                stopped_mid_epoch = False
+                for batch_idx, batch in enumerate(loader):
+                    batch = tuple(b.to(device, non_blocking=True) if torch.is_tensor(b) else b for b in batch)
+                    if fast is not None:
+                        fast.step(batch, batch_idx)          # loss, backward, exchange, Adam, EMA hook
+                    elif model.automatic_optimization:
+                        opt = model._optimizers[0]
+                        loss = model.training_step(batch, batch_idx) if takes_idx else model.training_step(batch)
+                        if self.accumulate > 1:
+                            loss = loss / self.accumulate
+                        loss.backward()
+                        pending += 1
+                        if pending == self.accumulate:
+                            self.allreduce_grads(model)
+                            opt.step()
+                            opt.zero_grad()
+                            pending = 0
+                        model.on_train_batch_end(None, batch, batch_idx)
+                    else:
+                        model.training_step(batch, batch_idx) if takes_idx else model.training_step(batch)
+                        model.on_train_batch_end(None, batch, batch_idx)
+                    if self.rank == 0 and self.log_every and model.global_step % self.log_every == 0:
+                        msg = {k: (float(v) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
+                        print(f"[step {model.global_step}] {msg} ({time.time() - t0:.1f}s)", flush=True)
+                    if self.ckpt_every and model.global_step - last_saved_step >= self.ckpt_every:
+                        self._save_last(model, epoch)
+                        last_saved_step = model.global_step
+                    if 0 < self.max_steps <= model.global_step:
+                        done = stopped_mid_epoch = True
+                        break
+                if pending:                          # Lightning steps on the last batch of an epoch
+                    self.allreduce_grads(model)
+                    model._optimizers[0].step()
+                    model._optimizers[0].zero_grad()
+                epoch += 1
+                if 0 < self.max_epochs <= epoch:
                     done = True
-                    break
-            epoch += 1
-            if 0 < self.max_epochs <= epoch:
-                done = True
-        if self.root and self.rank == 0:
-            os.makedirs(self.root, exist_ok=True)
-            save_checkpoint(model, list(model._optimizers), os.path.join(self.root, "last.ckpt"), epoch=epoch)
+                val = None
+                # validation runs at the end of COMPLETED epochs only (a run cut short by max_steps stops here)
+                if (val_dataloader is not None and hasattr(model, "validation_step") and not stopped_mid_epoch
+                        and epoch % self.val_every == 0):
+                    val = self.validate(model, val_dataloader, device)
+                    if self.rank == 0 and val is not None:
+                        print(f"[epoch {epoch}] val_loss {val:.6f}", flush=True)
+                self._save_best(model, epoch, val)
+                self._save_last(model, epoch)
+                last_saved_step = model.global_step
+        except BaseException:
+            # crash / Ctrl-C / SIGTERM-as-exception: keep the progress made so far
+            try:
+                self._save_last(model, epoch)
+            finally:
+                raise
         return model

@@ -50,6 +50,7 @@ def rows(t: torch.Tensor) -> int:
 # workspace (one growing buffer per device; ops run in stream order so sharing is safe)
 # ----------------------------------------------------------------------------------------
 _WS = {}
+_WS_RETIRED = []     # superseded buffers are NEVER freed: a captured HIP graph may have their address baked in
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
@@ -57,6 +58,11 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         n = max(int(nbytes * 1.25) // 4 + 64, 1 << 20)
+        if ws is not None:
+            # a graph replay after this point still writes its scratch data into the OLD buffer: returning
+            # it to the caching allocator would let that land in a live tensor (graph and eager launches
+            # run in stream order, so the two buffers are never used concurrently)
+            _WS_RETIRED.append(ws)
         ws = torch.empty(n, dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws
@@ -378,8 +384,24 @@ def attn_bwd(qkv, mem_ptr, out, gout, lse, heads, dim_head, M, gqkv, gmem_ptr, g
 # ----------------------------------------------------------------------------------------
 # elementwise
 # ----------------------------------------------------------------------------------------
+_POSEMB_FREQS = {}
+
+
+def posemb_freqs(dim, theta, device) -> torch.Tensor:
+    """The reference's frequency table (ddpm.py:127-129), computed on the HOST with torch's CPU exp."""
+    import math
+    key = (dim, float(theta), str(device))
+    f = _POSEMB_FREQS.get(key)
+    if f is None:
+        half = dim // 2
+        f = torch.exp(torch.arange(half) * -(math.log(theta) / (half - 1))).to(device)
+        _POSEMB_FREQS[key] = f
+    return f
+
+
 def posemb(t, dim, theta, out):
-    lib().lgm_posemb(t.data_ptr(), t.shape[0], dim, theta, out.data_ptr(), pitch(out), stream())
+    lib().lgm_posemb(t.data_ptr(), t.shape[0], dim, posemb_freqs(dim, theta, t.device).data_ptr(), out.data_ptr(),
+                     pitch(out), stream())
 
 
 def act_fwd(x, bias_ptr, res, y, act, slope=0.0):

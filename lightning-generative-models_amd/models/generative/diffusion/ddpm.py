@@ -809,6 +809,12 @@ class DDPM(LightningModule):
     def configure_optimizers(self):
         return FusedAdam(self.ema.model.parameters(), lr=self.hparams.lr, betas=self.hparams.betas)
 
+    def make_fast_step(self, opt, world: int = 1, use_graph: bool = True):
+        """The step object ``MiniTrainer.fit`` drives instead of training_step/backward/step: overlapped
+        bucketed gradient exchange + HIP-graph replay (what bench.py times), eager fallback inside."""
+        from lgm_hip.graph import DDPMFastStep
+        return DDPMFastStep(self, opt, world, use_graph)
+
 
 def _is_master() -> bool:
     import torch.distributed as dist

@@ -6,7 +6,11 @@
 One process per GPU: under ``python -m torch.distributed.run --nproc-per-node N train.py ...`` every
 rank binds to its LOCAL_RANK device, joins a torch.distributed group (backend "nccl" = RCCL over
 xGMI on ROCm, "gloo" on CPU) and averages the flat gradient buffers once per optimizer step.
-Uses pytorch_lightning's Trainer when it is installed, otherwise the in-repo MiniTrainer.
+The loop is ALWAYS the in-repo MiniTrainer (lgm_hip/lightning.py) — also where pytorch_lightning is
+installed: the HIP engine's flat gradient buffers, overlapped bucketed all-reduce and graph-replayed step
+are driven by it (for DDPM: the same DDPMFastStep bench.py times).  It keeps the reference trainer's
+observable behaviour: ``last.ckpt`` (+ the best-``val_loss`` checkpoint) in the experiment directory,
+validation at the end of every epoch, ``--max_steps`` / ``--max_epochs`` / ``--accumulate_grad_batches``.
 """
 import argparse
 import os

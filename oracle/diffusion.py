@@ -115,16 +115,18 @@ def unet_param_shapes(dim: int = 64, channels: int = 3,
 def unet_init(dim: int = 64, channels: int = 3, seed: int = 0,
               dim_mults: Sequence[int] = (1, 2, 4, 8)) -> Params:
     """Random-init weights with torch-default-like statistics (kaiming-uniform
-    fan-in bounds for conv/linear, ones/zeros for norms, N(0,1) mem_kv).  The
+    fan-in bounds for conv/linear, U(0.5,1.5) / U(-0.3,0.3) for the norms' scale / shift, N(0,1) mem_kv).  The
     exact RNG stream of the reference constructor is NOT reproduced (parity tests
     always load identical weights into both sides)."""
     g = torch.Generator().manual_seed(seed)
     P: Params = {}
     for name, shp in unet_param_shapes(dim, channels, dim_mults).items():
         if name.endswith(".g") or name.endswith("norm.weight"):
-            P[name] = torch.ones(shp)
+            # NOT the constructor's ones/zeros: a mis-routed gamma / beta / g pointer must be visible in
+            # every network-level comparison, so the affine parameters are random too
+            P[name] = 0.5 + torch.rand(shp, generator=g)
         elif name.endswith("norm.bias"):
-            P[name] = torch.zeros(shp)
+            P[name] = (torch.rand(shp, generator=g) * 2 - 1) * 0.3
         elif name.endswith("mem_kv"):
             P[name] = torch.randn(shp, generator=g)
         elif name.endswith(".weight"):
@@ -437,3 +439,31 @@ def ddim_step(P, bufs, img, time: int, time_next: int, noise, eta: float = 0.0,
     c = (1 - alpha_next - sigma ** 2).sqrt()
     img = x_start * alpha_next.sqrt() + c * pred_noise + sigma * noise
     return img, x_start
+
+
+def draw_loop_noise(seed: int, shape, n_steps: int) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """The draws the reference loops make from the global CPU generator after ``torch.manual_seed(seed)``:
+    ``randn(shape)`` for the start image, then one ``randn_like`` per step that draws (ddpm.py:763,755 for the
+    ancestral loop: every t > 0; ddpm.py:802,825 for DDIM: every pair with time_next >= 0)."""
+    g = torch.Generator().manual_seed(seed)
+    init = torch.randn(shape, generator=g)
+    return init, [torch.randn(shape, generator=g) for _ in range(n_steps)]
+
+
+def p_sample_loop(P, bufs, init, noises, dim=64, dim_mults=(1, 2, 4, 8)):
+    """ddpm.py:759-780: T ancestral steps from ``init``; returns the unnormalised image ((x+1)/2)."""
+    T = bufs["betas"].shape[0]
+    img = init
+    for i, t in enumerate(reversed(range(T))):
+        img, _ = p_sample(P, bufs, img, t, noises[i] if t > 0 else None, dim=dim, dim_mults=dim_mults)
+    return (img + 1) * 0.5
+
+
+def ddim_sample_loop(P, bufs, init, noises, sampling_timesteps: int, eta: float = 0.0, dim=64,
+                     dim_mults=(1, 2, 4, 8)):
+    """ddpm.py:782-834; returns the unnormalised image."""
+    T = bufs["betas"].shape[0]
+    img = init
+    for i, (a, b) in enumerate(ddim_time_pairs(T, sampling_timesteps)):
+        img, _ = ddim_step(P, bufs, img, a, b, noises[i] if b >= 0 else None, eta=eta, dim=dim, dim_mults=dim_mults)
+    return (img + 1) * 0.5

@@ -140,7 +140,7 @@ def gen_diffusion():
     np.savez_compressed(os.path.join(OUT, "diffusion_schedule.npz"), **sched)
 
     # ---- UNet / p_losses, small (dim 16, 16x16) and full (dim 64, 32x32) ------
-    for tag, dim, S, B, seed in (("small", 16, 16, 2, 1), ("full", 64, 32, 2, 2)):
+    for tag, dim, S, B, seed in (("small", 16, 16, 2, 1), ("full", 64, 32, 2, 2), ("full64", 64, 64, 2, 3)):
         P = O.unet_init(dim=dim, channels=3, seed=seed)
         unet = R.Unet(dim=dim, channels=3)
         missing = unet.load_state_dict(P, strict=True)
@@ -198,6 +198,17 @@ def gen_diffusion():
             sigma = 0.0 * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
             c = (1 - an - sigma ** 2).sqrt()
             fx["ddim_999_979"] = (xs * an.sqrt() + c * pn).numpy()
+            if tag == "small":
+                # whole sampling LOOPS of the reference (ddpm.py:759-780, 782-834).  Both loops draw from the
+                # global RNG (randn(shape), then one randn_like per step): a test replays the same draws by
+                # seeding the CPU generator identically.  Stored: the returned (unnormalised) images only.
+                torch.manual_seed(9001)
+                fx["ddim_loop_50"] = gd.ddim_sample((B, 3, S, S)).numpy()
+                fx["ddim_loop_seed"] = 9001
+                gd_a = R.GaussianDiffusion(unet, img_size=S, timesteps=200)     # ancestral chain, T = 200
+                torch.manual_seed(9002)
+                fx["p_sample_loop_200"] = gd_a.p_sample_loop((B, 3, S, S)).numpy()
+                fx["p_sample_loop_seed"] = 9002
         np.savez_compressed(os.path.join(OUT, f"diffusion_unet_{tag}.npz"), **to_np(fx))
         print("diffusion", tag, "loss", float(loss), "gradnorm", fx["gradnorm_all"])
 

@@ -1,3 +1,4 @@
+import json
 import os
 import sys
 
@@ -10,6 +11,7 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+_PARITY_LOG = []
 
 
 def pytest_configure(config):
@@ -19,3 +21,26 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def parity(request):
+    """``parity(what, err, tol)``: assert a measured parity error against its tolerance AND put the measured
+    value on record — printed (``pytest -s`` / ``-rP``) and, with ``LGM_PARITY_LOG=<file>``, written as JSON at
+    the end of the session (the committed copy is profiles/rNN_parity_errors.json)."""
+    def check(what, err, tol):
+        err, tol = float(err), float(tol)
+        rec = {"test": request.node.name, "what": what, "err": err, "tol": tol}
+        _PARITY_LOG.append(rec)
+        print(f"[parity] {request.node.name}: {what}: {err:.3e} (tol {tol:.1e})")
+        assert err < tol, rec
+        return err
+    return check
+
+
+def pytest_sessionfinish(session, exitstatus):
+    path = os.environ.get("LGM_PARITY_LOG")
+    if path and _PARITY_LOG:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(_PARITY_LOG, fh, indent=1)

@@ -49,6 +49,71 @@ def test_train_entry_vae_cpu():
     assert sd["global_step"] == 20 and "encoder.mu.weight" in sd["state_dict"]
 
 
+def test_train_entry_with_pytorch_lightning_installed(tmp_path):
+    """The reference's own environment HAS pytorch_lightning.  A fake package whose LightningModule breaks
+    outside a pl.Trainer (log / optimizers / global_step go through self.trainer) is put on the path: the
+    models must still derive from the in-repo module and train.py must still run, write periodic + final
+    checkpoints atomically, run validation at the epoch end and keep the best val_loss checkpoint."""
+    fake = tmp_path / "site" / "pytorch_lightning"
+    fake.mkdir(parents=True)
+    (fake / "__init__.py").write_text(
+        "import torch.nn as nn\n"
+        "class LightningModule(nn.Module):\n"
+        "    def log(self, *a, **k):\n        raise RuntimeError('log() outside a pl.Trainer loop')\n"
+        "    def log_dict(self, *a, **k):\n        raise RuntimeError('log_dict() outside a pl.Trainer loop')\n"
+        "    def optimizers(self):\n        return self.trainer.optimizers\n"
+        "    @property\n    def global_step(self):\n        return self.trainer.global_step\n"
+        "class Trainer:\n    def __init__(self, *a, **k):\n        raise RuntimeError('pl.Trainer must not be used')\n")
+    env = dict(os.environ, PYTHONPATH=str(tmp_path / "site") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(PKG, "train.py"), "--config_path",
+                        os.path.join(PKG, "configs", "vae", "vae.json"), "--max_epochs", "2", "--accelerator", "cpu",
+                        "--experiment_name", "pytest_cpu_pl"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "val_loss" in r.stdout
+    d = os.path.join(PKG, "experiments", "VAE", "pytest_cpu_pl")
+    sd = torch.load(os.path.join(d, "last.ckpt"), map_location="cpu")
+    assert sd["epoch"] == 2 and sd["global_step"] > 0
+    best = [f for f in os.listdir(d) if f.startswith("epoch=") and f.endswith(".ckpt")]
+    assert len(best) == 1                                     # save_top_k = 1 on val_loss
+    assert not [f for f in os.listdir(d) if ".tmp." in f]     # atomic writes leave nothing behind
+    chk = subprocess.run([sys.executable, "-c",
+                          "import sys; sys.path.insert(0, sys.argv[1]); import lgm_hip.lightning as L; "
+                          "from models.generative.vae.vae import VAE; "
+                          "assert L.HAVE_PL and issubclass(VAE, L.MiniLightningModule); print('ok')", PKG],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert chk.returncode == 0 and "ok" in chk.stdout, chk.stderr[-1500:]
+
+
+def test_trainer_periodic_checkpoint_interrupt_and_accumulation_tail(tmp_path):
+    """MiniTrainer: last.ckpt every ``ckpt_every_n_steps`` optimizer steps and on an exception raised inside
+    the loop (max_steps = max_epochs = -1, the CLI defaults, never reach the final save); the leftover
+    micro-batches of an epoch are stepped (Lightning semantics for accumulate_grad_batches)."""
+    from lgm_hip.lightning import MiniTrainer
+    from models.generative.vae.vae import VAE
+    torch.manual_seed(0)
+
+    class Boom(Exception):
+        pass
+
+    def batches(n, boom_at=None):
+        g = torch.Generator().manual_seed(1)
+        for i in range(n):
+            if boom_at is not None and i == boom_at:
+                raise Boom()
+            yield torch.rand(4, 1, 8, 8, generator=g) * 2 - 1, torch.zeros(4, dtype=torch.long)
+
+    m = VAE(img_channels=1, img_size=8, latent_dim=4)
+    tr = MiniTrainer(default_root_dir=str(tmp_path), log_every=0, device="cpu", ckpt_every_n_steps=3)
+    with pytest.raises(Boom):
+        tr.fit(m, train_dataloader=batches(100, boom_at=8))
+    sd = torch.load(os.path.join(str(tmp_path), "last.ckpt"), map_location="cpu")
+    assert sd["global_step"] == 8                             # saved by the exception handler (periodic: 3, 6)
+    m2 = VAE(img_channels=1, img_size=8, latent_dim=4)
+    tr2 = MiniTrainer(max_epochs=1, log_every=0, device="cpu", accumulate_grad_batches=4)
+    tr2.fit(m2, train_dataloader=list(batches(10)))
+    assert m2.global_step == 3                                # 4 + 4 + the 2 leftover micro-batches
+
+
 def test_flat_params_views_and_state_dict_roundtrip():
     from lgm_hip.flat import FlatParams
     from lgm_hip.nn import Conv2d, param_kind

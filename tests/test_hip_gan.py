@@ -10,6 +10,9 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
+# critic gradients THROUGH the gradient penalty (double backward through train-mode BatchNorm at B=4): measured
+# values are recorded in profiles/r02_parity_errors.json, the bound is explained in DESIGN.md §1.1
+GP_GRAD_TOL = 1e-3
 
 
 def rel(a, b):
@@ -91,8 +94,36 @@ def _load_wgan(img_size, ch, latent, dev):
     return m
 
 
+def _generator_grad_check(parity, m, fx_norm, g_loss_fn, img_size, ch, latent, z):
+    """Generator gradient norms against the reference fixture at 1e-4 — except where the REFERENCE's own fp32
+    result is further than that from exact arithmetic: the BatchNorm scale / shift gradients of the first
+    generator blocks are sums over B x H x W = 4 x 16 ... 4 x 256 terms that cancel to ~1e-3 of their magnitude,
+    so fp32 summation order moves them by ~1e-4 (the reference on another BLAS would differ from itself by as
+    much).  The float64 oracle is the arbiter there: the HIP result must be as close to it as 3x the
+    reference's own distance (both distances are recorded)."""
+    from oracle import gan as OG
+    G, D = OG.gan_init(img_size, ch, latent, seed=21)
+    G64 = {k: v.double().requires_grad_(True) for k, v in G.items()}
+    D64 = {k: v.double() for k, v in D.items()}
+    g_loss_fn(D64, OG.generator(G64, z.double(), img_size, ch), img_size).backward()
+    worst, worst_cond = 0.0, 0.0
+    for n, p in m.G.named_parameters():
+        ref, exact = float(fx_norm(n)), G64[n].grad.norm().item()
+        hip = p.grad.double().norm().item()
+        e_ref = abs(hip - ref) / max(ref, 1e-12)
+        if e_ref < RTOL:
+            worst = max(worst, e_ref)
+            continue
+        d_ref, d_hip = abs(ref - exact) / exact, abs(hip - exact) / exact
+        print(f"[parity] {n}: |hip-ref| {e_ref:.1e}; distance to the float64 oracle: reference {d_ref:.1e}, hip {d_hip:.1e}")
+        assert d_hip < max(RTOL, 3 * d_ref), (n, d_hip, d_ref)
+        worst_cond = max(worst_cond, d_hip)
+    parity("worst generator gradient norm (well-conditioned parameters) vs reference", worst, RTOL)
+    parity("worst generator gradient norm (cancelling BatchNorm sums) vs float64 oracle", worst_cond, 1e-3)
+
+
 @pytest.mark.parametrize("cfg", [(64, 3, 100), (28, 1, 128)])
-def test_wgan_gp_losses_and_gradients_match_reference_fixture(dev, golden_dir, cfg):
+def test_wgan_gp_losses_and_gradients_match_reference_fixture(dev, golden_dir, cfg, parity):
     img_size, ch, latent = cfg
     B = 4
     tag = str(img_size)
@@ -102,30 +133,31 @@ def test_wgan_gp_losses_and_gradients_match_reference_fixture(dev, golden_dir, c
     x = torch.rand(B, ch, img_size, img_size, generator=g) * 2 - 1
     z = torch.randn(B, latent, 1, 1, generator=g)
     x_hat = m.G(z.to(dev))
-    assert rel(x_hat, fx[f"x_hat_{tag}"]) < RTOL
+    parity("generator output x_hat", rel(x_hat, fx[f"x_hat_{tag}"]), RTOL)
     alpha = torch.as_tensor(fx[f"alpha_{tag}"]).to(dev)
     ld = m._calculate_d_loss(x.to(dev), x_hat, alpha=alpha)
     for k in ("d_loss", "d_loss_real", "d_loss_fake", "gradient_penalty"):
-        assert rel(ld[k], fx[f"{k}_{tag}"]) < 2 * RTOL, (k, float(ld[k]), float(fx[f"{k}_{tag}"]))
+        parity(k, rel(ld[k], fx[f"{k}_{tag}"]), RTOL)
     d_opt, g_opt = m.configure_optimizers()[0]
     d_opt.zero_grad()
     ld["d_loss"].backward()
+    wn, ws = 0.0, 0.0
     for n, p in m.D.named_parameters():
         ref_norm = float(fx[f"dgradnorm_{tag}:{n}"])
-        gn = p.grad.double().norm().item()
-        assert abs(gn - ref_norm) / max(ref_norm, 1e-12) < 1e-3, (n, gn, ref_norm)
+        wn = max(wn, abs(p.grad.double().norm().item() - ref_norm) / max(ref_norm, 1e-12))
         ref = fx[f"dgrad_{tag}:{n}"]
         got = p.grad if p.numel() < 20000 else p.grad.reshape(-1)[:: p.numel() // 256][:256]
-        assert rel(got, ref) < 2e-3, n
+        ws = max(ws, rel(got, ref))
+    parity("worst critic gradient norm (first + second order path)", wn, GP_GRAD_TOL)
+    parity("worst critic gradient tensor / 256-sample", ws, GP_GRAD_TOL)
     # generator loss / gradients
     g_opt.zero_grad()
     x_hat2 = m.G(z.to(dev))
     gl = m._calculate_g_loss(x_hat2)["g_loss"]
-    assert rel(gl, fx[f"g_loss_{tag}"]) < 2 * RTOL
+    parity("g_loss", rel(gl, fx[f"g_loss_{tag}"]), RTOL)
     gl.backward()
-    for n, p in m.G.named_parameters():
-        ref_norm = float(fx[f"ggradnorm_{tag}:{n}"])
-        assert abs(p.grad.double().norm().item() - ref_norm) / max(ref_norm, 1e-12) < 1e-3, n
+    from oracle import gan as OG
+    _generator_grad_check(parity, m, lambda n: fx[f"ggradnorm_{tag}:{n}"], OG.wgan_g_loss, img_size, ch, latent, z)
 
 
 def test_wgan_training_schedule_and_steps(dev):
@@ -187,7 +219,7 @@ def _sample(p):
 
 @pytest.mark.parametrize("cfg", [(64, 3, 100), (28, 1, 128)])
 @pytest.mark.parametrize("name", ["dcgan", "lsgan", "r1gan"])
-def test_gan_heads_match_reference_fixture(dev, golden_dir, cfg, name):
+def test_gan_heads_match_reference_fixture(dev, golden_dir, cfg, name, parity):
     """plain DCGAN (BCE), LSGAN, R1GAN (second-order sweep with the R1 functional) on
     the HIP critic / generator vs fixtures captured from the reference classes."""
     img_size, ch, latent = cfg
@@ -200,26 +232,29 @@ def test_gan_heads_match_reference_fixture(dev, golden_dir, cfg, name):
     x_hat = m.G(z.to(dev))
     ld = m._calculate_d_loss(x.to(dev), x_hat)
     for k, v in ld.items():
-        assert rel(v, fx[f"{name}_{k}_{tag}"]) < 2 * RTOL, (k, float(v), float(fx[f"{name}_{k}_{tag}"]))
+        parity(k, rel(v, fx[f"{name}_{k}_{tag}"]), RTOL)
     d_opt, g_opt = m.configure_optimizers()[0]
     d_opt.zero_grad()
     ld["d_loss"].backward()
+    wn, ws = 0.0, 0.0
     for n, p in m.D.named_parameters():
         ref_norm = float(fx[f"{name}_dgrad_{tag}norm:{n}"])
-        gn = p.grad.double().norm().item()
-        assert abs(gn - ref_norm) / max(ref_norm, 1e-12) < 1e-3, (n, gn, ref_norm)
-        assert rel(_sample(p.grad), fx[f"{name}_dgrad_{tag}:{n}"]) < 2e-3, n
+        wn = max(wn, abs(p.grad.double().norm().item() - ref_norm) / max(ref_norm, 1e-12))
+        ws = max(ws, rel(_sample(p.grad), fx[f"{name}_dgrad_{tag}:{n}"]))
+    tol = GP_GRAD_TOL if name == "r1gan" else RTOL         # R1 = the second-order sweep again
+    parity("worst critic gradient norm", wn, tol)
+    parity("worst critic gradient tensor / 256-sample", ws, tol)
     g_opt.zero_grad()
     gl = m._calculate_g_loss(m.G(z.to(dev)))["g_loss"]
-    assert rel(gl, fx[f"{name}_g_loss_{tag}"]) < 2 * RTOL
+    parity("g_loss", rel(gl, fx[f"{name}_g_loss_{tag}"]), RTOL)
     gl.backward()
-    for n, p in m.G.named_parameters():
-        ref_norm = float(fx[f"{name}_ggradnorm_{tag}:{n}"])
-        assert abs(p.grad.double().norm().item() - ref_norm) / max(ref_norm, 1e-12) < 1e-3, n
+    from oracle import gan as OG
+    g_fn = {"dcgan": OG.dcgan_g_loss, "lsgan": OG.lsgan_g_loss, "r1gan": OG.dcgan_g_loss}[name]
+    _generator_grad_check(parity, m, lambda n: fx[f"{name}_ggradnorm_{tag}:{n}"], g_fn, img_size, ch, latent, z)
 
 
 @pytest.mark.parametrize("cfg", [(64, 3, 100), (28, 1, 128)])
-def test_wgan_weight_clipping_and_rmsprop_match_reference_fixture(dev, golden_dir, cfg):
+def test_wgan_weight_clipping_and_rmsprop_match_reference_fixture(dev, golden_dir, cfg, parity):
     """constraint_method="clip": loss on the unclipped weights, clamp of every critic
     parameter, backward through the clipped weights, one fused RMSprop step (wgan.py:101-102,158-181)."""
     img_size, ch, latent = cfg
@@ -236,15 +271,16 @@ def test_wgan_weight_clipping_and_rmsprop_match_reference_fixture(dev, golden_di
     ld = m._calculate_d_loss(x.to(dev), x_hat)
     assert "gradient_penalty" not in ld
     for k, v in ld.items():
-        assert rel(v, fx[f"wgancp_{k}_{tag}"]) < 2 * RTOL, k
+        parity(k, rel(v, fx[f"wgancp_{k}_{tag}"]), RTOL)
     for p in m.D.parameters():
         assert float(p.detach().abs().max()) <= 0.01 + 1e-9
     d_opt.zero_grad()
     ld["d_loss"].backward()
+    wn = 0.0
     for n, p in m.D.named_parameters():
         ref_norm = float(fx[f"wgancp_dgrad_{tag}norm:{n}"])
-        gn = p.grad.double().norm().item()
-        assert abs(gn - ref_norm) / max(ref_norm, 1e-12) < 1e-3, (n, gn, ref_norm)
+        wn = max(wn, abs(p.grad.double().norm().item() - ref_norm) / max(ref_norm, 1e-12))
+    parity("worst critic gradient norm", wn, RTOL)
     d_opt.step()
-    for n, p in m.D.named_parameters():
-        assert rel(_sample(p.detach()), fx[f"wgancp_after_{tag}:{n}"]) < 1e-4, n
+    wa = max(rel(_sample(p.detach()), fx[f"wgancp_after_{tag}:{n}"]) for n, p in m.D.named_parameters())
+    parity("worst critic parameter after clamp + RMSprop step", wa, RTOL)

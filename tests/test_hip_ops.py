@@ -329,7 +329,9 @@ def test_elementwise_kernels(dev):
     half = 32
     f = torch.exp(torch.arange(half) * -(math.log(10000.0) / (half - 1)))
     ref = torch.cat(((t[:, None] * f).sin(), (t[:, None] * f).cos()), dim=-1)
-    assert (pe.cpu() - ref).abs().max() < 2e-4   # fp32 sin/cos of arguments up to 999 rad
+    err = float((pe.cpu() - ref).abs().max())
+    print(f"posemb max abs err vs host formula: {err:.2e}")
+    assert err < 1e-6        # host-computed frequency table: only sin/cos rounding is left
     assert abs(pe[1, 0].item() - 0.84147096) < 1e-6 and abs(pe[1, 32].item() - 0.54030234) < 1e-6
     # activations
     x = torch.randn(37, 64, generator=g, requires_grad=True)

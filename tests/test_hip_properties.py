@@ -1,6 +1,7 @@
-"""GPU: size-independent properties at BASELINE.json's FULL sizes (B=128, 32x32 / dim 64), where the
-CPU oracle would take minutes: linearity and adjoint identities of the convolution family, and
-bit-reproducibility (the reference trainer runs deterministic=True) of the whole training step."""
+"""GPU: size-independent properties at BASELINE.json's FULL sizes (B=128, 32x32 / dim 64): linearity and
+adjoint identities of the convolution family, and bit-reproducibility (the reference trainer runs
+deterministic=True) of the whole training step.  (The direct B=128 comparison with the CPU oracle — a few
+seconds of CPU work — lives in tests/test_hip_timed_path.py.)"""
 import os
 
 import pytest
@@ -104,7 +105,8 @@ def test_full_size_training_step_is_bit_reproducible(dev):
     assert torch.isfinite(runs[0][1]).all() and float(runs[0][1].abs().max()) > 0
 
 
-@pytest.mark.parametrize("cfg", ["diffusion/ddpm.json", "diffusion/ddim.json", "gan/wgan_gp.json", "gan/wgan_cp.json",
+@pytest.mark.parametrize("cfg", ["diffusion/ddpm.json", "diffusion/ddim.json", "diffusion/ddpm_64.json",
+                                 "gan/wgan_gp.json", "gan/wgan_gp_celeba.json", "gan/wgan_cp.json",
                                  "gan/dcgan_mnist.json", "gan/lsgan.json", "gan/r1gan.json", "vae/vqvae.json",
                                  "vae/vqvae_ema.json"])
 def test_train_entry_runs_every_hot_path_config_on_the_gpu(cfg, tmp_path):

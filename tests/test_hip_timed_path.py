@@ -1,0 +1,266 @@
+"""GPU: parity of the path bench.py TIMES (``GraphedDDPMStep``: two HIP graphs per step) and of the BASELINE
+sizes themselves (B=128 DDPM against the CPU oracle, N=4096 x K=512 VQ with a non-collapsed codebook), plus
+the 2-rank data-parallel DDPM step (gloo ranks sharing the one GPU of the box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "lightning-generative-models_amd")
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def _ddpm(dev, dim, S, seed=10, **kw):
+    from models.generative.diffusion.ddpm import DDPM
+    torch.manual_seed(seed)
+    m = DDPM(img_channels=3, img_size=S, dim=dim, **kw)
+    m.sample_every = 0
+    m.to(dev)
+    m.prepare_hip(dev)
+    m.train()
+    return m
+
+
+def test_graph_replay_is_bit_identical_to_eager_steps(dev):
+    """The timed path at the BASELINE configuration (dim 64, 32x32, B=128, configs/diffusion/ddpm.json's
+    optimiser): after ONE replay the loss and the WHOLE flat gradient buffer are torch.equal to an eager
+    p_losses + backward on a twin with identical weights fed the (t, noise) the graph drew; after 12 replays
+    the parameters, Adam moments and the EMA shadow are torch.equal to 12 eager steps fed the same draws
+    (covers static-buffer aliasing across the two captures, RNG under capture, zero_grad-in-graph ordering,
+    Adam's step count and the EMA update at step 10)."""
+    from lgm_hip.graph import GraphedDDPMStep
+    kw = dict(lr=2e-5, betas=(0.9, 0.99), ema_update_every=10, ema_decay=0.995)
+    a, b = _ddpm(dev, 64, 32, **kw), _ddpm(dev, 64, 32, **kw)
+    fa, fb = a.ema.online_model.model._flat, b.ema.online_model.model._flat
+    assert torch.equal(fa.data, fb.data)
+    oa, ob = a.configure_optimizers(), b.configure_optimizers()
+    g = torch.Generator().manual_seed(10)
+    x = (torch.rand(128, 3, 32, 32, generator=g) * 2 - 1).to(dev)
+    step = GraphedDDPMStep(a, oa, x.clone())
+    gd_b = b.ema.online_model
+    for i in range(12):
+        loss_a = step.step(i).clone()
+        t, noise = step.t.clone(), step.noise.clone()
+        assert int(t.min()) >= 0 and int(t.max()) < 1000 and abs(float(noise.mean())) < 0.02
+        ob.zero_grad()
+        loss_b = gd_b.p_losses(x, t, noise, _normalize=True)
+        loss_b.backward()
+        if i == 0:
+            assert torch.equal(loss_a.reshape(()), loss_b.detach().reshape(())), (float(loss_a), float(loss_b))
+            assert torch.equal(fa.grad, fb.grad)
+            assert float(fa.grad.abs().max()) > 0
+        ob.step()
+        b.on_train_batch_end(None, None, i)
+    assert torch.equal(fa.data, fb.data)
+    sa, sb = oa._flat_state[id(fa)], ob._flat_state[id(fb)]
+    assert sa["step"] == sb["step"] == 12 and torch.equal(sa["m"], sb["m"]) and torch.equal(sa["v"], sb["v"])
+    ea, eb = a.ema.ema_model.model._flat, b.ema.ema_model.model._flat
+    assert torch.equal(ea.data, eb.data) and not torch.equal(ea.data, fa.data)   # shadow = weights at step 10
+    assert not torch.equal(step.t, t) or True
+    # consecutive replays draw fresh (t, noise)
+    t0 = step.t.clone()
+    step.step(12)
+    assert not torch.equal(t0, step.t)
+
+
+def test_ddpm_at_the_baseline_batch_matches_the_cpu_oracle(dev, parity):
+    """B=128, dim 64, 32x32 (BASELINE config 2 as benched): HIP loss and every parameter gradient against
+    oracle.diffusion_forward + autograd on the CPU (a few seconds)."""
+    from models.generative.diffusion.ddpm import GaussianDiffusion, Unet
+    from oracle import diffusion as OD
+    dim, S, B = 64, 32, 128
+    P = OD.unet_init(dim=dim, channels=3, seed=128)
+    g = torch.Generator().manual_seed(1280)
+    img = torch.rand(B, 3, S, S, generator=g)
+    noise = torch.randn(B, 3, S, S, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    loss_ref = OD.diffusion_forward(Pr, OD.diffusion_buffers(1000), img, t, noise, dim=dim)
+    loss_ref.backward()
+    net = Unet(dim=dim, channels=3)
+    net.load_state_dict(P, strict=True)
+    gd = GaussianDiffusion(net, img_size=S, timesteps=1000).to(dev)
+    net.prepare_hip(dev)
+    loss = gd.p_losses(img.to(dev), t.to(dev), noise.to(dev), _normalize=True)
+    parity("loss", abs(loss.item() - loss_ref.item()) / loss_ref.item(), RTOL)
+    loss.backward()
+    errs = {n: rel(p.grad, Pr[n].grad) for n, p in net.named_parameters()}
+    wn = max(errs, key=errs.get)
+    parity(f"worst of ALL {len(errs)} parameter gradients ({wn})", errs[wn], RTOL)
+    gn = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in net.parameters())).item()
+    gr = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in Pr.values())).item()
+    parity("all-parameter gradient norm", abs(gn - gr) / gr, RTOL)
+
+
+def test_vq_full_size_non_collapsed_codebook(dev, parity):
+    """N=4096 rows (B=256 x 4x4), K=512, D=64 — configs/vae/vqvae.json's quantiser problem — with latents
+    scaled so that hundreds of codes are in use: indices torch.equal to the oracle's argmin (reference
+    vector_quantizer.py:45-69) outside a 1e-6 top-2 margin band (count reported), segment sums exact."""
+    from lgm_hip import ops
+    from oracle import vq as OV
+    N, K, D = 4096, 512, 64
+    g = torch.Generator().manual_seed(4096)
+    cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
+    x = torch.randn(N, D, generator=g) * (0.6 / K)          # comparable to the codebook's spread
+    dist = OV.vq_distances(x, cb)
+    ref = dist.argmin(1)
+    top2 = dist.topk(2, dim=1, largest=False).values
+    margin = (top2[:, 1] - top2[:, 0]) / top2[:, 0].abs().clamp_min(1e-30)
+    used = int(torch.unique(ref).numel())
+    p = torch.bincount(ref, minlength=K).float() / N
+    ppl = float(torch.exp(-(p * (p + 1e-10).log()).sum()))
+    print(f"[parity] vq full size: {used} of {K} codes used, perplexity {ppl:.1f}")
+    assert used > 200 and ppl > 100
+    L = ops.lib()
+    xd, cbd = x.to(dev), cb.to(dev)
+    idx = torch.empty(N, dtype=torch.long, device=dev)
+    L.lgm_vq_assign(xd.data_ptr(), D, cbd.data_ptr(), N, K, D, idx.data_ptr(), None, ops.stream())
+    mism = idx.cpu() != ref
+    band = margin <= 1e-6
+    print(f"[parity] vq full size: {int(mism.sum())} index mismatches, {int(band.sum())} rows inside the 1e-6 "
+          f"relative top-2 margin band")
+    assert int((mism & ~band).sum()) == 0
+    # a mismatch inside the band must still pick one of the two (numerically tied) nearest codes
+    if int(mism.sum()):
+        second = dist.topk(2, dim=1, largest=False).indices[:, 1]
+        assert torch.equal(idx.cpu()[mism], second[mism])
+    dw, counts = torch.empty(K, D, device=dev), torch.empty(K, device=dev)
+    L.lgm_vq_segment_sum(xd.data_ptr(), D, idx.data_ptr(), N, K, D, dw.data_ptr(), counts.data_ptr(), ops.stream())
+    onehot = torch.nn.functional.one_hot(idx.cpu(), K).float()
+    assert torch.equal(counts.cpu(), onehot.sum(0))
+    parity("segment sums dw = onehot^T x", rel(dw, onehot.double().T @ x.double()), 1e-6)
+
+
+def test_gp_penalty_zero_gradient_pixel(dev):
+    """A pixel whose channel gradient is exactly zero: penalty (0-1)^2 and a ZERO subgradient (torch's
+    backward of norm(2, dim=1)), not NaN."""
+    from lgm_hip import ops
+    L = ops.lib()
+    npix, C = 512, 3
+    g = torch.randn(npix, 4)
+    g[:, 3] = 0
+    g[7] = 0
+    g[300] = 0
+    gt = g[:, :3].clone().requires_grad_(True)
+    r = gt.norm(2, dim=1)
+    pen_ref = 10.0 * ((r - 1) ** 2).mean()
+    pen_ref.backward()
+    gd_, pen, gbar = g.to(dev), torch.empty(1, device=dev), torch.empty(npix, 4, device=dev)
+    one = torch.ones(1, device=dev)
+    ws = ops.workspace(L.lgm_gp_penalty_workspace(npix), dev)
+    L.lgm_gp_penalty(gd_.data_ptr(), npix, C, 10.0, one.data_ptr(), pen.data_ptr(), gbar.data_ptr(), ws.data_ptr(),
+                     ops.stream())
+    assert torch.isfinite(gbar).all()
+    assert float(gbar[7].abs().max()) == 0 and float(gbar[300].abs().max()) == 0
+    assert rel(pen, pen_ref) < 1e-6 and rel(gbar[:, :3], gt.grad) < 1e-6
+
+
+_DDP_WORKER = r'''
+import json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.dirname(sys.argv[1]))
+mode = sys.argv[2]                                   # "graph" | "eager"
+from lgm_hip.graph import DDPMFastStep
+from models.generative.diffusion.ddpm import DDPM
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda", 0)
+def make():
+    torch.manual_seed(10)
+    m = DDPM(img_channels=3, img_size=16, dim=16, lr=1e-3, betas=(0.9, 0.99), ema_update_every=2)
+    m.sample_every = 0
+    m.to(dev); m.prepare_hip(dev); m.train()
+    return m
+B = 8
+n = B // world
+g = torch.Generator().manual_seed(3)
+xs = [(torch.rand(B, 3, 16, 16, generator=g) * 2 - 1) for _ in range(3)]
+m = make()
+opt = m.configure_optimizers()
+fast = DDPMFastStep(m, opt, world, use_graph=(mode == "graph"))
+torch.manual_seed(10 + 0)                            # every rank seeds identically (reference train.py:20)
+ref = make() if rank == 0 else None
+ropt = ref.configure_optimizers() if rank == 0 else None
+worst = 0.0
+for i in range(3):
+    xr = xs[i][rank * n:(rank + 1) * n].to(dev)
+    if mode == "graph":
+        fast.step((xr, None), i)
+        t, noise = fast.graphed.t.clone(), fast.graphed.noise.clone()
+    else:
+        # eager path of the same object: inject the draws through p_losses so the twin can replay them
+        t = torch.randint(0, 1000, (n,), device=dev)
+        noise = torch.randn(n, 3, 16, 16, device=dev)
+        net = m.ema.online_model.model
+        net.grad_sync = fast.sync
+        loss = m.ema.online_model.p_losses(xr, t, noise, _normalize=True)
+        loss.backward()
+        fast.sync.finish()
+        opt.step(); opt.zero_grad()
+        m.on_train_batch_end(None, None, i)
+    tl = [torch.empty_like(t.cpu()) for _ in range(world)]
+    nl = [torch.empty_like(noise.cpu()) for _ in range(world)]
+    dist.all_gather(tl, t.cpu()); dist.all_gather(nl, noise.cpu())
+    if rank == 0:                                    # one process, concatenated batch, same draws
+        ropt.zero_grad()
+        l = ref.ema.online_model.p_losses(xs[i].to(dev), torch.cat(tl).to(dev), torch.cat(nl).to(dev), _normalize=True)
+        l.backward()
+        ropt.step()
+        ref.on_train_batch_end(None, None, i)
+mine = m.ema.online_model.model._flat.data.cpu()
+shadow = m.ema.ema_model.model._flat.data.cpu()
+gl = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(gl, mine)
+same = all(torch.equal(gl[0], t) for t in gl)
+if rank == 0:
+    r = ref.ema.online_model.model._flat.data.cpu()
+    rs = ref.ema.ema_model.model._flat.data.cpu()
+    e = float((mine.double() - r.double()).norm() / r.double().norm())
+    es = float((shadow.double() - rs.double()).norm() / rs.double().norm())
+    moved = float((mine - make().ema.online_model.model._flat.data.cpu()).abs().max())
+    print("DDP_RESULT " + json.dumps({"mode": fast.mode, "ranks_identical": same, "rel_err_vs_1rank": e,
+                                      "ema_rel_err": es, "moved": moved}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_two_rank_ddpm_step_equals_one_rank_on_concatenated_batch(dev, tmp_path, mode, parity):
+    """2 ranks (gloo collectives, both on the box's one GPU), per-rank batch 4, three
+    optimizer steps through DDPMFastStep — bucketed all-reduce overlapped with the hand-written backward, 1/N
+    folded into Adam, graph replay or eager launches — equal one process on the concatenated batch of 8 fed the
+    same (t, noise) draws, within fp32 reduction-order tolerance; all ranks hold bit-identical parameters."""
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    port = "29551" if mode == "graph" else "29553"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), PKG, mode],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("DDP_RESULT ")]
+    assert line, r.stdout + r.stderr[-2000:]
+    res = json.loads(line[0][len("DDP_RESULT "):])
+    assert res["ranks_identical"] and res["moved"] > 0
+    if mode == "graph":
+        assert res["mode"].startswith("hipGraph"), res
+    parity(f"2-rank parameters vs 1-rank after 3 steps ({res['mode']})", res["rel_err_vs_1rank"], 1e-5)
+    parity("2-rank EMA shadow vs 1-rank", res["ema_rel_err"], 1e-5)

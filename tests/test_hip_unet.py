@@ -42,36 +42,65 @@ def case(golden_dir, tag):
     return fx, dim, S, P, img, noise, torch.as_tensor(fx["t"])
 
 
-@pytest.mark.parametrize("tag", ["small", "full"])
-def test_unet_matches_reference_fixture(dev, golden_dir, tag):
+@pytest.mark.parametrize("tag", ["small", "full", "full64"])
+def test_unet_matches_reference_fixture(dev, golden_dir, tag, parity):
+    """small: dim 16 @16^2; full: dim 64 @32^2 (BASELINE config 2's network); full64: dim 64 @64^2 (config 5's).
+    Weights incl. RANDOM GroupNorm / RMSNorm affine parameters (oracle.unet_init)."""
     fx, dim, S, P, img, noise, t = case(golden_dir, tag)
     net, gd = build(dim, S, P, dev)
     x_t = torch.as_tensor(fx["x_t"]).to(dev)
     with torch.no_grad():
         out = net(x_t, t.to(dev))
-    assert rel(out, fx["unet_out"]) < RTOL
+    parity("unet_out", rel(out, fx["unet_out"]), RTOL)
     loss = gd.p_losses((img * 2 - 1).to(dev), t.to(dev), noise.to(dev))
-    assert abs(loss.item() - float(fx["loss"])) / float(fx["loss"]) < RTOL
+    parity("loss", abs(loss.item() - float(fx["loss"])) / float(fx["loss"]), RTOL)
     loss.backward()
     sd = dict(net.named_parameters())
-    worst = 0.0
+    worst, worst_n, worst_s = 0.0, 0.0, 0.0
     for k in fx:
         if k.startswith("grad:"):
-            e = rel(sd[k[5:]].grad, fx[k])
-            worst = max(worst, e)
-            assert e < RTOL, (k, e)
+            worst = max(worst, rel(sd[k[5:]].grad, fx[k]))
         elif k.startswith("gradnorm:"):
             n = k[len("gradnorm:"):]
             gn = sd[n].grad.double().norm().item()
-            assert abs(gn - float(fx[k])) / max(float(fx[k]), 1e-12) < RTOL, k
+            worst_n = max(worst_n, abs(gn - float(fx[k])) / max(float(fx[k]), 1e-12))
             flat = sd[n].grad.reshape(-1)
             samp = flat[:: max(1, flat.numel() // 64)][:64]
-            assert rel(samp, fx["gradsample:" + n]) < 5 * RTOL, k
+            worst_s = max(worst_s, rel(samp, fx["gradsample:" + n]))
+    if tag == "small":
+        parity("worst parameter gradient (26 tensors)", worst, RTOL)
+    else:
+        parity("worst parameter gradient norm (26 tensors)", worst_n, RTOL)
+        parity("worst 64-element gradient sample", worst_s, RTOL)
     gn = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in net.parameters())).item()
-    assert abs(gn - float(fx["gradnorm_all"])) / float(fx["gradnorm_all"]) < RTOL
+    parity("all-parameter gradient norm", abs(gn - float(fx["gradnorm_all"])) / float(fx["gradnorm_all"]), RTOL)
 
 
-def test_unet_matches_oracle_fresh_inputs(dev):
+def test_product_schedule_buffers_and_posemb_bit_exact(dev, golden_dir):
+    """The PRODUCT's 13 schedule buffers (not the oracle's) against the reference fixture, bit for bit, on the
+    host and after .to(device); lgm_posemb against the reference's SinusoidalPosEmb rows."""
+    from lgm_hip import ops
+    from models.generative.diffusion.ddpm import GaussianDiffusion, Unet
+    fx = dict(np.load(os.path.join(golden_dir, "diffusion_schedule.npz")))
+    gd = GaussianDiffusion(Unet(dim=16, channels=3), img_size=16, timesteps=1000)
+    idx = torch.as_tensor(fx["idx"])
+    names = [k for k in fx if k + "__sum" in fx]
+    assert len(names) == 13
+    for where in ("cpu", dev):
+        gd.to(where)
+        for name in names:
+            b = getattr(gd, name).cpu()
+            assert np.array_equal(b[idx].numpy(), fx[name]), (name, where)
+            assert b.double().sum().item() == float(fx[name + "__sum"]), (name, where)
+    tt = torch.as_tensor(fx["posemb_t"]).to(dev)
+    pe = torch.empty(tt.shape[0], 64, device=dev)
+    ops.posemb(tt, 64, 10000.0, pe)
+    err = float((pe.cpu() - torch.as_tensor(fx["posemb"])).abs().max())
+    print(f"[parity] posemb vs reference rows: max abs err {err:.2e}")
+    assert err < 1e-6
+
+
+def test_unet_matches_oracle_fresh_inputs(dev, parity):
     """dim 32, 32x32, B=3: every parameter gradient against the oracle's autograd."""
     from oracle import diffusion as OD
     dim, S, B = 32, 32, 3
@@ -86,11 +115,11 @@ def test_unet_matches_oracle_fresh_inputs(dev):
     loss_ref.backward()
     net, gd = build(dim, S, P, dev)
     loss = gd.p_losses(img.to(dev), t.to(dev), noise.to(dev), _normalize=True)
-    assert abs(loss.item() - loss_ref.item()) / loss_ref.item() < RTOL
+    parity("loss", abs(loss.item() - loss_ref.item()) / loss_ref.item(), RTOL)
     loss.backward()
-    for n, p in net.named_parameters():
-        e = rel(p.grad, Pr[n].grad)
-        assert e < 2 * RTOL, (n, e)
+    errs = {n: rel(p.grad, Pr[n].grad) for n, p in net.named_parameters()}
+    wn = max(errs, key=errs.get)
+    parity(f"worst of ALL {len(errs)} parameter gradients ({wn})", errs[wn], RTOL)
     # second backward without zero_grad accumulates (beta = 1 path)
     loss2 = gd.p_losses(img.to(dev), t.to(dev), noise.to(dev), _normalize=True)
     loss2.backward()
@@ -99,7 +128,7 @@ def test_unet_matches_oracle_fresh_inputs(dev):
 
 
 @pytest.mark.parametrize("B", [1, 5])
-def test_full_width_unet_ragged_batches_match_oracle(dev, B):
+def test_full_width_unet_ragged_batches_match_oracle(dev, B, parity):
     """dim 64 (the benchmark network), batches that do not fill the 3x3 kernels' image groups (8 images
     per tile at 4x4, 2 at 8x8): those layers must take the generic path and still match the oracle."""
     from oracle import diffusion as OD
@@ -115,13 +144,14 @@ def test_full_width_unet_ragged_batches_match_oracle(dev, B):
     loss_ref.backward()
     net, gd = build(dim, S, P, dev)
     loss = gd.p_losses(img.to(dev), t.to(dev), noise.to(dev), _normalize=True)
-    assert abs(loss.item() - loss_ref.item()) / loss_ref.item() < RTOL
+    parity("loss", abs(loss.item() - loss_ref.item()) / loss_ref.item(), RTOL)
     loss.backward()
-    worst = max(rel(p.grad, Pr[n].grad) for n, p in net.named_parameters())
-    assert worst < 3 * RTOL, worst
+    errs = {n: rel(p.grad, Pr[n].grad) for n, p in net.named_parameters()}
+    wn = max(errs, key=errs.get)
+    parity(f"worst of ALL {len(errs)} parameter gradients ({wn})", errs[wn], RTOL)
 
 
-def test_sampling_steps_match_reference_fixture(dev, golden_dir):
+def test_sampling_steps_match_reference_fixture(dev, golden_dir, parity):
     from lgm_hip import sampler
     fx, dim, S, P, img, noise, t = case(golden_dir, "small")
     net, gd = build(dim, S, P, dev, sampling_timesteps=50)
@@ -129,30 +159,39 @@ def test_sampling_steps_match_reference_fixture(dev, golden_dir):
     nz = torch.as_tensor(fx["p_sample_noise"]).to(dev)
     ch = sampler._Chain(gd, tuple(x_t.shape), x_t.to(dev))
     sampler.p_sample_step(ch, 500, nz)
-    assert rel(ch.image(False), fx["p_sample_500"]) < RTOL
+    parity("p_sample t=500", rel(ch.image(False), fx["p_sample_500"]), RTOL)
     ch = sampler._Chain(gd, tuple(x_t.shape), x_t.to(dev))
     sampler.p_sample_step(ch, 0, nz)
-    assert rel(ch.image(False), fx["p_sample_0"]) < RTOL
+    parity("p_sample t=0", rel(ch.image(False), fx["p_sample_0"]), RTOL)
     ch = sampler._Chain(gd, tuple(x_t.shape), x_t.to(dev))
     sampler.ddim_step(ch, 999, 979, None, 0.0)
-    assert rel(ch.image(False), fx["ddim_999_979"]) < RTOL
+    parity("ddim 999->979", rel(ch.image(False), fx["ddim_999_979"]), RTOL)
     # DDIM index lists are bit-exact with the reference's (tests/golden/diffusion_schedule.npz)
     sch = dict(np.load(os.path.join(golden_dir, "diffusion_schedule.npz")))
     pairs = gd.ddim_time_pairs()
     assert [pairs[0][0]] + [p[1] for p in pairs] == sch["ddim_times_50"].tolist()
-    # a short deterministic chain end-to-end against the oracle (eta = 0)
+
+
+def test_whole_sampling_loops_match_reference_fixture(dev, golden_dir, parity):
+    """The complete loops (reference ddpm.py:759-780 and :782-834) against images the REFERENCE returned:
+    the 50-pair DDIM chain (eta = 0) and a 200-step ancestral chain, replaying the reference's CPU-generator
+    draws (start image + one noise tensor per step)."""
+    from lgm_hip import sampler
     from oracle import diffusion as OD
-    bufs = OD.diffusion_buffers(1000)
-    x = x_t.clone()
-    ch = sampler._Chain(gd, tuple(x_t.shape), x_t.to(dev))
-    with torch.no_grad():
-        for (a, b) in pairs[:3]:
-            x, _ = OD.ddim_step(P, bufs, x, a, b, torch.zeros_like(x), dim=dim)
-            sampler.ddim_step(ch, a, b, None, 0.0)
-    assert rel(ch.image(False), x) < 5 * RTOL
+    fx, dim, S, P, img, noise, t = case(golden_dir, "small")
+    shape = tuple(fx["x_t"].shape)
+    net, gd = build(dim, S, P, dev, sampling_timesteps=50)
+    init, nz = OD.draw_loop_noise(int(fx["ddim_loop_seed"]), shape, 49)
+    out = sampler.ddim_sample(gd, shape, init_noise=init.to(dev), noises=[n.to(dev) for n in nz] + [None])
+    parity("50-pair DDIM loop, final image", rel(out, fx["ddim_loop_50"]), RTOL)
+    from models.generative.diffusion.ddpm import GaussianDiffusion
+    gd_a = GaussianDiffusion(net, img_size=S, timesteps=200).to(dev)
+    init, nz = OD.draw_loop_noise(int(fx["p_sample_loop_seed"]), shape, 199)
+    out = sampler.p_sample_loop(gd_a, shape, init_noise=init.to(dev), noises=[n.to(dev) for n in nz] + [None])
+    parity("200-step ancestral loop, final image", rel(out, fx["p_sample_loop_200"]), RTOL)
 
 
-def test_ddpm_module_training_steps(dev):
+def test_ddpm_module_training_steps(dev, parity):
     """LightningModule surface: training_step -> backward -> FusedAdam.step -> EMA, 3 steps,
     against the oracle + torch.optim.Adam on CPU."""
     from models.generative.diffusion.ddpm import DDPM
@@ -185,11 +224,11 @@ def test_ddpm_module_training_steps(dev):
         lr = OD.diffusion_forward(Pr, bufs, img, t, noise, dim=16)
         lr.backward()
         ref_opt.step()
-        assert abs(loss.item() - lr.item()) / lr.item() < 5 * RTOL, step
+        parity(f"loss at step {step}", abs(loss.item() - lr.item()) / lr.item(), RTOL)
     sd = m.ema.online_model.model.state_dict()
     for k in ("init_conv.weight", "downs.0.0.block1.proj.weight", "mid_attn.mem_kv", "final_conv.bias",
               "ups.1.2.to_out.1.g", "time_mlp.3.weight", "downs.2.1.mlp.1.bias"):
-        assert rel(sd[k], Pr[k]) < 5 * RTOL, k
+        parity(f"parameter after 3 Adam steps: {k}", rel(sd[k], Pr[k]), RTOL)
     # EMA shadow == the online weights at the last executed update (hard copy during warm-up)
     assert rel(m.ema.ema_model.model.state_dict()["init_conv.weight"], snap) < 1e-6
     # the stock training_step path (random t / noise on device) runs and returns a finite scalar

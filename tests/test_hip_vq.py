@@ -38,11 +38,10 @@ def test_vq_kernels_match_reference_fixture(dev, golden_dir):
     md = torch.empty(N, device=dev)
     L.lgm_vq_assign(xd.data_ptr(), D, cbd.data_ptr(), N, K, D, idx.data_ptr(), md.data_ptr(), ops.stream())
     ref_idx = torch.as_tensor(fx["indices"])
-    mism = (idx.cpu() != ref_idx)
-    # bit-exact wherever the reference's own top-2 margin is above fp32 rounding noise
-    margin = torch.as_tensor(fx["margin"])
-    assert int((mism & (margin > 1e-7)).sum()) == 0, f"{int(mism.sum())} index mismatches"
-    assert int(mism.sum()) == 0 or float(margin[mism].max()) <= 1e-7
+    # bit-exact, unconditionally: the smallest top-2 margin among the fixture's 128 rows is 4.6e-7 (0 rows at
+    # or under 1e-7), four orders of magnitude above the rounding noise of a distance of ~1e-4
+    assert float(torch.as_tensor(fx["margin"]).min()) > 1e-7
+    assert torch.equal(idx.cpu(), ref_idx), f"{int((idx.cpu() != ref_idx).sum())} index mismatches"
     dw, counts = torch.empty(K, D, device=dev), torch.empty(K, device=dev)
     L.lgm_vq_segment_sum(xd.data_ptr(), D, idx.data_ptr(), N, K, D, dw.data_ptr(), counts.data_ptr(), ops.stream())
     onehot = torch.nn.functional.one_hot(ref_idx, K).float()
@@ -82,7 +81,7 @@ def test_vq_kernels_match_reference_fixture(dev, golden_dir):
 
 
 @pytest.mark.parametrize("tag", ["plain", "ema"])
-def test_vqvae_training_step_matches_reference_fixture(dev, golden_dir, tag):
+def test_vqvae_training_step_matches_reference_fixture(dev, golden_dir, tag, parity):
     from models.generative.vae.vqvae import VQVAE
     from oracle import vq as OV
     fx = dict(np.load(os.path.join(golden_dir, "vq.npz")))
@@ -102,12 +101,12 @@ def test_vqvae_training_step_matches_reference_fixture(dev, golden_dir, tag):
     gx = torch.Generator().manual_seed(12)
     x = torch.rand(4, 3, 32, 32, generator=gx) * 2 - 1
     loss = m.training_step((x.to(dev), None), 0)
-    assert rel(m.last["latents"].permute(0, 3, 1, 2), fx[f"vqvae_{tag}_latents"]) < RTOL
-    assert abs(loss.item() - float(fx[f"vqvae_{tag}_loss"])) / float(fx[f"vqvae_{tag}_loss"]) < RTOL
+    parity("encoder latents", rel(m.last["latents"].permute(0, 3, 1, 2), fx[f"vqvae_{tag}_latents"]), RTOL)
+    parity("loss", abs(loss.item() - float(fx[f"vqvae_{tag}_loss"])) / float(fx[f"vqvae_{tag}_loss"]), RTOL)
     loss.backward()
     gn = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in m.parameters())).item()
-    assert abs(gn - float(fx[f"vqvae_{tag}_gradnorm"])) / float(fx[f"vqvae_{tag}_gradnorm"]) < 2 * RTOL
-    assert rel(m.encoder.layers[0].weight.grad, fx[f"vqvae_{tag}_grad_enc0"]) < 2 * RTOL
+    parity("all-parameter gradient norm", abs(gn - float(fx[f"vqvae_{tag}_gradnorm"])) / float(fx[f"vqvae_{tag}_gradnorm"]), RTOL)
+    parity("encoder.layers.0.weight gradient", rel(m.encoder.layers[0].weight.grad, fx[f"vqvae_{tag}_grad_enc0"]), RTOL)
     # optimizer step runs on the flat storage
     opt = m.configure_optimizers()
     opt.step()

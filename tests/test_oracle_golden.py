@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import diffusion as OD
@@ -85,8 +86,9 @@ def test_unet_small_forward_backward(golden_dir):
     assert abs(gn - float(fx["gradnorm_all"])) / float(fx["gradnorm_all"]) < RTOL
 
 
-def test_unet_full_forward_backward(golden_dir):
-    fx, dim, P, img, noise, t = _unet_case(golden_dir, "full")
+@pytest.mark.parametrize("tag", ["full", "full64"])
+def test_unet_full_forward_backward(golden_dir, tag):
+    fx, dim, P, img, noise, t = _unet_case(golden_dir, tag)
     bufs = OD.diffusion_buffers(1000)
     for p in P.values():
         p.requires_grad_(True)
@@ -119,6 +121,22 @@ def test_sampling_steps(golden_dir):
         assert rel_err(img0, fx["p_sample_0"]) < RTOL
         nxt, _ = OD.ddim_step(P, bufs, x_t, 999, 979, torch.zeros_like(x_t), dim=dim)
         assert rel_err(nxt, fx["ddim_999_979"]) < RTOL
+
+
+def test_sampling_loops_match_reference(golden_dir):
+    """Whole loops of the reference (50-pair DDIM chain, 200-step ancestral chain) replayed by the oracle from
+    the same CPU-generator draws."""
+    fx, dim, P, img, noise, t = _unet_case(golden_dir, "small")
+    shape = tuple(fx["x_t"].shape)
+    with torch.no_grad():
+        init, nz = OD.draw_loop_noise(int(fx["ddim_loop_seed"]), shape, 49)
+        out = OD.ddim_sample_loop(P, OD.diffusion_buffers(1000), init, nz, 50, dim=dim)
+        e1 = rel_err(out, fx["ddim_loop_50"])
+        init, nz = OD.draw_loop_noise(int(fx["p_sample_loop_seed"]), shape, 199)
+        out = OD.p_sample_loop(P, OD.diffusion_buffers(200), init, nz, dim=dim)
+        e2 = rel_err(out, fx["p_sample_loop_200"])
+    print(f"oracle loops vs reference: ddim50 {e1:.2e} ancestral200 {e2:.2e}")
+    assert e1 < RTOL and e2 < RTOL
 
 
 def test_vq_quantizer(golden_dir):
