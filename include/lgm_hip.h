@@ -331,6 +331,28 @@ int lgm_conv3x3_bf16x3(int mode, const LgmConvGeom* g, const float* a, int64_t a
                        int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Winograd F(2x2, 3x3) convolution in exact fp32 arithmetic (csrc/winograd.hip): the 3x3 / stride 1 / pad 1
+ * layers (Block.proj ddpm.py:160-171, Upsample's conv :93-97, the last stages' 3x3 convs :377,413) and their
+ * input gradients with 2.25x fewer MFMA FLOPs than the direct form.  Same contract as lgm_conv_xy (yx = 0) /
+ * lgm_conv_yx (yx = 1) except that the weights are passed TRANSFORMED: U = G g G^T in MFMA fragment order, as
+ * lgm_wino_weights writes them.
+ *   lgm_wino_weights: table rows (int64 x 6) = source offset (floats) of a slot w[Np][9][Cp] inside `src`,
+ *   Np, Cp (both multiples of 32), destination offset of the forward operand inside dst_f (Np*Cp*16 floats,
+ *   layout [Np/32][Cp/8][16][2][32][4]), destination offset of the input-gradient operand inside dst_b
+ *   (mirrored taps, roles of Np / Cp swapped), first block; one block per 32 x 32 (n, c) tile, total_blocks =
+ *   sum Np/32 * Cp/32.  Either destination may be NULL.
+ * ------------------------------------------------------------------------------------- */
+int64_t lgm_conv3x3_wino_supported(const LgmConvGeom* g, int yx);   /* 1 / 0 */
+int64_t lgm_conv3x3_wino_workspace(const LgmConvGeom* g, int yx);   /* split-K partial outputs (bytes) */
+int lgm_wino_weights(const float* src, float* dst_f, float* dst_b, const int64_t* table, int n_slots,
+                     int64_t total_blocks, void* stream);
+/* diagnostic only: buf != NULL makes lgm_conv3x3_wino run its cycle-stamped build (64 int64 per workgroup) */
+int lgm_wino_set_debug_buffer(void* buf, int mode);
+int lgm_conv3x3_wino(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,
+                     const float* bias, const float* res, int64_t res_pitch, float* out, int64_t out_pitch,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimiser kernels on flat storage.
  * torch.optim.Adam (coupled L2; decoupled=1 gives AdamW) — ddpm.py:1053-1059, vqvae.py:207-214,
  * wgan.py:183-195.  step: 1-based count (host value, or read from step_dev when non-NULL).
