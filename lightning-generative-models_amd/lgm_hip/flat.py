@@ -90,6 +90,9 @@ class FlatParams:
         self._t_table = None
         # opt-in split-precision convolutions (LGM_CONV_MODE=bf16x3): three bf16 planes of the weights
         # (forward layout) and of their transposed copies, in MFMA fragment order
+        self.wino = False           # Winograd-transformed 3x3 weights (see enable_wino)
+        self.data_uf = None
+        self.data_ub = None
         self.b3 = False
         self.planes = None
         self.planes_t = None
@@ -117,6 +120,43 @@ class FlatParams:
                                         self._t_table.shape[0], self._t_blocks, ops.stream())
         if self.b3:
             self._refresh_split_t()
+
+    # -- Winograd-transformed 3x3 weights (csrc/winograd.hip) -----------------------------------
+    def enable_wino(self):
+        """Allocate the transformed copies U = G g G^T of every 3x3 weight slot whose (padded) channel counts
+        are multiples of 32: forward operand and input-gradient operand, 16/9 of the slot each.
+        ``refresh_wino`` rewrites them from the current weights in ONE launch."""
+        from . import ops
+        if self.wino:
+            return
+        rows, off, blk = [], 0, 0
+        self._wino_off = {}
+        for s in self.slots:
+            if s.kind != "weight":
+                continue
+            Np, T, Cp = s.phys_shape
+            if T == 9 and Np % 32 == 0 and Cp % 32 == 0:
+                rows.append([s.offset, Np, Cp, off, off, blk])
+                self._wino_off[s.offset] = off
+                off += Np * Cp * 16
+                blk += (Np // 32) * (Cp // 32)
+        if not rows:
+            return
+        self._wino_table = torch.tensor(rows, dtype=torch.int64, device=self.device).contiguous()
+        self._wino_blocks = blk
+        self.data_uf = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.data_ub = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.wino = True
+        ops.register_wino_flat(self)
+
+    def refresh_wino(self, backward_operand: bool = True):
+        """Transformed copies of the CURRENT weights (call once per forward pass: the optimizer moved them)."""
+        from . import ops
+        if not self.wino:
+            return
+        ops.lib().lgm_wino_weights(self.data.data_ptr(), self.data_uf.data_ptr(),
+                                   self.data_ub.data_ptr() if backward_operand else None, self._wino_table.data_ptr(),
+                                   self._wino_table.shape[0], self._wino_blocks, ops.stream())
 
     # -- split-precision planes ---------------------------------------------------------------
     def enable_b3(self):

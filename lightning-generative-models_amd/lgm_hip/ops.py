@@ -163,6 +163,59 @@ def _b3_supported(g: ConvGeom, mode: int, a_pitch: int) -> bool:
     return v
 
 
+# Winograd F(2x2,3x3) for the 3x3 / stride 1 / pad 1 layers (exact fp32 arithmetic, 2.25x fewer MFMA FLOPs): the
+# default for flats that called enable_wino(); LGM_NO_WINO=1 routes them through the direct fp32 MFMA kernels.
+WINO = _os.environ.get("LGM_NO_WINO", "0") != "1"
+_WINO_FLATS = []
+_WINO_OK = {}
+_WINO_WS = {}
+
+
+def register_wino_flat(fp):
+    _WINO_FLATS.append(fp)
+
+
+def _wino_u(w_ptr: Optional[int], backward: bool):
+    """-> address of the transformed copy of the 3x3 weight slot at ``w_ptr`` (a registered flat buffer), or None"""
+    if w_ptr is None:
+        return None
+    for fp in _WINO_FLATS:
+        off = w_ptr - fp.data.data_ptr()
+        if 0 <= off < 4 * fp.total:
+            uo = fp._wino_off.get(off // 4) if off % 4 == 0 else None
+            if uo is None:
+                return None
+            return (fp.data_ub if backward else fp.data_uf).data_ptr() + 4 * uo
+    return None
+
+
+def _wino_supported(g: ConvGeom, yx: int) -> bool:
+    key = (g.B, g.H, g.W, g.Cw, g.Nw, g.KH, g.KW, g.stride, g.pad, yx)
+    v = _WINO_OK.get(key)
+    if v is None:
+        v = bool(g.KH == 3 and g.KW == 3 and lib().lgm_conv3x3_wino_supported(ctypes.byref(g), yx))
+        _WINO_OK[key] = v
+    return v
+
+
+def _wino_call(yx: int, g: ConvGeom, a, u_ptr: int, bias_ptr, res, out) -> bool:
+    """Launch the Winograd kernel when the operands qualify (16-byte aligned, pitch % 4); False = not taken."""
+    if a.data_ptr() % 16 or out.data_ptr() % 16 or pitch(a) % 4 or pitch(out) % 4 or (bias_ptr or 0) % 16:
+        return False
+    if res is not None and (res.data_ptr() % 16 or pitch(res) % 4):
+        return False
+    key = (g.B, g.H, g.W, g.Cw, g.Nw, yx)
+    n = _WINO_WS.get(key)
+    if n is None:
+        n = lib().lgm_conv3x3_wino_workspace(ctypes.byref(g), yx)
+        _WINO_WS[key] = n
+    ws = workspace(n, a.device) if n > 0 else None
+    lib().lgm_conv3x3_wino(yx, ctypes.byref(g), a.data_ptr(), pitch(a), u_ptr, bias_ptr, _p(res),
+                           pitch(res) if res is not None else 0, out.data_ptr(), pitch(out),
+                           None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
+    return True
+
+
 def _conv_ws(g: ConvGeom, yx: int, device):
     key = (g.B, g.H, g.W, g.Cw, g.Nw, g.KH, g.stride, g.pad, yx)
     n = _CONV_WS_BYTES.get(key)
@@ -175,6 +228,12 @@ def _conv_ws(g: ConvGeom, yx: int, device):
 def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
     if TIMER is not None:
         TIMER.begin("igemm_xy", _conv_flops(g), _conv_bytes(g))
+    if WINO and _WINO_FLATS and not B3 and _wino_supported(g, 0):
+        u = _wino_u(w_ptr, False)
+        if u is not None and _wino_call(0, g, x, u, bias_ptr, res, y):
+            if TIMER is not None:
+                TIMER.end()
+            return
     ws = _conv_ws(g, 0, x.device)
     pl = _b3_planes(w_ptr, False) if (B3 and _b3_supported(g, 0, pitch(x))) else None
     if pl is not None:
@@ -192,6 +251,12 @@ def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
 def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr: Optional[int] = None):
     if TIMER is not None:
         TIMER.begin("igemm_yx", _conv_flops(g), _conv_bytes(g))
+    if WINO and _WINO_FLATS and not B3 and _wino_supported(g, 1):
+        u = _wino_u(w_ptr, True)
+        if u is not None and _wino_call(1, g, y, u, bias_ptr, res, x):
+            if TIMER is not None:
+                TIMER.end()
+            return
     ws = _conv_ws(g, 1, y.device)
     pl = _b3_planes(wt_ptr, True) if (B3 and wt_ptr is not None and _b3_supported(g, 1, pitch(y))) else None
     if pl is not None:

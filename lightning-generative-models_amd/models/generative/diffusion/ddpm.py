@@ -311,6 +311,8 @@ class Unet(nn.Module):
         self._flat = FlatParams(first + rest, device)
         if ops.B3:                     # opt-in split-precision 3x3 convolutions (LGM_CONV_MODE=bf16x3)
             self._flat.enable_b3()
+        elif ops.WINO:                 # Winograd F(2x2,3x3) in exact fp32 arithmetic for the 3x3 layers
+            self._flat.enable_wino()
         # gradient-exchange buckets in backward completion order: [ups, mid, final] -> [init_conv, downs]
         # -> [FiLM + time MLP]  (registration order of `rest`: init_conv, downs, ups, mid_*, final_*)
         slots = {s.name: s for s in self._flat.slots}
@@ -389,6 +391,8 @@ class Unet(nn.Module):
         assert S % (2 ** (n - 1)) == 0, f"input size {S} must be divisible by {2 ** (n - 1)}"
         if self._flat.b3:
             self._flat.refresh_split()      # bf16 planes of the current weights (one launch)
+        if self._flat.wino:
+            self._flat.refresh_wino(backward_operand=save)   # U = G g G^T of the current weights (one launch)
         ss_all, time_saved = self._time_fwd(t, save)
         ssl = [ss_all[:, o:o + 2 * rb.dim_out] for o, rb in zip(self._ss_offsets, self.resblocks())]
         k = 0  # running resblock index
