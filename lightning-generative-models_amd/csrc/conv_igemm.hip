@@ -34,6 +34,16 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
                         float* out, float* bias_out, float beta, long slab, int splits, int tps, int total_ts,
                         hipStream_t s);
 
+// Winograd F(2x2,3x3) weight gradient (winograd.hip): always through slabs + the fixed-order reducer
+bool lgm_wino_wgrad_supported(const LgmConvGeom* g);
+void lgm_wino_wgrad_plan(const LgmConvGeom* g, int* splits, int* cps, int* total_chunks);
+int lgm_wino_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch, float* out,
+                          int bias, long slab, int splits, int cps, int total_chunks, hipStream_t s);
+static bool use_wino() {      // LGM_NO_WINO=1: direct fp32 MFMA kernels for the 3x3 layers (A/B comparisons)
+  static const bool off = getenv("LGM_NO_WINO") != nullptr && getenv("LGM_NO_WINO")[0] == '1';
+  return !off;
+}
+
 // 1x1 convolutions with a resident weight slice, X streamed (gemm_stream.hip)
 bool lgm_gemm_stream_supported(long M, int N, int K, long x_pitch, long out_pitch, long res_pitch);
 int lgm_gemm_stream_launch(const float* x, long x_pitch, const float* w, const float* bias, const float* res,
@@ -947,6 +957,11 @@ extern "C" int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g) {
     lgm_wgrad3x3_plan(g, &s3, &tps, &total);
     if (s3 > splits) splits = s3;
   }
+  if (use_3x3() && use_wino() && lgm_wino_wgrad_supported(g)) {
+    int sw, cps, total;
+    lgm_wino_wgrad_plan(g, &sw, &cps, &total);
+    if (sw > splits) splits = sw;
+  }
   if (g->KH == 1 && g->KW == 1 && g->Nw % 64 == 0 && g->Cw % 64 == 0) {
     int s1, per;
     lgm_wgrad1x1_plan(g, &s1, &per);
@@ -977,8 +992,13 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
                      (long)g->B * g->H * g->W * y_pitch < (1L << 29);
   static const bool no_w1x1 = getenv("LGM_NO_W1X1") != nullptr;   // A/B switch
   const bool fast1 = !fast3 && !no_w1x1 && lgm_wgrad1x1_supported(g, y_pitch, x_pitch);
-  int tps3 = 0, total3 = 0, per1 = 0;
-  if (fast3)
+  // Winograd: same operand limits as the direct 3x3 kernel; a gradient accumulated into existing values with the
+  // slabs bypassed (beta != 0 without a descriptor) is left to the direct kernel
+  const bool fastw = fast3 && use_wino() && lgm_wino_wgrad_supported(g);
+  int tps3 = 0, total3 = 0, per1 = 0, cpsw = 0, totalw = 0;
+  if (fastw)
+    lgm_wino_wgrad_plan(g, &a.splits, &cpsw, &totalw);
+  else if (fast3)
     lgm_wgrad3x3_plan(g, &a.splits, &tps3, &total3);
   else if (fast1)
     lgm_wgrad1x1_plan(g, &a.splits, &per1);
@@ -998,7 +1018,10 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
   a.tiles_m = lgm_cdiv(a.Nw, 64);
   a.tiles_n = lgm_cdiv(a.Q, 64);
   hipStream_t s = (hipStream_t)stream;
-  if (fast3) {
+  if (fastw) {
+    if (int rc = lgm_wino_wgrad_launch(g, y, y_pitch, x, x_pitch, a.out, gbias ? 1 : 0, a.slab, a.splits, cpsw, totalw, s))
+      return rc;
+  } else if (fast3) {
     if (int rc = lgm_wgrad3x3_launch(g, y, y_pitch, x, x_pitch, a.out, a.bias_out, beta, a.slab, a.splits, tps3,
                                      total3, s))
       return rc;

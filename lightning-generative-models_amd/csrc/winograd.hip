@@ -829,3 +829,457 @@ extern "C" int lgm_conv3x3_wino(int yx, const LgmConvGeom* g, const float* a, in
   return lgm_wino_launch(g, yx, a, a_pitch, u, bias, res, res_pitch, out, out_pitch, workspace, workspace_bytes,
                          (hipStream_t)stream);
 }
+
+// =====================================================================================================
+// Winograd weight gradient:  dU[xi][n][c] = sum_tiles dYt[xi][tile][n] * Xt[xi][tile][c],  gW = G^T dU G
+//   Xt = B^T d B of the 4x4 input tile (as in the forward kernel), dYt = A dY A^T of the 2x2 output-gradient tile:
+// 16 MFMAs per pair of tiles (8 output pixels) instead of 9 per pair of pixels.  The contraction index is the
+// TILE, so a lane's operand fragment is 4 tiles of ONE channel: the raw patches are staged in LDS channel-major
+// with the four tiles of a fragment contiguous ([channel][row][column mod 4][tile slot], rows padded to 100 / 36
+// floats: conflict-free ds_read_b128), and every lane transforms its own fragments in registers.
+//
+// A CHUNK = 8 tiles = 2 tile rows (the MFMA's two k values) x 4 slots: tiles tx = p, p+2, p+4, p+6 (parity p) of a
+// 16-pixel column group on the large maps, 2 slots x 2 images at 8x8, 1 slot x 4 images at 4x4 -- taking every
+// second tile keeps the four slots 4 pixel columns apart, so one 16-byte LDS row holds the same tile element of
+// all four.  A workgroup = 64 output channels x 64 input channels x a range of chunks (split-K); it writes one
+// slab [Nw][9][Cw] (+ bias partials) that the fixed-order slab reducer (lgm_wgrad_reduce_batch) sums.
+// Signs: the kernel builds dYt with row / column 3 negated (saves the negations); (G^T dU G) absorbs them.
+// =====================================================================================================
+namespace lgmwino {
+
+struct WGArgs {
+  const float* y;
+  const float* x;
+  float* out;          // slabs: split k at out + k * slab
+  int bias;            // 1: column sums of y into slab[n_w + n]
+  long slab, y_pitch, x_pitch;
+  int B, H, W, Nw, Cw;
+  int tiles_c, splits, cps, total_chunks;
+  int rpn, cgn;        // tile-row pairs per image (H / 4), 16-pixel column groups per row (W / 16, or 1)
+  long long* dbg;      // diagnostic build only: cycle stamps (start, after the prologue, after every phase, end)
+};
+
+template <int G>
+struct WGeo {
+  static constexpr int IPC = G == 8 ? 1 : G == 4 ? 2 : 4;   // images per chunk
+  static constexpr int XC = 16 / IPC;                        // patch columns per image
+  static constexpr int SPI = 4 / IPC;                        // tile slots per image
+};
+
+constexpr int XLD = 100;    // floats per input channel in an X buffer  (6 rows x 4 x 4, padded)
+constexpr int YLD = 36;     // floats per output channel in a Y buffer (4 rows x 2 x 4, padded)
+constexpr int WXBUF = 64 * XLD, WYBUF = 64 * YLD, WBUF = WXBUF + WYBUF;
+
+template <int G, bool DBG = false>
+__global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WGArgs p) {
+  int nstamp = 0;
+  auto stamp = [&]() {
+    if (DBG) {
+      if (threadIdx.x == 0 && nstamp < 62) p.dbg[blockIdx.x * 64 + 2 + nstamp] = (long long)__builtin_amdgcn_s_memtime();
+      ++nstamp;
+    }
+  };
+  stamp();
+  using GE = WGeo<G>;
+  constexpr int IPC = GE::IPC, XC = GE::XC, SPI = GE::SPI;
+  extern __shared__ __align__(16) float smem[];    // 3 x (X buffer, Y buffer)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wa = wid & 1, wb = wid >> 1;            // input-channel half (A operand), output-channel half (B)
+  const int lr = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int split = bid % p.splits;
+  bid /= p.splits;
+  const int tc = bid % p.tiles_c, tn = bid / p.tiles_c;
+  const int n0 = tn * 64, c0 = tc * 64;
+  const int ch_begin = split * p.cps;
+  const int ch_end = min(p.total_chunks, ch_begin + p.cps);
+
+  // ---- raw patch slots of this thread: X 6 x (position, channel quad), Y 2 x ----
+  const int q4 = (tid & 15) * 4;                    // first channel of the thread's quad
+  unsigned xdelta[6], xlds[6], ydelta[2], ylds[2];
+  unsigned xflag = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int pos = (tid >> 4) + 16 * j;            // (il, rho, colidx), 96 positions
+    const int il = pos / (6 * XC), rem = pos - il * 6 * XC;
+    const int rho = rem / XC, ci = rem - rho * XC;
+    xdelta[j] = (unsigned)(((il * p.H + rho) * p.W + ci) * (int)p.x_pitch + q4) * 4u;
+    const int s = il * SPI + (ci >> 2);
+    xlds[j] = (unsigned)(q4 * XLD + rho * 16 + (ci & 3) * 4 + s);
+    const unsigned f = (rho == 0 ? 1u : 0u) | (rho == 5 ? 2u : 0u) | (ci == 0 ? 4u : 0u) | (ci == XC - 1 ? 8u : 0u);
+    xflag |= f << (4 * j);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pos = (tid >> 4) + 16 * j;            // ((il * 4 + row) * SPI + sl) * 2 + dx, 32 positions
+    const int dx = pos & 1, t = pos >> 1;
+    const int sl = t % SPI, t2 = t / SPI;
+    const int row = t2 & 3, il = t2 >> 2;
+    ydelta[j] = (unsigned)(((il * p.H + row) * p.W + 4 * sl + dx) * (int)p.y_pitch + q4) * 4u;
+    ylds[j] = (unsigned)(q4 * YLD + row * 8 + dx * 4 + il * SPI + sl);
+  }
+  const long pixels = (long)p.B * p.H * p.W;
+  const unsigned nrec_y = (unsigned)((pixels * p.y_pitch - n0) * 4);
+  const unsigned nrec_x = (unsigned)(((pixels + p.W + 1) * p.x_pitch - c0) * 4);
+  auto make_rsrc = [](const float* base, unsigned nrec) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(p.y + n0, nrec_y);
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(p.x + c0 - (long)(p.W + 1) * p.x_pitch, nrec_x);
+
+  // chunk -> scalar offsets of its origin (image, row 4 rp, column c0px = 16 cg + 2 par) and its border mask
+  struct Ch {
+    unsigned sx, sy, border;
+  };
+  auto chunk = [&](int ch) -> Ch {
+    Ch c;
+    if (ch >= ch_end) {                             // past the range: every load falls out of both descriptors
+      c.sx = c.sy = 0x80000000u;
+      c.border = 0u;
+      return c;
+    }
+    const int par = ch & 1;
+    int t = ch >> 1;
+    const int cg = t % p.cgn;
+    t /= p.cgn;
+    const int rp = t % p.rpn;
+    const int img0 = (t / p.rpn) * IPC;
+    const unsigned pix = (unsigned)((img0 * p.H + 4 * rp) * p.W + 16 * cg + 2 * par);
+    c.sx = pix * (unsigned)p.x_pitch * 4u;
+    c.sy = pix * (unsigned)p.y_pitch * 4u;
+    c.border = (rp == 0 ? 1u : 0u) | (rp == p.rpn - 1 ? 2u : 0u) | (par == 0 && cg == 0 ? 4u : 0u) |
+               (par == 1 && cg == p.cgn - 1 ? 8u : 0u);
+    return c;
+  };
+  u32x4 rx[6], ry[2];
+  auto fetch_x = [&](int j, const Ch& c) {
+    const bool ok = ((xflag >> (4 * j)) & c.border & 15u) == 0u;
+    rx[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? xdelta[j] : nrec_x, c.sx, 0);
+  };
+  auto fetch_y = [&](int j, const Ch& c) { ry[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, ydelta[j], c.sy, 0); };
+  // (whole-vector bit_cast first: a per-element bit_cast of a loaded vector fed straight into a store wrote
+  // element 0 four times, ROCm 7.2 hipcc)
+  auto commit_x = [&](int j, float* buf) {
+    const f32x4 f = __builtin_bit_cast(f32x4, rx[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) buf[xlds[j] + i * XLD] = f[i];
+  };
+  auto commit_y = [&](int j, float* buf) {
+    const f32x4 f = __builtin_bit_cast(f32x4, ry[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) buf[WXBUF + ylds[j] + i * YLD] = f[i];
+  };
+
+  // ---- fragment builders: lane = (channel lr of its half, tile row lh); a fragment = the 4 tile slots ----
+  const int xrd = (wa * 32 + lr) * XLD + lh * 32;            // + (r * 16 + c * 4): element d[r][c] of the tile
+  const int yrd = WXBUF + (wb * 32 + lr) * YLD + lh * 16;    // + (dy * 8 + dx * 4)
+  f32x4 Xf[2][8], Yf[2][8];
+  f32x4 tq0[4], tq1[4], ec[2][3];
+  auto xr_read = [&](const float* buf, int hrow, int c, int k) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) ec[k][r] = *reinterpret_cast<const f32x4*>(buf + xrd + ((hrow + r) * 16 + c * 4));
+  };
+  auto xr_rows = [&](int hrow, int c, int k) {
+    if (hrow == 0) {
+      tq0[c] = sub4(ec[k][0], ec[k][2]);
+      tq1[c] = add4(ec[k][1], ec[k][2]);
+    } else {
+      tq0[c] = sub4(ec[k][1], ec[k][0]);
+      tq1[c] = sub4(ec[k][0], ec[k][2]);
+    }
+  };
+  auto xr_out = [&](int hrow, int o) {
+    const f32x4* t = (o >> 2) ? tq1 : tq0;
+    f32x4 v;
+    if ((o & 3) == 0) v = sub4(t[0], t[2]);
+    else if ((o & 3) == 1) v = add4(t[1], t[2]);
+    else if ((o & 3) == 2) v = sub4(t[2], t[1]);
+    else v = sub4(t[1], t[3]);
+    Xf[hrow][o] = v;
+  };
+  // dYt' (row / column 3 not negated): rows 0,1 = (y0, y0 + y1), rows 2,3' = (y0 - y1, y1); each row (a, b) -> a, a+b, a-b, b
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  auto y_build = [&](const float* buf, int hrow) {
+    const f32x4 y00 = *reinterpret_cast<const f32x4*>(buf + yrd), y01 = *reinterpret_cast<const f32x4*>(buf + yrd + 4),
+                y10 = *reinterpret_cast<const f32x4*>(buf + yrd + 8), y11 = *reinterpret_cast<const f32x4*>(buf + yrd + 12);
+    f32x4 a0, b0, a1, b1;
+    if (hrow == 0) {
+      a0 = y00; b0 = y01;
+      a1 = add4(y00, y10); b1 = add4(y01, y11);
+    } else {
+      a0 = sub4(y00, y10); b0 = sub4(y01, y11);
+      a1 = y10; b1 = y11;
+    }
+    Yf[hrow][0] = a0; Yf[hrow][1] = add4(a0, b0); Yf[hrow][2] = sub4(a0, b0); Yf[hrow][3] = b0;
+    Yf[hrow][4] = a1; Yf[hrow][5] = add4(a1, b1); Yf[hrow][6] = sub4(a1, b1); Yf[hrow][7] = b1;
+    // column sums of y (bias gradient): y00 + y01 is fragment 1 of rows 0,1; y10 + y11 fragment 5 of rows 2,3'
+    bsum = add4(bsum, hrow == 0 ? Yf[0][1] : Yf[1][5]);
+  };
+
+  // ---- prologue: raw[ch0] -> buffer 0, raw[ch0 + 1] -> buffer 1, raw[ch0 + 2] in registers ----
+  {
+    const Ch c0c = chunk(ch_begin), c1c = chunk(ch_begin + 1), c2c = chunk(ch_begin + 2);
+    u32x4 tx[6], ty[2];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) fetch_x(j, c0c);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fetch_y(j, c0c);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) tx[j] = rx[j];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ty[j] = ry[j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) fetch_x(j, c1c);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fetch_y(j, c1c);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const f32x4 f = __builtin_bit_cast(f32x4, tx[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) smem[xlds[j] + i * XLD] = f[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 f = __builtin_bit_cast(f32x4, ty[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) smem[WXBUF + ylds[j] + i * YLD] = f[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) commit_x(j, smem + WBUF);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) commit_y(j, smem + WBUF);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) fetch_x(j, c2c);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fetch_y(j, c2c);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    xr_read(smem, 0, c, c & 1);
+    xr_rows(0, c, c & 1);
+  }
+#pragma unroll
+  for (int o = 0; o < 8; ++o) xr_out(0, o);
+  y_build(smem, 0);
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int x = 0; x < 16; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float z;
+      asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z));     // AGPR-born zero (see wino_conv_kernel)
+      acc[x][r] = z;
+    }
+  asm volatile("s_nop 1");
+  stamp();
+
+  int rb0 = 0;
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const int rb1 = rb0 == 2 ? 0 : rb0 + 1, rb2 = rb1 == 2 ? 0 : rb1 + 1;
+    const float* R0 = smem + rb0 * WBUF;      // raw[ch]
+    const float* R1 = smem + rb1 * WBUF;      // raw[ch + 1]
+    float* Rw = smem + rb2 * WBUF;            // raw[ch + 2] (in registers) is committed here during this phase
+    const Ch c3 = chunk(ch + 3);
+    // 8 double steps as in wino_conv_kernel: steps 0..3 multiply rows 0,1 (fragment sets 0) while rows 2,3 are
+    // built from raw[ch]; steps 4..7 multiply rows 2,3 while rows 0,1 of the NEXT chunk are built from
+    // raw[ch + 1]; the raw patch of chunk ch + 2 is committed (4 dword LDS stores per 16-byte load: the LDS
+    // image is channel-major) and that of chunk ch + 3 fetched, two slots per step.
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      const int hb = y < 4 ? 1 : 0;
+      const float* Rs = y < 4 ? R0 : R1;
+      const int yy = y & 3;
+      if (yy == 1) {
+        xr_rows(hb, 0, 0);
+        xr_rows(hb, 1, 1);
+      }
+      if (yy == 2) {
+        xr_rows(hb, 2, 0);
+        xr_rows(hb, 3, 1);
+      }
+      if (yy < 2) {
+        xr_read(Rs, hb, 2 * yy, 0);
+        xr_read(Rs, hb, 2 * yy + 1, 1);
+      }
+      if (yy >= 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xr_out(hb, 4 * (yy - 2) + k);
+      }
+      if (yy == 1) y_build(Rs, hb);
+      {                                         // raw slots: X 0..5, Y 0..1 -> one per step
+        if (y < 6) {
+          commit_x(y, Rw);
+          fetch_x(y, c3);
+        } else {
+          commit_y(y - 6, Rw);
+          fetch_y(y - 6, c3);
+        }
+      }
+      const int ha = y < 4 ? 0 : 1;
+      const f32x4 a0 = Xf[ha][(2 * y) & 7], a1 = Xf[ha][(2 * y + 1) & 7];
+      const f32x4 b0 = Yf[ha][(2 * y) & 7], b1 = Yf[ha][(2 * y + 1) & 7];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        // D[output channel][input channel]: a lane ends up with ONE input channel (lr) and 16 output channels, so a
+        // dword store of one register covers 32 consecutive input channels of a gw[n][tap][.] row per half wave
+        // (two full 128-byte segments); the transposed orientation (16-byte stores, one row per lane) scatters
+        // every store over 32 rows and ran the epilogue 10x slower
+        acc[2 * y] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], acc[2 * y], 0, 0, 0);
+        acc[2 * y + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a1[s], acc[2 * y + 1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x096, 6, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    stamp();
+    rb0 = rb1;
+  }
+
+  // ---- epilogue: gW = G'^T dU' G' per (lane, register), G' = G with row 3 negated; 16-byte stores ----
+  asm volatile("s_nop 15\n\ts_nop 15");
+  float* out = p.out + (long)split * p.slab;
+  __amdgpu_buffer_rsrc_t rsrc_o;
+  {
+    const unsigned long long ob = reinterpret_cast<unsigned long long>(out);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ob);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ob >> 32));
+    rsrc_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                               __builtin_amdgcn_readfirstlane((unsigned)(p.Nw * 9 * p.Cw) * 4u), 0x00020000);
+  }
+  // lane: input channel c0 + wa*32 + lr; register r: output channel n0 + wb*32 + (r & 3) + 8 (r >> 2) + 4 lh
+  const unsigned row_bytes = 9u * (unsigned)p.Cw * 4u;
+  const unsigned vo = (unsigned)(n0 + wb * 32 + 4 * lh) * row_bytes + (unsigned)(c0 + wa * 32 + lr) * 4u;
+  const f32x2 half2 = {0.5f, 0.5f};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      // R[a][j] = sum_i G'[i][a] dU'[i][j]:  R0 = d0 + (d1 + d2)/2,  R1 = (d1 - d2)/2,  R2 = (d1 + d2)/2 - d3
+      f32x2 R[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float m[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m[i][e]) : "a"(acc[4 * i + j][4 * g + 2 * r2 + e]));
+        const f32x2 d0 = {m[0][0], m[0][1]}, d1 = {m[1][0], m[1][1]}, d2 = {m[2][0], m[2][1]}, d3 = {m[3][0], m[3][1]};
+        const f32x2 hs = add2(d1, d2) * half2, hd = sub2(d1, d2) * half2;
+        R[0][j] = add2(d0, hs);
+        R[1][j] = hd;
+        R[2][j] = sub2(hs, d3);
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const f32x2 hs = add2(R[a][1], R[a][2]) * half2, hd = sub2(R[a][1], R[a][2]) * half2;
+        const f32x2 w[3] = {add2(R[a][0], hs), hd, sub2(hs, R[a][3])};
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int r = 4 * g + 2 * r2 + e;
+            float v = w[b][e];
+            asm volatile("" : "+v"(v));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_o, vo,
+                                                  (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes + (unsigned)((a * 3 + b) * p.Cw) * 4u, 0);
+          }
+      }
+    }
+  }
+  if (p.bias && tc == 0 && wa == 0) {
+    // this lane's tiles: sum the four slots, then the two tile rows (lanes lr and lr + 32)
+    float v = (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]);
+    v += __shfl_xor(v, 32, 64);
+    if (lh == 0) out[(long)p.Nw * 9 * p.Cw + n0 + wb * 32 + lr] = v;
+  }
+  stamp();
+  if (DBG && threadIdx.x == 0) p.dbg[blockIdx.x * 64] = nstamp;
+}
+
+static bool wgrad_class(int H, int W, int* G, int* ipc) {
+  if (H != W || !pow2(H) || H < 4) return false;
+  *G = W >= 16 ? 8 : W == 8 ? 4 : 2;
+  *ipc = W >= 16 ? 1 : W == 8 ? 2 : 4;
+  return true;
+}
+
+}  // namespace lgmwino
+
+bool lgm_wino_wgrad_supported(const LgmConvGeom* g) {
+  using namespace lgmwino;
+  int G, ipc;
+  if (!(g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1)) return false;
+  if (g->Nw % 64 != 0 || g->Cw % 64 != 0) return false;
+  if (!wgrad_class(g->H, g->W, &G, &ipc)) return false;
+  if (g->B % ipc != 0) return false;
+  const long chunks = (long)(g->B / ipc) * (g->H / 4) * (g->W >= 16 ? g->W / 16 : 1) * 2;
+  return chunks >= 2;
+}
+
+// splits >= 2 always (the kernel only writes slabs); cps = chunks per split
+void lgm_wino_wgrad_plan(const LgmConvGeom* g, int* splits, int* cps, int* total_chunks) {
+  using namespace lgmwino;
+  int G, ipc;
+  wgrad_class(g->H, g->W, &G, &ipc);
+  const long chunks = (long)(g->B / ipc) * (g->H / 4) * (g->W >= 16 ? g->W / 16 : 1) * 2;
+  const long blocks = (long)(g->Nw / 64) * (g->Cw / 64);
+  long s = (256 + blocks - 1) / blocks;                  // one workgroup per CU when the chunks allow it
+  if (s > chunks / 2) s = chunks / 2;                    // at least two chunks per workgroup ...
+  if (s < 2) s = 2;                                      // ... and at least two slabs
+  long per = (chunks + s - 1) / s;
+  s = (chunks + per - 1) / per;
+  *splits = (int)s;
+  *cps = (int)per;
+  *total_chunks = (int)chunks;
+}
+
+int lgm_wino_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch, float* out,
+                          int bias, long slab, int splits, int cps, int total_chunks, hipStream_t s) {
+  using namespace lgmwino;
+  WGArgs p{};
+  p.y = y; p.x = x; p.out = out; p.bias = bias; p.slab = slab; p.y_pitch = y_pitch; p.x_pitch = x_pitch;
+  p.B = g->B; p.H = g->H; p.W = g->W; p.Nw = g->Nw; p.Cw = g->Cw;
+  p.tiles_c = g->Cw / 64;
+  p.splits = splits; p.cps = cps; p.total_chunks = total_chunks;
+  p.rpn = g->H / 4;
+  p.cgn = g->W >= 16 ? g->W / 16 : 1;
+  int G, ipc;
+  wgrad_class(g->H, g->W, &G, &ipc);
+  const unsigned nblocks = (unsigned)((g->Nw / 64) * (g->Cw / 64) * splits);
+  const size_t smem = (size_t)3 * WBUF * sizeof(float);
+#define LGM_WGL(GG)                                                                                              \
+  do {                                                                                                           \
+    auto kern = wino_wgrad_kernel<GG>;                                                                           \
+    static bool attr = false;                                                                                    \
+    if (!attr) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)smem);                                                                      \
+      attr = true;                                                                                               \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                              \
+  } while (0)
+  p.dbg = (long long*)lgm_wino_debug_buffer;
+  if (p.dbg && G == 8) {
+    auto kern = wino_wgrad_kernel<8, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);
+  } else if (G == 8) LGM_WGL(8);
+  else if (G == 4) LGM_WGL(4);
+  else LGM_WGL(2);
+#undef LGM_WGL
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
