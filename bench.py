@@ -1,19 +1,25 @@
 """bench.py — BASELINE.json metric: training images/sec, DDPM UNet 32x32, global batch 128.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload ddpm32|ddpm64|wgan_gp64|vqvae]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = the full optimiser step of the reference loop on a synthetic
-batch already resident in HBM: DDPM.training_step (t ~ randint, noise ~ randn on device,
-q_sample, UNet fwd, weighted MSE) -> loss.backward() (hand-written HIP backward) -> gradient
-all-reduce over RCCL when N > 1 -> fused Adam -> EMA update (every 10th step).  The periodic
-in-training sampling (reference F11, every 1000 steps) is outside the window.  Strong scaling:
-the global batch stays 128 (reference DataModule divides the config batch by the GPU count).
+One "step" = the full optimiser step of the reference loop on a synthetic batch already
+resident in HBM.  Default workload (the headline, BASELINE config 2): DDPM.training_step (t ~ randint,
+noise ~ randn on device, q_sample, UNet fwd, weighted MSE) -> hand-written HIP backward -> gradient all-reduce
+over RCCL when N > 1 -> fused Adam -> EMA update (every 10th step), replayed as two HIP graphs.  Strong
+scaling: the global batch stays 128 (reference DataModule divides the config batch by the GPU count).
+The other workloads are BASELINE's secondary configs measured the same way (one GPU):
+  ddpm64     config 5's network: DDPM UNet 64x64, B = 64 per GPU
+  wgan_gp64  config 3: WGAN-GP DCGAN G/D 64x64, B = 128, n_critic = 5 (one training_step = one D or G update)
+  vqvae      config 4: VQ-VAE 32x32, K = 512, B = 256 (--vq-ema for the EMA codebook)
 
-Rank 0 prints ONE JSON line.  Extra objects: "roofline" (convolution kernel family, fp32 MFMA
-peak 157.3 TFLOP/s; per-launch durations from HIP events on the launch stream in one extra
-instrumented step right after the timed region) and "cpu_baseline" (the CPU oracle, same
-workload at a bounded batch, on this host's cores).
+Rank 0 prints ONE JSON line with two extra objects:
+  "roofline"      the dominant SINGLE kernel of the convolution family (name as rocprofv3 prints it), timed live
+                  with HIP events on the launch stream in one extra instrumented step after the timed region:
+                  achieved = algorithmic FLOPs (2 B Ho Wo Cout KH KW Cin per launch) / event time, peak = fp32 MFMA
+                  157.3 TFLOP/s.  For the Winograd kernels the MFMA pipe executes 2.25x fewer FLOPs than the
+                  algorithmic count, so frac can exceed 1; mfma_executed_frac is the pipe's own utilisation.
+  "cpu_baseline"  the CPU oracle (kind "port"), same workload at a bounded batch, on this host's cores.
 """
 import argparse
 import json
@@ -30,63 +36,114 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
-GLOBAL_BATCH = 128
-IMG = 32
-DIM = 64
+WINO_FACTOR = 2.25              # direct 3x3 multiplies per Winograd F(2x2,3x3) multiply
 
 
-def cpu_baseline(batch=32, warmup=1, min_seconds=12.0, max_steps=200):
-    """The CPU oracle (validated against the reference by tests/golden) on this host's cores: whole
-    training steps (forward + backward + Adam) until ``min_seconds`` of timed work have accumulated."""
-    from oracle import diffusion as OD
-    torch.manual_seed(10)
+def _threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
         avail = os.cpu_count() or 1
-    nthreads = max(1, min(avail, 16))   # a 1-GPU box owns a 16-core share of the host
+    return max(1, min(avail, 16))   # a 1-GPU box owns a 16-core share of the host
+
+
+def _timed_cpu(one, batch, warmup, min_seconds, max_steps, what):
+    nthreads = _threads()
     torch.set_num_threads(nthreads)
-    P = {k: v.requires_grad_(True) for k, v in OD.unet_init(dim=DIM, channels=3, seed=0).items()}
-    bufs = OD.diffusion_buffers(1000)
-    opt = torch.optim.Adam(list(P.values()), lr=2e-5, betas=(0.9, 0.99))
-    x = torch.rand(batch, 3, IMG, IMG) * 2 - 1
-    times = []
-    i = 0
+    times, i = [], 0
     while i < warmup or (sum(times) < min_seconds and len(times) < max_steps):
         if i < warmup or len(times) % 10 == 0:
-            print(f"[bench] cpu_baseline step {i} ({nthreads} threads, {sum(times):.1f}s timed)", file=sys.stderr,
-                  flush=True)
+            print(f"[bench] cpu_baseline step {i} ({nthreads} threads, {sum(times):.1f}s timed)", file=sys.stderr, flush=True)
         t0 = time.perf_counter()
-        t = torch.randint(0, 1000, (batch,))
-        noise = torch.randn_like(x)
-        loss = OD.diffusion_forward(P, bufs, x, t, noise, dim=DIM)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+        one()
         if i >= warmup:
             times.append(time.perf_counter() - t0)
         i += 1
     total = sum(times)
     return {"value": round(batch * len(times) / total, 2), "unit": "images/s", "cores": nthreads, "kind": "port",
-            "sample": f"oracle fwd+bwd+Adam, B={batch}, 3x{IMG}x{IMG}: {len(times)} steps = {total:.1f} s of CPU work "
-                      f"after {warmup} warm-up"}
+            "sample": f"{what}: {len(times)} steps = {total:.1f} s of CPU work after {warmup} warm-up"}
 
 
-def torch_gpu_baseline(dev, batch=GLOBAL_BATCH, warmup=5, steps=10):
-    """Baseline leg, optional (--torch-gpu-baseline): the same oracle (the reference's arithmetic as plain
-    torch ops, i.e. what the reference's modules execute) with its tensors on the MI355X — PyTorch-ROCm eager
-    kernels (MIOpen / rocBLAS / ATen) + torch.optim.Adam.  A reported comparison point, not the target."""
+def cpu_baseline_ddpm(img, dim=64, batch=32, min_seconds=12.0):
+    """The CPU oracle (validated against the reference by tests/golden): whole training steps
+    (forward + backward + Adam) until ``min_seconds`` of timed work have accumulated."""
     from oracle import diffusion as OD
     torch.manual_seed(10)
-    P = {k: v.to(dev).requires_grad_(True) for k, v in OD.unet_init(dim=DIM, channels=3, seed=0).items()}
+    P = {k: v.requires_grad_(True) for k, v in OD.unet_init(dim=dim, channels=3, seed=0).items()}
+    bufs = OD.diffusion_buffers(1000)
+    opt = torch.optim.Adam(list(P.values()), lr=2e-5, betas=(0.9, 0.99))
+    x = torch.rand(batch, 3, img, img) * 2 - 1
+
+    def one():
+        t = torch.randint(0, 1000, (batch,))
+        noise = torch.randn_like(x)
+        loss = OD.diffusion_forward(P, bufs, x, t, noise, dim=dim)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    return _timed_cpu(one, batch, 1, min_seconds, 200, f"oracle fwd+bwd+Adam, B={batch}, 3x{img}x{img}")
+
+
+def cpu_baseline_wgan(batch=32, min_seconds=12.0):
+    from oracle import gan as OG
+    torch.manual_seed(10)
+    G, D = OG.gan_init(64, 3, 100, seed=0)
+    G = {k: v.requires_grad_(True) for k, v in G.items()}
+    D = {k: v.requires_grad_(True) for k, v in D.items()}
+    dopt = torch.optim.Adam(list(D.values()), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+    gopt = torch.optim.Adam(list(G.values()), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+    x = torch.rand(batch, 3, 64, 64) * 2 - 1
+    step = [0]
+
+    def one():      # reference schedule: 5 critic updates, then 1 generator update (wgan.py:58-82)
+        z = torch.randn(batch, 100, 1, 1)
+        x_hat = OG.generator(G, z, 64, 3)
+        if (step[0] + 1) % 6 != 0:
+            alpha = torch.rand(batch, 1, 1, 1)
+            ld = OG.wgan_d_loss(D, x, x_hat.detach(), alpha, 10.0, 64)
+            dopt.zero_grad()
+            ld["d_loss"].backward()
+            dopt.step()
+        else:
+            gl = OG.wgan_g_loss(D, x_hat, 64)
+            gopt.zero_grad()
+            gl.backward()
+            gopt.step()
+        step[0] += 1
+    return _timed_cpu(one, batch, 1, min_seconds, 300, f"oracle WGAN-GP training_step (5 D : 1 G) + Adam, B={batch}, 3x64x64")
+
+
+def cpu_baseline_vqvae(ema, batch=64, min_seconds=10.0):
+    from oracle import vq as OV
+    torch.manual_seed(10)
+    P = {k: v.requires_grad_(True) for k, v in OV.vqvae_init(seed=0).items()}
+    opt = torch.optim.Adam(list(P.values()), lr=1e-3, betas=(0.9, 0.999))
+    x = torch.rand(batch, 3, 32, 32) * 2 - 1
+    state = [(torch.zeros(512), P["vector_quantizer.embedding.weight"].detach().clone())] if ema else [None]
+
+    def one():
+        r = OV.vqvae_step(P, x, w_recon=1.0, w_vq=10.0 if ema else 1.0, ema_state=state[0])
+        opt.zero_grad()
+        r["loss"].backward()
+        opt.step()
+    return _timed_cpu(one, batch, 1, min_seconds, 400, f"oracle VQ-VAE fwd+bwd+Adam (use_ema={ema}), B={batch}, 3x32x32")
+
+
+def torch_gpu_baseline(dev, img, dim, batch, warmup=5, steps=10):
+    """Optional comparison leg (--torch-gpu-baseline, DDPM workloads): the same oracle (the reference's arithmetic as
+    plain torch ops) with its tensors on the MI355X — PyTorch-ROCm eager kernels (MIOpen / rocBLAS / ATen) +
+    torch.optim.Adam.  A reported comparison point, not the target."""
+    from oracle import diffusion as OD
+    torch.manual_seed(10)
+    P = {k: v.to(dev).requires_grad_(True) for k, v in OD.unet_init(dim=dim, channels=3, seed=0).items()}
     bufs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in OD.diffusion_buffers(1000).items()}
     opt = torch.optim.Adam(list(P.values()), lr=2e-5, betas=(0.9, 0.99))
-    x = (torch.rand(batch, 3, IMG, IMG) * 2 - 1).to(dev)
+    x = (torch.rand(batch, 3, img, img) * 2 - 1).to(dev)
 
     def one():
         t = torch.randint(0, 1000, (batch,), device=dev)
         noise = torch.randn_like(x)
-        loss = OD.diffusion_forward(P, bufs, x, t, noise, dim=DIM)
+        loss = OD.diffusion_forward(P, bufs, x, t, noise, dim=dim)
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -104,14 +161,92 @@ def torch_gpu_baseline(dev, batch=GLOBAL_BATCH, warmup=5, steps=10):
             "sample": f"oracle (torch eager ops on the GPU) fwd+bwd+Adam, B={batch}, mean of {steps} steps after {warmup}"}
 
 
+# ---- workloads: each returns (step(i) -> loss-like tensor, eager_step for the instrumented pass, info) ------------
+def setup_ddpm(args, dev, world, rank, img, global_batch):
+    from lgm_hip.graph import DDPMFastStep
+    from models.generative.diffusion.ddpm import DDPM
+    assert global_batch % world == 0
+    per_gpu = global_batch // world
+    model = DDPM(img_channels=3, img_size=img, dim=64, diffusion_timesteps=1000, sampling_timesteps=None,
+                 lr=2e-5, betas=(0.9, 0.99), ema_update_every=10, ema_decay=0.995)   # configs/diffusion/ddpm[_64].json
+    model.sample_every = 0
+    model.to(dev)
+    model.prepare_hip(dev)
+    model.train()
+    opt = model.configure_optimizers()
+    g = torch.Generator(device="cpu").manual_seed(10 + rank)
+    x = (torch.rand(per_gpu, 3, img, img, generator=g) * 2 - 1).to(dev)
+    y = torch.zeros(per_gpu, dtype=torch.long, device=dev)
+    # the object MiniTrainer.fit drives for a DDPM module: overlapped bucketed all-reduce + two-graph replay
+    fast = DDPMFastStep(model, opt, world, use_graph=not args.no_graph)
+    eager = DDPMFastStep.__new__(DDPMFastStep)
+    eager.__dict__.update(fast.__dict__)
+    eager.use_graph, eager.graphed = False, None
+
+    def step(i):
+        return fast.step((x, y), i)
+
+    def eager_step(i):
+        return eager.step((x, y), i)
+    flop_per_img = {32: 10.95e9, 64: 43.8e9}[img]     # forward x 3
+    info = dict(per_gpu=per_gpu, fast=fast, flop_per_img=flop_per_img, bytes_per_img=(69.6e6 if img == 32 else 278e6),
+                workload=f"configs/diffusion/{'ddpm' if img == 32 else 'ddpm_64'}.json UNet dim=64, 3x{img}x{img} synthetic "
+                         "NCHW fp32, training_step+backward+Adam+EMA")
+    return step, eager_step, info
+
+
+def setup_wgan(args, dev):
+    from lgm_hip.lightning import _CountingOptimizer
+    from models.generative.gan.wgan import WGAN
+    m = WGAN(img_channels=3, img_size=64, latent_dim=100, lr=1e-4, b1=0.5, b2=0.999, weight_decay=1e-5, n_critic=5,
+             grad_penalty=10, constraint_method="gp").to(dev)        # configs/gan/wgan_gp_celeba.json
+    m.prepare_hip(dev)
+    m.train()
+    m._optimizers = [_CountingOptimizer(o, m) for o in m.configure_optimizers()[0]]
+    x = torch.rand(128, 3, 64, 64, device=dev) * 2 - 1
+
+    def step(i):
+        m.training_step((x, None))
+        return m.logged.get("d_loss", m.logged.get("g_loss"))
+    info = dict(per_gpu=128, fast=None, flop_per_img=None, bytes_per_img=None,
+                workload="configs/gan/wgan_gp_celeba.json WGAN-GP DCGAN G/D, 3x64x64 synthetic, training_step "
+                         "(n_critic = 5: one critic OR generator update incl. GP double backward) + fused Adam")
+    return step, step, info
+
+
+def setup_vqvae(args, dev):
+    from models.generative.vae.vqvae import VQVAE
+    ema = args.vq_ema
+    v = VQVAE(img_channels=3, img_size=32, embedding_dim=64, num_embeddings=512, hidden_dim=128, num_residual_layers=2,
+              num_residual_hiddens=32, use_ema=ema, lr=1e-3, b1=0.9, b2=0.999,
+              loss_weights={"recon_loss": 1, "vq_loss": 10 if ema else 1}).to(dev)      # configs/vae/vqvae[_ema].json
+    v.prepare_hip(dev)
+    v.train()
+    opt = v.configure_optimizers()
+    xv = torch.rand(256, 3, 32, 32, device=dev) * 2 - 1
+
+    def step(i):
+        loss = v.training_step((xv, None), i)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    info = dict(per_gpu=256, fast=None, flop_per_img=None, bytes_per_img=None,
+                workload=f"configs/vae/vqvae{'_ema' if ema else ''}.json VQ-VAE 3x32x32, K=512 D=64, "
+                         "training_step+backward+Adam")
+    return step, step, info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="ddpm32", choices=["ddpm32", "ddpm64", "wgan_gp64", "vqvae"])
+    ap.add_argument("--vq-ema", action="store_true", help="vqvae workload: EMA codebook (configs/vae/vqvae_ema.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python (no HIP-graph replay)")
-    ap.add_argument("--batch", type=int, default=GLOBAL_BATCH, help="global batch (default 128 = the metric)")
+    ap.add_argument("--batch", type=int, default=None, help="global batch (default: the workload's config value)")
     ap.add_argument("--torch-gpu-baseline", action="store_true",
                     help="also time the oracle's plain torch ops on the GPU (PyTorch-ROCm eager) as a comparison point")
     args = ap.parse_args()
@@ -132,54 +267,25 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
         else:
             dist.init_process_group(backend)
-
     from lgm_hip import ops
-    from lgm_hip.lightning import MiniTrainer
-    from models.generative.diffusion.ddpm import DDPM
 
     torch.manual_seed(10)                         # reference train.py:20 seeds every rank identically
-    assert args.batch % world == 0
-    per_gpu = args.batch // world
-    model = DDPM(img_channels=3, img_size=IMG, dim=DIM, diffusion_timesteps=1000, sampling_timesteps=None,
-                 lr=2e-5, betas=(0.9, 0.99), ema_update_every=10, ema_decay=0.995)   # configs/diffusion/ddpm.json
-    model.sample_every = 0
-    model.to(dev)
-    model.prepare_hip(dev)
-    model.train()
-    opt = model.configure_optimizers()
-    trainer = MiniTrainer()
-    from lgm_hip.lightning import FlatGradSync
-    unet = model.ema.online_model.model
-    sync = FlatGradSync(unet._flat) if world > 1 else None
-    unet.grad_sync = sync          # buckets are all-reduced (async) while the backward is still running
-    if sync is not None:
-        opt.grad_scale = sync.grad_scale
-    g = torch.Generator(device="cpu").manual_seed(10 + rank)
-    x = (torch.rand(per_gpu, 3, IMG, IMG, generator=g) * 2 - 1).to(dev)
-    y = torch.zeros(per_gpu, dtype=torch.long, device=dev)
-    batch = (x, y)
+    wl = args.workload
+    if wl in ("ddpm32", "ddpm64"):
+        img = 32 if wl == "ddpm32" else 64
+        # ddpm32: strong scaling of the global batch 128 (the metric); ddpm64: 64 images per GPU (config 5, weak)
+        gb = args.batch if args.batch is not None else (128 if wl == "ddpm32" else 64 * world)
+        step, eager_step, info = setup_ddpm(args, dev, world, rank, img, gb)
+        scaling = "strong" if wl == "ddpm32" else "weak"
+        metric = f"training images/sec (DDPM UNet {img}x{img}, bs={gb if wl == 'ddpm32' else '64/GPU'})"
+    else:
+        assert world == 1, f"--workload {wl} is a single-GPU measurement"
+        step, eager_step, info = (setup_wgan if wl == "wgan_gp64" else setup_vqvae)(args, dev)
+        gb, scaling = info["per_gpu"], "weak"
+        metric = ("training images/sec (WGAN-GP 64x64, bs=128)" if wl == "wgan_gp64"
+                  else f"training images/sec (VQ-VAE 32x32 K=512{' EMA' if args.vq_ema else ''}, bs=256)")
+    per_gpu = info["per_gpu"]
 
-    def step(i):
-        loss = model.training_step(batch)
-        loss.backward()
-        if sync is not None:
-            sync.finish()
-        opt.step()
-        opt.zero_grad()
-        model.on_train_batch_end(None, batch, i)
-        return loss
-
-    eager_step = step
-    graphed = None
-    if not args.no_graph:
-        try:
-            from lgm_hip.graph import GraphedDDPMStep
-            graphed = GraphedDDPMStep(model, opt, x, sync)
-            step = graphed.step
-        except Exception as e:  # capture is an optimisation: fall back to eager launches
-            unet.grad_sync = sync
-            print(f"[bench] rank {rank}: HIP-graph capture unavailable ({type(e).__name__}: {e}); eager launches",
-                  file=sys.stderr, flush=True)
     tw = time.perf_counter()
     for i in range(args.warmup):
         step(i)
@@ -201,63 +307,83 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    final_loss = float(loss.item())
+    final_loss = float(loss.item()) if loss is not None else float("nan")
     if rank == 0:
-        print(f"[bench] timed region: {args.steps} steps in {elapsed:.3f}s "
-              f"({args.batch * args.steps / elapsed:.1f} img/s)", file=sys.stderr, flush=True)
+        print(f"[bench] timed region: {args.steps} steps in {elapsed:.3f}s ({gb * args.steps / elapsed:.1f} img/s)",
+              file=sys.stderr, flush=True)
 
     # ---- roofline leg: one extra instrumented step, per-launch HIP events on the launch stream
-    unet.grad_sync = sync
     ops.TIMER = ops.KernelTimer()
-    eager_step(args.warmup + args.steps)
-    summ = ops.TIMER.summary()
+    n_instr = 6 if wl == "wgan_gp64" else 1          # WGAN: a whole 5 D : 1 G cycle
+    for k in range(n_instr):
+        eager_step(args.warmup + args.steps + k)
+    fam = ops.TIMER.summary(False)
+    kern = ops.TIMER.summary(True)
     ops.TIMER = None
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = args.batch * args.steps / elapsed
-        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
-        name, d = dom
+        value = gb * args.steps / elapsed
+        name, d = max(((k, v) for k, v in kern.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        conv_ms = sum(v["ms"] for v in summ.values())
-        conv_fl = sum(v["flops"] for v in summ.values())
-        # HBM-side bytes per launch of the dominant family: PMC counters cannot be read from inside this
-        # process, so the figure comes from the committed rocprofv3 --pmc summary of this same command
-        # (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction)
+        wino = "wino_" in name
+        conv_ms = sum(v["ms"] for v in fam.values())
+        conv_fl = sum(v["flops"] for v in fam.values())
+        # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process;
+        # the figure comes from the committed rocprofv3 --pmc summary of this same command when there is one
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and args.batch == GLOBAL_BATCH and world == 1:
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(pmc) and wl == "ddpm32" and gb == 128 and world == 1:
             with open(pmc) as fh:
-                t = json.load(fh).get(name)
+                t = json.load(fh).get("kernels", {}).get(name)
             if t:
-                traffic, traffic_src = t["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
-        bytes_per_img = 69.6e6 + 1.472e9 / per_gpu        # algorithmic HBM bytes per image
+                traffic, traffic_src = t["traffic_bytes_per_launch"], "profiles/r02_pmc_traffic.json"
         roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_source": traffic_src,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
+                "launches_per_step": round(d["launches"] / n_instr, 2), "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(d.get("bytes", 0) / max(d["launches"], 1)) or None,
-                "hbm_frac_of_8TBps": round(value / world * bytes_per_img / 8.0e12, 4),
-                "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                "note": ("Winograd F(2x2,3x3) in fp32: the MFMA pipe executes algorithmic/2.25 FLOPs, frac may exceed 1; "
+                         "mfma_executed_frac = frac / 2.25 is the pipe's own utilisation" if wino else
+                         "direct fp32 MFMA kernel"),
+                "mfma_executed_frac": round(achieved / (WINO_FACTOR if wino else 1.0) / FP32_MFMA_PEAK_TFLOPS, 4),
+                "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                            for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]},
                 "family": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()},
-                "conv_family_ms_per_step": round(conv_ms, 3),
-                "conv_family_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
-                "step_flop_frac_of_peak": round(value * 10.95e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4)}
-        line = {"metric": "training images/sec (DDPM UNet 32x32, bs=128)", "value": round(value, 2),
-                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fam.items()},
+                "conv_family_ms_per_step": round(conv_ms / n_instr, 3),
+                "conv_family_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
+        if info["flop_per_img"]:
+            roof["step_flop_frac_of_peak"] = round(value * info["flop_per_img"] / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4)
+            bytes_per_img = info["bytes_per_img"] + 1.472e9 / per_gpu
+            roof["hbm_frac_of_8TBps"] = round(value / world * bytes_per_img / 8.0e12, 4)
+        launch = "eager"
+        if info["fast"] is not None:
+            launch = info["fast"].mode
+        conv_mode = "bf16x3 (LGM_CONV_MODE)" if ops.B3 else ("fp32 MFMA, Winograd F(2x2,3x3) for the 3x3 layers"
+                                                             if ops.WINO else "fp32 MFMA, direct")
+        line = {"metric": metric, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling,
+                "vs_baseline": None,
                 "dtype": "f32" if not ops.B3 else "f32 (3x3 conv fwd/dgrad: opt-in bf16x3 split MFMA, fp32-level error)",
                 "data": "synthetic",
-                "config": {"workload": "configs/diffusion/ddpm.json UNet dim=64, 3x32x32 synthetic NCHW fp32, "
-                                       "training_step+backward+Adam+EMA", "global_batch": args.batch,
-                           "per_gpu_batch": per_gpu, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),
-                           "launch": "hipGraph replay (2 graphs/step)" if graphed is not None else "eager",
-                           "conv_mode": "bf16x3 (LGM_CONV_MODE)" if ops.B3 else "fp32 MFMA"},
+                "config": {"workload": info["workload"], "global_batch": gb, "per_gpu_batch": per_gpu,
+                           "parallelism": f"dp{world}", "final_loss": round(final_loss, 5), "launch": launch,
+                           "conv_mode": conv_mode},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-        if world == 1 and args.torch_gpu_baseline:
-            line["torch_gpu_baseline"] = torch_gpu_baseline(dev, args.batch)
+            if wl == "ddpm32":
+                line["cpu_baseline"] = cpu_baseline_ddpm(32)
+            elif wl == "ddpm64":
+                line["cpu_baseline"] = cpu_baseline_ddpm(64, batch=8)
+            elif wl == "wgan_gp64":
+                line["cpu_baseline"] = cpu_baseline_wgan()
+            else:
+                line["cpu_baseline"] = cpu_baseline_vqvae(args.vq_ema)
+        if world == 1 and args.torch_gpu_baseline and wl in ("ddpm32", "ddpm64"):
+            line["torch_gpu_baseline"] = torch_gpu_baseline(dev, 32 if wl == "ddpm32" else 64, 64, gb)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

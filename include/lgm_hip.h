@@ -35,6 +35,9 @@ extern "C" {
 
 int lgm_abi_version(void);
 const char* lgm_last_error(void);
+/* diagnostic: name (as rocprofv3 prints it, without the argument list) of the primary kernel launched by the calling
+ * thread's last convolution-family call (lgm_conv_xy / _yx / _wgrad / lgm_conv3x3_wino) */
+const char* lgm_last_kernel(void);
 
 /* ---------------------------------------------------------------------------------------
  * Convolution family (implicit GEMM on v_mfma_f32_32x32x2_f32, exact fp32).

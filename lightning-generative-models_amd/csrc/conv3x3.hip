@@ -1189,6 +1189,7 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
     }                                                                                                  \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                    \
   } while (0)
+  lgm_note_kernel(mode == MODE_XY ? "lgm3x3::conv3x3_kernel<0>" : mode == MODE_YX ? "lgm3x3::conv3x3_kernel<1>" : "lgm3x3::conv3x3_kernel<2>");
   if (mode == MODE_XY) LGM_C3_LAUNCH(MODE_XY);
   else if (mode == MODE_YX) LGM_C3_LAUNCH(MODE_YX);
   else LGM_C3_LAUNCH(MODE_YXT);

@@ -402,6 +402,7 @@ int launch_igemm(IgemmArgs& a, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
+  lgm_note_kernel("igemm_kernel");
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits * a.phases)), dim3(256), smem, s, a);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
@@ -499,12 +500,12 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
                               (hipStream_t)stream);
   if (use_3x3() && use_gstream() && wide_ok(y, y_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 &&
       g->stride == 1 && g->pad == 0 && lgm_gemm_stream_supported((long)g->B * g->H * g->W, g->Nw, g->Cw, x_pitch, y_pitch, res ? res_pitch : 0))
-    return lgm_gemm_stream_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch, (long)g->B * g->H * g->W, g->Nw,
-                                  g->Cw, (hipStream_t)stream);
+    return lgm_note_kernel("gemm_stream_kernel"), lgm_gemm_stream_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch,
+                                                                        (long)g->B * g->H * g->W, g->Nw, g->Cw, (hipStream_t)stream);
   if (use_3x3() && wide_ok(y, y_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 && g->stride == 1 &&
       g->pad == 0 && lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Nw, g->Cw))
-    return lgm_gemm_rows_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch, (long)g->B * g->H * g->W, g->Nw, g->Cw,
-                                (hipStream_t)stream);
+    return lgm_note_kernel("gemm_rows_kernel"), lgm_gemm_rows_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch,
+                                                                    (long)g->B * g->H * g->W, g->Nw, g->Cw, (hipStream_t)stream);
   IgemmArgs a{};
   a.a = x; a.w = w; a.bias = bias; a.res = res; a.out = y;
   a.a_pitch = x_pitch; a.res_pitch = res_pitch; a.out_pitch = y_pitch;
@@ -1022,13 +1023,16 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
     if (int rc = lgm_wino_wgrad_launch(g, y, y_pitch, x, x_pitch, a.out, gbias ? 1 : 0, a.slab, a.splits, cpsw, totalw, s))
       return rc;
   } else if (fast3) {
+    lgm_note_kernel("lgm3x3::wgrad3x3_kernel");
     if (int rc = lgm_wgrad3x3_launch(g, y, y_pitch, x, x_pitch, a.out, a.bias_out, beta, a.slab, a.splits, tps3,
                                      total3, s))
       return rc;
   } else if (fast1) {
+    lgm_note_kernel("wgrad1x1_kernel");
     if (int rc = lgm_wgrad1x1_launch(g, y, y_pitch, x, x_pitch, a.out, a.bias_out, beta, a.slab, a.splits, per1, s))
       return rc;
   } else {
+    lgm_note_kernel("wgrad_kernel<64, 64, 1, 1>");
     hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
     LGM_LAUNCH_CHECK();
   }
@@ -1118,6 +1122,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const long long
 
 extern "C" int lgm_wgrad_reduce_batch(const int64_t* table, int n_entries, int64_t total_blocks, void* stream) {
   LGM_REQUIRE(table && n_entries > 0 && total_blocks > 0, "wgrad_reduce_batch: bad arguments");
+  lgm_note_kernel("wgrad_reduce_batch_kernel");
   hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const long long*>(table), n_entries);
   LGM_LAUNCH_CHECK();

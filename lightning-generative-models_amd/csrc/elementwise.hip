@@ -15,6 +15,9 @@ void lgm_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* lgm_last_error(void) { return g_err; }
+static thread_local const char* g_kernel = "";
+void lgm_note_kernel(const char* name) { g_kernel = name; }
+extern "C" const char* lgm_last_kernel(void) { return g_kernel; }
 extern "C" int lgm_abi_version(void) { return LGM_ABI_VERSION; }
 
 namespace {

@@ -11,6 +11,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // thread-local last error string (lgm_last_error)
 void lgm_set_error(const char* fmt, ...);
+// name (as rocprofv3 prints it, without the argument list) of the primary kernel the calling thread's last
+// convolution-family entry point launched: lets bench.py attribute its HIP-event timings to profiler rows
+void lgm_note_kernel(const char* name);
 
 #define LGM_REQUIRE(cond, ...)              \
   do {                                      \

@@ -768,6 +768,8 @@ int lgm_wino_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, 
     }                                                                                                           \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                             \
   } while (0)
+  lgm_note_kernel(TTW == 8 ? "lgmwino::wino_conv_kernel<8, false, 0>" : TTW == 4 ? "lgmwino::wino_conv_kernel<4, false, 0>"
+                                                                                : "lgmwino::wino_conv_kernel<2, false, 0>");
   if (!p.dbg) {
     if (TTW == 8) LGM_WLAUNCH(8, false, 0);
     else if (TTW == 4) LGM_WLAUNCH(4, false, 0);
@@ -1271,6 +1273,8 @@ int lgm_wino_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, co
     }                                                                                                            \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                              \
   } while (0)
+  lgm_note_kernel(G == 8 ? "lgmwino::wino_wgrad_kernel<8, false>" : G == 4 ? "lgmwino::wino_wgrad_kernel<4, false>"
+                                                                          : "lgmwino::wino_wgrad_kernel<2, false>");
   p.dbg = (long long*)lgm_wino_debug_buffer;
   if (p.dbg && G == 8) {
     auto kern = wino_wgrad_kernel<8, true>;

@@ -69,6 +69,7 @@ class _Lib:
         self._dll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         self._dll.lgm_last_error.restype = ctypes.c_char_p
+        self._dll.lgm_last_kernel.restype = ctypes.c_char_p
         for name, (res, args) in self.protos.items():
             fn = getattr(self._dll, name)  # AttributeError if the .so misses a declared symbol
             fn.restype = res

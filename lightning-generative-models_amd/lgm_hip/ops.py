@@ -96,13 +96,17 @@ class KernelTimer:
     def end(self):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.records.append((*self._cur, e))
+        fam, flops, nbytes, s = self._cur
+        k = lib()._dll.lgm_last_kernel()
+        k = k.decode() if k else ""
+        self.records.append((fam, k, flops, nbytes, s, e))
 
-    def summary(self):
+    def summary(self, by_kernel: bool = False):
+        """per operator family (igemm_xy / igemm_yx / wgrad), or per primary kernel name as rocprofv3 prints it"""
         torch.cuda.synchronize()
         out = {}
-        for name, flops, nbytes, s, e in self.records:
-            d = out.setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+        for fam, kern, flops, nbytes, s, e in self.records:
+            d = out.setdefault((kern or fam) if by_kernel else fam, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops
             d["bytes"] += nbytes
