@@ -231,6 +231,15 @@ int lgm_sample_step(const float* x, const float* v, const float* noise, float* o
                     int B, int C, int HW, int Cpad, float A, float Bv, int clip, float R, float Rm1,
                     float C0, float C1, float C2, float C3, void* stream);
 
+/* The same update for a HIP-graph-replayed chain (p_sample_loop ddpm.py:759-780, ddim_sample :782-834 without the
+ * per-step host round trip :775,829): scalars from row counter[0] of table[n_steps][8] = (A, Bv, R, Rm1, C0, C1, C2,
+ * C3), x updated IN PLACE; lgm_sampler_time writes t[b] = ttable[counter[0]] for the UNet forward of the step;
+ * advance != 0 appends counter[0] += 1 (the last node of a step). */
+int lgm_sampler_time(const int64_t* ttable, const int32_t* counter, int64_t* t, int B, void* stream);
+int lgm_sample_step_table(float* x, const float* v, const float* noise, float* x0_out, int B, int C, int HW,
+                          int Cpad, const float* table, const int32_t* counter, int clip, int advance,
+                          void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Vector quantiser (VQ-VAE) — models/modules/vector_quantizer.py.
  * x: latents as [N = B*H*W, D] rows (NHWC), codebook [K, D].

@@ -382,6 +382,17 @@ __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ 
 //   eps = (R*x - x0) / Rm1                    (predict_noise_from_start)
 //   out = C0*x0 + C1*x + C2*eps + C3*noise
 // x, v: NHWC pitch Cpad; noise: NCHW dense (or null); out: NHWC pitch Cpad; x0_out optional.
+// one update of one element; contraction off so that the by-value and the table-driven kernel round identically
+__device__ __forceinline__ void sample_update(float xv, float vv, float nz, float A, float Bv, int clip, float R,
+                                              float Rm1, float C0, float C1, float C2, float C3, float& o, float& x0) {
+#pragma clang fp contract(off)
+  x0 = A * xv + Bv * vv;
+  if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+  const float eps = (R * xv - x0) / Rm1;
+  o = C0 * x0 + C1 * xv + C2 * eps;
+  if (C3 != 0.f) o += C3 * nz;
+}
+
 __global__ __launch_bounds__(256) void sample_step_kernel(const float* __restrict__ x, const float* __restrict__ v,
                                                           const float* __restrict__ noise, float* __restrict__ out,
                                                           float* __restrict__ x0_out, int B, int C, int HW, int Cpad,
@@ -394,21 +405,72 @@ __global__ __launch_bounds__(256) void sample_step_kernel(const float* __restric
   const long pix = i / Cpad;
   float o = 0.f, x0 = 0.f;
   if (c < C) {
-    const float xv = x[i];
-    x0 = A * xv + Bv * v[i];
-    if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-    const float eps = (R * xv - x0) / Rm1;
-    o = C0 * x0 + C1 * xv + C2 * eps;
+    float nz = 0.f;
     if (noise && C3 != 0.f) {
       const int b = (int)(pix / HW), p = (int)(pix % HW);
-      o += C3 * noise[((long)b * C + c) * HW + p];
+      nz = noise[((long)b * C + c) * HW + p];
     }
+    sample_update(x[i], v[i], nz, A, Bv, clip, R, Rm1, C0, C1, C2, noise ? C3 : 0.f, o, x0);
   }
   out[i] = o;
   if (x0_out) x0_out[i] = x0;
 }
 
+// Graph-replayed sampling (lgm_hip/sampler.py): the per-step scalars come from a device table indexed by a
+// device-side step counter, so ONE captured graph serves every step of a chain.
+//   sampler_time_kernel : t[b] = ttable[counter]                              (before the UNet forward)
+//   sample_step_table   : sample_step with row `counter` of table[n][8] = (A, Bv, R, Rm1, C0, C1, C2, C3), in place
+//   sampler_advance     : counter += 1                                        (last node of the graph)
+__global__ void sampler_time_kernel(const long* __restrict__ ttable, const int* __restrict__ counter,
+                                    long* __restrict__ t, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) t[i] = ttable[counter[0]];
+}
+__global__ __launch_bounds__(256) void sample_step_table_kernel(float* __restrict__ x, const float* __restrict__ v,
+                                                                const float* __restrict__ noise,
+                                                                float* __restrict__ x0_out, int B, int C, int HW,
+                                                                int Cpad, const float* __restrict__ table,
+                                                                const int* __restrict__ counter, int clip) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * HW * Cpad;
+  if (i >= total) return;
+  const float* row = table + 8 * counter[0];
+  const float A = row[0], Bv = row[1], R = row[2], Rm1 = row[3], C0 = row[4], C1 = row[5], C2 = row[6], C3 = row[7];
+  const int c = (int)(i % Cpad);
+  const long pix = i / Cpad;
+  float o = 0.f, x0 = 0.f;
+  if (c < C) {
+    float nz = 0.f;
+    if (noise && C3 != 0.f) {
+      const int b = (int)(pix / HW), p = (int)(pix % HW);
+      nz = noise[((long)b * C + c) * HW + p];
+    }
+    sample_update(x[i], v[i], nz, A, Bv, clip, R, Rm1, C0, C1, C2, noise ? C3 : 0.f, o, x0);
+  }
+  x[i] = o;
+  if (x0_out) x0_out[i] = x0;
+}
+__global__ void sampler_advance_kernel(int* counter) { counter[0] += 1; }
+
 }  // namespace
+
+extern "C" int lgm_sampler_time(const int64_t* ttable, const int32_t* counter, int64_t* t, int B, void* stream) {
+  LGM_REQUIRE(ttable && counter && t && B > 0, "sampler_time: bad arguments");
+  hipLaunchKernelGGL(sampler_time_kernel, dim3(lgm_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const long*)ttable, (const int*)counter, (long*)t, B);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+extern "C" int lgm_sample_step_table(float* x, const float* v, const float* noise, float* x0_out, int B, int C, int HW,
+                                     int Cpad, const float* table, const int32_t* counter, int clip, int advance,
+                                     void* stream) {
+  LGM_REQUIRE(x && v && table && counter && B > 0 && C > 0 && HW > 0 && Cpad >= C, "sample_step_table: bad arguments");
+  hipLaunchKernelGGL(sample_step_table_kernel, dim3(lgm_cdiv((long)B * HW * Cpad, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, v, noise, x0_out, B, C, HW, Cpad, table, (const int*)counter, clip);
+  if (advance) hipLaunchKernelGGL(sampler_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)counter);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
 
 extern "C" int lgm_posemb(const int64_t* t, int B, int dim, const float* freqs, float* out, int64_t pitch,
                           void* stream) {

@@ -3,12 +3,20 @@
 Reference: GaussianDiffusion.p_sample_loop ddpm.py:759-780, ddim_sample :782-834,
 model_predictions :707-734, p_sample :748-757.  The reference copies the image to the host
 at EVERY step (``img.detach().cpu()`` :775,829); here the whole chain stays on the device:
-per step = one UNet forward (HIP engine, NHWC) + one fused update kernel (lgm_sample_step)
-whose per-timestep scalars come from host copies of the schedule buffers (no device syncs).
+per step = one UNet forward (HIP engine, NHWC) + one fused update kernel.
+
+Two ways to run a chain, bit-identical in their results (tests/test_hip_unet.py):
+  * graph replay (default on the GPU when only the final image is wanted): ONE HIP graph per (network, shape)
+    holds a whole step — t[b] <- device table[step counter], UNet forward, noise draw, in-place update with the
+    step's scalars read from a device table, counter += 1 — and is replayed once per step: no Python between
+    the ~230 launches of a step, no host syncs, no per-step allocations (``lgm_sample_step_table``);
+  * eager launches (``return_all_timesteps``, ``LGM_NO_SAMPLER_GRAPH=1``, or when capture fails): per-timestep
+    scalars from host copies of the schedule buffers (``lgm_sample_step``).
 """
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -79,6 +87,119 @@ class _Chain:
         return out
 
 
+def _p_sample_coeffs(gd, t: int):
+    """(A, Bv, R, Rm1, C0, C1, C2, C3) of one ancestral step — the scalars p_sample_step hands to the kernel"""
+    hs = _host_schedule(gd)
+    sigma = _f32(torch.as_tensor(0.5 * hs["posterior_log_variance_clipped"][t]).exp()) if t > 0 else 0.0
+    return (_f32(hs["sqrt_alphas_cumprod"][t]), -_f32(hs["sqrt_one_minus_alphas_cumprod"][t]),
+            _f32(hs["sqrt_recip_alphas_cumprod"][t]), _f32(hs["sqrt_recipm1_alphas_cumprod"][t]),
+            _f32(hs["posterior_mean_coef1"][t]), _f32(hs["posterior_mean_coef2"][t]), 0.0, sigma)
+
+
+def _ddim_coeffs(gd, t: int, t_next: int, eta: float):
+    hs = _host_schedule(gd)
+    head = (_f32(hs["sqrt_alphas_cumprod"][t]), -_f32(hs["sqrt_one_minus_alphas_cumprod"][t]),
+            _f32(hs["sqrt_recip_alphas_cumprod"][t]), _f32(hs["sqrt_recipm1_alphas_cumprod"][t]))
+    if t_next < 0:
+        return head + (1.0, 0.0, 0.0, 0.0)
+    a, an = hs["alphas_cumprod"][t], hs["alphas_cumprod"][t_next]
+    sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+    c = (1 - an - sigma ** 2).sqrt()
+    return head + (_f32(an.sqrt()), 0.0, _f32(c), _f32(sigma))
+
+
+_GRAPHS = {}      # (id(net), shape, with_noise) -> _GraphedChain
+
+
+class _GraphedChain:
+    """One captured sampling step for a (network, batch shape); replayed once per step of any chain on it."""
+
+    def __init__(self, gd, shape, with_noise: bool, max_steps: int = 4096):
+        self.net = gd.model
+        B, C, H, W = shape
+        dev = gd.betas.device
+        self.shape, self.with_noise = shape, with_noise
+        Cp = _r4(C)
+        self.x = torch.zeros((B, H, W, Cp), device=dev)
+        self.t = torch.zeros(B, dtype=torch.long, device=dev)
+        self.noise = torch.zeros(shape, device=dev) if with_noise else None     # injected noise goes here
+        self.table = torch.zeros((max_steps, 8), device=dev)
+        self.ttable = torch.zeros(max_steps, dtype=torch.long, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.inject = False
+        self.max_steps = max_steps
+        L = ops.lib()
+
+        def one_step():
+            st = ops.stream()
+            L.lgm_sampler_time(self.ttable.data_ptr(), self.counter.data_ptr(), self.t.data_ptr(), B, st)
+            v, _ = self.net.forward_nhwc(self.x, self.t, False, refresh_weights=False)
+            nz = None
+            if with_noise:
+                nz = self.noise if self.inject else torch.randn(shape, device=dev)
+            L.lgm_sample_step_table(self.x.data_ptr(), v.data_ptr(), None if nz is None else nz.data_ptr(), None, B, C,
+                                    H * W, Cp, self.table.data_ptr(), self.counter.data_ptr(), 1, 1, ops.stream())
+
+        self.net.refresh_derived_weights(False)
+        rng_state = torch.cuda.get_rng_state(dev)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):            # eager warm-up (sizes workspaces, sets kernel attributes)
+            for _ in range(2):
+                one_step()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self.graphs = {}
+        for inject in ((False, True) if with_noise else (False,)):
+            self.inject = inject
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                one_step()
+            self.graphs[inject] = g
+        torch.cuda.set_rng_state(rng_state, dev)     # capture leaves the random stream where it was
+
+    def run(self, x0_nhwc, times, coeffs, noises):
+        """times[i], coeffs[i] (8 floats) per step; noises: None (draw on device) or a list with one NCHW tensor or
+        None per step.  Returns the final NHWC image (a view of the static buffer)."""
+        n = len(times)
+        assert n <= self.max_steps
+        self.net.refresh_derived_weights(False)      # the weights may have moved since the last chain (EMA updates)
+        self.x.copy_(x0_nhwc)
+        self.table[:n].copy_(torch.tensor(coeffs, dtype=torch.float32), non_blocking=False)
+        self.ttable[:n].copy_(torch.tensor(times, dtype=torch.long))
+        self.counter.zero_()
+        for i in range(n):
+            if noises is not None and self.with_noise and noises[i] is not None:
+                self.noise.copy_(noises[i])
+                self.graphs[True].replay()
+            elif noises is not None and self.with_noise:
+                self.noise.zero_()
+                self.graphs[True].replay()
+            else:
+                self.graphs[False].replay()
+        return self.x
+
+
+def _graph_chain(gd, shape, with_noise: bool):
+    """-> a _GraphedChain for (network, shape), or None (graph replay disabled / capture failed: eager launches)"""
+    if os.environ.get("LGM_NO_SAMPLER_GRAPH", "0") == "1" or gd.betas.device.type != "cuda":
+        return None
+    key = (id(gd.model), tuple(shape), bool(with_noise))
+    ent = _GRAPHS.get(key)
+    if ent is None:
+        try:
+            gd.model.prepare_hip(gd.betas.device)
+            ent = _GraphedChain(gd, tuple(shape), with_noise)
+        except Exception as e:  # capture is an optimisation
+            import sys
+            print(f"[lgm_hip] sampler graph capture unavailable ({type(e).__name__}: {e}); eager launches",
+                  file=sys.stderr, flush=True)
+            ent = False
+        _GRAPHS[key] = ent
+    return ent or None
+
+
 def p_sample_step(chain: _Chain, t: int, noise: Optional[torch.Tensor]):
     """One ancestral step (p_sample :748-757): clip x0, posterior mean + sigma * noise (t > 0)."""
     hs = _host_schedule(chain.gd)
@@ -103,8 +224,14 @@ def ddim_step(chain: _Chain, t: int, t_next: int, noise: Optional[torch.Tensor],
 def p_sample_loop(gd, shape, return_all_timesteps=False, init_noise=None, noises: Optional[List[torch.Tensor]] = None):
     chain = _Chain(gd, shape, init_noise)
     dev = chain.x.device
+    ts = list(reversed(range(gd.num_timesteps)))
+    gc = None if return_all_timesteps else _graph_chain(gd, shape, True)
+    if gc is not None:
+        x = gc.run(chain.x, ts, [_p_sample_coeffs(gd, t) for t in ts], noises)
+        chain.x = x
+        return chain.image(gd.auto_normalize)
     frames = [chain.image(False)] if return_all_timesteps else None
-    for i, t in enumerate(reversed(range(gd.num_timesteps))):
+    for i, t in enumerate(ts):
         nz = None
         if t > 0:
             nz = noises[i] if noises is not None else torch.randn(shape, device=dev)
@@ -122,8 +249,15 @@ def ddim_sample(gd, shape, return_all_timesteps=False, init_noise=None, noises: 
     chain = _Chain(gd, shape, init_noise)
     dev = chain.x.device
     eta = gd.ddim_sampling_eta
+    pairs = gd.ddim_time_pairs()
+    gc = None if return_all_timesteps else _graph_chain(gd, shape, eta != 0.0)
+    if gc is not None:
+        x = gc.run(chain.x, [a for a, _ in pairs], [_ddim_coeffs(gd, a, b, eta) for a, b in pairs],
+                   noises if eta != 0.0 else None)
+        chain.x = x
+        return chain.image(gd.auto_normalize)
     frames = [chain.image(False)] if return_all_timesteps else None
-    for i, (t, t_next) in enumerate(gd.ddim_time_pairs()):
+    for i, (t, t_next) in enumerate(pairs):
         nz = None
         if t_next >= 0 and eta != 0.0:
             nz = noises[i] if noises is not None else torch.randn(shape, device=dev)

@@ -382,17 +382,16 @@ class Unet(nn.Module):
         gc.beta(l1.bias)
 
     # ---- network ----------------------------------------------------------------------------
-    def forward_nhwc(self, x, t, save: bool):
+    def forward_nhwc(self, x, t, save: bool, refresh_weights: bool = True):
         """x: [B, S, S, r4(channels)] NHWC (pad lanes zero), t: int64 [B].
-        Returns (out [B,S,S,r4(out_dim)], tape)."""
+        Returns (out [B,S,S,r4(out_dim)], tape).  ``refresh_weights=False``: the derived weight copies (Winograd /
+        split-precision operands) are known to be current — a sampling chain refreshes them once, not per step."""
         B, S, _, _ = x.shape
         dim = self.dim
         n = len(self.in_out)
         assert S % (2 ** (n - 1)) == 0, f"input size {S} must be divisible by {2 ** (n - 1)}"
-        if self._flat.b3:
-            self._flat.refresh_split()      # bf16 planes of the current weights (one launch)
-        if self._flat.wino:
-            self._flat.refresh_wino(backward_operand=save)   # U = G g G^T of the current weights (one launch)
+        if refresh_weights:
+            self.refresh_derived_weights(save)
         ss_all, time_saved = self._time_fwd(t, save)
         ssl = [ss_all[:, o:o + 2 * rb.dim_out] for o, rb in zip(self._ss_offsets, self.resblocks())]
         k = 0  # running resblock index
@@ -457,6 +456,12 @@ class Unet(nn.Module):
         if not save:
             return out, None
         return out, (time_saved, tape, sm1, sm2, sm3, ups_tape, sf, fin, x, [c[0].shape for c in cats])
+
+    def refresh_derived_weights(self, for_backward: bool):
+        if self._flat.b3:
+            self._flat.refresh_split()      # bf16 planes of the current weights (one launch)
+        if self._flat.wino:
+            self._flat.refresh_wino(backward_operand=for_backward)   # U = G g G^T of the current weights (one launch)
 
     def backward_nhwc(self, tape_all, gout):
         """Hand-written backward pass: parameter gradients into the flat gradient buffer."""

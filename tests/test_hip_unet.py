@@ -191,6 +191,33 @@ def test_whole_sampling_loops_match_reference_fixture(dev, golden_dir, parity):
     parity("200-step ancestral loop, final image", rel(out, fx["p_sample_loop_200"]), RTOL)
 
 
+def test_graph_replayed_sampling_is_bit_identical_to_eager_launches(dev, golden_dir, monkeypatch):
+    """The captured sampling step (device-side step counter + scalar table, in-place update) against the eager
+    per-step launches: same DDIM chain (eta = 0) and same ancestral chain with injected noise, torch.equal."""
+    from lgm_hip import sampler
+    from models.generative.diffusion.ddpm import GaussianDiffusion
+    from oracle import diffusion as OD
+    fx, dim, S, P, img, noise, t = case(golden_dir, "small")
+    shape = tuple(fx["x_t"].shape)
+    net, gd = build(dim, S, P, dev, sampling_timesteps=50)
+    gd_a = GaussianDiffusion(net, img_size=S, timesteps=60).to(dev)
+    init, nz = OD.draw_loop_noise(7, shape, 59)
+    nzd = [n.to(dev) for n in nz] + [None]
+    outs = {}
+    for mode in ("graph", "eager"):
+        monkeypatch.setenv("LGM_NO_SAMPLER_GRAPH", "0" if mode == "graph" else "1")
+        outs[mode] = (sampler.ddim_sample(gd, shape, init_noise=init.to(dev)),
+                      sampler.p_sample_loop(gd_a, shape, init_noise=init.to(dev), noises=nzd))
+    assert sampler._GRAPHS and all(v for v in sampler._GRAPHS.values()), "graph capture did not happen"
+    assert torch.equal(outs["graph"][0], outs["eager"][0])
+    assert torch.equal(outs["graph"][1], outs["eager"][1])
+    # device-drawn noise: runs, finite, and two chains differ (fresh draws per replay)
+    monkeypatch.setenv("LGM_NO_SAMPLER_GRAPH", "0")
+    a = sampler.p_sample_loop(gd_a, shape, init_noise=init.to(dev))
+    b = sampler.p_sample_loop(gd_a, shape, init_noise=init.to(dev))
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
 def test_ddpm_module_training_steps(dev, parity):
     """LightningModule surface: training_step -> backward -> FusedAdam.step -> EMA, 3 steps,
     against the oracle + torch.optim.Adam on CPU."""
