@@ -30,6 +30,8 @@
 // holds all 16 xi of its (tile, channel) pairs); the four output positions leave through a wave-private
 // LDS transpose as 16-byte stores with bias / residual fused.  Split-K writes partial OUTPUTS (the output
 // transform is linear) that the existing fixed-order reducer sums.
+#include <type_traits>
+
 #include "lgm_common.h"
 
 int lgm_splitk_reduce_launch(const float* ws, long ws_stride, int splits, const float* bias, const float* res,
@@ -411,21 +413,16 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
    // One iteration = one UNIT: the accumulators live only here (zeroed at the top, consumed by the epilogue
    // at the bottom), so that they stay in AGPRs across the phase loop; everything that is pipelined across
    // units (raw patch registers, LDS ring, weight ring, A fragments, phase iterators) lives outside.
+   // No zero-fill: the first phase of a unit issues its first MFMA of every accumulator with the constant 0 as C
+   // (256 v_accvgpr_write per unit cost ~2 k cycles of MFMA issue).  The accumulators are born as MFMA results, i.e.
+   // in AGPRs: a VGPR-class zero would make the loop-carried accumulators VGPR-class, and the compiler would then
+   // copy all 256 of them into AGPRs before, and back after, every phase.
    f32x16 acc[16];
-#pragma unroll
-   for (int x = 0; x < 16; ++x)
-#pragma unroll
-     for (int r = 0; r < 16; ++r) {
-       // zero born in an AGPR: a VGPR-class zero makes the loop-carried accumulators VGPR-class, and the compiler
-       // then copies all 256 of them into AGPRs before, and back after, every phase
-       float z;
-       asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z));
-       acc[x][r] = z;
-     }
-   asm volatile("s_nop 1");
    Phase fin = cur;
    bool last_of_unit;
-   do {
+   auto run_phase = [&](auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int rb1 = rb0 == 2 ? 0 : rb0 + 1, rb2 = rb1 == 2 ? 0 : rb1 + 1;
     const float* R0 = Rb + rb0 * 4 * RPLANE;    // raw[cur]
     const float* R1 = Rb + rb1 * 4 * RPLANE;    // raw[nx1]
@@ -479,8 +476,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
       for (int s = 0; s < 4; ++s) {
         // weights as the A operand, transformed tiles as B: D[channel][tile], so that a lane ends up with ONE tile
         // and four groups of 4 CONSECUTIVE channels (accumulator registers 4 g .. 4 g + 3) -> 16-byte stores
-        acc[2 * y] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], acc[2 * y], 0, 0, 0);
-        acc[2 * y + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a1[s], acc[2 * y + 1], 0, 0, 0);
+        acc[2 * y] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], FIRST && s == 0 ? zero16 : acc[2 * y], 0, 0, 0);
+        acc[2 * y + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a1[s], FIRST && s == 0 ? zero16 : acc[2 * y + 1], 0, 0, 0);
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -517,7 +514,9 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
       if (nx3.L != l3) slot_offsets(nx3, poff);
     }
     rb0 = rb1;
-   } while (!last_of_unit);
+   };
+   run_phase(std::true_type{});
+   while (!last_of_unit) run_phase(std::false_type{});
 
     {
       // ---- epilogue: lane-local output transform (every lane holds all 16 xi of its tile's 16 channels), then
