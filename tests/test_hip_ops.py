@@ -441,3 +441,33 @@ def test_device_image_transforms_match_reference_stack(dev, shape):
     ev = DeviceTransforms(S, train=False)(imgs.to(dev)).cpu()
     ref0 = torch.stack([OD.transform(imgs[i], S, False) for i in range(5)])
     assert float((ev - ref0).abs().max()) < 2e-5
+
+
+def test_attend_module_path(dev):
+    """models/modules/attend.py (reference models/modules/attend.py:97-126): stand-alone Attend()(q, k, v) on the HIP
+    attention kernel, with and without leading memory rows, against the reference's einsum / softmax formula."""
+    from models.modules.attend import Attend
+    g = torch.Generator().manual_seed(11)
+    b, h, n, d, M = 3, 4, 16, 32, 4
+    q = torch.randn(b, h, n, d, generator=g)
+    k = torch.randn(b, h, n + M, d, generator=g)
+    v = torch.randn(b, h, n + M, d, generator=g)
+    k[:, :, :M] = k[:1, :, :M]
+    v[:, :, :M] = v[:1, :, :M]
+
+    def ref(q, k, v):
+        sim = torch.einsum("bhid,bhjd->bhij", q, k) * d ** -0.5
+        return torch.einsum("bhij,bhjd->bhid", sim.softmax(dim=-1), v)
+    att = Attend()
+    with torch.no_grad():
+        out = att(q.to(dev), k.to(dev), v.to(dev))
+    assert rel(out, ref(q, k, v)) < RTOL
+    q2, k2, v2 = (t[:, :, :n].clone().requires_grad_(True) for t in (q, k[:, :, M:], v[:, :, M:]))
+    w = torch.randn(b, h, n, d, generator=g)
+    (ref(q2, k2, v2) * w).sum().backward()
+    qd, kd, vd = (t.detach().to(dev).requires_grad_(True) for t in (q2, k2, v2))
+    o = att(qd, kd, vd)
+    assert rel(o, ref(q2, k2, v2)) < RTOL
+    (o * w.to(dev)).sum().backward()
+    for a, r in ((qd, q2), (kd, k2), (vd, v2)):
+        assert rel(a.grad, r.grad) < RTOL
