@@ -100,7 +100,7 @@ struct IgemmArgs {
   int wide;           // output / residual / bias are 16-byte aligned with pitches % 4 == 0 (wide epilogue allowed)
 };
 
-template <int MODE, int BM, int BN, int TM, int TN>
+template <int MODE, int BM, int BN, int TM, int TN, bool UNI>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 wave grid");
   constexpr int A_PER = BM / 32;  // float4 per thread per chunk
@@ -162,7 +162,106 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
   }
 
+  // ---- UNI: Cg % BK == 0, so a K chunk lies inside ONE tap: the tap decode is wave-uniform (SALU, advanced
+  // incrementally) and every load is a raw buffer load  descriptor + per-thread byte offset + scalar offset.
+  // Per chunk a thread spends ~6 VALU instructions per gathered row (two bound checks, one select) instead of
+  // the ~30 of the general decode: beside fp32 MFMAs each VALU instruction costs issue slots the matrix pipe
+  // wants (DESIGN finding 11).  Zero padding = an offset at the descriptor's range (hardware returns 0).
+  unsigned va[A_PER], vb[B_PER];
+  int q_h[A_PER], q_w[A_PER];
+  unsigned nrec_a = 0;
+  __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+  int u_c0 = 0, u_ta = 0, u_tb = 0;        // scalar chunk state: channel origin, tap row / column
+  if constexpr (UNI) {
+    auto make_rsrc = [](const float* base, unsigned nrec) {
+      const unsigned long long ab = reinterpret_cast<unsigned long long>(base);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ab);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ab >> 32));
+      return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                               __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+    };
+    const int KWu = (MODE == MODE_YX) ? p.KWs : p.KW;
+    long shift;                             // descriptor origin = a - shift elements (keeps both offsets >= 0)
+    if (MODE == MODE_XY) {
+      shift = (long)(p.pad * p.W + p.pad) * p.a_pitch;
+      nrec_a = (unsigned)((((long)p.B * p.H * p.W) * p.a_pitch + shift) * 4);
+    } else {
+      shift = (long)((p.KHs - 1) * p.Wo + (p.KWs - 1)) * p.a_pitch;
+      nrec_a = (unsigned)((((long)p.B * p.Ho * p.Wo + (long)(p.KHs + 1) * p.Wo + p.KWs) * p.a_pitch + shift) * 4);
+    }
+    rsrc_a = make_rsrc(p.a - shift, nrec_a);
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      if (MODE == MODE_XY) {
+        q_h[i] = r_h[i];
+        q_w[i] = r_w[i];
+        va[i] = (unsigned)((((long)r_pix[i] + (long)(r_h[i] + p.pad) * p.W + (r_w[i] + p.pad)) * p.a_pitch + acol * 4) * 4);
+      } else {
+        q_h[i] = p.phases > 1 ? (r_h[i] - kh0) / p.stride : r_h[i];
+        q_w[i] = p.phases > 1 ? (r_w[i] - kw0) / p.stride : r_w[i];
+        va[i] = (unsigned)((((long)r_pix[i] + (long)q_h[i] * p.Wo + q_w[i]) * p.a_pitch + acol * 4) * 4);
+      }
+      if (!r_ok[i]) {
+        q_h[i] = -(1 << 20);               // fails every bound check
+        q_w[i] = -(1 << 20);
+      }
+    }
+    const unsigned nrec_b = (unsigned)((long)p.Nw * p.KH * p.KW * p.Cw * 4);
+    rsrc_b = make_rsrc(p.w, nrec_b);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      if (MODE == MODE_XY) {
+        const int n = n0 + arow + 32 * i;
+        vb[i] = n < p.N ? (unsigned)(((long)n * p.K + acol * 4) * 4) : nrec_b;
+      } else {
+        constexpr int TPR = BN / 4;
+        constexpr int RPP = 256 / TPR;
+        const int ncol = (tid % TPR) * 4, krow = tid / TPR;
+        vb[i] = n0 + ncol < p.N ? (unsigned)(((long)(krow + RPP * i) * (p.KH * p.KW) * p.Cw + n0 + ncol) * 4) : nrec_b;
+      }
+    }
+    const int tap0 = k_begin / p.Cg;
+    u_c0 = k_begin - tap0 * p.Cg;
+    u_ta = tap0 / KWu;
+    u_tb = tap0 - u_ta * KWu;
+  }
+
   f32x4 ra[A_PER], rb[B_PER];
+
+  auto load_chunk_uni = [&]() {
+    const int KWu = (MODE == MODE_YX) ? p.KWs : p.KW;
+    unsigned soff_a, soff_b;
+    if (MODE == MODE_XY) {
+      soff_a = (unsigned)((((long)u_ta * p.W + u_tb) * p.a_pitch + u_c0) * 4);
+      soff_b = (unsigned)(((u_ta * p.KW + u_tb) * p.Cg + u_c0) * 4);
+    } else {
+      soff_a = (unsigned)((((long)(p.KHs - 1 - u_ta) * p.Wo + (p.KWs - 1 - u_tb)) * p.a_pitch + u_c0) * 4);
+      const int tp = p.phases > 1 ? (kh0 + u_ta * p.stride) * p.KW + kw0 + u_tb * p.stride : u_ta * p.KW + u_tb;
+      soff_b = (unsigned)((((long)u_c0 * (p.KH * p.KW) + tp) * p.Cw) * 4);
+    }
+    soff_a = __builtin_amdgcn_readfirstlane(soff_a);
+    soff_b = __builtin_amdgcn_readfirstlane(soff_b);
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      bool ok;
+      if (MODE == MODE_XY)
+        ok = (unsigned)(q_h[i] + u_ta) < (unsigned)p.H && (unsigned)(q_w[i] + u_tb) < (unsigned)p.W;
+      else
+        ok = (unsigned)(q_h[i] - u_ta) < (unsigned)p.Ho && (unsigned)(q_w[i] - u_tb) < (unsigned)p.Wo;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? va[i] : nrec_a, soff_a, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vb[i], soff_b, 0));
+    u_c0 += BK;
+    if (u_c0 == p.Cg) {
+      u_c0 = 0;
+      if (++u_tb == KWu) {
+        u_tb = 0;
+        ++u_ta;
+      }
+    }
+  };
 
   auto load_chunk = [&](int k0) {
     // ---- A: one tap/channel decode per thread per chunk ----
@@ -262,13 +361,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (k_end - k_begin + BK - 1) / BK;
-  load_chunk(k_begin);
+  if constexpr (UNI) load_chunk_uni(); else load_chunk(k_begin);
   store_chunk(0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_chunk(k_begin + (kt + 1) * BK);
+    if (kt + 1 < nk) {
+      if constexpr (UNI) load_chunk_uni(); else load_chunk(k_begin + (kt + 1) * BK);
+    }
 
     const float* as = As + cur * A_TILE + (wm * 32 * TM + lr) * LDA + lh * 4;
     const float* bs;
@@ -389,14 +490,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   }
 }
 
-template <int MODE, int BM, int BN, int TM, int TN>
-int launch_igemm(IgemmArgs& a, hipStream_t s) {
+template <int MODE, int BM, int BN, int TM, int TN, bool UNI>
+int launch_igemm_t(IgemmArgs& a, hipStream_t s) {
   a.tiles_m = lgm_cdiv(a.M, BM);
   a.tiles_n = lgm_cdiv(a.N, BN);
   constexpr int A_TILE = BM * LDA;
   constexpr int B_TILE = (MODE == MODE_XY) ? BN * LDA : BK * BN;
   const size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
-  auto kern = igemm_kernel<MODE, BM, BN, TM, TN>;
+  auto kern = igemm_kernel<MODE, BM, BN, TM, TN, UNI>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -406,6 +507,23 @@ int launch_igemm(IgemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits * a.phases)), dim3(256), smem, s, a);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
+}
+
+// UNI (uniform-tap chunks, buffer loads): gathered channel count a multiple of BK, strided input gradients only in
+// their residue-class form, every byte offset below 2^31.  LGM_NO_IGEMM_UNI=1 keeps the general decode (A/B runs).
+static bool igemm_uni_enabled() {
+  static const int on = [] { const char* e = getenv("LGM_NO_IGEMM_UNI"); return !(e && e[0] == '1'); }();
+  return on != 0;
+}
+
+template <int MODE, int BM, int BN, int TM, int TN>
+int launch_igemm(IgemmArgs& a, hipStream_t s) {
+  const long gathered = MODE == MODE_XY ? (long)a.B * a.H * a.W : (long)a.B * a.Ho * a.Wo;
+  const long span = (gathered + (long)(a.KH + 2) * (a.W > a.Wo ? a.W : a.Wo) + a.KW) * a.a_pitch * 4;
+  const bool uni = igemm_uni_enabled() && a.Cg % BK == 0 && a.K % BK == 0 && span < (1L << 31) &&
+                   (long)a.Nw * a.KH * a.KW * a.Cw * 4 < (1L << 31) &&
+                   (MODE == MODE_XY || a.stride == 1 || a.phases > 1);
+  return uni ? launch_igemm_t<MODE, BM, BN, TM, TN, true>(a, s) : launch_igemm_t<MODE, BM, BN, TM, TN, false>(a, s);
 }
 
 // Split-K plan of the generic path: a GEMM with few output tiles and a long reduction (the fused FiLM

@@ -63,29 +63,66 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
 }
 
 // Segmented sums by code: dw[k][:] = sum_{rows with idx == k} x[row][:], counts[k] = #rows.
-// One 64-lane block per code (D <= 128: two floats per lane); rows visited in ascending order.
-__global__ __launch_bounds__(64) void vq_segment_sum_kernel(const float* __restrict__ x, long x_pitch,
-                                                            const int64_t* __restrict__ idx, int N, int D,
-                                                            float* __restrict__ dw, float* __restrict__ counts) {
-  const int k = blockIdx.x, lane = threadIdx.x;
+// One block of VQ_SEG_WAVES waves per code (D <= 128: two floats per lane).  Wave w scans the w-th contiguous
+// slice of the rows in ascending order, eight matching rows in flight at a time (a collapsed codebook puts
+// every row on one code: the row loads of that block are then a latency chain, so they are issued in
+// batches); the slices are combined in ascending order through LDS, so the result does not depend on timing.
+constexpr int VQ_SEG_WAVES = 16;
+__global__ __launch_bounds__(64 * VQ_SEG_WAVES) void vq_segment_sum_kernel(const float* __restrict__ x, long x_pitch,
+                                                                           const int64_t* __restrict__ idx, int N,
+                                                                           int D, float* __restrict__ dw,
+                                                                           float* __restrict__ counts) {
+  __shared__ float part[VQ_SEG_WAVES][128];
+  __shared__ int pcnt[VQ_SEG_WAVES];
+  const int k = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per = ((N + VQ_SEG_WAVES - 1) / VQ_SEG_WAVES + 63) & ~63;
+  const int lo = w * per, hi = min(N, lo + per);
+  const bool c0 = lane < D, c1 = lane + 64 < D;
   float a0 = 0.f, a1 = 0.f;
   int cnt = 0;
-  for (int r0 = 0; r0 < N; r0 += 64) {
+  for (int r0 = lo; r0 < hi; r0 += 64) {
     const int r = r0 + lane;
-    const bool m = r < N && idx[r] == (int64_t)k;
+    const bool m = r < hi && idx[r] == (int64_t)k;
     unsigned long long mask = __ballot(m);
     cnt += __popcll(mask);
     while (mask) {
-      const int j = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const float* xp = x + (long)(r0 + j) * x_pitch;
-      if (lane < D) a0 += xp[lane];
-      if (lane + 64 < D) a1 += xp[lane + 64];
+      float v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v0[u] = 0.f;
+        v1[u] = 0.f;
+        if (mask) {
+          const int j = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const float* xp = x + (long)(r0 + j) * x_pitch;
+          if (c0) v0[u] = xp[lane];
+          if (c1) v1[u] = xp[lane + 64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a0 += v0[u];
+        a1 += v1[u];
+      }
     }
   }
-  if (lane < D) dw[(long)k * D + lane] = a0;
-  if (lane + 64 < D) dw[(long)k * D + lane + 64] = a1;
-  if (lane == 0) counts[k] = (float)cnt;
+  part[w][lane] = a0;
+  part[w][lane + 64] = a1;
+  if (lane == 0) pcnt[w] = cnt;
+  __syncthreads();
+  if (w == 0) {
+    float s0 = 0.f, s1 = 0.f;
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < VQ_SEG_WAVES; ++i) {
+      s0 += part[i][lane];
+      s1 += part[i][lane + 64];
+      n += pcnt[i];
+    }
+    if (c0) dw[(long)k * D + lane] = s0;
+    if (c1) dw[(long)k * D + lane + 64] = s1;
+    if (lane == 0) counts[k] = (float)n;
+  }
 }
 
 // EMA codebook update (vector_quantizer.py:128-147), single block.
@@ -210,7 +247,7 @@ extern "C" int lgm_vq_assign(const float* x, int64_t x_pitch, const float* codeb
 extern "C" int lgm_vq_segment_sum(const float* x, int64_t x_pitch, const int64_t* indices, int N, int K, int D,
                                   float* dw, float* counts, void* stream) {
   LGM_REQUIRE(x && indices && dw && counts && N > 0 && K > 0 && D > 0 && D <= VQ_MAXD, "vq_segment_sum: bad arguments");
-  hipLaunchKernelGGL(vq_segment_sum_kernel, dim3(K), dim3(64), 0, (hipStream_t)stream, x, (long)x_pitch, indices, N, D,
+  hipLaunchKernelGGL(vq_segment_sum_kernel, dim3(K), dim3(64 * VQ_SEG_WAVES), 0, (hipStream_t)stream, x, (long)x_pitch, indices, N, D,
                      dw, counts);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
