@@ -835,9 +835,14 @@ struct WgradArgs {
   int B, H, W, Cw, Ho, Wo, Nw, KH, KW, stride, pad;
   int P, Q;        // pixels, T*Cw
   int tiles_m, tiles_n, splits, chunk;  // chunk = pixels per split (multiple of WBK)
+  int lWo, lHo, lW, lH;                 // FAST: log2 of the (power-of-two) map sizes
 };
 
-template <int BM, int BN, int TM, int TN>
+// FAST: Ho, Wo, H, W powers of two, B*H*W < 2^24, byte offsets < 2^31: the pixel decode of the gather is shifts
+// and masks and every load is a raw buffer load (zero fill = an offset at the descriptor's range) - ~12 VALU
+// instructions per gathered row instead of ~60 (two integer divisions each), which beside fp32 MFMAs is the
+// difference between a VALU-bound and an MFMA-bound loop (DESIGN finding 11).
+template <int BM, int BN, int TM, int TN, bool FAST>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
   static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 wave grid");
   constexpr int A_TPR = BM / 4, A_RPP = 256 / A_TPR, A_PER = WBK / A_RPP > 0 ? WBK / A_RPP : 1;
@@ -871,7 +876,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
 
   f32x4 ra[A_PER], rb[B_PER];
+  __amdgpu_buffer_rsrc_t rsrc_y, rsrc_x;
+  unsigned nrec_y = 0, nrec_x = 0, ya[A_PER];
+  const int khp = kh - p.pad, kwp = kw - p.pad;
+  if constexpr (FAST) {
+    auto make_rsrc = [](const float* base, unsigned nrec) {
+      const unsigned long long ab = reinterpret_cast<unsigned long long>(base);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ab);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ab >> 32));
+      return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                               __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+    };
+    nrec_y = (unsigned)((long)p.P * p.y_pitch * 4);
+    nrec_x = (unsigned)((long)p.B * p.H * p.W * p.x_pitch * 4);
+    rsrc_y = make_rsrc(p.y, nrec_y);
+    rsrc_x = make_rsrc(p.x, nrec_x);
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i)
+      ya[i] = a_nok ? (unsigned)(((long)(a_prow + A_RPP * i) * p.y_pitch + m0 + a_ncol) * 4) : nrec_y;
+  }
+  auto load_chunk_fast = [&](int pp0) {
+    const unsigned soff_y = __builtin_amdgcn_readfirstlane((unsigned)((long)pp0 * p.y_pitch * 4));
+    const int left = __builtin_amdgcn_readfirstlane(p.P - pp0);       // rows of this chunk that exist
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i)
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rsrc_y, (a_prow + A_RPP * i) < left ? ya[i] : nrec_y, soff_y, 0));
+    const unsigned xpb = (unsigned)p.x_pitch * 4u;
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const unsigned pix = (unsigned)(pp0 + b_prow + B_RPP * i);
+      const unsigned ow = pix & (unsigned)(p.Wo - 1), oh = (pix >> p.lWo) & (unsigned)(p.Ho - 1);
+      const unsigned b = pix >> (p.lWo + p.lHo);                     // >= B past the last pixel: offset out of range
+      const int ih = (int)oh * p.stride + khp, iw = (int)ow * p.stride + kwp;
+      const bool ok = b_qok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const unsigned idx = (((b << p.lH) + (unsigned)ih) << p.lW) + (unsigned)iw;
+      const unsigned off = (unsigned)__umul24(idx, xpb) + (unsigned)cch * 4u;
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? off : nrec_x, 0, 0));
+    }
+  };
   auto load_chunk = [&](int pp0) {
+    if constexpr (FAST) {
+      load_chunk_fast(pp0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int pix = pp0 + a_prow + A_RPP * i;
@@ -1150,8 +1198,17 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
     if (int rc = lgm_wgrad1x1_launch(g, y, y_pitch, x, x_pitch, a.out, a.bias_out, beta, a.slab, a.splits, per1, s))
       return rc;
   } else {
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    a.lWo = lg2(a.Wo); a.lHo = lg2(a.Ho); a.lW = lg2(a.W); a.lH = lg2(a.H);
+    static const bool no_fast = getenv("LGM_NO_WGRAD_FAST") != nullptr;   // A/B switch
+    const bool fast = !no_fast && a.lWo >= 0 && a.lHo >= 0 && a.lW >= 0 && a.lH >= 0 &&
+                      (long)a.B * a.H * a.W < (1L << 24) && x_pitch * 4 < (1L << 24) &&
+                      (long)a.B * a.H * a.W * x_pitch * 4 < (1L << 31) && ((long)a.P + WBK) * y_pitch * 4 < (1L << 31);
     lgm_note_kernel("wgrad_kernel<64, 64, 1, 1>");
-    hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
+    if (fast)
+      hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1, true>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1, false>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
     LGM_LAUNCH_CHECK();
   }
   const long n_b = gbias ? a.Nw : 0;
