@@ -290,6 +290,19 @@ int lgm_bn_reduce3(const float* v1, int64_t v1_pitch, const float* v2, int64_t v
 int lgm_bn_coef(int mode, const float* sums3, const float* gamma, const float* rstd,
                 const float* saved_m, int C, int64_t M, float* coef4, float* ggamma, float* gbeta,
                 float beta_acc, float* m_out, void* stream);
+/* lgm_bn_reduce3 followed by lgm_bn_coef, the coefficient math run inside the second reduction stage (two
+ * launches): modes bit 0 -> mode-0 set into coef8[0..4C) with ggamma0 / gbeta0 / m_out, bit 1 -> mode-1 set into
+ * coef8[4C..8C) with ggamma1 (needs saved_m).  sums3 (optional) also receives [S1,S2,S3]. */
+int lgm_bn_reduce3_coef(int modes, const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch,
+                        const float* a, int64_t a_pitch, const float* mean, const float* rstd,
+                        const float* gamma, const float* saved_m, int64_t rows, int C, float* coef8,
+                        float* ggamma0, float* gbeta0, float beta_acc0, float* m_out, float* ggamma1,
+                        float beta_acc1, float* sums3, void* workspace, void* stream);
+/* out_k = A1k*v1 + A2k*v2 + A3k*xhat + A4k for the two coefficient sets of coef8 = [2][4][C] (set 0 without its
+ * v2 term), one pass over v1, v2, a */
+int lgm_bn_affine3x2(const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch, const float* a,
+                     int64_t a_pitch, const float* mean, const float* rstd, const float* coef8, float* out0,
+                     int64_t out0_pitch, float* out1, int64_t out1_pitch, int64_t rows, int C, void* stream);
 /* out (+)= act( A1*v1 + A2*v2 + A3*xhat + A4 )   (any of the terms optional = NULL) */
 int lgm_bn_affine3(const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch,
                    const float* a, int64_t a_pitch, const float* mean, const float* rstd,

@@ -2,10 +2,11 @@
 // 158-161) including what the WGAN-GP double backward (wgan.py:117-156) needs.
 //
 // Everything is expressed with three primitives over [M = B*H*W, C] NHWC matrices:
-//   lgm_bn_stats     per-channel batch mean / rstd (two-pass, deterministic) + running-stat update
+//   lgm_bn_stats     per-channel batch mean / rstd (block-local two-sweep sums combined exactly, deterministic) + running-stat update
 //   lgm_bn_reduce3   per-channel  S1 = sum v1,  S2 = sum v1*xhat,  S3 = sum v1*v2
 //   lgm_bn_affine3   out = A1[c]*v1 + A2[c]*v2 + A3[c]*xhat + A4[c]      (xhat = (a-mean)*rstd)
-// plus two tiny coefficient kernels.  With them
+// plus the per-channel coefficient math, which lgm_bn_reduce3_coef runs inside the second reduction stage
+// (lgm_bn_coef is the stand-alone form), and lgm_bn_affine3x2 = two affine3 results from one pass.  With them
 //   forward        y = gamma*xhat + beta                       = affine3(A3 = gamma, A4 = beta)
 //   backward       ga = T(gn) = c (gn - mean(gn) - xhat mean(gn xhat)),  c = gamma*rstd
 //   GP 2nd order   adjoints of T w.r.t. its input, gamma and the batch statistics
@@ -71,6 +72,54 @@ __global__ __launch_bounds__(256) void bn_reduce_stage1(const float* __restrict_
   }
 }
 
+// batch statistics, stage 1: the block sums its rows, then sums the squared deviations from ITS OWN mean (second
+// sweep over the same rows, L2-resident); partial[b] = (sum_b, M2_b, n_b).  Stage 2 combines the blocks with
+// M2 = sum_b M2_b + n_b (mean_b - mean)^2 - the accuracy of the two-pass formula from one launch pair.
+__global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__ a, long a_pitch, long rows, int C,
+                                                       long rpb, float* __restrict__ partial) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long r0 = (long)blockIdx.y * rpb;
+  const long r1 = r0 + rpb < rows ? r0 + rpb : rows;
+  const bool live = c < C;
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live)
+    for (long rb = r0 + rl; rb < r1; rb += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long r = rb + 4 * u;
+        if (r < r1) t[u] += a[r * a_pitch + c];
+      }
+    }
+  sh[rl][cl] = (t[0] + t[1]) + (t[2] + t[3]);
+  __syncthreads();
+  const float sum = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+  const float n = (float)(r1 - r0);
+  const float mu = sum / n;
+  __syncthreads();
+  float q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live)
+    for (long rb = r0 + rl; rb < r1; rb += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long r = rb + 4 * u;
+        if (r < r1) {
+          const float d = a[r * a_pitch + c] - mu;
+          q[u] += d * d;
+        }
+      }
+    }
+  sh[rl][cl] = (q[0] + q[1]) + (q[2] + q[3]);
+  __syncthreads();
+  if (rl == 0 && live) {
+    float* o = partial + (long)blockIdx.y * 3 * C + c;
+    o[0] = sum;
+    o[C] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    o[2 * C] = n;
+  }
+}
+
 // stage 2: block = 64 of the 3C sums x 4 split lanes; lane l adds splits l, l+4, ... (two at a time,
 // unconditionally - rows past nsplit are clamped and weighted 0), fixed-order LDS combine
 __global__ __launch_bounds__(256) void bn_reduce_stage2(const float* __restrict__ partial, int nsplit, int C,
@@ -96,24 +145,111 @@ __global__ __launch_bounds__(256) void bn_reduce_stage2(const float* __restrict_
   if (jl == 0 && i < 3 * C) out3[i] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 
-// finalize batch statistics: mode 1 result -> mean; mode 2 result -> rstd (+ running stats, torch semantics:
-// running_var uses the unbiased estimate; momentum 0.1)
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, long M, int which, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  if (which == 0) {
-    const float m = sums[c] / (float)M;
-    mean[c] = m;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-  } else {
-    const float var = sums[c] / (float)M;
-    rstd[c] = rsqrtf(var + eps);
-    if (running_var) {
-      const float unb = M > 1 ? sums[c] / (float)(M - 1) : var;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+// stage 2 with the per-channel epilogue fused in (fixed summation order => deterministic):
+//   epi 1 (batch statistics from bn_stats_stage1's blocks): mean, M2 (Chan's combination), rstd, running stats
+//   epi 2 (coefficients): bit 0 -> bn_coef mode 0 into coef, bit 1 -> bn_coef mode 1 into coef + 4C
+struct BnEpi {
+  int epi, modes;
+  long M;
+  float eps, momentum, beta_acc0, beta_acc1;
+  float *mean, *rstd, *running_mean, *running_var;
+  const float *gamma, *rstd_in, *saved_m;
+  float *coef, *ggamma0, *gbeta0, *m_out, *ggamma1, *sums_out;
+};
+
+__global__ __launch_bounds__(256) void bn_stage2_epi_kernel(const float* __restrict__ partial, int nsplit, int C,
+                                                            const BnEpi e) {
+  // block = 16 channels x 16 split lanes: lane jl adds splits jl, jl+16, ... of the three sums (three loads in
+  // flight per step); the 16 lane results are combined by a fixed tree
+  __shared__ float sh[3][16][17];
+  __shared__ float shm[16];
+  const int cl = threadIdx.x & 15, jl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const long stride = 3L * C;
+  float acc[3] = {0.f, 0.f, 0.f};
+  if (c < C) {
+    for (int j = jl; j < nsplit; j += 16) {
+      const float* base = partial + (long)j * stride + c;
+      acc[0] += base[0];
+      acc[1] += base[C];
+      acc[2] += base[2 * C];
     }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sh[k][cl][jl] = acc[k];
+  __syncthreads();
+  auto tree = [&](int k) {
+    float t[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t[j] = sh[k][cl][j];
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int j = 0; j < w; ++j) t[j] += t[j + w];
+    return t[0];
+  };
+  const float invM = 1.f / (float)e.M;
+  if (e.epi == 1) {   // (sum_b, M2_b, n_b) blocks -> mean, then the between-block term of M2 in a second sweep
+    if (jl == 0) shm[cl] = tree(0) * invM;
+    __syncthreads();
+    const float m = shm[cl];
+    float btw = 0.f;
+    if (c < C)
+      for (int j = jl; j < nsplit; j += 16) {
+        const float* base = partial + (long)j * stride + c;
+        const float nb = base[2 * C];
+        const float d = base[0] / nb - m;
+        btw += nb * d * d;
+      }
+    sh[0][cl][jl] = btw;
+    __syncthreads();
+    if (jl != 0 || c >= C) return;
+    const float m2 = tree(1) + tree(0);
+    const float var = m2 * invM;
+    e.mean[c] = m;
+    e.rstd[c] = rsqrtf(var + e.eps);
+    if (e.running_mean) e.running_mean[c] = (1.f - e.momentum) * e.running_mean[c] + e.momentum * m;
+    if (e.running_var) {
+      const float unb = e.M > 1 ? m2 / (float)(e.M - 1) : var;
+      e.running_var[c] = (1.f - e.momentum) * e.running_var[c] + e.momentum * unb;
+    }
+    return;
+  }
+  if (jl != 0 || c >= C) return;
+  float S[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) S[k] = tree(k);
+  if (e.sums_out) {
+    e.sums_out[c] = S[0];
+    e.sums_out[C + c] = S[1];
+    e.sums_out[2 * C + c] = S[2];
+  }
+  const float g = e.gamma[c], rs = e.rstd_in[c];
+  const float cc = g * rs;
+  if (e.modes & 1) {
+    float* coef = e.coef;
+    coef[c] = cc;
+    coef[C + c] = 0.f;
+    coef[2 * C + c] = -cc * S[1] * invM;
+    coef[3 * C + c] = -cc * S[0] * invM;
+    if (e.ggamma0) e.ggamma0[c] = (e.beta_acc0 != 0.f ? e.beta_acc0 * e.ggamma0[c] : 0.f) + S[1];
+    if (e.gbeta0) e.gbeta0[c] = (e.beta_acc0 != 0.f ? e.beta_acc0 * e.gbeta0[c] : 0.f) + S[0];
+    if (e.m_out) {
+      e.m_out[c] = S[0] * invM;
+      e.m_out[C + c] = S[1] * invM;
+    }
+  }
+  if (e.modes & 2) {
+    float* coef = e.coef + 4L * C;
+    const float m1 = e.saved_m[c], m2 = e.saved_m[C + c];
+    const float ubar = S[0] * invM, mux = S[1] * invM;
+    const float Q = S[2] - m1 * S[0] - m2 * S[1];
+    const float k = cc * rs;
+    coef[c] = -k * m2;
+    coef[C + c] = -k * mux;
+    coef[2 * C + c] = k * 2.f * m2 * mux - g * Q * rs * rs * invM;
+    coef[3 * C + c] = k * (m2 * ubar + m1 * mux);
+    if (e.ggamma1) e.ggamma1[c] = (e.beta_acc1 != 0.f ? e.beta_acc1 * e.ggamma1[c] : 0.f) + Q * rs;
   }
 }
 
@@ -148,6 +284,37 @@ __global__ __launch_bounds__(256) void bn_affine3_kernel(const float* __restrict
   float* dst = out + r * out_pitch + c;
   if (accumulate) o += *reinterpret_cast<const f32x4*>(dst);
   *reinterpret_cast<f32x4*>(dst) = o;
+}
+
+// two affine3 results from one pass over (v1, v2, a): out_k = A1k*v1 + A2k*v2 + A3k*xhat + A4k, k = 0, 1
+// (coef = [2][4][C]; the gradient-penalty adjoint of T needs both)
+__global__ __launch_bounds__(256) void bn_affine3x2_kernel(const float* __restrict__ v1, long v1_pitch,
+                                                           const float* __restrict__ v2, long v2_pitch,
+                                                           const float* __restrict__ a, long a_pitch,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ coef, float* __restrict__ out0,
+                                                           long out0_pitch, float* __restrict__ out1, long out1_pitch,
+                                                           long rows, int C) {
+  const int c4n = C / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c4n) return;
+  const long r = i / c4n;
+  const int c = (int)(i % c4n) * 4;
+  const f32x4 x1 = *reinterpret_cast<const f32x4*>(v1 + r * v1_pitch + c);
+  const f32x4 x2 = *reinterpret_cast<const f32x4*>(v2 + r * v2_pitch + c);
+  const f32x4 xh = (*reinterpret_cast<const f32x4*>(a + r * a_pitch + c) - *reinterpret_cast<const f32x4*>(mean + c)) *
+                   *reinterpret_cast<const f32x4*>(rstd + c);
+  auto K = [&](int k, int j) { return *reinterpret_cast<const f32x4*>(coef + ((long)k * 4 + j) * C + c); };
+  // same association as bn_affine3_kernel: ((A4 + v1*A1) + v2*A2) + xhat*A3; A2 of set 0 is identically 0
+  f32x4 o0 = K(0, 3);
+  o0 += x1 * K(0, 0);
+  o0 += xh * K(0, 2);
+  f32x4 o1 = K(1, 3);
+  o1 += x1 * K(1, 0);
+  o1 += x2 * K(1, 1);
+  o1 += xh * K(1, 2);
+  *reinterpret_cast<f32x4*>(out0 + r * out0_pitch + c) = o0;
+  *reinterpret_cast<f32x4*>(out1 + r * out1_pitch + c) = o1;
 }
 
 // coefficient kernels (one thread per channel), coef layout [4][C] = A1, A2, A3, A4
@@ -208,6 +375,17 @@ int reduce3(int mode, const float* v1, long v1_pitch, const float* v2, long v2_p
   return LGM_OK;
 }
 
+int reduce3_epi(int mode, const float* v1, long v1_pitch, const float* v2, long v2_pitch, const float* a, long a_pitch,
+                const float* mean, const float* rstd, long rows, int C, float* ws, const BnEpi& e, hipStream_t s) {
+  const long rpb = bn_rows(rows);
+  const int ns = lgm_cdiv(rows, rpb);
+  hipLaunchKernelGGL(bn_reduce_stage1, dim3(lgm_cdiv(C, 64), ns), dim3(256), 0, s, v1, v1_pitch, v2, v2_pitch, a,
+                     a_pitch, mean, rstd, mode, rows, C, rpb, ws);
+  hipLaunchKernelGGL(bn_stage2_epi_kernel, dim3(lgm_cdiv(C, 16)), dim3(256), 0, s, (const float*)ws, ns, C, e);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
 }  // namespace
 
 extern "C" int64_t lgm_bn_workspace(int64_t rows, int C) {
@@ -219,15 +397,47 @@ extern "C" int lgm_bn_stats(const float* a, int64_t a_pitch, int64_t rows, int C
                             void* stream) {
   if (int rc = check_mc(a, a_pitch, rows, C, "bn_stats")) return rc;
   LGM_REQUIRE(mean && rstd && workspace, "bn_stats: null pointer");
+  // block-local sums and squared deviations, combined (and finalised) in the second stage: two launches
+  BnEpi e{};
+  e.epi = 1; e.M = (long)rows; e.eps = eps; e.momentum = momentum;
+  e.mean = mean; e.rstd = rstd; e.running_mean = running_mean; e.running_var = running_var;
+  const long rpb = bn_rows(rows);
+  const int ns = lgm_cdiv(rows, rpb);
   hipStream_t s = (hipStream_t)stream;
-  float* ws = (float*)workspace;
-  float* sums = ws + (long)lgm_cdiv(rows, bn_rows(rows)) * 3 * C;
-  if (int rc = reduce3(1, nullptr, 0, nullptr, 0, a, a_pitch, nullptr, nullptr, rows, C, sums, ws, s)) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(lgm_cdiv(C, 256)), dim3(256), 0, s, (const float*)sums, C, (long)rows, 0,
-                     eps, momentum, mean, rstd, running_mean, running_var);
-  if (int rc = reduce3(2, nullptr, 0, nullptr, 0, a, a_pitch, mean, nullptr, rows, C, sums, ws, s)) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(lgm_cdiv(C, 256)), dim3(256), 0, s, (const float*)sums, C, (long)rows, 1,
-                     eps, momentum, mean, rstd, running_mean, running_var);
+  hipLaunchKernelGGL(bn_stats_stage1, dim3(lgm_cdiv(C, 64), ns), dim3(256), 0, s, a, (long)a_pitch, (long)rows, C, rpb,
+                     (float*)workspace);
+  hipLaunchKernelGGL(bn_stage2_epi_kernel, dim3(lgm_cdiv(C, 16)), dim3(256), 0, s, (const float*)workspace, ns, C, e);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// reduce3 + bn_coef in two launches: modes bit 0 -> coefficient set of mode 0 (coef8[0..4C), ggamma0/gbeta0/m_out),
+// bit 1 -> set of mode 1 (coef8[4C..8C), ggamma1, needs saved_m).  sums3 (optional) also receives (S1, S2, S3).
+extern "C" int lgm_bn_reduce3_coef(int modes, const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch,
+                                   const float* a, int64_t a_pitch, const float* mean, const float* rstd,
+                                   const float* gamma, const float* saved_m, int64_t rows, int C, float* coef8,
+                                   float* ggamma0, float* gbeta0, float beta_acc0, float* m_out, float* ggamma1,
+                                   float beta_acc1, float* sums3, void* workspace, void* stream) {
+  if (int rc = check_mc(v1, v1_pitch, rows, C, "bn_reduce3_coef(v1)")) return rc;
+  LGM_REQUIRE(a && mean && rstd && gamma && coef8 && workspace && (modes & 3) && (!(modes & 2) || saved_m),
+              "bn_reduce3_coef: bad arguments");
+  BnEpi e{};
+  e.epi = 2; e.modes = modes; e.M = (long)rows; e.gamma = gamma; e.rstd_in = rstd; e.saved_m = saved_m;
+  e.coef = coef8; e.ggamma0 = ggamma0; e.gbeta0 = gbeta0; e.beta_acc0 = beta_acc0; e.m_out = m_out;
+  e.ggamma1 = ggamma1; e.beta_acc1 = beta_acc1; e.sums_out = sums3;
+  return reduce3_epi(0, v1, v1_pitch, v2, v2_pitch, a, a_pitch, mean, rstd, rows, C, (float*)workspace, e,
+                     (hipStream_t)stream);
+}
+
+extern "C" int lgm_bn_affine3x2(const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch, const float* a,
+                                int64_t a_pitch, const float* mean, const float* rstd, const float* coef8, float* out0,
+                                int64_t out0_pitch, float* out1, int64_t out1_pitch, int64_t rows, int C, void* stream) {
+  if (int rc = check_mc(out0, out0_pitch, rows, C, "bn_affine3x2(out0)")) return rc;
+  if (int rc = check_mc(out1, out1_pitch, rows, C, "bn_affine3x2(out1)")) return rc;
+  LGM_REQUIRE(v1 && v2 && a && mean && rstd && coef8, "bn_affine3x2: null pointer");
+  hipLaunchKernelGGL(bn_affine3x2_kernel, dim3(lgm_cdiv(rows * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, v1,
+                     (long)v1_pitch, v2, (long)v2_pitch, a, (long)a_pitch, mean, rstd, coef8, out0, (long)out0_pitch,
+                     out1, (long)out1_pitch, (long)rows, C);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

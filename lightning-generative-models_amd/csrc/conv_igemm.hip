@@ -716,10 +716,11 @@ __global__ __launch_bounds__(256) void smalln_yx_kernel(const SmallNArgs p) {
   for (long base = ((long)blockIdx.x * 4 + wid) * ppw; base < p.npix; base += per_iter) {
     const long pix = base + sub;
     const bool live = pix < p.npix;
-    const long pp = live ? pix : 0;
-    const int iw = (int)(pp % p.W);
-    const long t0 = pp / p.W;
-    const int ih = (int)(t0 % p.H), b = (int)(t0 / p.H);
+    const unsigned pp = live ? (unsigned)pix : 0u;     // npix < 2^31 (check_geom): 32-bit divisions
+    const unsigned t0 = pp / (unsigned)p.W;
+    const int iw = (int)(pp - t0 * (unsigned)p.W);
+    const int b = (int)(t0 / (unsigned)p.H);
+    const int ih = (int)(t0 - (unsigned)b * (unsigned)p.H);
     const int kh0 = (ih + p.pad) % p.stride, kw0 = (iw + p.pad) % p.stride;
     f32x4 yv[KHS * KWS];
     bool ok[KHS * KWS];

@@ -67,9 +67,6 @@ class BatchNorm2d(nn.Module):
         rows = ops.rows(a)
         L = ops.lib()
         fp = _flat(self.weight)
-        sums = torch.empty((3, C), dtype=torch.float32, device=a.device)
-        L.lgm_bn_reduce3(v.data_ptr(), ops.pitch(v), None, 0, a.data_ptr(), ops.pitch(a), sv.mean.data_ptr(),
-                         sv.rstd.data_ptr(), rows, C, sums.data_ptr(), _ws(a).data_ptr(), ops.stream())
         coef = torch.empty((4, C), dtype=torch.float32, device=a.device)
         mvec = torch.empty((2, C), dtype=torch.float32, device=a.device) if want_m else None
         gg = gb = None
@@ -78,8 +75,11 @@ class BatchNorm2d(nn.Module):
             gg, gb = gc.flat.gptr(self.weight), gc.flat.gptr(self.bias)
             beta = gc.beta(self.weight)
             gc.beta(self.bias)
-        L.lgm_bn_coef(0, sums.data_ptr(), fp.ptr(self.weight), sv.rstd.data_ptr(), None, C, rows, coef.data_ptr(),
-                      gg, gb, beta, None if mvec is None else mvec.data_ptr(), ops.stream())
+        # sums (v, v*xhat) and the coefficients of T in two launches (the per-channel math runs in stage 2)
+        L.lgm_bn_reduce3_coef(1, v.data_ptr(), ops.pitch(v), None, 0, a.data_ptr(), ops.pitch(a), sv.mean.data_ptr(),
+                              sv.rstd.data_ptr(), fp.ptr(self.weight), None, rows, C, coef.data_ptr(), gg, gb, beta,
+                              None if mvec is None else mvec.data_ptr(), None, 0.0, None, _ws(a).data_ptr(),
+                              ops.stream())
         if out is None:
             out = ops.new(a.shape, a)
             accumulate = False
@@ -98,24 +98,17 @@ class BatchNorm2d(nn.Module):
         rows = ops.rows(a)
         L = ops.lib()
         fp = _flat(self.weight)
-        sums = torch.empty((3, C), dtype=torch.float32, device=a.device)
-        L.lgm_bn_reduce3(u.data_ptr(), ops.pitch(u), gn.data_ptr(), ops.pitch(gn), a.data_ptr(), ops.pitch(a),
-                         sv.mean.data_ptr(), sv.rstd.data_ptr(), rows, C, sums.data_ptr(), _ws(a).data_ptr(),
-                         ops.stream())
+        # (1) T is self-adjoint in its argument: adjoint w.r.t. gn = T(u)            (coefficient set 0)
+        # (2) dependence of T on xhat / sigma (hence on a) and on gamma                (coefficient set 1)
+        # one reduction for the sums of u both sets need, one pass over (u, gn, a) for both results
         coef = torch.empty((2, 4, C), dtype=torch.float32, device=a.device)
-        # (1) T is self-adjoint in its argument: adjoint w.r.t. gn = T(u)
-        L.lgm_bn_coef(0, sums.data_ptr(), fp.ptr(self.weight), sv.rstd.data_ptr(), None, C, rows,
-                      coef[0].data_ptr(), None, None, 0.0, None, ops.stream())
+        L.lgm_bn_reduce3_coef(3, u.data_ptr(), ops.pitch(u), gn.data_ptr(), ops.pitch(gn), a.data_ptr(), ops.pitch(a),
+                              sv.mean.data_ptr(), sv.rstd.data_ptr(), fp.ptr(self.weight), mvec.data_ptr(), rows, C,
+                              coef.data_ptr(), None, None, 0.0, None, gc.flat.gptr(self.weight),
+                              gc.beta(self.weight), None, _ws(a).data_ptr(), ops.stream())
         gn_bar = ops.new(a.shape, a)
-        L.lgm_bn_affine3(u.data_ptr(), ops.pitch(u), None, 0, a.data_ptr(), ops.pitch(a), sv.mean.data_ptr(),
-                         sv.rstd.data_ptr(), coef[0, 0].data_ptr(), None, coef[0, 2].data_ptr(), coef[0, 3].data_ptr(),
-                         gn_bar.data_ptr(), ops.pitch(gn_bar), 0, 0, 0.0, rows, C, ops.stream())
-        # (2) dependence of T on xhat / sigma (hence on a) and on gamma
-        L.lgm_bn_coef(1, sums.data_ptr(), fp.ptr(self.weight), sv.rstd.data_ptr(), mvec.data_ptr(), C, rows,
-                      coef[1].data_ptr(), gc.flat.gptr(self.weight), None, gc.beta(self.weight), None, ops.stream())
         a_bar = ops.new(a.shape, a)
-        L.lgm_bn_affine3(u.data_ptr(), ops.pitch(u), gn.data_ptr(), ops.pitch(gn), a.data_ptr(), ops.pitch(a),
-                         sv.mean.data_ptr(), sv.rstd.data_ptr(), coef[1, 0].data_ptr(), coef[1, 1].data_ptr(),
-                         coef[1, 2].data_ptr(), coef[1, 3].data_ptr(), a_bar.data_ptr(), ops.pitch(a_bar), 0, 0, 0.0,
-                         rows, C, ops.stream())
+        L.lgm_bn_affine3x2(u.data_ptr(), ops.pitch(u), gn.data_ptr(), ops.pitch(gn), a.data_ptr(), ops.pitch(a),
+                           sv.mean.data_ptr(), sv.rstd.data_ptr(), coef.data_ptr(), gn_bar.data_ptr(),
+                           ops.pitch(gn_bar), a_bar.data_ptr(), ops.pitch(a_bar), rows, C, ops.stream())
         return gn_bar, a_bar
