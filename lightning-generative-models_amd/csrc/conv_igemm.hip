@@ -532,9 +532,11 @@ int igemm_splits(long M, int N, int K, int* kchunk) {
   const long tiles = (long)lgm_cdiv(M, 64) * lgm_cdiv(N, 64);
   const int nk = lgm_cdiv(K, BK);
   *kchunk = nk * BK;
-  if (tiles > 64 || N % 4 != 0) return 1;
-  long s = 256 / tiles;
-  if (s > nk / 4) s = nk / 4;
+  // up to 256 tiles a launch leaves at most one wave per SIMD: nothing hides the load -> LDS -> barrier latency
+  // of a chunk.  Split the reduction until ~4 workgroups share a CU (>= 8 chunks each).
+  if (tiles > 256 || N % 4 != 0) return 1;
+  long s = tiles > 64 ? 1024 / tiles : 256 / tiles;
+  if (s > nk / (tiles > 64 ? 8 : 4)) s = nk / (tiles > 64 ? 8 : 4);
   if (s < 2) return 1;
   const int per = lgm_cdiv(nk, s);
   *kchunk = per * BK;
