@@ -700,62 +700,80 @@ struct SmallNArgs {
 };
 
 // KHS x KWS = taps per residue class (KH/stride x KW/stride); LPP = Nw/4 lanes share one output pixel,
-// 64/LPP pixels per wave; all tap loads of a pixel are issued before they are consumed.
+// 64/LPP pixels per wave.  blockIdx.y = residue class (ih % stride, iw % stride): every pixel a block visits
+// meets the SAME taps, so their weights (for the lane's four gathered channels) live in registers for the
+// whole kernel - the first version read them from LDS per pixel, where the four pixels of a wave (alternating
+// parity) hit the same banks with different taps (4-way conflicts: LDS-bound at 1/13 of the FMA rate).
+// Zero padding = raw buffer loads at an offset past the descriptor's range.
 template <int KHS, int KWS>
 __global__ __launch_bounds__(256) void smalln_yx_kernel(const SmallNArgs p) {
-  extern __shared__ __align__(16) float wsm[];   // [T][4][Nw]
   const int T = p.KH * p.KW;
-  for (int i = threadIdx.x; i < T * 4 * p.Nw; i += 256) {
-    const int n = i % p.Nw, c = (i / p.Nw) % 4, t = i / (4 * p.Nw);
-    wsm[i] = p.w[((long)n * T + t) * 4 + c];
-  }
-  __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int LPP = p.Nw / 4;                       // power of two, <= 64
   const int ppw = 64 / LPP;
   const int sub = lane / LPP, cl = lane % LPP;   // pixel slot inside the wave, channel chunk
-  const long per_iter = (long)gridDim.x * 4 * ppw;
-  for (long base = ((long)blockIdx.x * 4 + wid) * ppw; base < p.npix; base += per_iter) {
-    const long pix = base + sub;
-    const bool live = pix < p.npix;
-    const unsigned pp = live ? (unsigned)pix : 0u;     // npix < 2^31 (check_geom): 32-bit divisions
-    const unsigned t0 = pp / (unsigned)p.W;
-    const int iw = (int)(pp - t0 * (unsigned)p.W);
-    const int b = (int)(t0 / (unsigned)p.H);
-    const int ih = (int)(t0 - (unsigned)b * (unsigned)p.H);
-    const int kh0 = (ih + p.pad) % p.stride, kw0 = (iw + p.pad) % p.stride;
+  const int ph = blockIdx.y / p.stride, pw = blockIdx.y % p.stride;
+  const int kh0 = (ph + p.pad) % p.stride, kw0 = (pw + p.pad) % p.stride;
+  const int dh0 = (ph + p.pad - kh0) / p.stride, dw0 = (pw + p.pad - kw0) / p.stride;
+  const int Hq = p.H / p.stride, Wq = p.W / p.stride;
+  const unsigned npq = (unsigned)(p.B * Hq * Wq);      // pixels of one class
+  f32x4 wr[KHS * KWS][4];                               // [tap][output channel] over the lane's 4 gathered channels
+#pragma unroll
+  for (int ta = 0; ta < KHS; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < KWS; ++tb) {
+      const int tap = (kh0 + ta * p.stride) * p.KW + kw0 + tb * p.stride;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + ((long)(cl * 4 + j) * T + tap) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wr[ta * KWS + tb][c][j] = v[c];
+      }
+    }
+  const unsigned nrec = (unsigned)((long)p.B * p.Ho * p.Wo * p.y_pitch * 4);
+  __amdgpu_buffer_rsrc_t rsrc_y;
+  {
+    const unsigned long long ab = reinterpret_cast<unsigned long long>(p.y);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ab);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ab >> 32));
+    rsrc_y = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                               __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+  }
+  const unsigned ypb = (unsigned)p.y_pitch * 4u;
+  const unsigned per_iter = gridDim.x * 4u * (unsigned)ppw;
+  for (unsigned base = (blockIdx.x * 4u + (unsigned)wid) * (unsigned)ppw; base < npq; base += per_iter) {
+    const unsigned pq = base + (unsigned)sub;
+    const bool live = pq < npq;
+    const unsigned t0 = pq / (unsigned)Wq;
+    const int iwq = (int)(pq - t0 * (unsigned)Wq);
+    const int b = (int)(t0 / (unsigned)Hq);
+    const int ihq = (int)(t0 - (unsigned)b * (unsigned)Hq);
     f32x4 yv[KHS * KWS];
-    bool ok[KHS * KWS];
 #pragma unroll
     for (int ta = 0; ta < KHS; ++ta)
 #pragma unroll
       for (int tb = 0; tb < KWS; ++tb) {
-        const int dh = ih + p.pad - (kh0 + ta * p.stride), dw = iw + p.pad - (kw0 + tb * p.stride);
-        const int th = dh / p.stride, tw = dw / p.stride;
-        const bool v = live && dh >= 0 && dw >= 0 && th < p.Ho && tw < p.Wo;
-        ok[ta * KWS + tb] = v;
-        const long off = v ? ((long)(b * p.Ho + th) * p.Wo + tw) * p.y_pitch + cl * 4 : 0L;
-        yv[ta * KWS + tb] = *reinterpret_cast<const f32x4*>(p.y + off);     // unconditional (clamped) load
+        const int th = ihq + dh0 - ta, tw = iwq + dw0 - tb;
+        const bool v = live && (unsigned)th < (unsigned)p.Ho && (unsigned)tw < (unsigned)p.Wo;
+        const unsigned off = (unsigned)((b * p.Ho + th) * p.Wo + tw) * ypb + (unsigned)cl * 16u;
+        yv[ta * KWS + tb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, v ? off : nrec, 0, 0));
       }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ta = 0; ta < KHS; ++ta)
+    for (int t = 0; t < KHS * KWS; ++t) {
+      const f32x4 y4 = yv[t];
 #pragma unroll
-      for (int tb = 0; tb < KWS; ++tb) {
-        const int tap = (kh0 + ta * p.stride) * p.KW + kw0 + tb * p.stride;
-        const float* wt = wsm + (long)tap * 4 * p.Nw + cl * 4;
-        const f32x4 y4 = ok[ta * KWS + tb] ? yv[ta * KWS + tb] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + c * p.Nw);
-          acc[c] += (y4[0] * wv[0] + y4[1] * wv[1]) + (y4[2] * wv[2] + y4[3] * wv[3]);
-        }
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 wv = wr[t][c];
+        acc[c] += (y4[0] * wv[0] + y4[1] * wv[1]) + (y4[2] * wv[2] + y4[3] * wv[3]);
       }
+    }
     for (int off = LPP >> 1; off > 0; off >>= 1) {   // fixed tree inside the pixel's lane group
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
     }
     if (cl == 0 && live) {
+      const long pix = ((long)b * p.H + ihq * p.stride + ph) * p.W + iwq * p.stride + pw;
       if (p.bias) acc += *reinterpret_cast<const f32x4*>(p.bias);
       if (p.res) acc += *reinterpret_cast<const f32x4*>(p.res + pix * p.res_pitch);
       *reinterpret_cast<f32x4*>(p.x + pix * p.x_pitch) = acc;
@@ -787,24 +805,18 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
                                 (hipStream_t)stream);
   const int lpp = g->Nw / 4;
   if (use_3x3() && g->Cw == 4 && g->Nw % 4 == 0 && lpp <= 64 && (lpp & (lpp - 1)) == 0 && g->stride == 2 &&
-      g->KH == 4 && g->KW == 4 && wide_ok(x, x_pitch, res, res_pitch, bias) &&
-      (long)g->KH * g->KW * 4 * g->Nw * 4 <= 64 * 1024) {
+      g->KH == 4 && g->KW == 4 && g->H % 2 == 0 && g->W % 2 == 0 && wide_ok(x, x_pitch, res, res_pitch, bias) &&
+      (long)g->B * g->Ho * g->Wo * y_pitch * 4 < (1L << 31)) {
     SmallNArgs q{};
     q.y = y; q.w = w; q.bias = bias; q.res = res; q.x = x;
     q.y_pitch = y_pitch; q.res_pitch = res_pitch; q.x_pitch = x_pitch;
     q.B = g->B; q.H = g->H; q.W = g->W; q.Ho = g->Ho; q.Wo = g->Wo; q.Nw = g->Nw;
     q.KH = g->KH; q.KW = g->KW; q.stride = g->stride; q.pad = g->pad;
     q.npix = (long)g->B * g->H * g->W;
-    const size_t smem = (size_t)g->KH * g->KW * 4 * g->Nw * sizeof(float);
-    static size_t attr = 0;
-    if (smem > attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(smalln_yx_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)smem);
-      attr = smem;
-    }
-    const long want = (q.npix + 4 * (64 / lpp) - 1) / (4 * (64 / lpp));
-    const unsigned nb = (unsigned)(want < 2048 ? want : 2048);
-    hipLaunchKernelGGL((smalln_yx_kernel<2, 2>), dim3(nb), dim3(256), smem, (hipStream_t)stream, q);
+    const long npq = q.npix / (g->stride * g->stride);
+    const long want = (npq + 4 * (64 / lpp) - 1) / (4 * (64 / lpp));
+    const unsigned nb = (unsigned)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL((smalln_yx_kernel<2, 2>), dim3(nb, g->stride * g->stride), dim3(256), 0, (hipStream_t)stream, q);
     LGM_LAUNCH_CHECK();
     return LGM_OK;
   }
