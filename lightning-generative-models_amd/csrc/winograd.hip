@@ -1237,9 +1237,20 @@ void lgm_wino_wgrad_plan(const LgmConvGeom* g, int* splits, int* cps, int* total
   wgrad_class(g->H, g->W, &G, &ipc);
   const long chunks = (long)(g->B / ipc) * (g->H / 4) * (g->W >= 16 ? g->W / 16 : 1) * 2;
   const long blocks = (long)(g->Nw / 64) * (g->Cw / 64);
-  long s = (256 + blocks - 1) / blocks;                  // one workgroup per CU when the chunks allow it
-  if (s > chunks / 2) s = chunks / 2;                    // at least two chunks per workgroup ...
-  if (s < 2) s = 2;                                      // ... and at least two slabs
+  // One workgroup per CU (4 waves = the CU's four SIMDs): 258 workgroups take twice as long as 256.  Pick the split
+  // count that minimises  rounds of 256 workgroups x (chunks per workgroup + ~3 chunks of prologue / epilogue);
+  // at least two chunks per workgroup and two slabs; ties go to fewer slabs.
+  long smax = chunks / 2 < 256 ? chunks / 2 : 256;
+  if (smax < 2) smax = 2;
+  long s = 2, best = -1;
+  for (long c = 2; c <= smax; ++c) {
+    const long rounds = (blocks * c + 255) / 256;
+    const long cost = rounds * ((chunks + c - 1) / c + 3);
+    if (best < 0 || cost < best) {
+      best = cost;
+      s = c;
+    }
+  }
   long per = (chunks + s - 1) / s;
   s = (chunks + per - 1) / per;
   *splits = (int)s;
