@@ -420,6 +420,30 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
    f32x16 acc[16];
    Phase fin = cur;
    bool last_of_unit;
+   // Epilogue operands fetched HERE, a whole unit ahead: the four bias vectors and the residual rows of channel
+   // group 0.  vmcnt counts loads and stores in issue order, so a load issued after a store can only be waited for
+   // together with that store: every epilogue load is therefore issued BEFORE the stores it would otherwise queue
+   // behind (groups 1..3 of the residual: one group ahead, inside the epilogue).  Before this the epilogue waited
+   // for the write acknowledgement of the previous channel group four times per unit.
+   const bool ep_res = p.splits == 1 && p.res != nullptr;
+   const unsigned rbase_u = (unsigned)((((long)(cur.b0 * p.H + cur.h0) * p.W + cur.w0) * p.res_pitch + cur.n0) * 4);
+   f32x4 rv[2][4];
+   auto load_res = [&](int g, f32x4 (&dst)[4]) {   // the four output positions (dy, dx) of the lane's tile
+#pragma unroll
+     for (int q = 0; q < 4; ++q) {
+       const unsigned rpos = (unsigned)(((q >> 1) * p.W + (q & 1)) * p.res_pitch * 4);
+       dst[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+       if (ep_res)
+         dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, evoff_r + g * 32, rbase_u + rpos, 0));
+     }
+   };
+   load_res(0, rv[0]);
+   f32x4 bvs[4];
+#pragma unroll
+   for (int g = 0; g < 4; ++g) {
+     bvs[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+     if (p.splits == 1 && p.bias) bvs[g] = *reinterpret_cast<const f32x4*>(p.bias + cur.n0 + wcb * 32 + 8 * g + 4 * lh);
+   }
    auto run_phase = [&](auto first_tag) {
     constexpr bool FIRST = decltype(first_tag)::value;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -528,13 +552,13 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
       const long pit = direct ? p.out_pitch : (long)p.N;
       const unsigned sbase = (unsigned)((((long)(fin.b0 * p.H + fin.h0) * p.W + fin.w0) * pit + fin.n0) * 4) +
                              (direct ? 0u : (unsigned)((long)fin.split * p.ws_stride * 4));
-      const unsigned rbase = (unsigned)((((long)(fin.b0 * p.H + fin.h0) * p.W + fin.w0) * p.res_pitch + fin.n0) * 4);
       const unsigned eo = direct ? evoff : evoff_w;
       const __amdgpu_buffer_rsrc_t rsrc_d = direct ? rsrc_o : rsrc_w;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (direct && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + fin.n0 + wcb * 32 + 8 * g + 4 * lh);
+        const f32x4 bv = bvs[g];
+        // next group's residual rows: ahead of this group's stores (see the unit top) and of its ~90 instructions
+        if (g < 3) load_res(g + 1, rv[(g + 1) & 1]);
         // S = A^T M for the group's 4 registers x 4 columns jx, as packed pairs over r
         f32x2 sv[2][4][2];
 #pragma unroll
@@ -571,16 +595,15 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
                   for (int e = 0; e < 4; ++e) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[e]) : "a"(acc[xs][4 * g + e]));
                 }
             }
-            if (direct && p.res) {
-              const unsigned rpos = (unsigned)((dy * p.W + dx) * p.res_pitch * 4);
-              v = add4(v, __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, evoff_r + g * 32, rbase + rpos, 0)));
-            }
+            v = add4(v, rv[g & 1][2 * dy + dx]);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_d, eo + g * 32, sbase + spos, 0);
             // A store of more than 8 bytes must not have its data registers overwritten in the next 2 wait states;
             // hipcc pads that for its own instructions but the next writers here are inline asm (accumulator reads,
             // packed adds), which it does not see.  Without the pad: wrong second dwords in lanes 12-15 / 28-31 of
-            // every store but the last one of a channel group.
-            asm volatile("s_nop 1" ::: "memory");
+            // every store but the last one of a channel group.  The pad names the stored value as an operand: a
+            // bare `s_nop` does not keep the scheduler from placing the next (non-volatile) packed add - whose result
+            // may be allocated to the just-freed data registers - between the store and the pad.
+            asm volatile("s_nop 1" : "+v"(v) : : "memory");
           }
       }
     }
