@@ -729,16 +729,19 @@ int lgm_wino_splits(const LgmConvGeom* g, int gather_channels, int out_channels)
   const long base = (long)(g->B / NI) * (g->H / (2 * TTH)) * (g->W / (2 * TTW)) * (out_channels / 64);
   if (base >= 1024) return 1;
   const int phases = gather_channels / KC;
-  long smax = phases / 4 < 8 ? phases / 4 : 8;    // at least four phases (32 channels) per split
+  long smax = phases / 2 < 32 ? phases / 2 : 32;    // at least two phases (16 channels) per split
   if (smax < 1) smax = 1;
+  // cost in phase times (~2.1 us): rounds of 256 workgroups x (phases per unit + ~1.5 of prologue / epilogue) + the
+  // partial sums every extra split writes and the reducer reads back (8 bytes per output element at ~3 TB/s) -
+  // 1.3 phases per split on the 4x4 maps at B = 128, 0.16 at B = 16, where splitting deeper is what fills the chip
+  const double per_split = 8.0 * (double)g->B * g->H * g->W * out_channels / 3.0e12 / 2.1e-6;
   long s = 1;
   double best = 1e30;
   for (long c = 1; c <= smax; ++c) {
     const long pps = (phases + c - 1) / c;
     if ((phases + pps - 1) / pps != c) continue;
     const double rounds = (double)((base * c + 255) / 256);
-    // per unit: pps phases + ~1.5 phases of prologue / epilogue; partial-sum traffic penalty per split
-    const double cost = rounds * ((double)pps + 1.5) / (double)phases + 0.03 * (double)(c - 1);
+    const double cost = rounds * ((double)pps + 1.5) + (c > 1 ? 2.4 : 0.0) + per_split * (double)(c - 1);
     if (cost < best - 1e-9) {
       best = cost;
       s = c;
