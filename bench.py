@@ -225,16 +225,19 @@ def setup_vqvae(args, dev):
     opt = v.configure_optimizers()
     xv = torch.rand(256, 3, 32, 32, device=dev) * 2 - 1
 
+    fast = v.make_fast_step(opt, 1, use_graph=not args.no_graph)    # what MiniTrainer.fit drives for a VQVAE
+
+    eager = v.make_fast_step(opt, 1, use_graph=False)               # the roofline leg times individual launches
+
     def step(i):
-        loss = v.training_step((xv, None), i)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        return loss
-    info = dict(per_gpu=256, fast=None, flop_per_img=None, bytes_per_img=None,
+        return fast.step((xv, None), i)
+
+    def eager_step(i):
+        return eager.step((xv, None), i)
+    info = dict(per_gpu=256, fast=fast, flop_per_img=None, bytes_per_img=None,
                 workload=f"configs/vae/vqvae{'_ema' if ema else ''}.json VQ-VAE 3x32x32, K=512 D=64, "
                          "training_step+backward+Adam")
-    return step, step, info
+    return step, eager_step, info
 
 
 def main():

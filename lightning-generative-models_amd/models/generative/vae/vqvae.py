@@ -311,6 +311,16 @@ class VQVAE(LightningModule):
                          weight_decay=self.hparams.weight_decay)
 
 
+    def make_fast_step(self, opt, world: int = 1, use_graph: bool = True):
+        """The step object ``MiniTrainer.fit`` drives (and bench.py times): training_step + backward replayed
+        from one HIP graph, eager fallback inside.  The EMA codebook's batch statistics are all-reduced inside the
+        forward when N > 1: that step stays eager."""
+        from lgm_hip.graph import ModuleFastStep
+        self.prepare_hip(next(self.parameters()).device)
+        return ModuleFastStep(self, opt, world, use_graph,
+                              collective_inside=isinstance(self.vector_quantizer, VectorQuantizerEMA))
+
+
 class _VQVAEStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, m: VQVAE, x, w_recon, w_vq):

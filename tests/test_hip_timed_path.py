@@ -149,6 +149,45 @@ def test_vq_full_size_non_collapsed_codebook(dev, parity):
     parity("segment sums dw = onehot^T x", rel(dw, onehot.double().T @ x.double()), 1e-6)
 
 
+
+@pytest.mark.parametrize("ema", [False, True])
+def test_vqvae_graph_replay_is_bit_identical_to_eager_steps(dev, ema):
+    """What bench.py --workload vqvae times and MiniTrainer.fit drives (``VQVAE.make_fast_step`` ->
+    ``ModuleFastStep``: training_step + backward in ONE HIP graph, Adam eager): after 6 steps on 6 different
+    batches the parameters, the Adam moments, the EMA codebook buffers and every logged value are torch.equal to
+    the same steps issued from eager launches - i.e. the warm-up / capture left the training state (codebook EMA,
+    random stream) untouched and the static buffers do not alias."""
+    from models.generative.vae.vqvae import VQVAE
+
+    def make():
+        torch.manual_seed(3)
+        m = VQVAE(img_channels=3, img_size=32, embedding_dim=64, num_embeddings=512, hidden_dim=128,
+                  num_residual_layers=2, num_residual_hiddens=32, use_ema=ema, lr=1e-3, b1=0.9, b2=0.999,
+                  loss_weights={"recon_loss": 1, "vq_loss": 10 if ema else 1}).to(dev)
+        m.prepare_hip(dev)
+        m.train()
+        return m, m.configure_optimizers()
+
+    (a, oa), (b, ob) = make(), make()
+    assert torch.equal(a._flat.data, b._flat.data)
+    fa, fb = a.make_fast_step(oa, 1, True), b.make_fast_step(ob, 1, False)
+    g = torch.Generator().manual_seed(4)
+    for i in range(6):
+        x = (torch.rand(64, 3, 32, 32, generator=g) * 2 - 1).to(dev)
+        la = fa.step((x, None), i).detach().clone()
+        lb = fb.step((x.clone(), None), i).detach().clone()
+        assert torch.equal(la, lb), (i, float(la), float(lb))
+        for k in b.logged:
+            assert torch.equal(a.logged[k].detach(), b.logged[k].detach()), (i, k)
+    assert fa.mode.startswith("hipGraph") and fb.mode == "eager"
+    assert torch.equal(a._flat.data, b._flat.data)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sb:
+        assert torch.equal(sa[k], sb[k]), k
+    for pa, pb in zip(oa.state_dict()["state"].values(), ob.state_dict()["state"].values()):
+        for k in pb:
+            assert torch.equal(torch.as_tensor(pa[k]), torch.as_tensor(pb[k])), k
+
 def test_gp_penalty_zero_gradient_pixel(dev):
     """A pixel whose channel gradient is exactly zero: penalty (0-1)^2 and a ZERO subgradient (torch's
     backward of norm(2, dim=1)), not NaN."""
