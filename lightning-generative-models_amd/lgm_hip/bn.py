@@ -37,6 +37,22 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(channels))
         self.register_buffer("running_var", torch.ones(channels))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        # the counter is bookkeeping only (momentum is fixed): it is advanced on the host and written into the
+        # buffer when a state dict is taken - `buffer += 1` was one 1-thread launch per BatchNorm forward
+        # (13 per critic step)
+        self._nbt_pending = 0
+        self._register_state_dict_hook(BatchNorm2d._flush_counter_hook)
+        self._register_load_state_dict_pre_hook(self._reset_counter_hook)
+
+    @staticmethod
+    def _flush_counter_hook(module, state_dict, prefix, local_metadata):
+        if module._nbt_pending:
+            module.num_batches_tracked += module._nbt_pending
+            module._nbt_pending = 0
+            state_dict[prefix + "num_batches_tracked"] = module.num_batches_tracked.detach()
+
+    def _reset_counter_hook(self, *args, **kwargs):
+        self._nbt_pending = 0
 
     # ---- forward: h = act(gamma*xhat + beta) ------------------------------------------------
     def fwd(self, a, act: int, slope: float = 0.0, training: bool = True):
@@ -49,7 +65,7 @@ class BatchNorm2d(nn.Module):
             L.lgm_bn_stats(a.data_ptr(), ops.pitch(a), ops.rows(a), C, self.eps, self.momentum, mean.data_ptr(),
                            rstd.data_ptr(), self.running_mean.data_ptr(), self.running_var.data_ptr(),
                            _ws(a).data_ptr(), ops.stream())
-            self.num_batches_tracked += 1
+            self._nbt_pending += 1
         else:
             mean.copy_(self.running_mean)
             rstd.copy_((self.running_var + self.eps).rsqrt())

@@ -1,5 +1,5 @@
 """Per-launch listing of one training step from a rocprofv3 (rocpd sqlite) kernel trace: kernel, grid, workgroup,
-duration, and how many rounds of (256 CUs x workgroups per CU) the grid needs - a grid of 258 single-occupancy
+duration (STEP_BACK=n: the n-th step before the last), and how many rounds of (256 CUs x workgroups per CU) the grid needs - a grid of 258 single-occupancy
 workgroups takes two rounds.  usage: python tools/rocpd_launches.py results.db [out.csv]"""
 import re
 import sqlite3
@@ -24,7 +24,9 @@ def main():
     rows = list(c.execute(f"select {namecol}, start, end, {', '.join(want)} from kernels order by start"))
     # one step = the span between the last two adam_kernel launches
     adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
-    lo, hi = (adam[-2] + 1, adam[-1] + 1) if len(adam) >= 2 else (0, len(rows))
+    import os
+    back = int(os.environ.get("STEP_BACK", "0"))      # 0 = the last step, 1 = the one before, ...
+    lo, hi = (adam[-2 - back] + 1, adam[-1 - back] + 1) if len(adam) >= 2 + back else (0, len(rows))
     out = ["kernel,grid,workgroup,lds,us"]
     for r in rows[lo:hi]:
         d = dict(zip(want, r[3:]))
