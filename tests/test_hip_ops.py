@@ -85,6 +85,15 @@ CONV_CASES = [
     (64, 32, 32, 256, 64, 1, 1, 0),   # resident-weight streaming 1x1 conv, K = 256 forward, K = 64 input gradient
     (64, 32, 32, 128, 64, 1, 1, 0),   # resident-weight streaming 1x1 conv, 64-column slice (N = 64), K = 128
     (64, 32, 32, 64, 64, 1, 1, 0),    # resident-weight streaming 1x1 conv, 64-column slice, K = 64
+    # DCGAN critic / generator shapes: uniform-tap chunks (raw buffer loads), residue-class input gradient,
+    # shift/mask weight-gradient gather, image-end kernels
+    (3, 64, 64, 3, 64, 4, 2, 1),      # image end: general decode forward, smalln input gradient with 16 lanes per pixel
+    (2, 64, 64, 3, 128, 4, 2, 1),     # image end of the generator: smalln input gradient with 32 lanes per pixel
+    (2, 32, 32, 64, 128, 4, 2, 1),
+    (5, 16, 16, 128, 256, 4, 2, 1),   # ragged batch
+    (1, 8, 8, 256, 512, 4, 2, 1),     # 16 output pixels: one partial pixel chunk in the weight gradient, split-K forward
+    (3, 12, 20, 32, 64, 4, 2, 1),     # maps that are not powers of two: uniform taps yes, shift/mask gather no
+    (2, 8, 8, 512, 1024, 4, 2, 1),    # 128-wide column tiles, long reduction
 ]
 
 
