@@ -88,6 +88,8 @@ class FlatParams:
         self._grad_views_bound = False
         self.data_t = None          # transposed copies of the weight slots (see refresh_transposed)
         self._t_table = None
+        self._t_skip = set()
+        self._wino_off = {}
         # opt-in split-precision convolutions (LGM_CONV_MODE=bf16x3): three bf16 planes of the weights
         # (forward layout) and of their transposed copies, in MFMA fragment order
         self.wino = False           # Winograd-transformed 3x3 weights (see enable_wino)
@@ -104,8 +106,12 @@ class FlatParams:
         from . import ops
         if self._t_table is None:
             rows, blk = [], 0
+            # slots whose input gradient runs on the Winograd operand (data_ub) need no transposed copy: 33 M of the
+            # UNet's 35.7 M parameters.  ``tptr`` returns None for them, so a geometry the Winograd kernel does not
+            # take falls back to the direct kernel's untransposed-weight mode instead of reading a stale copy.
+            self._t_skip = set(self._wino_off) if (self.wino and ops.WINO and not self.b3) else set()
             for s in self.slots:
-                if s.kind != "weight":
+                if s.kind != "weight" or s.offset in self._t_skip:
                     continue
                 Np, T, Cp = s.phys_shape
                 rows.append([s.offset, Np, T, Cp, blk])
@@ -203,7 +209,10 @@ class FlatParams:
     def tptr(self, p: nn.Parameter):
         if self.data_t is None:
             return None
-        return self.data_t.data_ptr() + 4 * self.by_param[id(p)].offset
+        off = self.by_param[id(p)].offset
+        if off in self._t_skip:
+            return None
+        return self.data_t.data_ptr() + 4 * off
 
     # -- pointers --------------------------------------------------------------------------
     def ptr(self, p: nn.Parameter) -> int:
