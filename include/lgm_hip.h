@@ -279,6 +279,21 @@ int64_t lgm_bn_workspace(int64_t rows, int C);
 int lgm_bn_stats(const float* a, int64_t a_pitch, int64_t rows, int C, float eps, float momentum,
                  float* mean, float* rstd, float* running_mean, float* running_var, void* workspace,
                  void* stream);
+/* BatchNorm statistics folded into the producing convolution (dcgan.py:86-90,158-161: Conv2d / ConvTranspose2d
+ * followed by BatchNorm2d): lgm_conv_xy_stats / lgm_conv_yx_stats are lgm_conv_xy / lgm_conv_yx without bias and
+ * residual that also leave, per row tile, (sum, squared deviations from the tile's mean, rows) of every output
+ * column in stats[tile][3][C]; *stats_tiles = tiles written, 0 when this geometry cannot (then call lgm_bn_stats).
+ * stats holds lgm_conv_stats_floats(g, yx) floats.  lgm_bn_stats_from_tiles finishes mean / rstd / running stats. */
+int64_t lgm_conv_stats_floats(const LgmConvGeom* g, int yx);
+int lgm_conv_xy_stats(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w, float* y,
+                      int64_t y_pitch, void* workspace, int64_t workspace_bytes, float* stats,
+                      int* stats_tiles, void* stream);
+int lgm_conv_yx_stats(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
+                      const float* w_t, float* x, int64_t x_pitch, void* workspace, int64_t workspace_bytes,
+                      float* stats, int* stats_tiles, void* stream);
+int lgm_bn_stats_from_tiles(const float* partial, int ntiles, int C, int64_t rows, float eps, float momentum,
+                            float* mean, float* rstd, float* running_mean, float* running_var,
+                            void* stream);
 /* sums3 = [sum v1, sum v1*xhat, sum v1*v2] per channel ([3][C]); a / v2 optional */
 int lgm_bn_reduce3(const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch,
                    const float* a, int64_t a_pitch, const float* mean, const float* rstd,

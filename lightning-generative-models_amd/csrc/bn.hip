@@ -411,6 +411,21 @@ extern "C" int lgm_bn_stats(const float* a, int64_t a_pitch, int64_t rows, int C
   return LGM_OK;
 }
 
+// batch statistics from row-tile partials (sum, M2, n) a producing convolution left behind (lgm_conv_xy_stats /
+// lgm_conv_yx_stats): the second reduction stage alone - the read pass over the activation is gone
+extern "C" int lgm_bn_stats_from_tiles(const float* partial, int ntiles, int C, int64_t rows, float eps, float momentum,
+                                       float* mean, float* rstd, float* running_mean, float* running_var,
+                                       void* stream) {
+  LGM_REQUIRE(partial && ntiles > 0 && C > 0 && rows > 0 && mean && rstd, "bn_stats_from_tiles: bad arguments");
+  BnEpi e{};
+  e.epi = 1; e.M = (long)rows; e.eps = eps; e.momentum = momentum;
+  e.mean = mean; e.rstd = rstd; e.running_mean = running_mean; e.running_var = running_var;
+  hipLaunchKernelGGL(bn_stage2_epi_kernel, dim3(lgm_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, ntiles, C,
+                     e);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
 // reduce3 + bn_coef in two launches: modes bit 0 -> coefficient set of mode 0 (coef8[0..4C), ggamma0/gbeta0/m_out),
 // bit 1 -> set of mode 1 (coef8[4C..8C), ggamma1, needs saved_m).  sums3 (optional) also receives (S1, S2, S3).
 extern "C" int lgm_bn_reduce3_coef(int modes, const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch,

@@ -98,6 +98,12 @@ struct IgemmArgs {
   // the products multiplied by zero.  phases = s*s (or 1 = off); then M, K, tiles_m describe ONE class.
   int phases, KHs, KWs;
   int wide;           // output / residual / bias are 16-byte aligned with pitches % 4 == 0 (wide epilogue allowed)
+  // BatchNorm statistics of the OUTPUT folded into the epilogue (full tiles, no bias / residual / split-K): every
+  // workgroup adds, per output column, the sum of its BM rows and their squared deviations from the tile's own mean
+  // to stats[row tile][3][N] = (sum, M2, BM) - exactly what bn_stats_stage1 writes, so lgm_bn_stats_from_tiles
+  // (Chan's combination in the second reduction stage) takes it from there and the read pass over the
+  // activation disappears.
+  float* stats;
 };
 
 template <int MODE, int BM, int BN, int TM, int TN, bool UNI>
@@ -434,6 +440,52 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
     return;
   }
+  if (p.stats) {      // host guarantees: full tiles everywhere, wide epilogue, splits == 1, no bias / residual
+    // C/D map: a lane holds, of column lr of tile (i, j), rows i*32 + (r&3) + 8*(r>>2) + 4*lh
+    float* st = smem;                       // [2 passes][wm][wn][TN][32]; the K loop ended with a barrier
+    float colsum[TN], part[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += acc[i][j][r];
+      v += __shfl_xor(v, 32, 64);
+      if (lh == 0) st[((wm * 2 + wn) * TN + j) * 32 + lr] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      colsum[j] = st[((0 * 2 + wn) * TN + j) * 32 + lr] + st[((1 * 2 + wn) * TN + j) * 32 + lr];
+      const float mu = colsum[j] * (1.f / (float)BM);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[i][j][r] - mu;
+          q += d * d;
+        }
+      q += __shfl_xor(q, 32, 64);
+      part[j] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      if (lh == 0) st[((wm * 2 + wn) * TN + j) * 32 + lr] = part[j];
+    __syncthreads();
+    if (wm == 0 && lh == 0) {
+      float* o = p.stats + ((long)(pc * p.tiles_m + tm) * 3) * p.N;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 32 * TN + j * 32 + lr;
+        o[n] = colsum[j];
+        o[p.N + n] = st[((0 * 2 + wn) * TN + j) * 32 + lr] + st[((1 * 2 + wn) * TN + j) * 32 + lr];
+        o[2 * p.N + n] = (float)BM;
+      }
+    }
+  }
   if (p.wide && m0 + BM <= p.M && n0 + BN <= p.N) {
     // full tile, 16-byte aligned output: wave-private LDS transpose (the A/B tiles are dead), residual
     // rows loaded up front, unconditional 16-byte stores (see lgm_common.h; a conditional dword store per
@@ -543,8 +595,11 @@ int igemm_splits(long M, int N, int K, int* kchunk) {
   return lgm_cdiv(nk, per);
 }
 
+// stats / stats_tiles (optional): request the BatchNorm statistics of the output from the epilogue; *stats_tiles = the
+// number of row tiles written (0: this launch could not produce them - split-K, ragged tiles, bias / residual)
 template <int MODE>
-int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool wide, hipStream_t s) {
+int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool wide, hipStream_t s,
+                   float* stats = nullptr, int* stats_tiles = nullptr) {
   a.wide = wide && a.N % 4 == 0 ? 1 : 0;
   a.phases = 1;
   a.KHs = a.KH;
@@ -561,8 +616,22 @@ int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool 
   a.splits = 1;
   a.kchunk = lgm_cdiv(a.K, BK) * BK;
   a.ws = nullptr;
-  if (a.N > 64 && t128 * lgm_cdiv(a.N, 128) >= 384) return launch_igemm<MODE, 128, 128, 2, 2>(a, s);
-  if (t128 * lgm_cdiv(a.N, 64) >= 384) return launch_igemm<MODE, 128, 64, 2, 1>(a, s);
+  a.stats = nullptr;
+  if (stats_tiles) *stats_tiles = 0;
+  auto want_stats = [&](int bm, int bn) {
+    if (stats && stats_tiles && a.wide && !a.bias && !a.res && a.M % bm == 0 && a.N % bn == 0) {
+      a.stats = stats;
+      *stats_tiles = (int)(a.M / bm) * a.phases;
+    }
+  };
+  if (a.N > 64 && t128 * lgm_cdiv(a.N, 128) >= 384) {
+    want_stats(128, 128);
+    return launch_igemm<MODE, 128, 128, 2, 2>(a, s);
+  }
+  if (t128 * lgm_cdiv(a.N, 64) >= 384) {
+    want_stats(128, 64);
+    return launch_igemm<MODE, 128, 64, 2, 1>(a, s);
+  }
   int kchunk;
   const int splits = a.phases > 1 ? 1 : igemm_splits(a.M, a.N, a.K, &kchunk);
   if (splits > 1 && wide && workspace && workspace_bytes >= (int64_t)splits * a.M * a.N * (int64_t)sizeof(float)) {
@@ -573,6 +642,7 @@ int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool 
     return lgm_splitk_reduce_launch(a.ws, (long)a.M * a.N, splits, a.bias, a.res, a.res_pitch, a.out, a.out_pitch, a.M,
                                     a.N, s);
   }
+  want_stats(64, 64);
   return launch_igemm<MODE, 64, 64, 1, 1>(a, s);
 }
 
@@ -605,9 +675,11 @@ extern "C" int64_t lgm_conv_workspace(const LgmConvGeom* g, int yx) {
   return s > 1 ? (int64_t)s * g->B * g->H * g->W * oc * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w,
-                           const float* bias, const float* res, int64_t res_pitch, float* y,
-                           int64_t y_pitch, void* workspace, int64_t workspace_bytes, void* stream) {
+static int conv_xy_impl(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w,
+                        const float* bias, const float* res, int64_t res_pitch, float* y,
+                        int64_t y_pitch, void* workspace, int64_t workspace_bytes, float* stats, int* stats_tiles,
+                        void* stream) {
+  if (stats_tiles) *stats_tiles = 0;
   if (int rc = check_geom(g)) return rc;
   LGM_REQUIRE(x && w && y, "conv_xy: null pointer");
   LGM_REQUIRE(g->Cw % 4 == 0, "conv_xy: Cw=%d must be a multiple of 4 (pad channels)", g->Cw);
@@ -633,7 +705,31 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
   a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
   a.M = g->B * g->Ho * g->Wo; a.N = g->Nw; a.K = g->KH * g->KW * g->Cw; a.Cg = g->Cw;
   return dispatch_igemm<MODE_XY>(a, workspace, workspace_bytes, wide_ok(y, y_pitch, res, res_pitch, bias),
-                                 (hipStream_t)stream);
+                                 (hipStream_t)stream, stats, stats_tiles);
+}
+
+extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w,
+                           const float* bias, const float* res, int64_t res_pitch, float* y,
+                           int64_t y_pitch, void* workspace, int64_t workspace_bytes, void* stream) {
+  return conv_xy_impl(g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, workspace, workspace_bytes, nullptr, nullptr,
+                      stream);
+}
+
+// lgm_conv_xy that also leaves the per-row-tile BatchNorm statistics of y in stats[tile][3][Nw] (see IgemmArgs::stats);
+// *stats_tiles = tiles written, 0 when this geometry / path cannot (the caller then runs lgm_bn_stats on y).
+// stats must hold lgm_conv_stats_floats(g, 0) floats.
+extern "C" int lgm_conv_xy_stats(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w, float* y,
+                                 int64_t y_pitch, void* workspace, int64_t workspace_bytes, float* stats,
+                                 int* stats_tiles, void* stream) {
+  LGM_REQUIRE(stats && stats_tiles, "conv_xy_stats: null statistics buffer");
+  return conv_xy_impl(g, x, x_pitch, w, nullptr, nullptr, 0, y, y_pitch, workspace, workspace_bytes, stats, stats_tiles,
+                      stream);
+}
+
+extern "C" int64_t lgm_conv_stats_floats(const LgmConvGeom* g, int yx) {
+  if (check_geom(g) != LGM_OK) return -1;
+  const long rows = yx ? (long)g->B * g->H * g->W : (long)g->B * g->Ho * g->Wo;
+  return (int64_t)(lgm_cdiv(rows, 64) + 4) * 3 * (yx ? g->Cw : g->Nw);      // 64-row tiles are the smallest
 }
 
 namespace {
@@ -782,9 +878,11 @@ __global__ __launch_bounds__(256) void smalln_yx_kernel(const SmallNArgs p) {
 }
 }  // namespace
 
-extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
-                           const float* w_t, const float* bias, const float* res, int64_t res_pitch, float* x,
-                           int64_t x_pitch, void* workspace, int64_t workspace_bytes, void* stream) {
+static int conv_yx_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
+                        const float* w_t, const float* bias, const float* res, int64_t res_pitch, float* x,
+                        int64_t x_pitch, void* workspace, int64_t workspace_bytes, float* stats, int* stats_tiles,
+                        void* stream) {
+  if (stats_tiles) *stats_tiles = 0;
   if (int rc = check_geom(g)) return rc;
   LGM_REQUIRE(x && w && y, "conv_yx: null pointer");
   LGM_REQUIRE(g->Nw % 4 == 0 && g->Cw % 4 == 0, "conv_yx: Nw=%d, Cw=%d must be multiples of 4", g->Nw, g->Cw);
@@ -827,7 +925,23 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
   a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
   a.M = g->B * g->H * g->W; a.N = g->Cw; a.K = g->KH * g->KW * g->Nw; a.Cg = g->Nw;
   return dispatch_igemm<MODE_YX>(a, workspace, workspace_bytes, wide_ok(x, x_pitch, res, res_pitch, bias),
-                                 (hipStream_t)stream);
+                                 (hipStream_t)stream, stats, stats_tiles);
+}
+
+extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
+                           const float* w_t, const float* bias, const float* res, int64_t res_pitch, float* x,
+                           int64_t x_pitch, void* workspace, int64_t workspace_bytes, void* stream) {
+  return conv_yx_impl(g, y, y_pitch, w, w_t, bias, res, res_pitch, x, x_pitch, workspace, workspace_bytes, nullptr,
+                      nullptr, stream);
+}
+
+// the transposed convolution with the BatchNorm statistics of x left in stats (see lgm_conv_xy_stats)
+extern "C" int lgm_conv_yx_stats(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
+                                 const float* w_t, float* x, int64_t x_pitch, void* workspace, int64_t workspace_bytes,
+                                 float* stats, int* stats_tiles, void* stream) {
+  LGM_REQUIRE(stats && stats_tiles, "conv_yx_stats: null statistics buffer");
+  return conv_yx_impl(g, y, y_pitch, w, w_t, nullptr, nullptr, 0, x, x_pitch, workspace, workspace_bytes, stats,
+                      stats_tiles, stream);
 }
 
 // =====================================================================================

@@ -55,13 +55,20 @@ class BatchNorm2d(nn.Module):
         self._nbt_pending = 0
 
     # ---- forward: h = act(gamma*xhat + beta) ------------------------------------------------
-    def fwd(self, a, act: int, slope: float = 0.0, training: bool = True):
+    def fwd(self, a, act: int, slope: float = 0.0, training: bool = True, stats=None):
+        """stats = (partials, tiles) from the producing convolution's epilogue (Conv2d.fwd(stats=True)): the
+        statistics are finished from them and the read pass over ``a`` is skipped."""
         C = a.shape[-1]
         fp = _flat(self.weight)
         st = torch.empty((2, C), dtype=torch.float32, device=a.device)
         mean, rstd = st[0], st[1]
         L = ops.lib()
-        if training:
+        if training and stats is not None and stats[1] > 0:
+            L.lgm_bn_stats_from_tiles(stats[0].data_ptr(), stats[1], C, ops.rows(a), self.eps, self.momentum,
+                                      mean.data_ptr(), rstd.data_ptr(), self.running_mean.data_ptr(),
+                                      self.running_var.data_ptr(), ops.stream())
+            self._nbt_pending += 1
+        elif training:
             L.lgm_bn_stats(a.data_ptr(), ops.pitch(a), ops.rows(a), C, self.eps, self.momentum, mean.data_ptr(),
                            rstd.data_ptr(), self.running_mean.data_ptr(), self.running_var.data_ptr(),
                            _ws(a).data_ptr(), ops.stream())

@@ -85,14 +85,18 @@ class Conv2d(nn.Module):
         g = self.geom(B, H, W)
         return (B, g.Ho, g.Wo, _r4(self.cout))
 
-    def fwd(self, x, out=None, res=None):
+    def fwd(self, x, out=None, res=None, stats=False):
+        """stats=True (bias-free convolution feeding a train-mode BatchNorm): returns (y, (partials, tiles)) with the
+        batch statistics of y left behind by the convolution's epilogue (tiles == 0: not for this geometry)."""
         B, H, W, C = x.shape
         assert C == _r4(self.cin), f"conv expects {_r4(self.cin)} (padded) channels, got {C}"
         g = self.geom(B, H, W)
         fp = _flat(self.weight)
         y = out if out is not None else ops.new((B, g.Ho, g.Wo, _r4(self.cout)), x)
+        if stats and self.bias is None and res is None:
+            return y, ops.conv_stats(0, g, x, fp.ptr(self.weight), y)
         ops.conv_xy(g, x, fp.ptr(self.weight), fp.ptr(self.bias) if self.bias is not None else None, res, y)
-        return y
+        return (y, (None, 0)) if stats else y
 
     def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None):
         """gW, gb into flat grads; returns gx = dgrad(gy) (+ res) (+ existing gx when accumulate)."""
@@ -181,14 +185,17 @@ class ConvTranspose2d(nn.Module):
             self._geoms[key] = g
         return g
 
-    def fwd(self, x, out=None, res=None):
+    def fwd(self, x, out=None, res=None, stats=False):
+        """stats=True: as Conv2d.fwd - (y, (partials, tiles)) with the batch statistics of y from the epilogue."""
         B, H, W, C = x.shape
         assert C == _r4(self.cin)
         g = self.geom(B, H, W)
         fp = _flat(self.weight)
         y = out if out is not None else ops.new((B, g.H, g.W, _r4(self.cout)), x)
+        if stats and self.bias is None and res is None:
+            return y, ops.conv_stats(1, g, x, fp.ptr(self.weight), y)
         ops.conv_yx(g, x, fp.ptr(self.weight), fp.ptr(self.bias) if self.bias is not None else None, res, y)
-        return y
+        return (y, (None, 0)) if stats else y
 
     def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None):
         B, H, W, _ = x.shape

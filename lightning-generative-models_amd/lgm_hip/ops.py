@@ -252,6 +252,30 @@ def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
         TIMER.end()
 
 
+def conv_stats(yx: int, g: ConvGeom, a, w_ptr: int, out, wt_ptr: Optional[int] = None):
+    """conv_xy (yx = 0) / conv_yx (yx = 1) without bias and residual whose epilogue also leaves the BatchNorm
+    statistics of ``out`` per row tile.  Returns (partials tensor, tiles) - tiles == 0: this geometry could not,
+    run lgm_bn_stats on ``out``.  Only the generic implicit-GEMM kernels do this (the DCGAN 4x4 / stride-2 layers)."""
+    L = lib()
+    if TIMER is not None:
+        TIMER.begin("igemm_yx" if yx else "igemm_xy", _conv_flops(g), _conv_bytes(g))
+    ws = _conv_ws(g, yx, a.device)
+    oc = g.Cw if yx else g.Nw
+    stats = torch.empty(L.lgm_conv_stats_floats(ctypes.byref(g), yx), dtype=torch.float32, device=a.device)
+    nt = ctypes.c_int(0)
+    wsp, wsb = (None, 0) if ws is None else (ws.data_ptr(), ws.numel() * 4)
+    if yx:
+        L.lgm_conv_yx_stats(ctypes.byref(g), a.data_ptr(), pitch(a), w_ptr, wt_ptr, out.data_ptr(), pitch(out), wsp, wsb,
+                            stats.data_ptr(), ctypes.addressof(nt), stream())
+    else:
+        L.lgm_conv_xy_stats(ctypes.byref(g), a.data_ptr(), pitch(a), w_ptr, out.data_ptr(), pitch(out), wsp, wsb,
+                            stats.data_ptr(), ctypes.addressof(nt), stream())
+    if TIMER is not None:
+        TIMER.end()
+    assert oc == out.shape[-1]
+    return stats, int(nt.value)
+
+
 def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr: Optional[int] = None):
     if TIMER is not None:
         TIMER.begin("igemm_yx", _conv_flops(g), _conv_bytes(g))

@@ -92,11 +92,14 @@ class Generator(_Net):
         h = z4
         n = len(self.model)
         for i, blk in enumerate(self.model):
-            a = blk[0].fwd(h)
             if i < n - 1:
-                hn, sv = blk[1].fwd(a, ops.ACT_RELU, 0.0, self.training)
+                # train mode: the transposed convolution's epilogue leaves the batch statistics of its output
+                # (lgm_conv_yx_stats), BatchNorm finishes them without reading the activation again
+                a, st = blk[0].fwd(h, stats=True)
+                hn, sv = blk[1].fwd(a, ops.ACT_RELU, 0.0, self.training, stats=st)
                 tape.append((h, sv, hn))
             else:
+                a = blk[0].fwd(h)
                 hn = ops.new(a.shape, a)
                 ops.act_fwd(a, None, None, hn, ops.ACT_TANH)
                 tape.append((h, a, hn))
@@ -172,11 +175,15 @@ class Discriminator(_Net):
         tape = []
         h = x4
         for blk, (ci, co, k, s, p, bn, final) in zip(self.model, self.spec):
-            a = blk[0].fwd(h)
             sv = None
             if bn:
-                hn, sv = blk[1].fwd(a, ops.ACT_LRELU, SLOPE, self.training)
-            elif not final:
+                a, st = blk[0].fwd(h, stats=True)                # batch statistics from the convolution's epilogue
+                hn, sv = blk[1].fwd(a, ops.ACT_LRELU, SLOPE, self.training, stats=st)
+                tape.append((h, a, sv, hn))
+                h = hn
+                continue
+            a = blk[0].fwd(h)
+            if not final:
                 hn = ops.new(a.shape, a)
                 ops.act_fwd(a, None, None, hn, ops.ACT_LRELU, SLOPE)
             else:

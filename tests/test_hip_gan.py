@@ -122,6 +122,45 @@ def _generator_grad_check(parity, m, fx_norm, g_loss_fn, img_size, ch, latent, z
     parity("worst generator gradient norm (cancelling BatchNorm sums) vs float64 oracle", worst_cond, 1e-3)
 
 
+
+@pytest.mark.parametrize("case", [(0, 128, 32, 64, 128), (0, 128, 16, 128, 256), (0, 96, 64, 32, 256), (1, 8, 16, 128, 64),
+                                  (1, 16, 8, 256, 128), (1, 128, 4, 1024, 512), (0, 8, 32, 64, 128), (1, 3, 4, 64, 64)])
+def test_batchnorm_statistics_from_the_convolution_epilogue(dev, case, parity):
+    """Conv2d / ConvTranspose2d (4x4, stride 2, no bias) -> train-mode BatchNorm as the DCGAN critic / generator
+    chain them: the convolution's epilogue leaves per-row-tile (sum, M2, rows) and lgm_bn_stats_from_tiles finishes
+    mean / rstd / running statistics without reading the activation.  Checked against float64 statistics of the
+    SAME output tensor and against the stand-alone lgm_bn_stats (128x64, 64x64 and 128x128 tiles forward, the
+    residue-class input-gradient form for the transposed layers); the last two cases are geometries the epilogue
+    cannot serve (split-K forward; 48 rows per residue class) and must report 0 tiles."""
+    from lgm_hip import ops
+    from lgm_hip.bn import BatchNorm2d
+    from lgm_hip.flat import FlatParams
+    from lgm_hip.nn import Conv2d, ConvTranspose2d, param_kind
+    transposed, B, hw, ci, co = case
+    torch.manual_seed(sum(case))
+    conv = (ConvTranspose2d if transposed else Conv2d)(ci, co, 4, 2, 1, bias=False)
+    bn_a, bn_b = BatchNorm2d(co), BatchNorm2d(co)
+    net = torch.nn.ModuleList([conv, bn_a, bn_b]).to(dev)
+    FlatParams([(n, p, param_kind(n, p)) for n, p in net.named_parameters()], dev)
+    x = torch.randn(B, hw, hw, ci, device=dev) + 0.3
+    y, st = conv.fwd(x, stats=True)
+    rows = y.shape[0] * y.shape[1] * y.shape[2]
+    if case in ((0, 8, 32, 64, 128), (1, 3, 4, 64, 64)):
+        assert st[1] == 0
+        return
+    assert st[1] > 0
+    y64 = y.double().reshape(rows, co)
+    m64, v64 = y64.mean(0), y64.var(0, unbiased=False)
+    h_a, sv_a = bn_a.fwd(y, ops.ACT_LRELU, 0.2, True, stats=st)
+    h_b, sv_b = bn_b.fwd(y, ops.ACT_LRELU, 0.2, True)
+    r64 = (v64 + bn_a.eps).rsqrt()
+    parity("mean from epilogue tiles (|d mean| * rstd)", float(((sv_a.mean.double() - m64).abs() * r64).max()), 2e-6)
+    parity("rstd from epilogue tiles (relative)", float(((sv_a.rstd.double() - r64).abs() / r64).max()), 2e-6)
+    parity("BatchNorm output, tiles vs stand-alone statistics", rel(h_a, h_b), 2e-6)
+    parity("running_var, tiles vs stand-alone", rel(bn_a.running_var, bn_b.running_var), 2e-6)
+    parity("running_mean, tiles vs stand-alone (|d| * rstd)",
+           float(((bn_a.running_mean.double() - bn_b.running_mean.double()).abs() * r64).max()), 2e-6)
+
 @pytest.mark.parametrize("cfg", [(64, 3, 100), (28, 1, 128)])
 def test_wgan_gp_losses_and_gradients_match_reference_fixture(dev, golden_dir, cfg, parity):
     img_size, ch, latent = cfg
