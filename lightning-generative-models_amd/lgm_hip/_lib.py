@@ -66,6 +66,10 @@ class _Lib:
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # torch first: liblgm_hip.so must bind to the HIP runtime torch ships (same SONAME).  Loaded on its own it
+        # pulls in /opt/rocm's copy, torch then brings a second one, and launches on torch's streams fail with
+        # "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         self._dll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         self._dll.lgm_last_error.restype = ctypes.c_char_p
