@@ -27,6 +27,9 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL otherwise fails in hipIpcGetMemHandle)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "lightning-generative-models_amd")):
     if _p not in sys.path:

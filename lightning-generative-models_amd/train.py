@@ -19,9 +19,11 @@ from datetime import datetime
 from pathlib import Path
 from pprint import pprint
 
-import torch
-import torch.distributed as dist
-import yaml
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this stack
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import yaml  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
