@@ -109,7 +109,8 @@ struct Args {
   int units, per, splits, pps;
   float* ws;
   long ws_stride;
-  int dbg_mode;        // 0: stamps per phase / epilogue, 1: per double step, 2: before and after every barrier
+  int dbg_mode;        // 0: stamps per phase / epilogue, 1: per double step, 2: before and after every barrier,
+                       // 5: mode 0 + the prologue in four parts (setup | fetch issue | landed + barrier | transform)
   long long* dbg;      // diagnostic build only (wino_conv_kernel<true>): per-workgroup cycle stamps
 };
 
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
                                                   p.res ? npix * p.res_pitch * 4 : 4);
 
   // ---- prologue ----
+  if (DBG && p.dbg_mode == 5) stamp();             // mode 5: the prologue in four parts (setup | fetch issue | landed + barrier | first transform)
   Phase cur;
   cur.valid = true;
   decode(cur, L0);
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
     slot_offsets(nx1, poff);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) fetch_at(j, nx1, poff);
+    if (DBG && p.dbg_mode == 5) stamp();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) *reinterpret_cast<u32x4*>(Rb + plds[j]) = r0[j];      // raw[cur] -> buffer 0
 #pragma unroll
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
     slot_offsets(nx3, poff);
   }
   __syncthreads();
+  if (DBG && p.dbg_mode == 5) stamp();
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     tr_read(Rb, 0, c, c);
