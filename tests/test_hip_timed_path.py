@@ -188,6 +188,45 @@ def test_vqvae_graph_replay_is_bit_identical_to_eager_steps(dev, ema):
         for k in pb:
             assert torch.equal(torch.as_tensor(pa[k]), torch.as_tensor(pb[k])), k
 
+
+@pytest.mark.parametrize("ema", [False, True])
+def test_vqvae_trainer_fast_path_checkpoint_resume(dev, tmp_path, ema):
+    """MiniTrainer.fit drives a VQVAE through ``make_fast_step`` (HIP-graph replay): a Lightning-layout checkpoint
+    written after 3 steps resumes - new process state, graph captured again at the first batch after the resume -
+    to exactly the parameters, EMA codebook buffers and Adam moments of 6 uninterrupted steps."""
+    from lgm_hip.graph import ModuleFastStep
+    from lgm_hip.lightning import MiniTrainer, save_checkpoint
+    from models.generative.vae.vqvae import VQVAE
+
+    def make():
+        torch.manual_seed(3)
+        return VQVAE(img_channels=3, img_size=32, embedding_dim=64, num_embeddings=512, hidden_dim=64,
+                     num_residual_layers=2, num_residual_hiddens=32, use_ema=ema, lr=1e-3, b1=0.9, b2=0.999,
+                     loss_weights={"recon_loss": 1, "vq_loss": 10 if ema else 1})
+
+    g = torch.Generator().manual_seed(6)
+    batches = [(torch.rand(32, 3, 32, 32, generator=g) * 2 - 1, torch.zeros(32, dtype=torch.long)) for _ in range(6)]
+
+    def fit(m, data, ckpt=None):
+        tr = MiniTrainer(max_epochs=1, default_root_dir=None, log_every=0, device=dev)
+        tr.fit(m, train_dataloader=data, ckpt_path=ckpt)
+        return m, tr
+
+    a, tra = fit(make(), batches)
+    assert isinstance(tra.fast, ModuleFastStep) and tra.fast.mode.startswith("hipGraph")
+    b1, _ = fit(make(), batches[:3])
+    path = str(tmp_path / "step3.ckpt")
+    save_checkpoint(b1, list(b1._optimizers), path)
+    b2, trb = fit(make(), batches[3:], ckpt=path)
+    assert b2.global_step == 6 == a.global_step and trb.fast.mode.startswith("hipGraph")
+    sa, sb = a.state_dict(), b2.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    oa, ob = a._optimizers[0].state_dict()["state"], b2._optimizers[0].state_dict()["state"]
+    for i in oa:
+        for k in oa[i]:
+            assert torch.equal(torch.as_tensor(oa[i][k]), torch.as_tensor(ob[i][k])), (i, k)
+
 def test_gp_penalty_zero_gradient_pixel(dev):
     """A pixel whose channel gradient is exactly zero: penalty (0-1)^2 and a ZERO subgradient (torch's
     backward of norm(2, dim=1)), not NaN."""
