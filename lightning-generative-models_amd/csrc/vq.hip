@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
   extern __shared__ float e2s[];   // ||e_k||^2
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     float s = 0.f;
-    for (int d = 0; d < D; ++d) s += cb[(long)k * D + d] * cb[(long)k * D + d];
+    for (int d = 0; d < D; ++d) s = fmaf(cb[(long)k * D + d], cb[(long)k * D + d], s);   // explicit: both searches agree bit for bit
     e2s[k] = s;
   }
   __syncthreads();
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     xv[d] = xp[d];
-    x2 += xv[d] * xv[d];
+    x2 = fmaf(xv[d], xv[d], x2);
     xv[d] *= 2.f;           // reference: - 2 * flat @ W.T  ==  (2 flat) @ W.T
   }
   float best = INFINITY;
@@ -59,6 +59,97 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
   if (tl == 0) {
     idx_out[row] = (int64_t)bi;
     if (dist_out) dist_out[row] = best;
+  }
+}
+
+// The same search with the roles turned round: a LANE owns a code (its D floats stay in registers for the whole
+// kernel), the block walks its rows, whose 2x values every lane reads from LDS as a broadcast.  The row-major
+// version above streams the codebook through every team (64 scalar loads per code per lane) and ran at 5 % of the
+// fp32 FMA rate; this one reads x once and the codebook once per block.  Arithmetic is IDENTICAL per (row, code) -
+// the same sequential FMA chain over d, the same (x2 + e2) - dot, lowest index on ties - so indices and distances
+// are bit-identical to the kernel above (tested).  Four rows at a time = four independent chains per lane.
+// block = K threads (K a multiple of 64, <= 512: the code's D floats + four chains must fit 256 registers); LDS: rows 2x values, x2, per-wave partial minima.
+template <int D>
+__global__ __launch_bounds__(512) void vq_assign_bycode_kernel(const float* __restrict__ x, long x_pitch,
+                                                                const float* __restrict__ cb, int N, int K, int rpb,
+                                                                int64_t* __restrict__ idx_out,
+                                                                float* __restrict__ dist_out) {
+  extern __shared__ __align__(16) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int r0 = blockIdx.x * rpb, nrows = min(rpb, N - r0);
+  if (nrows <= 0) return;
+  float* xs = sm;                                   // [rpb][D]  (2 x)
+  float* x2s = xs + rpb * D;                        // [rpb]
+  float* redd = x2s + rpb;                          // [rpb][nwaves] best distance per wave
+  int* redi = reinterpret_cast<int*>(redd + rpb * nwaves);
+  // this lane's code
+  float e[D];
+  float e2 = 0.f;
+  {
+    const float* ep = cb + (long)tid * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) e[d] = ep[d];
+    for (int d = 0; d < D; ++d) e2 = fmaf(e[d], e[d], e2);
+  }
+  // rows of the block: x2 and 2x exactly as the row-major kernel forms them
+  for (int r = tid; r < nrows; r += blockDim.x) {
+    const float* xp = x + (long)(r0 + r) * x_pitch;
+    float x2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float v = xp[d];
+      x2 = fmaf(v, v, x2);
+      xs[r * D + d] = v * 2.f;
+    }
+    x2s[r] = x2;
+  }
+  __syncthreads();
+  for (int rb = 0; rb < nrows; rb += 4) {
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = rb + q < nrows ? rb + q : rb;          // clamp: the extra chains are discarded
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + r * D + d);   // broadcast read
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dot[q] = fmaf(xv[j], e[d + j], dot[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (rb + q >= nrows) break;
+      float best = (x2s[rb + q] + e2) - dot[q];
+      int bi = tid;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob < best || (ob == best && oi < bi)) {
+          best = ob;
+          bi = oi;
+        }
+      }
+      if (lane == 0) {
+        redd[(rb + q) * nwaves + wave] = best;
+        redi[(rb + q) * nwaves + wave] = bi;
+      }
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < nrows; r += blockDim.x) {
+    float best = redd[r * nwaves];
+    int bi = redi[r * nwaves];
+    for (int w = 1; w < nwaves; ++w) {
+      const float ob = redd[r * nwaves + w];
+      const int oi = redi[r * nwaves + w];
+      if (ob < best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    idx_out[r0 + r] = (int64_t)bi;
+    if (dist_out) dist_out[r0 + r] = best;
   }
 }
 
@@ -231,6 +322,22 @@ extern "C" int lgm_vq_assign(const float* x, int64_t x_pitch, const float* codeb
   LGM_REQUIRE(x && codebook && indices && N > 0 && K > 0, "vq_assign: bad arguments");
   LGM_REQUIRE(K * (int)sizeof(float) <= 60 * 1024, "vq_assign: K=%d too large", K);
   hipStream_t s = (hipStream_t)stream;
+  static const bool row_major = getenv("LGM_VQ_ASSIGN_ROWS") != nullptr;      // A/B switch: the row-major search
+  if (!row_major && K % 64 == 0 && K <= 512 && (D == 32 || D == 64) && N >= 4 * 256) {
+    const int rpb = lgm_cdiv(N, 512);                                         // two blocks per CU's worth of rows
+    const int nb = lgm_cdiv(N, rpb);
+    const size_t sm = ((size_t)rpb * D + rpb + 2 * (size_t)rpb * (K / 64)) * sizeof(float);
+    if (sm <= 64 * 1024) {
+      if (D == 64)
+        hipLaunchKernelGGL(vq_assign_bycode_kernel<64>, dim3(nb), dim3(K), sm, s, x, (long)x_pitch, codebook, N, K, rpb,
+                           indices, min_dist);
+      else
+        hipLaunchKernelGGL(vq_assign_bycode_kernel<32>, dim3(nb), dim3(K), sm, s, x, (long)x_pitch, codebook, N, K, rpb,
+                           indices, min_dist);
+      LGM_LAUNCH_CHECK();
+      return LGM_OK;
+    }
+  }
   const dim3 grid(lgm_cdiv(N, 32)), block(256);
   const size_t smem = (size_t)K * sizeof(float);
   switch (D) {

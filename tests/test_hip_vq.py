@@ -166,3 +166,51 @@ def test_vq_ema_statistics_are_summed_over_ranks(dev, tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "EMA_SYNC same=True ref=True" in r.stdout, r.stdout + r.stderr[-1500:]
+
+
+_ASSIGN_WORKER = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from lgm_hip import ops
+dev = torch.device("cuda", 0)
+d = torch.load(sys.argv[3])
+x, cb = d["x"].to(dev), d["cb"].to(dev)
+N, D = x.shape
+K = cb.shape[0]
+idx = torch.empty(N, dtype=torch.long, device=dev); md = torch.empty(N, device=dev)
+ops.lib().lgm_vq_assign(x.data_ptr(), D, cb.data_ptr(), N, K, D, idx.data_ptr(), md.data_ptr(), ops.stream())
+torch.save({"idx": idx.cpu(), "md": md.cpu()}, sys.argv[4])
+"""
+
+
+@pytest.mark.parametrize("shape", [(16384, 512, 64), (4100, 256, 32), (1024, 64, 64)])
+def test_vq_assign_code_major_equals_row_major_bit_for_bit(dev, tmp_path, shape):
+    """The code-major nearest-code search (a lane owns a code; what every N >= 1024 call runs) against the row-major
+    kernel the reference fixture pins (LGM_VQ_ASSIGN_ROWS=1, in a fresh process): indices AND minimum distances
+    torch.equal - same FMA chain per (row, code), same tie-break - at the benchmark size, a ragged row count and
+    the smallest eligible one.  Inputs include exact ties (duplicated codes) and near-ties."""
+    import subprocess
+    import sys
+    from lgm_hip import ops
+    N, K, D = shape
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(N, D, generator=g) * 0.05
+    cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
+    cb[K // 2] = cb[3]                                   # exact tie: the lower index must win
+    cb[K - 1] = cb[7] * (1 + 1e-7)                       # near tie
+    x[:K] = cb + 1e-4 * torch.randn(K, D, generator=g)   # rows sitting on codes
+    inp, out = str(tmp_path / "in.pt"), str(tmp_path / "out.pt")
+    torch.save({"x": x, "cb": cb}, inp)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LGM_VQ_ASSIGN_ROWS="1")
+    r = subprocess.run([sys.executable, "-c", _ASSIGN_WORKER, root, os.path.join(root, "lightning-generative-models_amd"),
+                        inp, out], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = torch.load(out)
+    xd, cbd = x.to(dev), cb.to(dev)
+    idx = torch.empty(N, dtype=torch.long, device=dev)
+    md = torch.empty(N, device=dev)
+    ops.lib().lgm_vq_assign(xd.data_ptr(), D, cbd.data_ptr(), N, K, D, idx.data_ptr(), md.data_ptr(), ops.stream())
+    assert torch.equal(idx.cpu(), ref["idx"]), f"{int((idx.cpu() != ref['idx']).sum())} index mismatches"
+    assert torch.equal(md.cpu(), ref["md"])
+    assert int(idx[3]) == 3 and int(idx[K // 2]) == 3     # rows on the duplicated code: the lower index wins
