@@ -273,13 +273,14 @@ class VQVAE(LightningModule):
         x4, enc_saved, vq_saved, dec_saved, xh = tape
         B, H, W, Cp = x4.shape
         C = self.hparams.img_channels
-        gc = GradCtx(self._flat)
+        gc = GradCtx(self._flat, defer=True)     # weight-gradient slabs of all layers reduced by ONE launch (flush)
         gxh = ops.new(xh.shape, xh)
         ops.lib().lgm_weighted_mse_bwd(xh.data_ptr(), x4.data_ptr(), Cp, None, None, g_recon.data_ptr(), B, C, H * W,
                                        Cp, gxh.data_ptr(), ops.stream())
         gq = self.decoder.bwd(gc, dec_saved, gxh)
         glat = self.vector_quantizer.bwd(gc, vq_saved, gq, g_vq)
         self.encoder.bwd(gc, enc_saved, glat)
+        gc.flush()
         self._flat.bind_grad_views()
 
     def forward(self, x: torch.Tensor):
