@@ -876,6 +876,108 @@ __global__ __launch_bounds__(256) void smalln_yx_kernel(const SmallNArgs p) {
     }
   }
 }
+
+// Lane-per-pixel form of the same operator (Nw a multiple of 32, maps with an even side >= 16): a workgroup owns a
+// TR x TC tile of ONE residue class (256 output pixels, one per thread), stages the (TR+1) x (TC+1) patch of y it
+// needs through LDS in 32-channel chunks (coalesced 16-byte loads; rows padded to 36 floats so that the 16-byte
+// reads of neighbouring pixels fall on different banks) and every thread runs its own 4 x Nw x 4 FMA chain with the
+// tap weights as scalar operands (uniform addresses: s_load).  No cross-lane reduction, no redundant work: ~22
+// instructions per pixel against ~60 in the lane-group form above, which stays for the small maps.
+template <int KHS, int KWS, int T>      // T = KH * KW as a constant: the weight offsets become s_load immediates
+__global__ __launch_bounds__(256) void smalln_yx_lp_kernel(const SmallNArgs p, int lgc) {
+  static_assert(KHS == 2 && KWS == 2, "patch = tile + 1 in both directions");
+  extern __shared__ __align__(16) float ys[];            // [(TR + 1) * (TC + 1)][36], then the class's weights
+  constexpr int CH = 32, LDY = 36;
+  const int TC = 1 << lgc, TR = 256 >> lgc, PC = TC + 1, PR = TR + 1;
+  float* wsm = ys + PR * PC * LDY;                       // [KHS * KWS][Nw][4]: every lane reads the same 16 bytes (LDS
+                                                         // broadcast) - scalar loads shared lgkmcnt with the patch
+                                                         // reads and drained it 21 times per chunk
+  const int Hq = p.H / p.stride, Wq = p.W / p.stride;
+  const int tiles_c = (Wq + TC - 1) >> lgc, tiles_r = (Hq + TR - 1) / TR;
+  int t = blockIdx.x;
+  const int tc = t % tiles_c;
+  t /= tiles_c;
+  const int tr = t % tiles_r, b = t / tiles_r;
+  const int ph = blockIdx.y / p.stride, pw = blockIdx.y % p.stride;
+  const int kh0 = (ph + p.pad) % p.stride, kw0 = (pw + p.pad) % p.stride;
+  const int dh0 = (ph + p.pad - kh0) / p.stride, dw0 = (pw + p.pad - kw0) / p.stride;
+  const int th0 = tr * TR + dh0 - 1, tw0 = tc * TC + dw0 - 1;      // y coordinates of patch position (0, 0)
+  const int tid = threadIdx.x;
+  const int r = tid >> lgc, c = tid & (TC - 1);
+  const int ihq = tr * TR + r, iwq = tc * TC + c;
+  const bool live = ihq < Hq && iwq < Wq;
+  const unsigned nrec = (unsigned)((long)p.B * p.Ho * p.Wo * p.y_pitch * 4);
+  __amdgpu_buffer_rsrc_t rsrc_y;
+  {
+    const unsigned long long ab = reinterpret_cast<unsigned long long>(p.y);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ab);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ab >> 32));
+    rsrc_y = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                               __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+  }
+  const unsigned ypb = (unsigned)p.y_pitch * 4u;
+  // staging role: 8 threads per patch position (32 channels = 8 x 16 bytes), position k * 32 + sp in pass k.  The
+  // positions do not change from chunk to chunk: their y offsets are decoded once, and a chunk issues all its loads
+  // before the first LDS write (a load -> wait -> write loop serialised ten memory latencies per chunk)
+  constexpr int KMAX = 10;                           // ceil((TR + 1) * (TC + 1) / 32) for both tile shapes
+  const int sq = tid & 7, sp = tid >> 3;
+  unsigned yoff[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int pos = k * 32 + sp;
+    const int pr = pos / PC, pc = pos - pr * PC;
+    const int th = th0 + pr, tw = tw0 + pc;
+    const bool ok = pos < PR * PC && (unsigned)th < (unsigned)p.Ho && (unsigned)tw < (unsigned)p.Wo;
+    yoff[k] = ok ? (unsigned)((b * p.Ho + th) * p.Wo + tw) * ypb + (unsigned)sq * 16u : nrec;
+  }
+  for (int i = tid; i < KHS * KWS * p.Nw; i += 256) {
+    const int tp = i / p.Nw, n = i - tp * p.Nw;
+    const int ta = tp / KWS, tb = tp - ta * KWS;
+    const int tap = (kh0 + ta * p.stride) * p.KW + kw0 + tb * p.stride;
+    *reinterpret_cast<f32x4*>(wsm + (long)i * 4) = *reinterpret_cast<const f32x4*>(p.w + ((long)n * T + tap) * 4);
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 st[KMAX];
+  auto fetch = [&](int n0) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      st[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, yoff[k], (unsigned)(n0 * 4), 0));
+  };
+  fetch(0);
+  for (int n0 = 0; n0 < p.Nw; n0 += CH) {
+    if (n0) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int pos = k * 32 + sp;
+      if (pos < PR * PC) *reinterpret_cast<f32x4*>(ys + pos * LDY + sq * 4) = st[k];
+    }
+    if (n0 + CH < p.Nw) fetch(n0 + CH);             // the next chunk travels while this one is multiplied
+    __syncthreads();
+#pragma unroll
+    for (int ta = 0; ta < KHS; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < KWS; ++tb) {
+        const float* yp = ys + ((r + 1 - ta) * PC + (c + 1 - tb)) * LDY;
+        const float* wp = wsm + ((ta * KWS + tb) * p.Nw + n0) * 4;
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+          const f32x4 y4 = *reinterpret_cast<const f32x4*>(yp + q * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + (q * 4 + j) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(y4[j], w4[k], acc[k]);
+          }
+        }
+      }
+  }
+  if (live) {
+    const long pix = ((long)b * p.H + ihq * p.stride + ph) * p.W + iwq * p.stride + pw;
+    if (p.bias) acc += *reinterpret_cast<const f32x4*>(p.bias);
+    if (p.res) acc += *reinterpret_cast<const f32x4*>(p.res + pix * p.res_pitch);
+    *reinterpret_cast<f32x4*>(p.x + pix * p.x_pitch) = acc;
+  }
+}
 }  // namespace
 
 static int conv_yx_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
@@ -911,6 +1013,23 @@ static int conv_yx_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch, c
     q.B = g->B; q.H = g->H; q.W = g->W; q.Ho = g->Ho; q.Wo = g->Wo; q.Nw = g->Nw;
     q.KH = g->KH; q.KW = g->KW; q.stride = g->stride; q.pad = g->pad;
     q.npix = (long)g->B * g->H * g->W;
+    static const bool no_lp = getenv("LGM_SMALLN_LANES") != nullptr;      // A/B switch: the lane-group form everywhere
+    const int Hq = g->H / 2, Wq = g->W / 2;
+    if (!no_lp && g->Nw % 32 == 0 && Hq >= 8 && Wq >= 16) {
+      const int lgc = Wq >= 32 ? 5 : 4;                                  // 8 x 32 or 16 x 16 pixels of a class
+      const int TC = 1 << lgc, TR = 256 >> lgc;
+      const size_t smem = ((size_t)(TR + 1) * (TC + 1) * 36 + (size_t)16 * g->Nw) * sizeof(float);
+      const unsigned nbl = (unsigned)(g->B * lgm_cdiv(Hq, TR) * lgm_cdiv(Wq, TC));
+      static size_t attr = 0;
+      if (smem > attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(smalln_yx_lp_kernel<2, 2, 16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = smem;
+      }
+      hipLaunchKernelGGL((smalln_yx_lp_kernel<2, 2, 16>), dim3(nbl, 4), dim3(256), smem, (hipStream_t)stream, q, lgc);
+      LGM_LAUNCH_CHECK();
+      return LGM_OK;
+    }
     const long npq = q.npix / (g->stride * g->stride);
     const long want = (npq + 4 * (64 / lpp) - 1) / (4 * (64 / lpp));
     const unsigned nb = (unsigned)(want < 1024 ? want : 1024);
