@@ -37,9 +37,14 @@ class DataModule:
         self.train = SyntheticImages(n_train, img_channels, img_size, seed=10 + self.rank)
         self.val = SyntheticImages(num_samples - n_train, img_channels, img_size, seed=1000 + self.rank)
 
+    # pinned host batches (reference: pin_memory=True, datamodule.py:24): the trainer's non_blocking copy is then a
+    # real asynchronous H2D - from pageable memory it blocks the host until the previous step has drained
+    def _pin(self):
+        return bool(self.pin_memory) and torch.cuda.is_available()
+
     def train_dataloader(self):
         return DataLoader(self.train, batch_size=self.batch_size, shuffle=True, drop_last=True,
-                          generator=torch.Generator().manual_seed(10))
+                          generator=torch.Generator().manual_seed(10), pin_memory=self._pin())
 
     def val_dataloader(self):
-        return DataLoader(self.val, batch_size=self.batch_size, shuffle=False, drop_last=True)
+        return DataLoader(self.val, batch_size=self.batch_size, shuffle=False, drop_last=True, pin_memory=self._pin())

@@ -90,7 +90,8 @@ def main(argv=None):
     else:
         device = torch.device("cpu")
     trainer = MiniTrainer(max_epochs=args.max_epochs, max_steps=args.max_steps, default_root_dir=args.experiment_dir,
-                          accumulate_grad_batches=args.accumulate_grad_batches, device=device)
+                          accumulate_grad_batches=args.accumulate_grad_batches, device=device,
+                          check_val_every_n_epoch=args.check_val_every_n_epoch)   # reference train.py: Trainer(...)
     trainer.fit(model, datamodule=datamodule, ckpt_path=args.ckpt_path)
     if world > 1:
         dist.barrier()

@@ -67,7 +67,7 @@ def test_train_entry_with_pytorch_lightning_installed(tmp_path):
     env = dict(os.environ, PYTHONPATH=str(tmp_path / "site") + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, os.path.join(PKG, "train.py"), "--config_path",
                         os.path.join(PKG, "configs", "vae", "vae.json"), "--max_epochs", "2", "--accelerator", "cpu",
-                        "--experiment_name", "pytest_cpu_pl"], capture_output=True, text=True, timeout=300, env=env)
+                        "--check_val_every_n_epoch", "1", "--experiment_name", "pytest_cpu_pl"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "val_loss" in r.stdout
     d = os.path.join(PKG, "experiments", "VAE", "pytest_cpu_pl")
