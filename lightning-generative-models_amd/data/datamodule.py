@@ -31,7 +31,8 @@ class DataModule:
         self.rank = dist.get_rank() if world > 1 else 0
         self.name, self.img_size, self.img_channels = str(name), img_size, img_channels
         self.batch_size = int(batch_size / world)
-        self.num_workers, self.pin_memory = num_workers, pin_memory
+        self.num_workers, self.pin_memory = int(num_workers), pin_memory
+        self.persistent_workers = bool(persistent_workers) and self.num_workers > 0
         self.train_val_split = train_val_split
         n_train = int(num_samples * train_val_split)
         self.train = SyntheticImages(n_train, img_channels, img_size, seed=10 + self.rank)
@@ -44,7 +45,9 @@ class DataModule:
 
     def train_dataloader(self):
         return DataLoader(self.train, batch_size=self.batch_size, shuffle=True, drop_last=True,
-                          generator=torch.Generator().manual_seed(10), pin_memory=self._pin())
+                          generator=torch.Generator().manual_seed(10), pin_memory=self._pin(),
+                          num_workers=self.num_workers, persistent_workers=self.persistent_workers)
 
     def val_dataloader(self):
-        return DataLoader(self.val, batch_size=self.batch_size, shuffle=False, drop_last=True, pin_memory=self._pin())
+        return DataLoader(self.val, batch_size=self.batch_size, shuffle=False, drop_last=True, pin_memory=self._pin(),
+                          num_workers=self.num_workers, persistent_workers=self.persistent_workers)
