@@ -928,12 +928,18 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WGArgs p) {
   const int ch_end = min(p.total_chunks, ch_begin + p.cps);
 
   // ---- raw patch slots of this thread: X 6 x (position, channel quad), Y 2 x ----
-  const int q4 = (tid & 15) * 4;                    // first channel of the thread's quad
+  // A wave stages 16 POSITIONS x 4 channel quads (quad = lane & 3 + 4 * wave): the channel-major LDS address is
+  // channel * XLD + f(position) with XLD a multiple of 4 (16-byte fragment reads), so 16 quads in one store hit only
+  // two bank offsets (4 * XLD mod 32 = 16) and the 4 positions beside them four more - an 8-way conflict on every
+  // commit (SQ_LDS_BANK_CONFLICT: 71 % of this kernel's LDS cycles).  16 consecutive positions give 16 distinct
+  // offsets ((col & 3) * 4 + slot), times the two quad offsets = all 32 banks, two lanes each: the minimum.
+  const int q4 = ((tid & 3) + 4 * (tid >> 6)) * 4;  // first channel of the thread's quad
+  const int pslot = (tid >> 2) & 15;                // position of the thread inside a pass of 16
   unsigned xdelta[6], xlds[6], ydelta[2], ylds[2];
   unsigned xflag = 0;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    const int pos = (tid >> 4) + 16 * j;            // (il, rho, colidx), 96 positions
+    const int pos = pslot + 16 * j;                 // (il, rho, colidx), 96 positions
     const int il = pos / (6 * XC), rem = pos - il * 6 * XC;
     const int rho = rem / XC, ci = rem - rho * XC;
     xdelta[j] = (unsigned)(((il * p.H + rho) * p.W + ci) * (int)p.x_pitch + q4) * 4u;
@@ -944,7 +950,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WGArgs p) {
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int pos = (tid >> 4) + 16 * j;            // ((il * 4 + row) * SPI + sl) * 2 + dx, 32 positions
+    const int pos = pslot + 16 * j;                 // ((il * 4 + row) * SPI + sl) * 2 + dx, 32 positions
     const int dx = pos & 1, t = pos >> 1;
     const int sl = t % SPI, t2 = t / SPI;
     const int row = t2 & 3, il = t2 >> 2;
