@@ -227,6 +227,34 @@ def test_vqvae_trainer_fast_path_checkpoint_resume(dev, tmp_path, ema):
         for k in oa[i]:
             assert torch.equal(torch.as_tensor(oa[i][k]), torch.as_tensor(ob[i][k])), (i, k)
 
+
+def test_module_fast_step_mixed_batch_shapes(dev):
+    """A batch of another shape in the middle of a run (a ragged last batch, a larger evaluation batch) goes through
+    eager launches - which may grow the shared workspace the captured graph has baked in - and the next full batch
+    replays the graph again: parameters equal an all-eager twin after B = 64, 64, 24, 96, 64, 64."""
+    from models.generative.vae.vqvae import VQVAE
+
+    def make():
+        torch.manual_seed(5)
+        m = VQVAE(img_channels=3, img_size=32, embedding_dim=64, num_embeddings=512, hidden_dim=64,
+                  num_residual_layers=2, num_residual_hiddens=32, use_ema=True, lr=1e-3, b1=0.9, b2=0.999,
+                  loss_weights={"recon_loss": 1, "vq_loss": 10}).to(dev)
+        m.prepare_hip(dev)
+        m.train()
+        return m, m.configure_optimizers()
+
+    (a, oa), (b, ob) = make(), make()
+    fa, fb = a.make_fast_step(oa, 1, True), b.make_fast_step(ob, 1, False)
+    g = torch.Generator().manual_seed(8)
+    for i, B in enumerate((64, 64, 24, 96, 64, 64)):
+        x = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).to(dev)
+        la, lb = fa.step((x, None), i), fb.step((x.clone(), None), i)
+        assert torch.equal(la.detach(), lb.detach()), (i, B)
+    assert fa.mode.startswith("hipGraph") and fa.static[0].shape[0] == 64
+    assert torch.equal(a._flat.data, b._flat.data)
+    for k, v in b.state_dict().items():
+        assert torch.equal(a.state_dict()[k], v), k
+
 def test_gp_penalty_zero_gradient_pixel(dev):
     """A pixel whose channel gradient is exactly zero: penalty (0-1)^2 and a ZERO subgradient (torch's
     backward of norm(2, dim=1)), not NaN."""
