@@ -24,6 +24,18 @@ def _ws(a):
     return ops.workspace(ops.lib().lgm_bn_workspace(rows, C), a.device)
 
 
+# While a training step is being captured into a HIP graph (lgm_hip/graph.py) every train-mode forward appends its
+# module here: a replay runs those forwards again without passing through Python, so the step object advances the
+# host-side batch counters of exactly these modules after each replay.
+CAPTURE_TRACE = None
+
+
+def _count_forward(module):
+    module._nbt_pending += 1
+    if CAPTURE_TRACE is not None:
+        CAPTURE_TRACE.append(module)
+
+
 class BatchNorm2d(nn.Module):
     """Parameters/buffers named as nn.BatchNorm2d (weight, bias, running_mean, running_var,
     num_batches_tracked).  Only train-mode (batch statistics) is on the hot path; eval mode uses
@@ -67,12 +79,12 @@ class BatchNorm2d(nn.Module):
             L.lgm_bn_stats_from_tiles(stats[0].data_ptr(), stats[1], C, ops.rows(a), self.eps, self.momentum,
                                       mean.data_ptr(), rstd.data_ptr(), self.running_mean.data_ptr(),
                                       self.running_var.data_ptr(), ops.stream())
-            self._nbt_pending += 1
+            _count_forward(self)
         elif training:
             L.lgm_bn_stats(a.data_ptr(), ops.pitch(a), ops.rows(a), C, self.eps, self.momentum, mean.data_ptr(),
                            rstd.data_ptr(), self.running_mean.data_ptr(), self.running_var.data_ptr(),
                            _ws(a).data_ptr(), ops.stream())
-            self._nbt_pending += 1
+            _count_forward(self)
         else:
             mean.copy_(self.running_mean)
             rstd.copy_((self.running_var + self.eps).rsqrt())

@@ -21,27 +21,103 @@ from typing import Optional
 import torch
 
 from . import ops
+from .lightning import multi_rank
+
+
+class _TrainingState:
+    """Everything a warm-up / capture run of a training step may advance and a run that never tried to capture
+    would not have: parameters and buffers (EMA codebooks, running statistics), the device random stream, the
+    host-side BatchNorm batch counters and what the module logged.  ``restore()`` is called from a ``finally``: a
+    capture that FAILS leaves the same state behind as one that succeeds, so the eager fallback is identical to a
+    run that was eager from the start."""
+
+    def __init__(self, modules, device):
+        from .bn import BatchNorm2d
+        self.device = device
+        self.tensors = []
+        seen = set()
+        for m in modules:
+            for t in list(m.parameters()) + list(m.buffers()):
+                if id(t) not in seen:
+                    seen.add(id(t))
+                    self.tensors.append(t)
+        self.snap = [t.detach().clone() for t in self.tensors]
+        self.bns = [b for m in modules for b in m.modules() if isinstance(b, BatchNorm2d)]
+        self.nbt = [b._nbt_pending for b in self.bns]
+        self.logged = [(m, dict(m.logged)) for m in modules if hasattr(m, "logged")]
+        self.rng = torch.cuda.get_rng_state(device)
+
+    def restore(self):
+        with torch.no_grad():
+            for t, s in zip(self.tensors, self.snap):
+                t.copy_(s)
+        for b, n in zip(self.bns, self.nbt):
+            b._nbt_pending = n
+        for m, lg in self.logged:
+            m.logged.clear()
+            m.logged.update(lg)
+        torch.cuda.set_rng_state(self.rng, self.device)
+
+
+def _capture(fn, warmup: int, pool=None):
+    """Eager warm-up of ``fn`` on a side stream (sizes workspaces, sets kernel attributes), then its capture into a
+    HIP graph.  Returns (graph, fn's return value inside the capture, BatchNorm modules whose train-mode forward
+    ran inside it — a replay does not pass through Python, so the step object advances their host-side batch
+    counters itself).  thread_local: only THIS thread is held to the capture rules — the RCCL watchdog thread of a
+    multi-GPU job keeps polling its events while the step is being captured."""
+    from . import bn
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            fn()
+    cur.wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    bn.CAPTURE_TRACE = []
+    try:
+        kw = dict(capture_error_mode="thread_local")
+        if pool is not None:
+            kw["pool"] = pool
+        with torch.cuda.graph(g, **kw):
+            out = fn()
+        trace = bn.CAPTURE_TRACE
+    finally:
+        bn.CAPTURE_TRACE = None
+    return g, out, trace
 
 
 class GraphedDDPMStep:
     """``inject=True`` (parity tests): ``t`` / ``noise`` are static INPUT buffers the caller fills before each
     step instead of being drawn inside graph 1.  Either way ``self.t`` / ``self.noise`` hold the values the
-    last replay used."""
+    last replay used.
+
+    One rank: two graphs (forward + backward phase 1 | backward phase 2).  With a gradient exchange (``sync``) the
+    backward is cut at every bucket boundary — four graphs — so that each bucket's all-reduce is issued the moment
+    its slice is final and runs beside everything that follows it:
+
+        g1a  t, noise, q_sample, UNet forward, loss, backward of final block + up path   -> buckets [ups], [final]
+        g1b  backward of the middle blocks                                               -> bucket  [mid]
+        g2a  backward of the down path + init conv                                       -> bucket  [init, downs]
+        g2b  backward of the time MLP / FiLM projections                                 -> bucket  [FiLM, time]
+    """
 
     def __init__(self, model, opt, x: torch.Tensor, sync=None, warmup: int = 3, inject: bool = False):
-        from models.generative.diffusion.ddpm import hip_loss_backward_phase1, hip_loss_forward
+        from models.generative.diffusion.ddpm import hip_loss_backward_phase1a, hip_loss_forward
         self.model, self.opt, self.sync = model, opt, sync
         self.gd = model.ema.online_model
         self.net = self.gd.model
         self.x = x                                   # static input buffer (copy new batches into it)
         self.one = torch.ones(1, device=x.device)
-        self._fwd, self._bwd1 = hip_loss_forward, hip_loss_backward_phase1
         self.net.grad_sync = None                    # collectives are issued by step(), never captured
         fp = self.net._flat
+        net = self.net
         self.t = torch.zeros(x.shape[0], dtype=torch.long, device=x.device) if inject else None
         self.noise = torch.zeros_like(x) if inject else None
+        split = sync is not None
 
-        def part1():
+        def part1a():
             gd = self.gd
             if inject:
                 t, noise = self.t, self.noise
@@ -49,41 +125,60 @@ class GraphedDDPMStep:
                 t = torch.randint(0, gd.num_timesteps, (x.shape[0],), device=x.device).long()
                 noise = torch.randn_like(self.x)
                 self.t, self.noise = t, noise
-            loss, ctx = self._fwd(gd, self.x, t, noise, gd.auto_normalize, True)
+            loss, ctx = hip_loss_forward(gd, self.x, t, noise, gd.auto_normalize, True)
             fp.zero_grad()
-            return loss, self._bwd1(ctx, self.one)
+            return loss, hip_loss_backward_phase1a(ctx, self.one)
+
+        def whole():
+            _, st = part1a()
+            net.backward_phase2(net.backward_phase1b(st))
 
         # warm-up and capture must not perturb the random stream: a run that captures at batch 0 and a run that
         # resumes from a checkpoint (and captures later) draw the same (t, noise) for the same seed
         rng_state = torch.cuda.get_rng_state(x.device)
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):                # eager warm-up (sizes workspaces, sets kernel attributes)
-            for _ in range(warmup):
-                _, st = part1()
-                self.net.backward_phase2(st)
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        self.g1 = torch.cuda.CUDAGraph()
-        # thread_local: only THIS thread is held to the capture rules -- the RCCL watchdog thread of a
-        # multi-GPU job keeps polling its events while the step is being captured
-        with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
-            self.loss, st = part1()
-        self.g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode="thread_local"):
-            self.net.backward_phase2(st)
-        self._st = st                                # keeps the captured buffers alive
-        torch.cuda.set_rng_state(rng_state, x.device)
+        try:
+            # (the eager warm-up runs the WHOLE step: the pieces share workspaces and kernel attributes)
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):            # eager warm-up (sizes workspaces, sets kernel attributes)
+                for _ in range(warmup):
+                    whole()
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            if split:
+                g1a, (self.loss, st), _ = _capture(part1a, 0)
+                pool = g1a.pool()
+                g1b, st, _ = _capture(lambda: net.backward_phase1b(st), 0, pool)
+                g2a, st, _ = _capture(lambda: net.backward_phase2a(st), 0, pool)
+                g2b, _, _ = _capture(lambda: net.backward_phase2b(st), 0, pool)
+                self.graphs = [g1a, g1b, g2a, g2b]
+            else:
+                def part1():
+                    loss, st1 = part1a()
+                    return loss, net.backward_phase1b(st1)
+                g1, (self.loss, st), _ = _capture(part1, 0)
+                g2, _, _ = _capture(lambda: net.backward_phase2(st), 0, g1.pool())
+                self.graphs = [g1, g2]
+            self._st = st                            # keeps the captured buffers alive
+        finally:
+            torch.cuda.set_rng_state(rng_state, x.device)
 
     def step(self, batch_idx: int = 0):
         net, sync = self.net, self.sync
-        self.g1.replay()
-        if sync is not None:
-            sync.ready(net._ups_start, net._flat.total)
-        self.g2.replay()
-        if sync is not None:
+        if sync is None:
+            for g in self.graphs:
+                g.replay()
+        else:
+            g1a, g1b, g2a, g2b = self.graphs
+            g1a.replay()
+            sync.ready(net._ups_start, net._mid_start)
+            sync.ready(net._final_start, net._flat.total)
+            g1b.replay()
+            sync.ready(net._mid_start, net._final_start)
+            g2a.replay()
             sync.ready(net._head_end, net._ups_start)
+            g2b.replay()
             sync.ready(0, net._head_end)
             sync.finish()
         self.opt.step()
@@ -145,7 +240,7 @@ class DDPMFastStep:
             self.opt.zero_grad()
             m.on_train_batch_end(None, batch, batch_idx)
             self.net.grad_sync = None
-        m.log("train_loss", loss, prog_bar=True, logger=True, sync_dist=False)
+        m.log("train_loss", loss, prog_bar=True, logger=True, sync_dist=multi_rank())
         return loss
 
 
@@ -171,6 +266,7 @@ class ModuleFastStep:
         self.static = None
         self.loss = None
         self._captured_logs = {}
+        self._bn_trace = []
         self.mode = "eager"
 
     # ---- one step from eager launches ---------------------------------------------------------------------------
@@ -191,36 +287,17 @@ class ModuleFastStep:
     def _capture(self, batch):
         m = self.model
         dev = self.flat.grad.device
+        state = None
         try:
             static = tuple(b.clone() if torch.is_tensor(b) else b for b in batch)
-            keep = [t for t in list(m.parameters()) + list(m.buffers())]
-            snap = [t.detach().clone() for t in keep]
-            logged = dict(getattr(m, "logged", {}))
-            rng_state = torch.cuda.get_rng_state(dev)
-            cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):            # eager warm-up: sizes workspaces, sets kernel attributes
-                for _ in range(2):
-                    self._fwd_bwd(static, 0)
-            cur.wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+            state = _TrainingState([m], dev)
             if hasattr(m, "logged"):
                 m.logged.clear()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                loss = self._fwd_bwd(static, 0)
+            g, loss, trace = _capture(lambda: self._fwd_bwd(static, 0), 2)
             # what training_step logged during capture lives in the graph's memory: every replay refreshes those
             # tensors in place, so they are what the module reports after each replayed step
             self._captured_logs = dict(getattr(m, "logged", {}))
-            with torch.no_grad():                    # undo what the warm-up did to the training state
-                for t, s in zip(keep, snap):
-                    t.copy_(s)
-            torch.cuda.set_rng_state(rng_state, dev)
-            if hasattr(m, "logged"):
-                m.logged.clear()
-                m.logged.update(logged)
-            self.graph, self.static, self.loss = g, static, loss
+            self.graph, self.static, self.loss, self._bn_trace = g, static, loss, trace
             self.mode = "hipGraph replay (1 graph/step)"
         except Exception as e:  # capture is an optimisation: fall back to eager launches
             import sys
@@ -228,6 +305,9 @@ class ModuleFastStep:
                   file=sys.stderr, flush=True)
             self.use_graph = False
             self.graph = None
+        finally:
+            if state is not None:                    # on BOTH paths: undo what warm-up / capture did to the training state
+                state.restore()
 
     def step(self, batch, batch_idx: int = 0):
         if self.use_graph and self.graph is None:
@@ -240,9 +320,99 @@ class ModuleFastStep:
                     s.copy_(b)
             g.replay()
             loss = self.loss
+            for b in self._bn_trace:                 # BatchNorm forwards inside the graph: host-side batch counters
+                b._nbt_pending += 1
             if hasattr(self.model, "logged"):
                 self.model.logged.update(self._captured_logs)
         else:
             loss = self._fwd_bwd(batch, batch_idx)
         self._finish(batch, batch_idx)
         return loss
+
+
+class WGANFastStep:
+    """Fast step for the WGAN / WGAN-GP module (manual optimisation, reference wgan.py:58-82): the critic update and
+    the generator update are captured ONCE each into a HIP graph — z ~ randn, G forward, (alpha ~ rand, three critic
+    forwards, the gradient-penalty double backward | critic forward + input-gradient sweep + G backward) — and
+    replayed; the n_critic : 1 schedule (keyed on ``global_step``), the gradient exchange (N > 1: ONE all-reduce of
+    the flat buffer the update wrote, 1/N folded into the fused optimizer), the optimizer kernel and logging stay on
+    the host.  Warm-up and capture leave the training state (BatchNorm running statistics, random stream) untouched;
+    eager fallback in the same process when capture is not possible or a batch has another shape."""
+
+    def __init__(self, model, opts, world: int = 1, use_graph: bool = True):
+        from .lightning import FlatGradSync
+        self.model, self.world = model, world
+        self.d_opt, self.g_opt = opts
+        for o in opts:
+            inner = getattr(o, "_opt", o)
+            if world > 1:
+                inner.grad_scale = 1.0 / world
+        if world > 1:
+            model._grads_prescaled = True
+        self.sync = {"d": FlatGradSync(model.D._flat), "g": FlatGradSync(model.G._flat)} if world > 1 else None
+        self.use_graph = use_graph
+        self.graphs = {}          # "d" / "g" -> (graph, static x, captured logs, BatchNorm trace)
+        self.mode = "eager"
+
+    # the two updates, without exchange / optimizer step (what a graph holds)
+    def _critic(self, x):
+        m = self.model
+        x_hat = m.G.random_sample(x.size(0))
+        ld = m._calculate_d_loss(x, x_hat)
+        m.D._flat.zero_grad()
+        ld["d_loss"].backward()
+        return ld
+
+    def _generator(self, x):
+        m = self.model
+        x_hat = m.G.random_sample(x.size(0))
+        ld = m._calculate_g_loss(x_hat)
+        m.G._flat.zero_grad()
+        ld["g_loss"].backward()
+        return ld
+
+    def _capture(self, key, x):
+        m = self.model
+        state = None
+        try:
+            static = x.clone()
+            fn = self._critic if key == "d" else self._generator
+            state = _TrainingState([m], x.device)
+            g, logs, trace = _capture(lambda: fn(static), 2)
+            self.graphs[key] = (g, static, dict(logs), trace)
+            self.mode = "hipGraph replay (critic graph / generator graph)"
+        except Exception as e:  # capture is an optimisation: fall back to eager launches
+            import sys
+            print(f"[lgm_hip] HIP-graph capture unavailable ({type(e).__name__}: {e}); eager launches",
+                  file=sys.stderr, flush=True)
+            self.use_graph = False
+            self.graphs.pop(key, None)
+        finally:
+            if state is not None:
+                state.restore()
+
+    def step(self, batch, batch_idx: int = 0):
+        m = self.model
+        x = batch[0]
+        critic = (m.global_step + 1) % (m.hparams.n_critic + 1) != 0
+        key = "d" if critic else "g"
+        if self.use_graph and key not in self.graphs and m.training:
+            self._capture(key, x)
+        ent = self.graphs.get(key)
+        if ent is not None and ent[1].shape == x.shape:
+            g, static, logs, trace = ent
+            static.copy_(x)
+            g.replay()
+            for b in trace:
+                b._nbt_pending += 1
+        else:
+            logs = self._critic(x) if critic else self._generator(x)
+        if self.sync is not None:
+            sy = self.sync[key]
+            sy.ready(0, sy.flat.total)
+            sy.finish()
+        opt = self.d_opt if critic else self.g_opt
+        opt.step()                                   # the counting proxy advances global_step (the schedule's clock)
+        opt.zero_grad()
+        m.log_dict(logs, prog_bar=True, logger=True, sync_dist=self.world > 1)
+        return logs

@@ -31,6 +31,12 @@ from torch import nn
 HAVE_PL = importlib.util.find_spec("pytorch_lightning") is not None     # informational (see above)
 
 
+def multi_rank() -> bool:
+    """What the reference passes as ``sync_dist`` (``torch.cuda.device_count() > 1``, i.e. "this is a DDP run"),
+    stated for this engine: more than one rank in the process group."""
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 class _AttrDict(dict):
     def __getattr__(self, k):
         try:
@@ -63,6 +69,8 @@ class MiniLightningModule(nn.Module):
         self._global_step = 0
         self.automatic_optimization = True
         self.logged: Dict[str, Any] = {}
+        self._sync_dist_names = set()
+        self._grads_prescaled = False       # True: the optimizers fold 1/world into their kernels (grad_scale)
         self._optimizers: List[Any] = []
         self.trainer = None
         self.logger = None
@@ -94,11 +102,36 @@ class MiniLightningModule(nn.Module):
             return b.device
         return torch.device("cpu")
 
-    def log(self, name, value, **kw):
+    def log(self, name, value, sync_dist=False, **kw):
+        """``sync_dist=True`` (reference: ``sync_dist=torch.cuda.device_count() > 1``, ddpm.py:1017-1023, wgan.py:77-82):
+        the value REPORTED for this name is the mean over ranks.  Lazy and batched: nothing is exchanged here; the
+        trainer calls ``synced_logs()`` once per logging interval, which averages all such scalars with ONE small
+        all-reduce (Lightning issues one per logged scalar per step)."""
         self.logged[name] = value
+        if sync_dist:
+            self._sync_dist_names.add(name)
 
-    def log_dict(self, d, **kw):
+    def log_dict(self, d, sync_dist=False, **kw):
         self.logged.update(d)
+        if sync_dist:
+            self._sync_dist_names.update(d.keys())
+
+    def synced_logs(self) -> Dict[str, float]:
+        """Host floats of everything logged so far; names logged with ``sync_dist=True`` are averaged over the
+        ranks with one all-reduce of the stacked scalars.  Collective when world > 1: every rank must call it at
+        the same step (the trainer does, on its logging interval)."""
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        vals = {k: v for k, v in self.logged.items() if torch.is_tensor(v) and v.numel() == 1 or isinstance(v, (int, float))}
+        names = sorted(n for n in self._sync_dist_names if n in vals)
+        out = {k: float(v) for k, v in vals.items() if k not in names}
+        if names:
+            dev = self.device
+            t = torch.stack([torch.as_tensor(vals[n], dtype=torch.float32).detach().reshape(()).to(dev) for n in names])
+            if world > 1:
+                dist.all_reduce(t)
+                t = t / world
+            out.update(zip(names, t.tolist()))
+        return out
 
     def optimizers(self):
         if len(self._optimizers) == 1:
@@ -117,7 +150,8 @@ class MiniLightningModule(nn.Module):
             for fp in flats:
                 if fp.written:
                     dist.all_reduce(fp.grad)
-                    fp.grad.div_(world)
+                    if not self._grads_prescaled:    # else the fused optimizer multiplies by 1/world (grad_scale)
+                        fp.grad.div_(world)
                     fp.written = False
             for p in self.parameters():
                 if getattr(p, "_lgm_flat", None) is None and p.grad is not None:
@@ -180,6 +214,67 @@ class FlatGradSync:
         return 1.0 / self.world
 
 
+class BufferSync:
+    """DDP's ``broadcast_buffers=True`` for this engine (reference: DDPStrategy, utils/lightning_utils.py:37-43 —
+    torch DDP re-broadcasts rank 0's module buffers at the start of every training forward, so BatchNorm running
+    statistics and the VQ-EMA buffers never drift between ranks).
+
+    The floating-point buffers the module's training writes (``module.ddp_buffers()`` when it offers one, else every
+    floating-point buffer) are re-pointed at views of ONE flat tensor, so the broadcast is one small collective per
+    step instead of one per buffer.  Buffers keep their names, shapes and values (state_dicts are unchanged)."""
+
+    def __init__(self, module: nn.Module, group=None):
+        self.module, self.group = module, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.flat: Optional[torch.Tensor] = None
+        self._owners = []
+        self.pack()
+
+    def _targets(self):
+        if hasattr(self.module, "ddp_buffers"):
+            wanted = {id(b) for b in self.module.ddp_buffers()}
+        else:
+            wanted = None
+        out = []
+        for mod in self.module.modules():
+            for name, b in mod._buffers.items():
+                if b is None or not b.dtype.is_floating_point:
+                    continue
+                if wanted is None or id(b) in wanted:
+                    out.append((mod, name, b))
+        return out
+
+    def pack(self):
+        tg = self._targets()
+        self._owners = []
+        if not tg:
+            self.flat = None
+            return
+        dev = tg[0][2].device
+        n = sum((b.numel() + 3) // 4 * 4 for _, _, b in tg)
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for mod, name, b in tg:
+            v = flat[off:off + b.numel()].view(b.shape)
+            v.copy_(b.detach().to(torch.float32))
+            mod._buffers[name] = v
+            self._owners.append((mod, name, v.data_ptr()))
+            off += (b.numel() + 3) // 4 * 4
+        self.flat = flat
+
+    def still_packed(self) -> bool:
+        return all(mod._buffers[name] is not None and mod._buffers[name].data_ptr() == p for mod, name, p in self._owners)
+
+    def broadcast(self):
+        """Rank 0's buffer block to every rank (no-op on one rank)."""
+        if self.world == 1 or self.flat is None:
+            return
+        if not self.still_packed():                  # module.to() / load with assign=True replaced the tensors
+            self.pack()
+        dist.broadcast(self.flat, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                       group=self.group)
+
+
 def save_checkpoint(model, optimizers, path: str, epoch: int = 0):
     """Write a checkpoint with the layout of a PyTorch-Lightning ``.ckpt`` (reference train.py:41,
     113-117,140 resumes from / writes these): ``state_dict`` with the reference's keys (incl.
@@ -187,11 +282,15 @@ def save_checkpoint(model, optimizers, path: str, epoch: int = 0):
     (= optimizer steps), ``optimizer_states`` in torch's own per-parameter format, hyper-parameters.
     Atomic: written to a temporary file in the same directory, then renamed over ``path``."""
     tmp = f"{path}.tmp.{os.getpid()}"
-    torch.save({"epoch": int(epoch), "global_step": int(model.global_step),
-                "pytorch-lightning_version": "2.0.0+lgm_hip", "state_dict": model.state_dict(),
-                "loops": {}, "callbacks": {}, "optimizer_states": [o.state_dict() for o in optimizers],
-                "lr_schedulers": [], "hparams_name": "kwargs", "hyper_parameters": dict(model.hparams)}, tmp)
-    os.replace(tmp, path)
+    try:
+        torch.save({"epoch": int(epoch), "global_step": int(model.global_step),
+                    "pytorch-lightning_version": "2.0.0+lgm_hip", "state_dict": model.state_dict(),
+                    "loops": {}, "callbacks": {}, "optimizer_states": [o.state_dict() for o in optimizers],
+                    "lr_schedulers": [], "hparams_name": "kwargs", "hyper_parameters": dict(model.hparams)}, tmp)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):                      # a failed write leaves nothing behind
+            os.remove(tmp)
 
 
 class MiniTrainer:
@@ -223,7 +322,8 @@ class MiniTrainer:
             return
         for fp in _flat_grads_of(module):
             dist.all_reduce(fp.grad)
-            fp.grad.div_(self.world)
+            if not getattr(module, "_grads_prescaled", False):   # else 1/world is folded into the fused optimizer
+                fp.grad.div_(self.world)
         # parameters that are not flat-bound (CPU plumbing models)
         for p in module.parameters():
             if getattr(p, "_lgm_flat", None) is None and p.grad is not None:
@@ -297,14 +397,22 @@ class MiniTrainer:
             for o, osd in zip(opts, ckpt.get("optimizer_states", [])):
                 o.load_state_dict(osd)
         model._optimizers = [_CountingOptimizer(o, model) for o in opts]
+        if self.world > 1 and opts and all(hasattr(o, "grad_scale") for o in opts):
+            # SUM all-reduce + 1/world folded into the fused optimizer kernels: no divide pass over the gradients
+            for o in opts:
+                o.grad_scale = 1.0 / self.world
+            model._grads_prescaled = True
+        # DDP side semantics (reference: DDPStrategy): rank 0's buffers re-broadcast before every training forward
+        self.buffer_sync = BufferSync(model) if self.world > 1 else None
         loader = train_dataloader if train_dataloader is not None else datamodule.train_dataloader()
         if val_dataloader is None and datamodule is not None and hasattr(datamodule, "val_dataloader"):
             val_dataloader = datamodule.val_dataloader()
         model.train()
         fast = None
-        if (self.fast_path and model.automatic_optimization and self.accumulate == 1 and device.type == "cuda"
-                and hasattr(model, "make_fast_step")):
-            fast = model.make_fast_step(model._optimizers[0], self.world)
+        if (self.fast_path and self.accumulate == 1 and device.type == "cuda" and hasattr(model, "make_fast_step")):
+            # automatic optimisation: one optimizer; manual optimisation (GANs): the module's optimizer list
+            fast = model.make_fast_step(model._optimizers[0] if model.automatic_optimization else model._optimizers,
+                                        self.world)
         self.fast = fast
         epoch = int(ckpt.get("epoch", 0)) if ckpt is not None else 0
         done = False
@@ -317,6 +425,8 @@ class MiniTrainer:
                 stopped_mid_epoch = False
                 for batch_idx, batch in enumerate(loader):
                     batch = tuple(b.to(device, non_blocking=True) if torch.is_tensor(b) else b for b in batch)
+                    if self.buffer_sync is not None:
+                        self.buffer_sync.broadcast()         # one flat broadcast of rank 0's buffer block
                     if fast is not None:
                         fast.step(batch, batch_idx)          # loss, backward, exchange, Adam, EMA hook
                     elif model.automatic_optimization:
@@ -335,9 +445,10 @@ class MiniTrainer:
                     else:
                         model.training_step(batch, batch_idx) if takes_idx else model.training_step(batch)
                         model.on_train_batch_end(None, batch, batch_idx)
-                    if self.rank == 0 and self.log_every and model.global_step % self.log_every == 0:
-                        msg = {k: (float(v) if torch.is_tensor(v) else v) for k, v in model.logged.items()}
-                        print(f"[step {model.global_step}] {msg} ({time.time() - t0:.1f}s)", flush=True)
+                    if self.log_every and model.global_step % self.log_every == 0:
+                        msg = model.synced_logs()            # collective (sync_dist scalars): every rank takes part
+                        if self.rank == 0:
+                            print(f"[step {model.global_step}] {msg} ({time.time() - t0:.1f}s)", flush=True)
                     if self.ckpt_every and model.global_step - last_saved_step >= self.ckpt_every:
                         self._save_last(model, epoch)
                         last_saved_step = model.global_step
@@ -348,7 +459,8 @@ class MiniTrainer:
                     self.allreduce_grads(model)
                     model._optimizers[0].step()
                     model._optimizers[0].zero_grad()
-                epoch += 1
+                if not stopped_mid_epoch:            # an epoch cut short by max_steps is not a completed epoch:
+                    epoch += 1                       # a resume from its checkpoint runs that epoch again
                 if 0 < self.max_epochs <= epoch:
                     done = True
                 val = None
@@ -361,10 +473,16 @@ class MiniTrainer:
                 self._save_best(model, epoch, val)
                 self._save_last(model, epoch)
                 last_saved_step = model.global_step
-        except BaseException:
-            # crash / Ctrl-C / SIGTERM-as-exception: keep the progress made so far
-            try:
-                self._save_last(model, epoch)
-            finally:
-                raise
+        except BaseException as e:
+            # Ctrl-C / SIGTERM-as-exception / a host-side error: keep the progress made so far.  NOT after a device
+            # error: state_dict() copies from the GPU, and after a fault or a hang that can block for ever instead of
+            # letting the process exit non-zero.
+            device_error = isinstance(e, (torch.AcceleratorError if hasattr(torch, "AcceleratorError") else ())) or \
+                any(s in f"{type(e).__name__}: {e}" for s in ("HIP error", "hipError", "CUDA error", "LgmError", "NCCL", "RCCL"))
+            if isinstance(e, (KeyboardInterrupt, SystemExit)) or not device_error:
+                try:
+                    self._save_last(model, epoch)
+                finally:
+                    raise
+            raise
         return model

@@ -108,17 +108,30 @@ def _ddim_coeffs(gd, t: int, t_next: int, eta: float):
     return head + (_f32(an.sqrt()), 0.0, _f32(c), _f32(sigma))
 
 
-_GRAPHS = {}      # (id(net), shape, with_noise) -> _GraphedChain
+# net -> {(shape, with_noise): _GraphedChain}.  Weak on the network: a sampled model that goes away takes its graphs
+# (and their memory pool) with it.  Every entry remembers which flat parameter storage its launches were captured
+# against (see _GraphedChain.matches): a graph bakes buffer ADDRESSES in, so after prepare_hip() rebuilt the flat
+# storage (model.to(), replaced parameter storage) the entry is dropped and the step recaptured.
+import weakref
+
+_GRAPHS = weakref.WeakKeyDictionary()
+_CAPTURE_RETRY_AFTER = 8      # a failed capture is retried after this many eager chains, not cached for ever
 
 
 class _GraphedChain:
     """One captured sampling step for a (network, batch shape); replayed once per step of any chain on it."""
 
     def __init__(self, gd, shape, with_noise: bool, max_steps: int = 4096):
-        self.net = gd.model
+        net = gd.model
+        self._net = weakref.ref(net)                 # the cache is keyed weakly on the network: no strong reference here
         B, C, H, W = shape
         dev = gd.betas.device
         self.shape, self.with_noise = shape, with_noise
+        fp = net._flat
+        # identity of everything whose address the captured launches carry: the flat object and its buffers
+        self._bound = (weakref.ref(fp), fp.data.data_ptr(),
+                       None if fp.data_uf is None else fp.data_uf.data_ptr(),
+                       None if fp.data_t is None else fp.data_t.data_ptr())
         Cp = _r4(C)
         self.x = torch.zeros((B, H, W, Cp), device=dev)
         self.t = torch.zeros(B, dtype=torch.long, device=dev)
@@ -133,14 +146,14 @@ class _GraphedChain:
         def one_step():
             st = ops.stream()
             L.lgm_sampler_time(self.ttable.data_ptr(), self.counter.data_ptr(), self.t.data_ptr(), B, st)
-            v, _ = self.net.forward_nhwc(self.x, self.t, False, refresh_weights=False)
+            v, _ = net.forward_nhwc(self.x, self.t, False, refresh_weights=False)
             nz = None
             if with_noise:
                 nz = self.noise if self.inject else torch.randn(shape, device=dev)
             L.lgm_sample_step_table(self.x.data_ptr(), v.data_ptr(), None if nz is None else nz.data_ptr(), None, B, C,
                                     H * W, Cp, self.table.data_ptr(), self.counter.data_ptr(), 1, 1, ops.stream())
 
-        self.net.refresh_derived_weights(False)
+        net.refresh_derived_weights(False)
         rng_state = torch.cuda.get_rng_state(dev)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -159,12 +172,20 @@ class _GraphedChain:
             self.graphs[inject] = g
         torch.cuda.set_rng_state(rng_state, dev)     # capture leaves the random stream where it was
 
+    def matches(self, net) -> bool:
+        """True while the network still owns the flat storage this step was captured against."""
+        fp = net._flat
+        ref, data, uf, dt = self._bound
+        return (fp is not None and ref() is fp and fp.still_bound() and fp.data.data_ptr() == data
+                and (None if fp.data_uf is None else fp.data_uf.data_ptr()) == uf
+                and (None if fp.data_t is None else fp.data_t.data_ptr()) == dt)
+
     def run(self, x0_nhwc, times, coeffs, noises):
         """times[i], coeffs[i] (8 floats) per step; noises: None (draw on device) or a list with one NCHW tensor or
         None per step.  Returns the final NHWC image (a view of the static buffer)."""
         n = len(times)
         assert n <= self.max_steps
-        self.net.refresh_derived_weights(False)      # the weights may have moved since the last chain (EMA updates)
+        self._net().refresh_derived_weights(False)   # the weights may have moved since the last chain (EMA updates)
         self.x.copy_(x0_nhwc)
         self.table[:n].copy_(torch.tensor(coeffs, dtype=torch.float32), non_blocking=False)
         self.ttable[:n].copy_(torch.tensor(times, dtype=torch.long))
@@ -185,19 +206,33 @@ def _graph_chain(gd, shape, with_noise: bool):
     """-> a _GraphedChain for (network, shape), or None (graph replay disabled / capture failed: eager launches)"""
     if os.environ.get("LGM_NO_SAMPLER_GRAPH", "0") == "1" or gd.betas.device.type != "cuda":
         return None
-    key = (id(gd.model), tuple(shape), bool(with_noise))
-    ent = _GRAPHS.get(key)
+    net = gd.model
+    net.prepare_hip(gd.betas.device)                 # may rebuild the flat storage (model.to(), new parameter storage)
+    per_net = _GRAPHS.get(net)
+    if per_net is None:
+        per_net = {}
+        _GRAPHS[net] = per_net
+    key = (tuple(shape), bool(with_noise))
+    ent = per_net.get(key)
+    if isinstance(ent, _GraphedChain) and not ent.matches(net):
+        ent = None                                   # captured against buffers the network no longer uses
+        per_net.pop(key, None)
+    if isinstance(ent, int):                         # a capture failed earlier: eager for a while, then try again
+        if ent > 0:
+            per_net[key] = ent - 1
+            return None
+        ent = None
     if ent is None:
         try:
-            gd.model.prepare_hip(gd.betas.device)
             ent = _GraphedChain(gd, tuple(shape), with_noise)
         except Exception as e:  # capture is an optimisation
             import sys
             print(f"[lgm_hip] sampler graph capture unavailable ({type(e).__name__}: {e}); eager launches",
                   file=sys.stderr, flush=True)
-            ent = False
-        _GRAPHS[key] = ent
-    return ent or None
+            per_net[key] = _CAPTURE_RETRY_AFTER
+            return None
+        per_net[key] = ent
+    return ent
 
 
 def p_sample_step(chain: _Chain, t: int, noise: Optional[torch.Tensor]):

@@ -19,7 +19,7 @@ from torch import nn
 
 from lgm_hip import ops
 from lgm_hip.flat import FlatParams, _r4
-from lgm_hip.lightning import LightningModule
+from lgm_hip.lightning import LightningModule, multi_rank
 from lgm_hip.nn import Conv2d, GradCtx, GroupNorm, Linear, RMSNorm, param_kind
 from lgm_hip.optim import EMA, FusedAdam
 
@@ -319,6 +319,12 @@ class Unet(nn.Module):
         self._head_end = slots[rest[0][0]].offset
         rest_names = [n for n, _, _ in rest]
         self._ups_start = min(slots[n].offset for n in rest_names if n.startswith("ups."))
+        self._mid_start = min(slots[n].offset for n in rest_names if n.startswith("mid_"))
+        self._final_start = min(slots[n].offset for n in rest_names if n.startswith("final_"))
+        assert self._ups_start < self._mid_start < self._final_start
+        assert all(self._ups_start <= slots[n].offset < self._mid_start for n in rest_names if n.startswith("ups."))
+        assert all(self._mid_start <= slots[n].offset < self._final_start for n in rest_names if n.startswith("mid_"))
+        assert all(slots[n].offset >= self._final_start for n in rest_names if n.startswith("final_"))
         assert all(slots[n].offset >= self._ups_start for n in rest_names
                    if n.startswith(("ups.", "mid_", "final_")))
         assert all(self._head_end <= slots[n].offset < self._ups_start for n in rest_names
@@ -470,7 +476,13 @@ class Unet(nn.Module):
 
     def backward_phase1(self, tape_all, gout):
         """final conv -> final block -> up path -> middle.  After it the gradient slice
-        [_ups_start, total) of the flat buffer is final (first exchange bucket)."""
+        [_ups_start, total) of the flat buffer is final (first exchange buckets)."""
+        return self.backward_phase1b(self.backward_phase1a(tape_all, gout))
+
+    def backward_phase1a(self, tape_all, gout):
+        """final conv -> final block -> up path.  After it the slices [_ups_start, _mid_start) and
+        [_final_start, total) of the flat gradient buffer are final: 18.6 M of the 35.7 M parameters, whose exchange
+        overlaps everything that follows."""
         time_saved, tape, sm1, sm2, sm3, ups_tape, sf, fin, x_in, cat_shapes = tape_all
         fp = self._flat
         gc = GradCtx(fp, defer=True)     # weight-gradient slabs: one batched reduce per exchange bucket
@@ -509,6 +521,18 @@ class Unet(nn.Module):
             b1.bwd(gc, s1, _chan(gcat2, 0, co), gsl[k], gcat1, False); k -= 1
             gcats[s] = (gcat1, gcat2)
             g_next = _chan(gcat1, 0, co)
+        gc.flush()
+        sync = getattr(self, "grad_sync", None)
+        if sync is not None:
+            sync.ready(self._ups_start, self._mid_start)
+            sync.ready(self._final_start, fp.total)
+        return dict(gc=gc, tape=tape, time_saved=time_saved, gss_all=gss_all, gsl=gsl, k=k, gcats=gcats,
+                    gcatF=gcatF, g_next=g_next, x_in=x_in, mid=(sm1, sm2, sm3))
+
+    def backward_phase1b(self, st):
+        """middle blocks.  After it [_mid_start, _final_start) is final (10.2 M parameters)."""
+        gc, gsl, k, g_next, x_in = (st[key] for key in ("gc", "gsl", "k", "g_next", "x_in"))
+        sm1, sm2, sm3 = st["mid"]
         gm2 = ops.new(sm3[0].shape, x_in)
         self.mid_block2.bwd(gc, sm3, g_next, gsl[k], gm2, False); k -= 1
         gm1 = ops.new(gm2.shape, x_in)
@@ -520,15 +544,19 @@ class Unet(nn.Module):
         gc.flush()
         sync = getattr(self, "grad_sync", None)
         if sync is not None:
-            sync.ready(self._ups_start, fp.total)
-        return dict(gc=gc, tape=tape, time_saved=time_saved, gss_all=gss_all, gsl=gsl, k=k, gcats=gcats,
-                    gcatF=gcatF, gcur=gcur, x_in=x_in)
+            sync.ready(self._mid_start, self._final_start)
+        st = dict(st)
+        st.update(k=k, gcur=gcur)
+        return st
 
     def backward_phase2(self, st):
         """down path -> init conv -> time embedding / FiLM projections."""
+        self.backward_phase2b(self.backward_phase2a(st))
+
+    def backward_phase2a(self, st):
+        """down path -> init conv.  After it [_head_end, _ups_start) is final."""
         gc, tape, gsl, k, gcats, gcatF, gcur, x_in = (st[key] for key in
                                                       ("gc", "tape", "gsl", "k", "gcats", "gcatF", "gcur", "x_in"))
-        fp = self._flat
         dim = self.dim
         n = len(self.in_out)
         sync = getattr(self, "grad_sync", None)
@@ -560,11 +588,17 @@ class Unet(nn.Module):
         gc.flush()
         if sync is not None:
             sync.ready(self._head_end, self._ups_start)
+        return st
+
+    def backward_phase2b(self, st):
+        """time embedding / FiLM projections.  After it [0, _head_end) is final."""
+        gc = st["gc"]
+        sync = getattr(self, "grad_sync", None)
         self._time_bwd(gc, st["time_saved"], st["gss_all"])
         gc.flush()
         if sync is not None:
             sync.ready(0, self._head_end)
-        fp.bind_grad_views()
+        self._flat.bind_grad_views()
 
     def forward(self, x: torch.Tensor, time: torch.Tensor, x_self_cond=None) -> torch.Tensor:
         """NCHW in / NCHW out, like the reference Unet.forward (:428-471)."""
@@ -734,6 +768,11 @@ def hip_loss_forward(gd: "GaussianDiffusion", img, t, noise, normalize: bool, sa
 
 def hip_loss_backward_phase1(ctx, gl):
     """Loss gradient + first half of the UNet backward.  ``gl``: device scalar [1] = dL/dloss."""
+    return ctx[0].model.backward_phase1b(hip_loss_backward_phase1a(ctx, gl))
+
+
+def hip_loss_backward_phase1a(ctx, gl):
+    """Loss gradient + backward of the final block and the up path (see Unet.backward_phase1a)."""
     gd, tape, out, target, t, (B, C, H, W) = ctx[:6]
     if tape is None:
         raise RuntimeError("p_losses forward ran without saving activations")
@@ -742,7 +781,7 @@ def hip_loss_backward_phase1(ctx, gl):
     ops.lib().lgm_weighted_mse_bwd(out.data_ptr(), target.data_ptr(), Cp, t.data_ptr(),
                                    gd.loss_weight.data_ptr(), gl.data_ptr(), B, C, H * W, Cp,
                                    gout.data_ptr(), ops.stream())
-    return gd.model.backward_phase1(tape, gout)
+    return gd.model.backward_phase1a(tape, gout)
 
 
 class _PLossFn(torch.autograd.Function):
@@ -784,12 +823,17 @@ class DDPM(LightningModule):
         self.ema.online_model.model.prepare_hip(device)
         self.ema.ema_model.model.prepare_hip(device)
 
+    def ddp_buffers(self):
+        """Buffers training writes (re-broadcast from rank 0 before every forward, lgm_hip.lightning.BufferSync): none —
+        the 13 schedule tables are constants and the EMA shadow is updated identically on every rank."""
+        return []
+
     def _common_step(self, batch, mode: str):
         assert mode in ["train", "val", "test"], f"Invalid mode: {mode}"
         data, _ = batch
         model = self.ema.model if self.training else self.ema.ema_model
         loss = model(data)
-        self.log(f"{mode}_loss", loss, prog_bar=True, logger=True, sync_dist=False)
+        self.log(f"{mode}_loss", loss, prog_bar=True, logger=True, sync_dist=multi_rank())
         if self.sample_every and self.global_step % self.sample_every == 0 and _is_master():
             self._log_sample()
         return loss

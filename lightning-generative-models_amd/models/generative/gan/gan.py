@@ -10,7 +10,7 @@ from typing import List
 
 import torch
 
-from lgm_hip.lightning import LightningModule
+from lgm_hip.lightning import LightningModule, multi_rank
 from lgm_hip.optim import FusedAdam
 
 
@@ -49,7 +49,7 @@ class GAN(LightningModule):
             self.manual_backward(loss_dict["g_loss"])
             g_optim.step()
         loss_dict = {f"{mode}_{k}": v for k, v in loss_dict.items()}
-        self.log_dict(loss_dict, prog_bar=True, logger=True, sync_dist=False)
+        self.log_dict(loss_dict, prog_bar=True, logger=True, sync_dist=multi_rank())
         return x, x_hat, loss_dict
 
     def training_step(self, batch):

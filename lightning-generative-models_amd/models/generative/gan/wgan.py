@@ -14,6 +14,7 @@ from typing import List
 import torch
 
 from lgm_hip import ops
+from lgm_hip.lightning import multi_rank
 from lgm_hip.nn import GradCtx
 from lgm_hip.optim import FusedAdam, FusedRMSprop
 from models.generative.gan.dcgan import DCGAN, _to_nhwc
@@ -49,7 +50,14 @@ class WGAN(DCGAN):
             g_optim.zero_grad(set_to_none=True)
             self.manual_backward(loss_dict["g_loss"])
             g_optim.step()
-        self.log_dict(loss_dict, prog_bar=True, logger=True, sync_dist=False)
+        self.log_dict(loss_dict, prog_bar=True, logger=True, sync_dist=multi_rank())
+
+    def make_fast_step(self, opts, world: int = 1, use_graph: bool = True):
+        """The step object ``MiniTrainer.fit`` drives instead of ``training_step``: the critic update and the generator
+        update replayed from one HIP graph each, schedule / exchange / optimizer kernel on the host (what bench.py
+        times for this workload)."""
+        from lgm_hip.graph import WGANFastStep
+        return WGANFastStep(self, opts, world, use_graph)
 
     def _calculate_d_loss(self, x, x_hat, alpha=None):
         """reference :84-110.  ``alpha`` may be injected (parity tests); default U[0,1) per sample."""

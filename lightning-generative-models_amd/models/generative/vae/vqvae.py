@@ -17,7 +17,7 @@ from torch import nn
 
 from lgm_hip import ops
 from lgm_hip.flat import FlatParams, _r4
-from lgm_hip.lightning import LightningModule
+from lgm_hip.lightning import LightningModule, multi_rank
 from lgm_hip.nn import Conv2d, ConvTranspose2d, GradCtx, param_kind
 from lgm_hip.optim import FusedAdam
 
@@ -298,7 +298,7 @@ class VQVAE(LightningModule):
         loss, recon, vq, ppl = _VQVAEStepFn.apply(self._anchor(x.device), self, x, float(w["recon_loss"]),
                                                   float(w["vq_loss"]))
         self.log_dict({f"{split}_loss": loss, f"{split}_recon_loss": recon, f"{split}_vq_loss": vq,
-                       f"{split}_perplexity": ppl}, prog_bar=True, logger=True, sync_dist=False)
+                       f"{split}_perplexity": ppl}, prog_bar=True, logger=True, sync_dist=multi_rank())
         return loss
 
     def training_step(self, batch, batch_idx):

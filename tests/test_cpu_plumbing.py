@@ -197,3 +197,114 @@ def test_data_parallel_gloo_world2(tmp_path):
     assert sorted(rk for rk, _, _ in recs) == ["0", "1"], r.stdout
     for rk, err, ok in recs:
         assert float(err) < 1e-6 and ok == "True", (rk, err, ok)
+
+
+_WORKER_SEMANTICS = r'''
+import os, sys, torch, torch.distributed as dist
+from torch import nn
+sys.path.insert(0, sys.argv[1])
+from lgm_hip.lightning import BufferSync, MiniLightningModule, MiniTrainer, multi_rank
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+
+class Net(MiniLightningModule):
+    """two BatchNorm layers (per-rank running statistics, the DCGAN situation) + one constant buffer"""
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(4, 4)
+        self.bn1, self.bn2 = nn.BatchNorm1d(4), nn.BatchNorm1d(4)
+        self.register_buffer("table", torch.arange(5, dtype=torch.float32))
+    def training_step(self, batch, batch_idx):
+        x, = batch
+        loss = self.bn2(self.lin(self.bn1(x))).square().mean()
+        self.log("train_loss", loss, sync_dist=multi_rank())
+        self.log("rank_plain", torch.tensor(float(rank)))            # not synced: stays per-rank
+        return loss
+    def configure_optimizers(self):
+        return torch.optim.SGD(self.parameters(), lr=0.1)
+
+torch.manual_seed(0)
+m = Net()
+# --- C2: buffers of rank 0 re-broadcast before every training forward, as ONE flat tensor ------------------------
+bs = BufferSync(m)
+assert bs.flat is not None and bs.still_packed()
+names = dict(m.named_buffers())
+lo = bs.flat.data_ptr()
+assert all(lo <= b.data_ptr() < lo + 4 * bs.flat.numel() for k, b in names.items() if b.dtype.is_floating_point)   # views of ONE block
+sd_keys = sorted(m.state_dict().keys())
+m.bn1.running_mean.fill_(float(rank + 1)); m.bn2.running_var.fill_(10.0 * (rank + 1))
+bs.broadcast()
+c2 = bool(torch.all(m.bn1.running_mean == 1.0)) and bool(torch.all(m.bn2.running_var == 10.0))
+c2 = c2 and sorted(m.state_dict().keys()) == sd_keys and torch.equal(m.table, torch.arange(5.0))
+# --- through the trainer: ranks see different data, running statistics still agree after fit -------------------------
+g = torch.Generator().manual_seed(100 + rank)
+data = [(torch.randn(8, 4, generator=g) * (rank + 1),) for _ in range(6)]
+tr = MiniTrainer(max_epochs=1, log_every=3, device="cpu")
+tr.fit(m, train_dataloader=data)
+stat = torch.cat([m.bn1.running_mean, m.bn1.running_var, m.bn2.running_mean, m.bn2.running_var])
+gathered = [torch.zeros_like(stat) for _ in range(world)]
+dist.all_gather(gathered, stat)
+# rank r != 0 holds: rank 0's statistics before the last forward, updated with its OWN last batch (DDP semantics);
+# one more broadcast makes them identical
+tr.buffer_sync.broadcast()
+stat2 = torch.cat([m.bn1.running_mean, m.bn1.running_var, m.bn2.running_mean, m.bn2.running_var])
+g2 = [torch.zeros_like(stat2) for _ in range(world)]
+dist.all_gather(g2, stat2)
+c2 = c2 and all(torch.equal(t, g2[0]) for t in g2) and torch.equal(g2[0], gathered[0])
+# parameters identical on every rank (gradient averaging), i.e. the exchange ran
+pv = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+gp = [torch.zeros_like(pv) for _ in range(world)]
+dist.all_gather(gp, pv)
+c1 = all(torch.allclose(t, gp[0], atol=0, rtol=0) for t in gp)
+# --- C3: sync_dist scalars = mean over ranks, ONE collective per interval -------------------------------------------
+m.logged.clear()
+m.log("a", torch.tensor(float(rank)), sync_dist=True)
+m.log_dict({"b": torch.tensor(2.0 * rank), "c": 7.0}, sync_dist=True)
+m.log("mine", torch.tensor(100.0 + rank))
+calls = []
+orig = dist.all_reduce
+def counting(*a, **k):
+    calls.append(1)
+    return orig(*a, **k)
+dist.all_reduce = counting
+out = m.synced_logs()
+dist.all_reduce = orig
+mean_r = sum(range(world)) / world
+c3 = (abs(out["a"] - mean_r) < 1e-6 and abs(out["b"] - 2 * mean_r) < 1e-6 and out["c"] == 7.0
+      and out["mine"] == 100.0 + rank and len(calls) == 1)
+print(f"RANK{rank} c1={c1} c2={c2} c3={c3}", flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_ddp_side_semantics_gloo_world2(tmp_path):
+    """SURVEY §2.1 C2 / C3 (reference DDPStrategy, utils/lightning_utils.py:37-43; sync_dist ddpm.py:1017-1023):
+    rank 0's buffers are re-broadcast before every training forward as one flat block; scalars logged with
+    sync_dist=True are reported as the mean over ranks from one batched all-reduce per logging interval."""
+    script = tmp_path / "worker_sem.py"
+    script.write_text(_WORKER_SEMANTICS)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script), PKG],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import re
+    recs = re.findall(r"RANK(\d) c1=(True|False) c2=(True|False) c3=(True|False)", r.stdout)
+    assert sorted(rk for rk, *_ in recs) == ["0", "1"], r.stdout
+    for rec in recs:
+        assert rec[1:] == ("True", "True", "True"), rec
+
+
+def test_max_steps_mid_epoch_is_not_a_completed_epoch(tmp_path):
+    """A run stopped by max_steps inside an epoch records that epoch as NOT completed: a resume from its last.ckpt
+    runs the epoch again instead of skipping the rest of it (and max_epochs accounting stays right)."""
+    from lgm_hip.lightning import MiniTrainer
+    from models.generative.vae.vae import VAE
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1)
+    data = [(torch.rand(4, 1, 8, 8, generator=g) * 2 - 1, torch.zeros(4, dtype=torch.long)) for _ in range(5)]
+    m = VAE(img_channels=1, img_size=8, latent_dim=4)
+    MiniTrainer(max_steps=7, default_root_dir=str(tmp_path), log_every=0, device="cpu").fit(m, train_dataloader=data)
+    sd = torch.load(os.path.join(str(tmp_path), "last.ckpt"), map_location="cpu")
+    assert sd["global_step"] == 7 and sd["epoch"] == 1        # epoch 0 complete (5 steps), epoch 1 cut after 2
+    assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
