@@ -1,24 +1,29 @@
 """bench.py — BASELINE.json metric: training images/sec, DDPM UNet 32x32, global batch 128.
 
-    python bench.py --gpus N --steps K --warmup W [--workload ddpm32|ddpm64|wgan_gp64|vqvae]
+    python bench.py --gpus N --steps K --warmup W [--workload ddpm32|ddpm64|wgan_gp64|vqvae] [--only]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = the full optimiser step of the reference loop on a synthetic batch already
 resident in HBM.  Default workload (the headline, BASELINE config 2): DDPM.training_step (t ~ randint,
 noise ~ randn on device, q_sample, UNet fwd, weighted MSE) -> hand-written HIP backward -> gradient all-reduce
-over RCCL when N > 1 -> fused Adam -> EMA update (every 10th step), replayed as two HIP graphs.  Strong
+over RCCL when N > 1 -> fused Adam -> EMA update (every 10th step), replayed as HIP graphs.  Strong
 scaling: the global batch stays 128 (reference DataModule divides the config batch by the GPU count).
-The other workloads are BASELINE's secondary configs measured the same way (one GPU):
-  ddpm64     config 5's network: DDPM UNet 64x64, B = 64 per GPU
-  wgan_gp64  config 3: WGAN-GP DCGAN G/D 64x64, B = 128, n_critic = 5 (one training_step = one D or G update)
-  vqvae      config 4: VQ-VAE 32x32, K = 512, B = 256 (--vq-ema for the EMA codebook)
 
-Rank 0 prints ONE JSON line with two extra objects:
-  "roofline"      the dominant SINGLE kernel of the convolution family (name as rocprofv3 prints it), timed live
-                  with HIP events on the launch stream in one extra instrumented step after the timed region:
-                  achieved = algorithmic FLOPs (2 B Ho Wo Cout KH KW Cin per launch) / event time, peak = fp32 MFMA
-                  157.3 TFLOP/s.  For the Winograd kernels the MFMA pipe executes 2.25x fewer FLOPs than the
-                  algorithmic count, so frac can exceed 1; mfma_executed_frac is the pipe's own utilisation.
+Rank 0 prints ONE JSON line.  Its top level is the headline; on one GPU (and without --only) the same line carries
+  "secondary"       BASELINE's other configs measured the same way right after the headline leg, each with its own
+                    "roofline" and "cpu_baseline":
+                      ddpm64     config 5's network: DDPM UNet 64x64, B = 64 per GPU
+                      wgan_gp64  config 3: WGAN-GP DCGAN G/D 64x64, B = 128, n_critic = 5 (one training_step = one D or G update)
+                      vqvae / vqvae_ema   config 4: VQ-VAE 32x32, K = 512, B = 256 (plain / EMA codebook)
+  "per_rank_proxy"  ms per step of the headline workload at the per-rank batches of 2 / 4 / 8 GPUs (64 / 32 / 16
+                    images) on this one GPU: what a rank computes between its gradient exchanges under strong scaling.
+Objects of every workload:
+  "roofline"      the dominant SINGLE kernel of the convolution family (name with template arguments, as rocprofv3
+                  prints it), timed live with HIP events on the launch stream in one extra instrumented step after the
+                  timed region.  frac = EXECUTED MFMA FLOPs / event time / 157.3 TFLOP/s (<= 1 by construction): a
+                  Winograd F(2x2,3x3) kernel executes algorithmic / 2.25 FLOPs; algorithmic_tflops is the
+                  2 B Ho Wo Cout KH KW Cin count over the same time.  ceiling_img_per_s = the fp32 MFMA roof of the
+                  algorithm actually run (Winograd on the 3x3 layers), next to SURVEY.md's direct-convolution ceiling.
   "cpu_baseline"  the CPU oracle (kind "port"), same workload at a bounded batch, on this host's cores.
 """
 import argparse
@@ -27,7 +32,11 @@ import os
 import sys
 import time
 
-# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL otherwise fails in hipIpcGetMemHandle)
+# Multi-process GPU work on this pool's driver stack needs dmabuf IPC: the image exports HSA_ENABLE_IPC_MODE_LEGACY=0
+# (build-environment notes: "the host driver only supports dmabuf IPC, and without it RCCL / CUDA-tensor sharing
+# across processes fails with hipIpcGetMemHandle: invalid argument").  The environment's value always wins; the
+# default below only covers a shell that lost it, and main() prints the effective value and its source on stderr.
+_IPC_ENV_SOURCE = "environment" if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ else "bench.py default"
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,6 +49,28 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 WINO_FACTOR = 2.25              # direct 3x3 multiplies per Winograd F(2x2,3x3) multiply
+HBM_PEAK = 8.0e12               # bytes / s (MI355X_MICROARCH.md)
+
+
+def _conv_work(module, batch):
+    """MAC counter over the convolution modules of a network AFTER it ran at ``batch`` (their geometries are cached):
+    per layer, in registration order, (forward multiply-accumulates per image with the LOGICAL channel counts — no
+    padding lanes —, input + output bytes per image in fp32).  Returns (layers, n_params)."""
+    from lgm_hip.nn import Conv2d, ConvTranspose2d
+    layers = []
+    for m in module.modules():
+        if not isinstance(m, (Conv2d, ConvTranspose2d)):
+            continue
+        for g in m._geoms.values():
+            if g.B != batch:
+                continue
+            # the geometry's X side (H, W) is the convolution's input, and the LARGE map of a transposed convolution
+            mm = float(g.Ho) * g.Wo * m.cin * m.cout * g.KH * g.KW
+            xin, yout = ((g.H * g.W * m.cin, g.Ho * g.Wo * m.cout) if isinstance(m, Conv2d)
+                         else (g.Ho * g.Wo * m.cin, g.H * g.W * m.cout))
+            layers.append((mm, 4.0 * (xin + yout)))
+            break
+    return layers, sum(p.numel() for p in module.parameters())
 
 
 def _threads():
@@ -191,8 +222,9 @@ def setup_ddpm(args, dev, world, rank, img, global_batch):
 
     def eager_step(i):
         return eager.step((x, y), i)
-    flop_per_img = {32: 10.95e9, 64: 43.8e9}[img]     # forward x 3
-    info = dict(per_gpu=per_gpu, fast=fast, flop_per_img=flop_per_img, bytes_per_img=(69.6e6 if img == 32 else 278e6),
+    def work():     # forward x 3; bytes per image + (weights x 3, Adam 28 B/param, EMA / 10) per step
+        return {32: 10.95e9, 64: 43.8e9}[img], (69.6e6 if img == 32 else 278e6), 1.472e9, {}
+    info = dict(per_gpu=per_gpu, fast=fast, work=work, n_instr=1, model=model,
                 workload=f"configs/diffusion/{'ddpm' if img == 32 else 'ddpm_64'}.json UNet dim=64, 3x{img}x{img} synthetic "
                          "NCHW fp32, training_step+backward+Adam+EMA")
     return step, eager_step, info
@@ -201,35 +233,67 @@ def setup_ddpm(args, dev, world, rank, img, global_batch):
 def setup_wgan(args, dev):
     from lgm_hip.lightning import _CountingOptimizer
     from models.generative.gan.wgan import WGAN
+    B = 128
     m = WGAN(img_channels=3, img_size=64, latent_dim=100, lr=1e-4, b1=0.5, b2=0.999, weight_decay=1e-5, n_critic=5,
              grad_penalty=10, constraint_method="gp").to(dev)        # configs/gan/wgan_gp_celeba.json
     m.prepare_hip(dev)
     m.train()
     m._optimizers = [_CountingOptimizer(o, m) for o in m.configure_optimizers()[0]]
-    x = torch.rand(128, 3, 64, 64, device=dev) * 2 - 1
+    x = torch.rand(B, 3, 64, 64, device=dev) * 2 - 1
+    # what MiniTrainer.fit drives for a WGAN: critic graph / generator graph, schedule + Adam on the host
+    fast = m.make_fast_step(m._optimizers, 1, use_graph=not args.no_graph)
+    eager = m.make_fast_step(m._optimizers, 1, use_graph=False)
 
     def step(i):
-        m.training_step((x, None))
-        return m.logged.get("d_loss", m.logged.get("g_loss"))
-    info = dict(per_gpu=128, fast=None, flop_per_img=None, bytes_per_img=None,
+        ld = fast.step((x, None), i)
+        return ld.get("d_loss", ld.get("g_loss"))
+
+    def eager_step(i):
+        ld = eager.step((x, None), i)
+        return ld.get("d_loss", ld.get("g_loss"))
+
+    def work():
+        """Exact multiply-accumulate count of one training_step (reference wgan.py:58-156), from the layers' cached
+        geometries.  G, D = forward MACs per image; g_i / d_i per layer.
+          critic update    G fwd + 3 D fwd (real, fake, interpolates) + 2 x [D wgrad + D dgrad without layer 1]
+                           + first-order input gradient on the interpolates (D) + its double backward:
+                           sweep 1 = wgrad of every layer (D) + W * u of layers 1..4 (D - d_5);
+                           sweep 2 = dgrad + wgrad of layers 2..4, wgrad of layer 1
+          generator update G fwd + D fwd + D dgrad (all layers) + G wgrad + G dgrad without layer 1
+          one training_step = (5 critic + 1 generator) / 6"""
+        gl, gp_ = _conv_work(m.G, B)
+        dl, dp_ = _conv_work(m.D, B)
+        G, D = sum(a for a, _ in gl), sum(a for a, _ in dl)
+        d = [a for a, _ in dl]
+        critic = G + 3 * D + 2 * (2 * D - d[0]) + D + D + (D - d[-1]) + 2 * sum(d[1:-1]) + d[0]
+        gen = G + D + D + G + (G - gl[0][0])
+        flop = 2.0 * (5 * critic + gen) / 6
+        # bytes: every convolution-shaped pass reads its input and writes its output once; + weights per pass, Adam 28 B/param
+        gb, db = sum(b for _, b in gl), sum(b for _, b in dl)
+        critic_b = gb + 3 * db + 2 * 2 * db + db + 2 * db + 2 * db
+        gen_b = gb + db + db + 2 * gb
+        byts = (5 * critic_b + gen_b) / 6
+        per_step = (5 * (dp_ * (4 * 9 + 28) + gp_ * 4) + (gp_ * (4 * 3 + 28) + dp_ * 4 * 2)) / 6
+        return flop, byts, per_step, dict(G_fwd_gflop=round(2 * G / 1e9, 4), D_fwd_gflop=round(2 * D / 1e9, 4),
+                                          critic_update_gflop=round(2 * critic / 1e9, 4),
+                                          generator_update_gflop=round(2 * gen / 1e9, 4))
+    info = dict(per_gpu=B, fast=fast, work=work, n_instr=6,
                 workload="configs/gan/wgan_gp_celeba.json WGAN-GP DCGAN G/D, 3x64x64 synthetic, training_step "
                          "(n_critic = 5: one critic OR generator update incl. GP double backward) + fused Adam")
-    return step, step, info
+    return step, eager_step, info
 
 
-def setup_vqvae(args, dev):
+def setup_vqvae(args, dev, ema):
     from models.generative.vae.vqvae import VQVAE
-    ema = args.vq_ema
+    B = 256
     v = VQVAE(img_channels=3, img_size=32, embedding_dim=64, num_embeddings=512, hidden_dim=128, num_residual_layers=2,
               num_residual_hiddens=32, use_ema=ema, lr=1e-3, b1=0.9, b2=0.999,
               loss_weights={"recon_loss": 1, "vq_loss": 10 if ema else 1}).to(dev)      # configs/vae/vqvae[_ema].json
     v.prepare_hip(dev)
     v.train()
     opt = v.configure_optimizers()
-    xv = torch.rand(256, 3, 32, 32, device=dev) * 2 - 1
-
+    xv = torch.rand(B, 3, 32, 32, device=dev) * 2 - 1
     fast = v.make_fast_step(opt, 1, use_graph=not args.no_graph)    # what MiniTrainer.fit drives for a VQVAE
-
     eager = v.make_fast_step(opt, 1, use_graph=False)               # the roofline leg times individual launches
 
     def step(i):
@@ -237,10 +301,177 @@ def setup_vqvae(args, dev):
 
     def eager_step(i):
         return eager.step((xv, None), i)
-    info = dict(per_gpu=256, fast=fast, flop_per_img=None, bytes_per_img=None,
+
+    def work():
+        """Convolutions: forward + weight gradient + input gradient (not for the image-end layer of the encoder);
+        quantiser: 2 N K D for the nearest-code search (N = B * 16 latent vectors) and as much for the one-hot^T x
+        statistics (EMA) / codebook gradient."""
+        el, _ = _conv_work(v.encoder, B)
+        dl, _ = _conv_work(v.decoder, B)
+        macs = 3 * (sum(a for a, _ in el) + sum(a for a, _ in dl)) - el[0][0]
+        n_lat, K, D = 16, 512, 64
+        macs += 2 * n_lat * K * D
+        n_params = sum(p.numel() for p in v.parameters())
+        byts = 3 * (sum(b for _, b in el) + sum(b for _, b in dl)) + 2 * 4 * n_lat * D * 2
+        return 2.0 * macs, byts, n_params * (4 * 3 + 28.0), dict(
+            encoder_fwd_mflop=round(2 * sum(a for a, _ in el) / 1e6, 3), decoder_fwd_mflop=round(2 * sum(a for a, _ in dl) / 1e6, 3),
+            quantiser_mflop_per_step=round(2 * 2 * B * n_lat * K * D / 1e6, 1))
+    info = dict(per_gpu=B, fast=fast, work=work, n_instr=1,
                 workload=f"configs/vae/vqvae{'_ema' if ema else ''}.json VQ-VAE 3x32x32, K=512 D=64, "
                          "training_step+backward+Adam")
     return step, eager_step, info
+
+
+def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline=True, cpu=True):
+    """Warm-up, the timed region (barrier + synchronize on both sides, max over ranks), the instrumented roofline
+    step and the CPU baseline of ONE workload.  Returns the workload's JSON object (rank 0) or None."""
+    from lgm_hip import ops
+    torch.manual_seed(10)                         # reference train.py:20 seeds every rank identically
+    if wl in ("ddpm32", "ddpm64"):
+        img = 32 if wl == "ddpm32" else 64
+        # ddpm32: strong scaling of the global batch 128 (the metric); ddpm64: 64 images per GPU (config 5, weak)
+        gb = batch if batch is not None else (128 if wl == "ddpm32" else 64 * world)
+        step, eager_step, info = setup_ddpm(args, dev, world, rank, img, gb)
+        scaling = "strong" if wl == "ddpm32" else "weak"
+        metric = f"training images/sec (DDPM UNet {img}x{img}, bs={gb if wl == 'ddpm32' else '64/GPU'})"
+    else:
+        assert world == 1, f"--workload {wl} is a single-GPU measurement"
+        step, eager_step, info = (setup_wgan(args, dev) if wl == "wgan_gp64" else setup_vqvae(args, dev, wl == "vqvae_ema"))
+        gb, scaling = info["per_gpu"], "weak"
+        metric = ("training images/sec (WGAN-GP 64x64, bs=128)" if wl == "wgan_gp64"
+                  else f"training images/sec (VQ-VAE 32x32 K=512{' EMA' if wl == 'vqvae_ema' else ''}, bs=256)")
+    per_gpu = info["per_gpu"]
+
+    tw = time.perf_counter()
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] {wl}: warm-up done: {warmup} steps in {time.perf_counter() - tw:.2f}s", file=sys.stderr, flush=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item()) if loss is not None else float("nan")
+    ms = elapsed / steps * 1e3
+    value = gb * steps / elapsed
+    if rank == 0:
+        print(f"[bench] {wl}: timed region: {steps} steps in {elapsed:.3f}s ({value:.1f} img/s)", file=sys.stderr, flush=True)
+    launch = info["fast"].mode if info["fast"] is not None else "eager"
+    if not roofline:
+        return {"ms_per_step": round(ms, 3), "value": round(value, 2), "launch": launch, "steps": steps, "warmup": warmup}
+
+    # ---- roofline leg: one extra instrumented step (a whole 5 D : 1 G cycle for the WGAN), per-launch HIP events on
+    # the launch stream.  One un-instrumented eager pass first: the timed region replayed graphs, and the first launches
+    # issued from Python afterwards pay one-off costs (allocator growth, lazily sized workspaces) that are not the kernels'
+    n_instr = info["n_instr"]
+    for k in range(n_instr):
+        eager_step(warmup + steps + k)
+    torch.cuda.synchronize()
+    ops.TIMER = ops.KernelTimer()
+    for k in range(n_instr):
+        eager_step(warmup + steps + n_instr + k)
+    fam = ops.TIMER.summary(False)
+    kern = ops.TIMER.summary(True)
+    ops.TIMER = None
+    if rank != 0:
+        return None
+
+    def executed(name, flops):       # FLOPs the MFMA pipe executes for `flops` algorithmic ones
+        return flops / WINO_FACTOR if "wino_" in name else flops
+    name, d = max(((k, v) for k, v in kern.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
+    alg_tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    exe_tflops = executed(name, d["flops"]) / (d["ms"] * 1e-3) / 1e12
+    conv_ms = sum(v["ms"] for v in fam.values())
+    conv_fl = sum(v["flops"] for v in fam.values())
+    conv_exe = sum(executed(k, v["flops"]) for k, v in kern.items())
+    wino_alg = sum(v["flops"] for k, v in kern.items() if "wino_" in k)
+    # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the
+    # figure comes from the committed rocprofv3 --pmc summary of this same command (tools/pmc_kernels.py), if any
+    traffic, traffic_src = None, None
+    for cand in ("r03_pmc_traffic.json",):
+        pmc = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(pmc) and wl == "ddpm32" and gb == 128 and world == 1:
+            with open(pmc) as fh:
+                t = json.load(fh).get("kernels", {}).get(name)
+            if t:
+                traffic, traffic_src = t["traffic_bytes_per_launch"], f"profiles/{cand}"
+    flop_per_img, bytes_per_img, bytes_per_step, detail = info["work"]()
+    roof = {"bound": "mfma", "kernel": name, "achieved": round(exe_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(exe_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_tflops": round(alg_tflops, 2),
+            "executed_flops_per_launch": round(executed(name, d["flops"]) / d["launches"]),
+            "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
+            "launches_per_step": round(d["launches"] / n_instr, 2), "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": round(d.get("bytes", 0) / max(d["launches"], 1)) or None,
+            "note": ("achieved / frac count the FLOPs the MFMA pipe EXECUTES: a Winograd F(2x2,3x3) kernel executes "
+                     "algorithmic / 2.25; algorithmic_tflops is the direct-convolution count over the same time"),
+            "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                            "executed_tflops": round(executed(k, v["flops"]) / (v["ms"] * 1e-3) / 1e12, 2),
+                            "frac": round(executed(k, v["flops"]) / (v["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                        for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:10]},
+            "family": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                           "algorithmic_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fam.items()},
+            "conv_family_ms_per_step": round(conv_ms / n_instr, 3),
+            "conv_family_executed_frac": round(conv_exe / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "conv_family_algorithmic_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
+    # step level: algorithmic work (SURVEY.md §8(d) / the MAC counter) against both roofs, and the MFMA ceiling of the
+    # algorithm actually run (Winograd on the layers that took it in the instrumented step)
+    exe_per_img = flop_per_img - (wino_alg / n_instr / per_gpu) * (1.0 - 1.0 / WINO_FACTOR)
+    roof["flop_per_img"] = round(flop_per_img)
+    roof["executed_flop_per_img"] = round(exe_per_img)
+    roof["step_algorithmic_frac_of_peak"] = round(value * flop_per_img / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4)
+    roof["step_executed_frac_of_peak"] = round(value * exe_per_img / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4)
+    roof["ceiling_img_per_s"] = round(FP32_MFMA_PEAK_TFLOPS * 1e12 * world / exe_per_img, 1)
+    roof["ceiling_img_per_s_direct_conv"] = round(FP32_MFMA_PEAK_TFLOPS * 1e12 * world / flop_per_img, 1)
+    roof["hbm_frac_of_8TBps"] = round(value / world * (bytes_per_img + bytes_per_step / per_gpu) / HBM_PEAK, 4)
+    if detail:
+        roof["work"] = detail
+    conv_mode = "bf16x3 (LGM_CONV_MODE)" if ops.B3 else ("fp32 MFMA, Winograd F(2x2,3x3) for the 3x3 layers"
+                                                         if ops.WINO else "fp32 MFMA, direct")
+    line = {"metric": metric, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None,
+            "dtype": "f32" if not ops.B3 else "f32 (3x3 conv fwd/dgrad: opt-in bf16x3 split MFMA, fp32-level error)",
+            "data": "synthetic",
+            "config": {"workload": info["workload"], "global_batch": gb, "per_gpu_batch": per_gpu,
+                       "parallelism": f"dp{world}", "final_loss": round(final_loss, 5), "launch": launch,
+                       "conv_mode": conv_mode},
+            "roofline": roof}
+    if world == 1 and cpu and not args.no_cpu_baseline:
+        secs = args.cpu_seconds
+        if wl == "ddpm32":
+            line["cpu_baseline"] = cpu_baseline_ddpm(32, min_seconds=secs)
+        elif wl == "ddpm64":
+            line["cpu_baseline"] = cpu_baseline_ddpm(64, batch=8, min_seconds=secs)
+        elif wl == "wgan_gp64":
+            line["cpu_baseline"] = cpu_baseline_wgan(min_seconds=secs)
+        else:
+            line["cpu_baseline"] = cpu_baseline_vqvae(wl == "vqvae_ema", min_seconds=secs)
+    if world == 1 and args.torch_gpu_baseline and wl in ("ddpm32", "ddpm64"):
+        line["torch_gpu_baseline"] = torch_gpu_baseline(dev, 32 if wl == "ddpm32" else 64, 64, gb)
+    return line
+
+
+def _release():
+    """between workloads: drop what the finished one allocated (models, graph pools, caches keyed by its buffers)"""
+    import gc
+    from lgm_hip import ops
+    gc.collect()
+    ops.forget_dead_flats()
+    torch.cuda.empty_cache()
 
 
 def main():
@@ -248,14 +479,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="ddpm32", choices=["ddpm32", "ddpm64", "wgan_gp64", "vqvae"])
-    ap.add_argument("--vq-ema", action="store_true", help="vqvae workload: EMA codebook (configs/vae/vqvae_ema.json)")
+    ap.add_argument("--workload", default="ddpm32", choices=["ddpm32", "ddpm64", "wgan_gp64", "vqvae", "vqvae_ema"])
+    ap.add_argument("--vq-ema", action="store_true", help="vqvae workload: EMA codebook (= --workload vqvae_ema)")
+    ap.add_argument("--only", action="store_true", help="only the named workload: no secondary configs, no per-rank proxy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="timed CPU work per cpu_baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python (no HIP-graph replay)")
     ap.add_argument("--batch", type=int, default=None, help="global batch (default: the workload's config value)")
     ap.add_argument("--torch-gpu-baseline", action="store_true",
                     help="also time the oracle's plain torch ops on the GPU (PyTorch-ROCm eager) as a comparison point")
     args = ap.parse_args()
+    if args.vq_ema and args.workload == "vqvae":
+        args.workload = "vqvae_ema"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -267,134 +502,60 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if rank == 0:
+        print(f"[bench] world={world} backend={backend} HSA_ENABLE_IPC_MODE_LEGACY="
+              f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '<unset>')} ({_IPC_ENV_SOURCE})", file=sys.stderr, flush=True)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
-        else:
-            dist.init_process_group(backend)
-    from lgm_hip import ops
-
-    torch.manual_seed(10)                         # reference train.py:20 seeds every rank identically
-    wl = args.workload
-    if wl in ("ddpm32", "ddpm64"):
-        img = 32 if wl == "ddpm32" else 64
-        # ddpm32: strong scaling of the global batch 128 (the metric); ddpm64: 64 images per GPU (config 5, weak)
-        gb = args.batch if args.batch is not None else (128 if wl == "ddpm32" else 64 * world)
-        step, eager_step, info = setup_ddpm(args, dev, world, rank, img, gb)
-        scaling = "strong" if wl == "ddpm32" else "weak"
-        metric = f"training images/sec (DDPM UNet {img}x{img}, bs={gb if wl == 'ddpm32' else '64/GPU'})"
-    else:
-        assert world == 1, f"--workload {wl} is a single-GPU measurement"
-        step, eager_step, info = (setup_wgan if wl == "wgan_gp64" else setup_vqvae)(args, dev)
-        gb, scaling = info["per_gpu"], "weak"
-        metric = ("training images/sec (WGAN-GP 64x64, bs=128)" if wl == "wgan_gp64"
-                  else f"training images/sec (VQ-VAE 32x32 K=512{' EMA' if args.vq_ema else ''}, bs=256)")
-    per_gpu = info["per_gpu"]
-
-    tw = time.perf_counter()
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if rank == 0:
-        print(f"[bench] warm-up done: {args.warmup} steps in {time.perf_counter() - tw:.2f}s", file=sys.stderr, flush=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    final_loss = float(loss.item()) if loss is not None else float("nan")
-    if rank == 0:
-        print(f"[bench] timed region: {args.steps} steps in {elapsed:.3f}s ({gb * args.steps / elapsed:.1f} img/s)",
-              file=sys.stderr, flush=True)
-
-    # ---- roofline leg: one extra instrumented step, per-launch HIP events on the launch stream
-    n_instr = 6 if wl == "wgan_gp64" else 1          # WGAN: a whole 5 D : 1 G cycle
-    # one un-instrumented eager pass first: the timed region may have replayed graphs, and the first launches issued
-    # from Python afterwards pay one-off costs (allocator growth, lazily sized workspaces) that are not the kernels'
-    for k in range(n_instr):
-        eager_step(args.warmup + args.steps + k)
-    torch.cuda.synchronize()
-    ops.TIMER = ops.KernelTimer()
-    for k in range(n_instr):
-        eager_step(args.warmup + args.steps + n_instr + k)
-    fam = ops.TIMER.summary(False)
-    kern = ops.TIMER.summary(True)
-    ops.TIMER = None
-
-    if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = gb * args.steps / elapsed
-        name, d = max(((k, v) for k, v in kern.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        wino = "wino_" in name
-        conv_ms = sum(v["ms"] for v in fam.values())
-        conv_fl = sum(v["flops"] for v in fam.values())
-        # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process;
-        # the figure comes from the committed rocprofv3 --pmc summary of this same command when there is one
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(pmc) and wl == "ddpm32" and gb == 128 and world == 1:
-            with open(pmc) as fh:
-                t = json.load(fh).get("kernels", {}).get(name)
-            if t:
-                traffic, traffic_src = t["traffic_bytes_per_launch"], "profiles/r02_pmc_traffic.json"
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
-                "launches_per_step": round(d["launches"] / n_instr, 2), "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
-                "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": round(d.get("bytes", 0) / max(d["launches"], 1)) or None,
-                "note": ("Winograd F(2x2,3x3) in fp32: the MFMA pipe executes algorithmic/2.25 FLOPs, frac may exceed 1; "
-                         "mfma_executed_frac = frac / 2.25 is the pipe's own utilisation" if wino else
-                         "direct fp32 MFMA kernel"),
-                "mfma_executed_frac": round(achieved / (WINO_FACTOR if wino else 1.0) / FP32_MFMA_PEAK_TFLOPS, 4),
-                "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                            for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]},
-                "family": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fam.items()},
-                "conv_family_ms_per_step": round(conv_ms / n_instr, 3),
-                "conv_family_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
-        if info["flop_per_img"]:
-            roof["step_flop_frac_of_peak"] = round(value * info["flop_per_img"] / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4)
-            bytes_per_img = info["bytes_per_img"] + 1.472e9 / per_gpu
-            roof["hbm_frac_of_8TBps"] = round(value / world * bytes_per_img / 8.0e12, 4)
-        launch = "eager"
-        if info["fast"] is not None:
-            launch = info["fast"].mode
-        conv_mode = "bf16x3 (LGM_CONV_MODE)" if ops.B3 else ("fp32 MFMA, Winograd F(2x2,3x3) for the 3x3 layers"
-                                                             if ops.WINO else "fp32 MFMA, direct")
-        line = {"metric": metric, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling,
-                "vs_baseline": None,
-                "dtype": "f32" if not ops.B3 else "f32 (3x3 conv fwd/dgrad: opt-in bf16x3 split MFMA, fp32-level error)",
-                "data": "synthetic",
-                "config": {"workload": info["workload"], "global_batch": gb, "per_gpu_batch": per_gpu,
-                           "parallelism": f"dp{world}", "final_loss": round(final_loss, 5), "launch": launch,
-                           "conv_mode": conv_mode},
-                "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
-            if wl == "ddpm32":
-                line["cpu_baseline"] = cpu_baseline_ddpm(32)
-            elif wl == "ddpm64":
-                line["cpu_baseline"] = cpu_baseline_ddpm(64, batch=8)
-            elif wl == "wgan_gp64":
-                line["cpu_baseline"] = cpu_baseline_wgan()
+        # a rendezvous or a first collective that cannot complete must END the run with the RCCL error text and a
+        # non-zero exit code, not hang it: bounded process-group timeout + asynchronous error handling, and a probe
+        # all-reduce right here, where a communicator set-up error has a clear message
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("LGM_DIST_TIMEOUT", "240")))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)   # RCCL over xGMI
             else:
-                line["cpu_baseline"] = cpu_baseline_vqvae(args.vq_ema)
-        if world == 1 and args.torch_gpu_baseline and wl in ("ddpm32", "ddpm64"):
-            line["torch_gpu_baseline"] = torch_gpu_baseline(dev, 32 if wl == "ddpm32" else 64, 64, gb)
+                dist.init_process_group(backend, timeout=tmo)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)                   # first collective: communicator set-up errors surface HERE
+            torch.cuda.synchronize()
+            assert int(probe.item()) == world, f"all-reduce probe returned {probe.item()} on {world} ranks"
+        except BaseException as e:
+            print(f"[bench] rank {rank}: process group / first collective failed: {type(e).__name__}: {e}",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+
+    single = world == 1 and not args.only and args.workload == "ddpm32" and args.batch is None
+    line = run_workload(args.workload, args, dev, world, rank, args.steps, args.warmup, batch=args.batch)
+    if single and rank == 0:
+        # ---- BASELINE's secondary configs, each measured the same way, then the per-rank batches of the
+        # strong-scaled headline on this one GPU
+        sec = {}
+        for wl, st, wu in (("ddpm64", 15, 3), ("wgan_gp64", 60, 12), ("vqvae", 100, 10), ("vqvae_ema", 100, 10)):
+            _release()
+            try:
+                r = run_workload(wl, args, dev, 1, 0, st, wu)
+                sec[wl] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
+                                             "roofline", "cpu_baseline") if k in r}
+            except Exception as e:      # a secondary leg must never take the headline line down with it
+                sec[wl] = {"error": f"{type(e).__name__}: {e}"}
+                print(f"[bench] secondary workload {wl} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        line["secondary"] = sec
+        proxy = {}
+        for b in (64, 32, 16):
+            _release()
+            try:
+                r = run_workload("ddpm32", args, dev, 1, 0, 20, 5, batch=b, roofline=False, cpu=False)
+                proxy[f"b{b}"] = r["ms_per_step"]
+            except Exception as e:
+                proxy[f"b{b}"] = None
+                print(f"[bench] per-rank proxy B={b} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        proxy["note"] = ("ms per step of the headline workload on ONE GPU at the per-rank batch of 2 / 4 / 8 GPUs "
+                         "(global batch 128): compute between the gradient exchanges under strong scaling")
+        line["per_rank_proxy"] = proxy
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1355,6 +1355,7 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
       attr = smem;                                                                                     \
     }                                                                                                  \
+    lgm_note_kernel("lgm3x3::wgrad3x3_kernel<" #TWV ", " #GSV ">");                                    \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                    \
   } while (0)
 #define LGM_W3_LAUNCH(TWV)                                                                             \

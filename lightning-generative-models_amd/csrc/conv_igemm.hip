@@ -555,7 +555,9 @@ int launch_igemm_t(IgemmArgs& a, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  lgm_note_kernel("igemm_kernel");
+  static char name[64] = "";
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_kernel<%d, %d, %d, %d, %d, %s>", MODE, BM, BN, TM, TN, UNI ? "true" : "false");
+  lgm_note_kernel(name);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits * a.phases)), dim3(256), smem, s, a);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
@@ -1452,7 +1454,7 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
     const bool fast = !no_fast && a.lWo >= 0 && a.lHo >= 0 && a.lW >= 0 && a.lH >= 0 &&
                       (long)a.B * a.H * a.W < (1L << 24) && x_pitch * 4 < (1L << 24) &&
                       (long)a.B * a.H * a.W * x_pitch * 4 < (1L << 31) && ((long)a.P + WBK) * y_pitch * 4 < (1L << 31);
-    lgm_note_kernel("wgrad_kernel<64, 64, 1, 1>");
+    lgm_note_kernel(fast ? "wgrad_kernel<64, 64, 1, 1, true>" : "wgrad_kernel<64, 64, 1, 1, false>");
     if (fast)
       hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1, true>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
     else

@@ -141,6 +141,15 @@ def register_b3_flat(fp):
     _B3_FLATS.append(fp)
 
 
+def forget_dead_flats():
+    """Drop the registrations of flat buffers that no longer exist and every per-weight workspace (slab buffers keyed
+    by gradient address, reducer tables).  Only safe when no live HIP graph was captured against those workspaces:
+    bench.py calls it BETWEEN workloads, after the previous workload's models and graphs are gone."""
+    _WINO_FLATS[:] = [r for r in _WINO_FLATS if r() is not None]
+    _WGRAD_WS.clear()
+    _WGRAD_TABLES.clear()
+
+
 def _b3_planes(ptr: Optional[int], transposed: bool):
     """-> (address of the slot's plane 0, plane stride in elements) when ``ptr`` is a 3x3 weight slot of a
     registered flat buffer, else None"""
@@ -176,14 +185,19 @@ _WINO_WS = {}
 
 
 def register_wino_flat(fp):
-    _WINO_FLATS.append(fp)
+    import weakref as _wr
+    _WINO_FLATS[:] = [r for r in _WINO_FLATS if r() is not None]     # weak: a model that goes away frees its copies
+    _WINO_FLATS.append(_wr.ref(fp))
 
 
 def _wino_u(w_ptr: Optional[int], backward: bool):
     """-> address of the transformed copy of the 3x3 weight slot at ``w_ptr`` (a registered flat buffer), or None"""
     if w_ptr is None:
         return None
-    for fp in _WINO_FLATS:
+    for ref in _WINO_FLATS:
+        fp = ref()
+        if fp is None:
+            continue
         off = w_ptr - fp.data.data_ptr()
         if 0 <= off < 4 * fp.total:
             uo = fp._wino_off.get(off // 4) if off % 4 == 0 else None

@@ -208,9 +208,24 @@ def test_graph_replayed_sampling_is_bit_identical_to_eager_launches(dev, golden_
         monkeypatch.setenv("LGM_NO_SAMPLER_GRAPH", "0" if mode == "graph" else "1")
         outs[mode] = (sampler.ddim_sample(gd, shape, init_noise=init.to(dev)),
                       sampler.p_sample_loop(gd_a, shape, init_noise=init.to(dev), noises=nzd))
-    assert sampler._GRAPHS and all(v for v in sampler._GRAPHS.values()), "graph capture did not happen"
+    ents = [e for per in sampler._GRAPHS.values() for e in per.values()]
+    assert ents and all(isinstance(e, sampler._GraphedChain) for e in ents), "graph capture did not happen"
     assert torch.equal(outs["graph"][0], outs["eager"][0])
     assert torch.equal(outs["graph"][1], outs["eager"][1])
+    # the cache follows the network's flat storage: after the parameter storage was replaced (module.to(), a loaded
+    # model) prepare_hip() rebuilds the flat buffers, the entry captured against the old ones is dropped and the step
+    # recaptured -- sampling then uses the NEW weights (a stale graph would keep reading the old buffers)
+    monkeypatch.setenv("LGM_NO_SAMPLER_GRAPH", "0")
+    old = sampler._GRAPHS[net][(shape, False)]
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.data = (p_.data * 1.01).clone()          # new storage, different values
+    assert not net._flat.still_bound()
+    new_img = sampler.ddim_sample(gd, shape, init_noise=init.to(dev))
+    assert sampler._GRAPHS[net][(shape, False)] is not old and sampler._GRAPHS[net][(shape, False)].matches(net)
+    monkeypatch.setenv("LGM_NO_SAMPLER_GRAPH", "1")
+    assert torch.equal(new_img, sampler.ddim_sample(gd, shape, init_noise=init.to(dev)))
+    assert not torch.equal(new_img, outs["graph"][0])
     # device-drawn noise: runs, finite, and two chains differ (fresh draws per replay)
     monkeypatch.setenv("LGM_NO_SAMPLER_GRAPH", "0")
     a = sampler.p_sample_loop(gd_a, shape, init_noise=init.to(dev))
