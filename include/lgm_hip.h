@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGM_ABI_VERSION 1
+#define LGM_ABI_VERSION 2   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial */
 #define LGM_OK 0
 #define LGM_ERR_INVALID (-1)
 #define LGM_ERR_UNSUPPORTED (-2)
@@ -115,6 +115,17 @@ int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C, int G, flo
                const float* gamma, const float* beta, const float* ss, int64_t ss_pitch, int act,
                const float* res, int64_t res_pitch, float* y, int64_t y_pitch, float* mean,
                float* rstd, float* coefA, float* coefB, void* stream);
+/* The same, with x still in pieces: the convolution that produces x (Block.proj, ddpm.py:160-171) split its reduction
+ * and left `splits` partial planes [B*HW][C] (dense, `plane_stride` floats apart) instead of running its reducer
+ * (lgm_conv3x3_wino_partial).  The planes are summed here in the reducer's fixed order (plane 0, 1, ..., then
+ * conv_bias), the finished x is WRITTEN to `x` (the backward pass reads it) and normalised in the same pass: one
+ * launch and one round trip of x less per convolution.  Only shapes with lgm_gn_planes_supported(...) == 1. */
+int64_t lgm_gn_planes_supported(int B, int HW, int C, int G);
+int lgm_gn_fwd_planes(const float* planes, int64_t plane_stride, int splits, const float* conv_bias, float* x,
+                      int64_t x_pitch, int B, int HW, int C, int G, float eps, const float* gamma,
+                      const float* beta, const float* ss, int64_t ss_pitch, int act, const float* res,
+                      int64_t res_pitch, float* y, int64_t y_pitch, float* mean, float* rstd, float* coefA,
+                      float* coefB, void* stream);
 /* Backward.  gx (optionally accumulated), ggamma/gbeta (= affine_beta*old + new), gss [B, >=2C]
  * (optional; = gss_beta*old + new).  workspace: 5*B*C floats. */
 int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
@@ -123,6 +134,15 @@ int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitc
                const float* coefB, float* gx, int64_t gx_pitch, int accumulate_gx, float* ggamma,
                float* gbeta, float affine_beta, float* gss, int64_t gss_pitch, float gss_beta,
                float* workspace, void* stream);
+/* Backward with gy given as the partial planes of the input-gradient convolution that produces it (ResnetBlock:
+ * block2.proj's input gradient feeds only block1.norm's backward, ddpm.py:176-200); gy itself is never written.
+ * rows / desc: both NULL (gamma / beta gradients complete on return) or the deferred form of lgm_gn_bwd_deferred. */
+int lgm_gn_bwd_planes(const float* x, int64_t x_pitch, const float* gy_planes, int64_t plane_stride, int splits, int B,
+                      int HW, int C, int G, const float* gamma, const float* beta, const float* ss,
+                      int64_t ss_pitch, int act, const float* mean, const float* rstd, const float* coefA,
+                      const float* coefB, float* gx, int64_t gx_pitch, int accumulate_gx, float* ggamma,
+                      float* gbeta, float affine_beta, float* gss, int64_t gss_pitch, float gss_beta,
+                      float* workspace, float* rows, int64_t* desc, void* stream);
 /* Deferred form: when the one-pass kernel applies, the per-image rows [sc*S2 | sc*S1] (B x 2C floats) are left in
  * `rows` and `desc` is filled in the format of lgm_conv_wgrad_deferred (images play the role of splits), so that
  * lgm_wgrad_reduce_batch produces ggamma / gbeta of many layers in one launch; otherwise the gradients are
@@ -382,7 +402,33 @@ int lgm_conv3x3_bf16x3(int mode, const LgmConvGeom* g, const float* a, int64_t a
  *   (mirrored taps, roles of Np / Cp swapped), first block; one block per 32 x 32 (n, c) tile, total_blocks =
  *   sum Np/32 * Cp/32.  Either destination may be NULL.
  * ------------------------------------------------------------------------------------- */
-int64_t lgm_conv3x3_wino_supported(const LgmConvGeom* g, int yx);   /* 1 / 0 */
+int64_t lgm_conv3x3_wino_supported(const LgmConvGeom* g, int yx);   /* 1 / 0 (dense operands fit 32-bit offsets) */
+/* 1 when the caller's pitched operands also fit the kernel's 32-bit byte offsets (res_pitch 0: no residual) */
+int64_t lgm_conv3x3_wino_fits(const LgmConvGeom* g, int64_t a_pitch, int64_t out_pitch, int64_t res_pitch);
+/* Partial form: the split-K planes stay in `workspace` for a consumer that sums them itself (lgm_gn_fwd_planes /
+ * lgm_gn_bwd_planes) - no reducer launch, and the split count is planned without its cost.  partial[0] = planes
+ * left (1: none, `out` is complete incl. bias), partial[1] = plane stride in floats.  With planes, `out` is not
+ * written and `bias` not applied (the consumer adds it). */
+int64_t lgm_conv3x3_wino_workspace_partial(const LgmConvGeom* g, int yx);
+/* Backward PAIR of a 3x3 layer (autograd's conv backward, Block.proj ddpm.py:160-171): the input gradient
+ * gx = W^T * gy (+ res) and the weight / bias gradient gw = beta*gw + gy (x) x in ONE launch - at the per-GPU batches
+ * of a strong-scaled run each of them fills a fraction of the chip and is latency-bound, side by side they take
+ * the time of one.  Same kernels' code and arithmetic as lgm_conv3x3_wino(yx = 1) + lgm_conv_wgrad: bit-identical.
+ * u_b = the input-gradient operand lgm_wino_weights writes; dgrad_ws / partial as lgm_conv3x3_wino[_partial]
+ * (partial NULL: finished gx); workspace sizes from lgm_conv3x3_wino_bwd_workspaces; desc NULL: gw complete on return, else
+ * the deferred form of lgm_conv_wgrad_deferred. */
+int64_t lgm_conv3x3_wino_bwd_supported(const LgmConvGeom* g, int64_t gy_pitch, int64_t x_pitch, int64_t gx_pitch,
+                                       int64_t res_pitch);
+/* out[0] / out[1] = bytes of dgrad_ws / wgrad_ws the pair needs (its two split counts are planned jointly, so they
+ * differ from the stand-alone kernels'); partial != 0: for the partial-planes form */
+int lgm_conv3x3_wino_bwd_workspaces(const LgmConvGeom* g, int partial, int64_t* out);
+int lgm_conv3x3_wino_bwd(const LgmConvGeom* g, const float* gy, int64_t gy_pitch, const float* x, int64_t x_pitch,
+                         const float* u_b, const float* res, int64_t res_pitch, float* gx, int64_t gx_pitch,
+                         void* dgrad_ws, int64_t dgrad_ws_bytes, int64_t* partial, float* gw, float* gbias, float beta,
+                         void* wgrad_ws, int64_t wgrad_ws_bytes, int64_t* desc, void* stream);
+int lgm_conv3x3_wino_partial(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,
+                             const float* bias, float* out, int64_t out_pitch, void* workspace,
+                             int64_t workspace_bytes, int64_t* partial, void* stream);
 int64_t lgm_conv3x3_wino_workspace(const LgmConvGeom* g, int yx);   /* split-K partial outputs (bytes) */
 int lgm_wino_weights(const float* src, float* dst_f, float* dst_b, const int64_t* table, int n_slots,
                      int64_t total_blocks, void* stream);

@@ -1409,8 +1409,7 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
                      (long)g->B * g->H * g->W * y_pitch < (1L << 29);
   static const bool no_w1x1 = getenv("LGM_NO_W1X1") != nullptr;   // A/B switch
   const bool fast1 = !fast3 && !no_w1x1 && lgm_wgrad1x1_supported(g, y_pitch, x_pitch);
-  // Winograd: same operand limits as the direct 3x3 kernel; a gradient accumulated into existing values with the
-  // slabs bypassed (beta != 0 without a descriptor) is left to the direct kernel
+  // Winograd: same operand limits as the direct 3x3 kernel (the kernel always writes slabs, the reducer applies beta)
   const bool fastw = fast3 && use_wino() && lgm_wino_wgrad_supported(g);
   int tps3 = 0, total3 = 0, per1 = 0, cpsw = 0, totalw = 0;
   if (fastw)
@@ -1476,6 +1475,79 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
                        (const float*)workspace, a.slab, gw, n_w, gbias, n_b, a.splits, beta);
     LGM_LAUNCH_CHECK();
   }
+  return LGM_OK;
+}
+
+// ---- backward pair of a 3x3 layer: input gradient + weight gradient in ONE launch (csrc/winograd.hip) -------------
+bool lgm_wino_supported(const LgmConvGeom* g, int gather_channels, int out_channels);
+struct WinoPairPlan {
+  int csplits, wsplits, cps, total_chunks;
+};
+WinoPairPlan lgm_wino_pair_plan(const LgmConvGeom* g, bool fused);
+int lgm_wino_pair_launch(const LgmConvGeom* g, const float* gy, long gy_pitch, const float* x, long x_pitch,
+                         const float* u_b, const float* res, long res_pitch, float* gx, long gx_pitch, void* dws,
+                         long dws_bytes, int64_t* partial, float* slabs, int bias, long slab, hipStream_t s);
+
+/* out[0] / out[1]: bytes of the input gradient's split-K workspace / of the weight gradient's slab workspace that
+ * lgm_conv3x3_wino_bwd needs for this geometry (the pair plans its two split counts jointly) */
+extern "C" int lgm_conv3x3_wino_bwd_workspaces(const LgmConvGeom* g, int partial, int64_t* out) {
+  LGM_REQUIRE(g && out && check_geom(g) == LGM_OK, "conv3x3_wino_bwd_workspaces: bad arguments");
+  const WinoPairPlan pl = lgm_wino_pair_plan(g, partial != 0);
+  out[0] = pl.csplits > 1 ? (int64_t)pl.csplits * g->B * g->H * g->W * g->Cw * (int64_t)sizeof(float) : 0;
+  out[1] = (int64_t)pl.wsplits * ((int64_t)g->Nw * 9 * g->Cw + g->Nw) * (int64_t)sizeof(float);
+  return LGM_OK;
+}
+
+extern "C" int64_t lgm_conv3x3_wino_bwd_supported(const LgmConvGeom* g, int64_t gy_pitch, int64_t x_pitch,
+                                                  int64_t gx_pitch, int64_t res_pitch) {
+  if (check_geom(g) != LGM_OK) return 0;
+  static const bool no_pair = getenv("LGM_NO_PAIR") != nullptr;   // A/B switch: separate launches
+  if (no_pair || !use_3x3() || !use_wino()) return 0;
+  const long pix = (long)g->B * g->H * g->W + g->W + 1;
+  if (!(lgm_wgrad3x3_supported(g) && lgm_wino_wgrad_supported(g) && lgm_wino_supported(g, g->Nw, g->Cw))) return 0;
+  if (gy_pitch % 4 || x_pitch % 4 || gx_pitch % 4 || res_pitch % 4) return 0;
+  return (pix * x_pitch < (1L << 29) && pix * gy_pitch < (1L << 29) && pix * gx_pitch < (1L << 29) &&
+          pix * res_pitch < (1L << 29)) ? 1 : 0;
+}
+
+extern "C" int lgm_conv3x3_wino_bwd(const LgmConvGeom* g, const float* gy, int64_t gy_pitch, const float* x,
+                                    int64_t x_pitch, const float* u_b, const float* res, int64_t res_pitch, float* gx,
+                                    int64_t gx_pitch, void* dgrad_ws, int64_t dgrad_ws_bytes, int64_t* partial, float* gw,
+                                    float* gbias, float beta, void* wgrad_ws, int64_t wgrad_ws_bytes, int64_t* desc,
+                                    void* stream) {
+  LGM_REQUIRE(g && gy && x && u_b && gx && gw, "conv3x3_wino_bwd: null pointer");
+  LGM_REQUIRE(lgm_conv3x3_wino_bwd_supported(g, gy_pitch, x_pitch, gx_pitch, res ? res_pitch : 0),
+              "conv3x3_wino_bwd: unsupported geometry / pitches (ask lgm_conv3x3_wino_bwd_supported first)");
+  LGM_REQUIRE(lgm_aligned16(gy) && lgm_aligned16(x) && lgm_aligned16(u_b) && lgm_aligned16(gx) && lgm_aligned16(gw) &&
+                  (!gbias || lgm_aligned16(gbias)) && (!res || lgm_aligned16(res)) && gy_pitch >= g->Nw &&
+                  x_pitch >= g->Cw && gx_pitch >= g->Cw && (!res || res_pitch >= g->Cw) && !(partial && res),
+              "conv3x3_wino_bwd: 16-byte aligned operands expected (and no residual with partial planes)");
+  const WinoPairPlan pl = lgm_wino_pair_plan(g, partial != nullptr);
+  const int splits = pl.wsplits;
+  const long n_w = (long)g->Nw * 9 * g->Cw;
+  const long slab = n_w + g->Nw;
+  LGM_REQUIRE(wgrad_ws && wgrad_ws_bytes >= (int64_t)splits * slab * (int64_t)sizeof(float) && lgm_aligned16(wgrad_ws),
+              "conv3x3_wino_bwd: weight-gradient workspace too small (%lld bytes needed)", (long long)splits * slab * 4);
+  LGM_REQUIRE(pl.csplits == 1 || (dgrad_ws && lgm_aligned16(dgrad_ws) &&
+                                  dgrad_ws_bytes >= (int64_t)pl.csplits * g->B * g->H * g->W * g->Cw * (int64_t)sizeof(float)),
+              "conv3x3_wino_bwd: input-gradient workspace too small (ask lgm_conv3x3_wino_bwd_workspaces)");
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = lgm_wino_pair_launch(g, gy, gy_pitch, x, x_pitch, u_b, res, res_pitch, gx, gx_pitch, dgrad_ws,
+                                    dgrad_ws_bytes, partial, (float*)wgrad_ws, gbias ? 1 : 0, slab, s))
+    return rc;
+  const long n_b = gbias ? g->Nw : 0;
+  if (desc) {
+    union { float f; int64_t i; } bb;
+    bb.i = 0;
+    bb.f = beta;
+    desc[0] = (int64_t)(uintptr_t)wgrad_ws; desc[1] = slab; desc[2] = (int64_t)(uintptr_t)gw; desc[3] = n_w;
+    desc[4] = (int64_t)(uintptr_t)gbias; desc[5] = n_b; desc[6] = splits; desc[7] = bb.i;
+    return LGM_OK;
+  }
+  const long groups = (n_w + n_b + 3) / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lgm_cdiv(groups, 64)), dim3(256), 0, s, (const float*)wgrad_ws,
+                     slab, gw, n_w, gbias, n_b, splits, beta);
+  LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
 

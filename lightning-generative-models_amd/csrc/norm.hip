@@ -154,7 +154,9 @@ __global__ __launch_bounds__(NT) void gn_fused_fwd_kernel(const float* __restric
                                                            long ss_pitch, int act, const float* __restrict__ res,
                                                            long res_pitch, float* __restrict__ y, long y_pitch,
                                                            float* __restrict__ mean, float* __restrict__ rstd,
-                                                           float* __restrict__ A, float* __restrict__ Bc) {
+                                                           float* __restrict__ A, float* __restrict__ Bc,
+                                                           const float* __restrict__ planes, long pstride, int splits,
+                                                           const float* __restrict__ cbias, float* __restrict__ xw) {
   __shared__ float sh[NT * 4];
   __shared__ float chs[256];
   __shared__ float gmean[64], grstd[64];
@@ -188,8 +190,30 @@ __global__ __launch_bounds__(NT) void gn_fused_fwd_kernel(const float* __restric
   };
 
   f32x4 v[NV];
+  if (planes) {
+    // x is still in pieces: the producing convolution split its reduction and left `splits` partial planes
+    // [B*HW][C] (dense) instead of running its reducer.  Sum them here in the reducer's fixed order (plane 0, 1, ...,
+    // then the convolution's bias), and write the finished x once - the backward pass reads it.
+    const float* pb = planes + ((long)b * HW) * C + c0 + q * 4;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(xb + (long)(pl + k * ppb) * pitch);
+    for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(pb + (long)(pl + k * ppb) * C);
+    for (int sidx = 1; sidx < splits; ++sidx) {
+      const float* ps = pb + (long)sidx * pstride;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k] += *reinterpret_cast<const f32x4*>(ps + (long)(pl + k * ppb) * C);
+    }
+    if (cbias) {
+      const f32x4 cb4 = *reinterpret_cast<const f32x4*>(cbias + c0 + q * 4);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k] += cb4;
+    }
+    float* xo = xw + (long)b * HW * pitch + c0 + q * 4;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(xo + (long)(pl + k * ppb) * pitch) = v[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(xb + (long)(pl + k * ppb) * pitch);
+  }
   f32x4 s = v[0];
 #pragma unroll
   for (int k = 1; k < NV; ++k) s += v[k];
@@ -432,7 +456,8 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
                                                            float* __restrict__ gss, long gss_pitch, float gss_beta,
                                                            float* __restrict__ S1, float* __restrict__ S2,
                                                            float* __restrict__ gx, long gx_pitch, int accumulate,
-                                                           float* __restrict__ T) {
+                                                           float* __restrict__ T, const float* __restrict__ planes,
+                                                           long pstride, int splits) {
   __shared__ float sh[NT * 8];
   __shared__ float wa1[256], wa2[256];
   __shared__ __align__(16) float cP[256], cQ[256], cR[256];
@@ -448,9 +473,21 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
   const float* gb = gy + (long)b * HW * gy_pitch + c;
   f32x4 xv[NV], g[NV];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    xv[k] = *reinterpret_cast<const f32x4*>(xb + (long)(pl + k * ppb) * x_pitch);
-    g[k] = *reinterpret_cast<const f32x4*>(gb + (long)(pl + k * ppb) * gy_pitch);
+  for (int k = 0; k < NV; ++k) xv[k] = *reinterpret_cast<const f32x4*>(xb + (long)(pl + k * ppb) * x_pitch);
+  if (planes) {
+    // gy = sum of the partial planes the producing input-gradient convolution left (fixed order, no bias): gy itself
+    // has no other reader, so it is never written
+    const float* pb = planes + ((long)b * HW) * C + c;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const f32x4*>(pb + (long)(pl + k * ppb) * C);
+    for (int sidx = 1; sidx < splits; ++sidx) {
+      const float* ps = pb + (long)sidx * pstride;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) g[k] += *reinterpret_cast<const f32x4*>(ps + (long)(pl + k * ppb) * C);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const f32x4*>(gb + (long)(pl + k * ppb) * gy_pitch);
   }
   const f32x4 a = *reinterpret_cast<const f32x4*>(A + (long)b * C + c);
   const f32x4 bc = *reinterpret_cast<const f32x4*>(Bc + (long)b * C + c);
@@ -559,38 +596,86 @@ int gn_check(int B, int HW, int C, int G) {
 
 }  // namespace
 
-extern "C" int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C, int G, float eps,
-                          const float* gamma, const float* beta, const float* ss, int64_t ss_pitch,
-                          int act, const float* res, int64_t res_pitch, float* y, int64_t y_pitch,
-                          float* mean, float* rstd, float* coefA, float* coefB, void* stream) {
+// Block decomposition of the GroupNorm kernels.  A block owns (image, cb channels), cb a whole number of groups:
+//   * by default >= 32 channels (full 128-byte rows per pixel);
+//   * when that leaves fewer than 256 blocks (small per-GPU batches: B = 16 gave 32 blocks of 1024 threads on a
+//     256-CU chip, 14 us of pure latency per launch) the blocks are narrowed, down to ONE group per block;
+//   * one-pass kernels: nt threads = (cb / 4) channel quads x ppb pixel lanes, nv = HW / ppb 16-byte values per thread
+//     in registers; nt is lowered until the pixel lanes divide the map (a 4x4 map has 16 pixels: 256 threads at
+//     cb = 32 would be 32 lanes).  nv == 0: no one-pass kernel, the two-pass kernels run with the same cb.
+struct GnPlan {
+  int cb, nt, nv;
+};
+static GnPlan gn_plan(int B, int HW, int C, int G, bool bwd) {
+  GnPlan p;
+  const int Cg = C / G;
+  int cb = gn_cb(C, G);
+  static const bool wide_only = getenv("LGM_GN_WIDE") != nullptr;   // A/B switch: never narrow the blocks
+  if (!wide_only)
+    while ((long)B * (C / cb) < 256 && cb > Cg && (cb / 2) % Cg == 0 && (cb / 2) % 4 == 0) cb /= 2;
+  p.cb = cb;
+  p.nt = (long)HW * cb >= 16384 ? 1024 : 256;
+  p.nv = 0;
+  static const bool no_fused = getenv("LGM_GN_TWO_PASS") != nullptr;   // A/B switch
+  if (no_fused) return p;
+  const int cand[4] = {p.nt, 256, 128, 64};
+  for (int i = 0; i < 4; ++i) {
+    const int nt = cand[i];
+    if (i > 0 && nt >= cand[0]) continue;
+    const int tq = cb / 4;
+    if (nt < cb || nt % tq) continue;
+    const int ppb = nt / tq;
+    if (HW % ppb) continue;
+    const int nv = HW / ppb;
+    if (nv == 1 || nv == 2 || nv == 4 || nv == 8 || (!bwd && nv == 16 && nt == 256)) {
+      p.nt = nt;
+      p.nv = nv;
+      return p;
+    }
+  }
+  return p;
+}
+
+extern "C" int64_t lgm_gn_planes_supported(int B, int HW, int C, int G) {
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || C % 4 || G > 64) return 0;
+  const int cb = gn_cb(C, G);
+  if (!(cb % 4 == 0 && C % cb == 0 && cb / 4 <= 256 && cb <= 256)) return 0;
+  return (gn_plan(B, HW, C, G, false).nv > 0 && gn_plan(B, HW, C, G, true).nv > 0) ? 1 : 0;   // both one-pass kernels
+}
+
+static int gn_fwd_impl(const float* x, int64_t x_pitch, int B, int HW, int C, int G, float eps,
+                       const float* gamma, const float* beta, const float* ss, int64_t ss_pitch,
+                       int act, const float* res, int64_t res_pitch, float* y, int64_t y_pitch,
+                       float* mean, float* rstd, float* coefA, float* coefB, const float* planes, long pstride,
+                       int splits, const float* cbias, void* stream) {
   if (int rc = gn_check(B, HW, C, G)) return rc;
   LGM_REQUIRE(x && gamma && beta && y && mean && rstd && coefA && coefB, "gn_fwd: null pointer");
   LGM_REQUIRE(x_pitch % 4 == 0 && y_pitch % 4 == 0 && (!res || res_pitch % 4 == 0), "gn_fwd: pitch %% 4 != 0");
   hipStream_t s = (hipStream_t)stream;
-  const int cb = gn_cb(C, G);
+  const GnPlan pln = gn_plan(B, HW, C, G, false);
+  const int cb = pln.cb;
   static const bool small_only = getenv("LGM_GN_256") != nullptr;   // A/B switch
-  static const bool no_fused = getenv("LGM_GN_TWO_PASS") != nullptr;   // A/B switch
-  {   // one-pass kernel when the block's slice fits its registers (NV 16-byte values per thread)
-    const int nt = (long)HW * cb >= 16384 ? 1024 : 256;
-    const int ppb = nt / (cb / 4);
-    const int nv = HW % ppb == 0 ? HW / ppb : 0;
-    if (!no_fused && (nv == 1 || nv == 2 || nv == 4 || nv == 8 || (nv == 16 && nt == 256))) {
+  if (pln.nv > 0) {   // one-pass kernel: the block's slice fits its registers (NV 16-byte values per thread)
+    const int nt = pln.nt, nv = pln.nv;
 #define GN_FUSED(NTV, NVV)                                                                                            \
   hipLaunchKernelGGL((gn_fused_fwd_kernel<NTV, NVV>), dim3(B * (C / cb)), dim3(NTV), 0, s, x, (long)x_pitch, HW, C, G, \
                      cb, eps, gamma, beta, ss, (long)ss_pitch, act, res, (long)res_pitch, y, (long)y_pitch, mean,    \
-                     rstd, coefA, coefB)
-      if (nt == 1024) {
-        if (nv == 1) GN_FUSED(1024, 1); else if (nv == 2) GN_FUSED(1024, 2); else if (nv == 4) GN_FUSED(1024, 4);
-        else GN_FUSED(1024, 8);
-      } else {
-        if (nv == 1) GN_FUSED(256, 1); else if (nv == 2) GN_FUSED(256, 2); else if (nv == 4) GN_FUSED(256, 4);
-        else if (nv == 8) GN_FUSED(256, 8); else GN_FUSED(256, 16);
-      }
+                     rstd, coefA, coefB, planes, pstride, splits, cbias, (float*)x)
+#define GN_FUSED_NV(NTV)                                                                       \
+  do {                                                                                         \
+    if (nv == 1) GN_FUSED(NTV, 1); else if (nv == 2) GN_FUSED(NTV, 2); else if (nv == 4) GN_FUSED(NTV, 4); \
+    else GN_FUSED(NTV, 8);                                                                     \
+  } while (0)
+    if (nt == 1024) GN_FUSED_NV(1024);
+    else if (nt == 256) { if (nv == 16) GN_FUSED(256, 16); else GN_FUSED_NV(256); }
+    else if (nt == 128) GN_FUSED_NV(128);
+    else GN_FUSED_NV(64);
+#undef GN_FUSED_NV
 #undef GN_FUSED
-      LGM_LAUNCH_CHECK();
-      return LGM_OK;
-    }
+    LGM_LAUNCH_CHECK();
+    return LGM_OK;
   }
+  LGM_REQUIRE(!planes, "gn_fwd_planes: this shape has no one-pass kernel (ask lgm_gn_planes_supported first)");
   if (!small_only && (long)HW * cb >= 16384)
     hipLaunchKernelGGL(gn_stats_kernel<1024>, dim3(B * (C / cb)), dim3(1024), 0, s, x, (long)x_pitch, HW, C, G, cb, eps,
                        gamma, beta, ss, (long)ss_pitch, mean, rstd, coefA, coefB);
@@ -604,16 +689,36 @@ extern "C" int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C,
   return LGM_OK;
 }
 
+extern "C" int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C, int G, float eps,
+                          const float* gamma, const float* beta, const float* ss, int64_t ss_pitch,
+                          int act, const float* res, int64_t res_pitch, float* y, int64_t y_pitch,
+                          float* mean, float* rstd, float* coefA, float* coefB, void* stream) {
+  return gn_fwd_impl(x, x_pitch, B, HW, C, G, eps, gamma, beta, ss, ss_pitch, act, res, res_pitch, y, y_pitch, mean, rstd,
+                     coefA, coefB, nullptr, 0, 0, nullptr, stream);
+}
+
+extern "C" int lgm_gn_fwd_planes(const float* planes, int64_t plane_stride, int splits, const float* conv_bias,
+                                 float* x, int64_t x_pitch, int B, int HW, int C, int G, float eps,
+                                 const float* gamma, const float* beta, const float* ss, int64_t ss_pitch,
+                                 int act, const float* res, int64_t res_pitch, float* y, int64_t y_pitch,
+                                 float* mean, float* rstd, float* coefA, float* coefB, void* stream) {
+  LGM_REQUIRE(planes && splits >= 1 && plane_stride >= (int64_t)B * HW * C && lgm_aligned16(planes) &&
+                  plane_stride % 4 == 0 && (!conv_bias || lgm_aligned16(conv_bias)),
+              "gn_fwd_planes: bad partial planes");
+  return gn_fwd_impl(x, x_pitch, B, HW, C, G, eps, gamma, beta, ss, ss_pitch, act, res, res_pitch, y, y_pitch, mean, rstd,
+                     coefA, coefB, planes, (long)plane_stride, splits, conv_bias, stream);
+}
+
 static int gn_bwd_impl(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
                        int C, int G, const float* gamma, const float* beta, const float* ss,
                        int64_t ss_pitch, int act, const float* mean, const float* rstd,
                        const float* coefA, const float* coefB, float* gx, int64_t gx_pitch,
                        int accumulate_gx, float* ggamma, float* gbeta, float affine_beta, float* gss,
                        int64_t gss_pitch, float gss_beta, float* workspace, float* rows, int64_t* desc,
-                       void* stream) {
+                       void* stream, const float* planes = nullptr, long pstride = 0, int splits = 0) {
   if (desc) desc[6] = 0;      // nothing deferred unless the one-pass kernel below takes it
   if (int rc = gn_check(B, HW, C, G)) return rc;
-  LGM_REQUIRE(x && gy && gamma && beta && mean && rstd && coefA && coefB && gx && ggamma && gbeta && workspace,
+  LGM_REQUIRE(x && (gy || planes) && gamma && beta && mean && rstd && coefA && coefB && gx && ggamma && gbeta && workspace,
               "gn_bwd: null pointer");
   LGM_REQUIRE(x_pitch % 4 == 0 && gy_pitch % 4 == 0 && gx_pitch % 4 == 0, "gn_bwd: pitch %% 4 != 0");
   hipStream_t s = (hipStream_t)stream;
@@ -623,25 +728,26 @@ static int gn_bwd_impl(const float* x, int64_t x_pitch, const float* gy, int64_t
   float* P = S2 + bc;
   float* Qc = P + bc;
   float* Rc = Qc + bc;
-  const int cb = gn_cb(C, G);
+  const GnPlan pln = gn_plan(B, HW, C, G, true);
+  const int cb = pln.cb;
   static const bool small_only = getenv("LGM_GN_256") != nullptr;
-  static const bool no_fused = getenv("LGM_GN_TWO_PASS") != nullptr;   // A/B switch
   {   // one-pass kernel when the block's x and gy slices fit its registers
-    const int nt = (long)HW * cb >= 16384 ? 1024 : 256;
-    const int ppb = nt / (cb / 4);
-    const int nv = HW % ppb == 0 ? HW / ppb : 0;
-    if (!no_fused && (nv == 1 || nv == 2 || nv == 4 || nv == 8)) {
+    const int nt = pln.nt, nv = pln.nv;
+    if (nv > 0) {
 #define GN_FUSED(NTV, NVV)                                                                                             \
   hipLaunchKernelGGL((gn_fused_bwd_kernel<NTV, NVV>), dim3(B * (C / cb)), dim3(NTV), 0, s, x, (long)x_pitch, gy,        \
                      (long)gy_pitch, coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss, \
-                     (long)gss_pitch, gss_beta, S1, S2, gx, (long)gx_pitch, accumulate_gx, rows)
-      if (nt == 1024) {
-        if (nv == 1) GN_FUSED(1024, 1); else if (nv == 2) GN_FUSED(1024, 2); else if (nv == 4) GN_FUSED(1024, 4);
-        else GN_FUSED(1024, 8);
-      } else {
-        if (nv == 1) GN_FUSED(256, 1); else if (nv == 2) GN_FUSED(256, 2); else if (nv == 4) GN_FUSED(256, 4);
-        else GN_FUSED(256, 8);
-      }
+                     (long)gss_pitch, gss_beta, S1, S2, gx, (long)gx_pitch, accumulate_gx, rows, planes, pstride, splits)
+#define GN_FUSED_NV(NTV)                                                                       \
+  do {                                                                                         \
+    if (nv == 1) GN_FUSED(NTV, 1); else if (nv == 2) GN_FUSED(NTV, 2); else if (nv == 4) GN_FUSED(NTV, 4); \
+    else GN_FUSED(NTV, 8);                                                                     \
+  } while (0)
+      if (nt == 1024) GN_FUSED_NV(1024);
+      else if (nt == 256) GN_FUSED_NV(256);
+      else if (nt == 128) GN_FUSED_NV(128);
+      else GN_FUSED_NV(64);
+#undef GN_FUSED_NV
 #undef GN_FUSED
       if (rows && desc) {   // the caller sums the per-image rows of many layers with ONE lgm_wgrad_reduce_batch launch
         union { float f; int64_t i; } bb;
@@ -657,6 +763,7 @@ static int gn_bwd_impl(const float* x, int64_t x_pitch, const float* gy, int64_t
       return LGM_OK;
     }
   }
+  LGM_REQUIRE(!planes, "gn_bwd_planes: this shape has no one-pass kernel (ask lgm_gn_planes_supported first)");
   if (!small_only && (long)HW * cb >= 16384)
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<1024>, dim3(B * (C / cb)), dim3(1024), 0, s, x, (long)x_pitch, gy,
                        (long)gy_pitch, coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss,
@@ -698,6 +805,24 @@ extern "C" int lgm_gn_bwd_deferred(const float* x, int64_t x_pitch, const float*
   return gn_bwd_impl(x, x_pitch, gy, gy_pitch, B, HW, C, G, gamma, beta, ss, ss_pitch, act, mean, rstd, coefA, coefB, gx,
                      gx_pitch, accumulate_gx, ggamma, gbeta, affine_beta, gss, gss_pitch, gss_beta, workspace, rows, desc,
                      stream);
+}
+
+/* gy given as the split-K partial planes of the producing input-gradient convolution (see lgm_gn_fwd_planes);
+ * deferred gamma / beta rows as lgm_gn_bwd_deferred when rows / desc are given */
+extern "C" int lgm_gn_bwd_planes(const float* x, int64_t x_pitch, const float* gy_planes, int64_t plane_stride, int splits,
+                                 int B, int HW, int C, int G, const float* gamma, const float* beta, const float* ss,
+                                 int64_t ss_pitch, int act, const float* mean, const float* rstd,
+                                 const float* coefA, const float* coefB, float* gx, int64_t gx_pitch,
+                                 int accumulate_gx, float* ggamma, float* gbeta, float affine_beta, float* gss,
+                                 int64_t gss_pitch, float gss_beta, float* workspace, float* rows, int64_t* desc,
+                                 void* stream) {
+  LGM_REQUIRE(gy_planes && splits >= 1 && plane_stride >= (int64_t)B * HW * C && lgm_aligned16(gy_planes) &&
+                  plane_stride % 4 == 0, "gn_bwd_planes: bad partial planes");
+  LGM_REQUIRE((!rows && !desc) || (rows && desc && lgm_aligned16(rows) && lgm_aligned16(ggamma) && lgm_aligned16(gbeta)),
+              "gn_bwd_planes: rows / descriptor must come together, gradients 16-byte aligned");
+  return gn_bwd_impl(x, x_pitch, nullptr, C, B, HW, C, G, gamma, beta, ss, ss_pitch, act, mean, rstd, coefA, coefB, gx,
+                     gx_pitch, accumulate_gx, ggamma, gbeta, affine_beta, gss, gss_pitch, gss_beta, workspace, rows, desc,
+                     stream, gy_planes, (long)plane_stride, splits);
 }
 
 // =====================================================================================

@@ -154,8 +154,11 @@ struct Geo {
   static constexpr int NJ = (2 * NP + 255) / 256;
 };
 
+// The kernel body as a device function of (arguments, logical block id, logical grid size): it runs as its own
+// launch (wino_conv_kernel) or as the first block range of the backward PAIR launch (wino_bwd_pair_kernel: input
+// gradient and weight gradient of one layer side by side, see below).
 template <int G, bool DBG, int EXP = 0>
-__global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
+__device__ __forceinline__ void wino_conv_body(const Args& p, const int bidx, const int nblk) {
   using GE = Geo<G>;
   constexpr int TTW = GE::TTW, TTH = GE::TTH, NI = GE::NI, lgTTW = GE::lgTTW, lgTT = GE::lgTT, PH = GE::PH,
                 PWr = GE::PWr, PWh = GE::PWh, NP = GE::NP, RPLANE = GE::RPLANE, NJ = GE::NJ;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
   int nstamp = 0;
   auto stamp = [&]() {
     if (DBG) {
-      if (threadIdx.x == 0 && nstamp < 62) p.dbg[blockIdx.x * 64 + 2 + nstamp] = (long long)__builtin_amdgcn_s_memtime();
+      if (threadIdx.x == 0 && nstamp < 62) p.dbg[bidx * 64 + 2 + nstamp] = (long long)__builtin_amdgcn_s_memtime();
       ++nstamp;
     }
   };
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
   const int wtb = wid & 1, wcb = wid >> 1;       // MFMA role: tile half, output-channel half
   const int lr = lane & 31, lh = lane >> 5;
 
-  const int Lb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int Lb = xcd_swizzle(bidx, nblk);
   const int L0 = Lb * p.per;
   const int L1 = min(p.units, L0 + p.per);
   if (L0 >= L1) return;
@@ -615,9 +618,14 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
   }
   if (EXP & 1) asm volatile("" ::"v"(dummy2[0]), "v"(dummy2[1]));
   if (DBG && threadIdx.x == 0) {
-    p.dbg[blockIdx.x * 64] = nstamp;
-    p.dbg[blockIdx.x * 64 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    p.dbg[bidx * 64] = nstamp;
+    p.dbg[bidx * 64 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
   }
+}
+
+template <int G, bool DBG, int EXP = 0>
+__global__ __launch_bounds__(256, 1) void wino_conv_kernel(const Args p) {
+  wino_conv_body<G, DBG, EXP>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -723,10 +731,16 @@ bool lgm_wino_supported(const LgmConvGeom* g, int gather_channels, int out_chann
   if (!(g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1)) return false;
   if (gather_channels % 8 != 0 || out_channels % 64 != 0) return false;
   if (!plan_unit(g->H, g->W, &a, &b, &c)) return false;
+  // 32-bit byte offsets inside the kernel: dense operands must stay below 2^31 bytes (callers with wider pitches
+  // are checked again at the call: lgm_conv3x3_wino_fits)
+  const long pix = (long)g->B * g->H * g->W + g->W + 1;
+  if (pix * gather_channels >= (1L << 29) || pix * out_channels >= (1L << 29)) return false;
   return g->B % c == 0;
 }
 
-int lgm_wino_splits(const LgmConvGeom* g, int gather_channels, int out_channels) {
+// fused = the consumer sums the partial planes itself (lgm_gn_fwd_planes / lgm_gn_bwd_planes): no reducer launch, and
+// its read of the reduced tensor is replaced by a read of the planes
+int lgm_wino_splits(const LgmConvGeom* g, int gather_channels, int out_channels, bool fused = false) {
   using namespace lgmwino;
   int TTH, TTW, NI;
   if (!plan_unit(g->H, g->W, &TTH, &TTW, &NI)) return 1;
@@ -738,14 +752,14 @@ int lgm_wino_splits(const LgmConvGeom* g, int gather_channels, int out_channels)
   // cost in phase times (~2.1 us): rounds of 256 workgroups x (phases per unit + ~1.5 of prologue / epilogue) + the
   // partial sums every extra split writes and the reducer reads back (8 bytes per output element at ~3 TB/s) -
   // 1.3 phases per split on the 4x4 maps at B = 128, 0.16 at B = 16, where splitting deeper is what fills the chip
-  const double per_split = 8.0 * (double)g->B * g->H * g->W * out_channels / 3.0e12 / 2.1e-6;
+  const double per_split = (fused ? 6.0 : 8.0) * (double)g->B * g->H * g->W * out_channels / 3.0e12 / 2.1e-6;
   long s = 1;
   double best = 1e30;
   for (long c = 1; c <= smax; ++c) {
     const long pps = (phases + c - 1) / c;
     if ((phases + pps - 1) / pps != c) continue;
     const double rounds = (double)((base * c + 255) / 256);
-    const double cost = rounds * ((double)pps + 1.5) + (c > 1 ? 2.4 : 0.0) + per_split * (double)(c - 1);
+    const double cost = rounds * ((double)pps + 1.5) + (c > 1 ? (fused ? 0.2 : 2.4) : 0.0) + per_split * (double)(c - 1);
     if (cost < best - 1e-9) {
       best = cost;
       s = c;
@@ -754,11 +768,16 @@ int lgm_wino_splits(const LgmConvGeom* g, int gather_channels, int out_channels)
   return (int)s;
 }
 
-int lgm_wino_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, const float* u, const float* bias,
-                    const float* res, long res_pitch, float* out, long out_pitch, void* workspace,
-                    long workspace_bytes, hipStream_t s) {
+// partial (optional, int64 x 2): the caller's consumer sums the split-K planes itself.  On return partial[0] = number
+// of planes left in `workspace` (1: none, `out` is complete with bias / residual applied), partial[1] = plane stride
+// in floats; with planes, `out`, `bias` and `res` are NOT touched / applied.
+// arguments, grid and unit class of one forward / input-gradient launch
+static void wino_prepare(const LgmConvGeom* g, int yx, const float* a, long a_pitch, const float* u, const float* bias,
+                         const float* res, long res_pitch, float* out, long out_pitch, void* workspace,
+                         long workspace_bytes, bool fused, lgmwino::Args& p, unsigned* nblocks_out, int* ttw_out,
+                         int force_splits = 0) {
   using namespace lgmwino;
-  Args p{};
+  p = Args{};
   p.a = a; p.u = u; p.bias = bias; p.res = res; p.out = out;
   p.a_pitch = a_pitch; p.res_pitch = res_pitch; p.out_pitch = out_pitch;
   p.B = g->B; p.H = g->H; p.W = g->W;
@@ -770,7 +789,7 @@ int lgm_wino_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, 
   p.tb_w = g->W / (2 * TTW);
   p.tiles_n = p.N / 64;
   const long M = (long)g->B * g->H * g->W;
-  p.splits = lgm_wino_splits(g, p.C, p.N);
+  p.splits = force_splits > 0 ? force_splits : lgm_wino_splits(g, p.C, p.N, fused);
   if (p.splits > 1) {
     const long need = (long)p.splits * M * p.N * (long)sizeof(float);
     if (!workspace || workspace_bytes < need || !lgm_aligned16(workspace)) p.splits = 1;
@@ -781,7 +800,20 @@ int lgm_wino_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, 
   p.splits = lgm_cdiv(p.C / KC, p.pps);
   p.units = (int)((long)(g->B / NI) * p.tb_h * p.tb_w * p.tiles_n * p.splits);
   p.per = lgm_cdiv(p.units, 256);
-  const unsigned nblocks = (unsigned)lgm_cdiv(p.units, p.per);
+  *nblocks_out = (unsigned)lgm_cdiv(p.units, p.per);
+  *ttw_out = TTW;
+}
+
+int lgm_wino_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, const float* u, const float* bias,
+                    const float* res, long res_pitch, float* out, long out_pitch, void* workspace,
+                    long workspace_bytes, hipStream_t s, int64_t* partial = nullptr) {
+  using namespace lgmwino;
+  Args p;
+  unsigned nblocks;
+  int TTW;
+  wino_prepare(g, yx, a, a_pitch, u, bias, res, res_pitch, out, out_pitch, workspace, workspace_bytes, partial != nullptr,
+               p, &nblocks, &TTW);
+  const long M = (long)g->B * g->H * g->W;
   p.dbg = (long long*)lgm_wino_debug_buffer;
   p.dbg_mode = lgm_wino_debug_mode & 15;
   const int e = p.dbg ? (lgm_wino_debug_mode >> 4) : 0;
@@ -817,6 +849,12 @@ int lgm_wino_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, 
     LGM_WLAUNCH(2, true, 0);
   }
 #undef LGM_WLAUNCH
+  if (partial) {
+    partial[0] = p.splits;
+    partial[1] = p.ws_stride;
+    LGM_LAUNCH_CHECK();
+    return LGM_OK;
+  }
   if (p.splits > 1)
     return lgm_splitk_reduce_launch(p.ws, p.ws_stride, p.splits, bias, res, res_pitch, out, out_pitch, M, p.N, s);
   LGM_LAUNCH_CHECK();
@@ -824,6 +862,13 @@ int lgm_wino_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, 
 }
 
 // ---- C-ABI ------------------------------------------------------------------------------------
+// every tensor the kernel addresses with 32-bit byte offsets fits (pitched operands: the caller's pitches)
+extern "C" int64_t lgm_conv3x3_wino_fits(const LgmConvGeom* g, int64_t a_pitch, int64_t out_pitch, int64_t res_pitch) {
+  if (!g) return 0;
+  const long pix = (long)g->B * g->H * g->W + g->W + 1;
+  return (pix * a_pitch < (1L << 29) && pix * out_pitch < (1L << 29) && pix * res_pitch < (1L << 29)) ? 1 : 0;
+}
+
 extern "C" int64_t lgm_conv3x3_wino_supported(const LgmConvGeom* g, int yx) {
   if (!g) return 0;
   return lgm_wino_supported(g, yx ? g->Nw : g->Cw, yx ? g->Cw : g->Nw) ? 1 : 0;
@@ -834,6 +879,14 @@ extern "C" int64_t lgm_conv3x3_wino_workspace(const LgmConvGeom* g, int yx) {
   const int gc = yx ? g->Nw : g->Cw, oc = yx ? g->Cw : g->Nw;
   if (!lgm_wino_supported(g, gc, oc)) return 0;
   const int s = lgm_wino_splits(g, gc, oc);
+  return s > 1 ? (int64_t)s * g->B * g->H * g->W * oc * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int64_t lgm_conv3x3_wino_workspace_partial(const LgmConvGeom* g, int yx) {
+  if (!g) return -1;
+  const int gc = yx ? g->Nw : g->Cw, oc = yx ? g->Cw : g->Nw;
+  if (!lgm_wino_supported(g, gc, oc)) return 0;
+  const int s = lgm_wino_splits(g, gc, oc, true);
   return s > 1 ? (int64_t)s * g->B * g->H * g->W * oc * (int64_t)sizeof(float) : 0;
 }
 
@@ -856,9 +909,23 @@ extern "C" int lgm_conv3x3_wino(int yx, const LgmConvGeom* g, const float* a, in
   LGM_REQUIRE(a_pitch % 4 == 0 && a_pitch >= gc && lgm_aligned16(a) && lgm_aligned16(u) && lgm_aligned16(out) &&
               out_pitch % 4 == 0 && out_pitch >= oc && (!res || (lgm_aligned16(res) && res_pitch % 4 == 0 && res_pitch >= oc)) &&
               (!bias || lgm_aligned16(bias)), "conv3x3_wino: 16-byte aligned operands with pitch %% 4 == 0 expected");
-  LGM_REQUIRE(((long)g->B * g->H * g->W + g->W + 1) * a_pitch < (1L << 29), "conv3x3_wino: tensor too large for 32-bit offsets");
+  LGM_REQUIRE(lgm_conv3x3_wino_fits(g, a_pitch, out_pitch, res ? res_pitch : 0), "conv3x3_wino: tensor too large for 32-bit offsets");
   return lgm_wino_launch(g, yx, a, a_pitch, u, bias, res, res_pitch, out, out_pitch, workspace, workspace_bytes,
                          (hipStream_t)stream);
+}
+
+extern "C" int lgm_conv3x3_wino_partial(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,
+                                        const float* bias, float* out, int64_t out_pitch, void* workspace,
+                                        int64_t workspace_bytes, int64_t* partial, void* stream) {
+  LGM_REQUIRE(g && a && u && out && partial, "conv3x3_wino_partial: null pointer");
+  const int gc = yx ? g->Nw : g->Cw, oc = yx ? g->Cw : g->Nw;
+  LGM_REQUIRE(lgm_wino_supported(g, gc, oc), "conv3x3_wino_partial: unsupported geometry");
+  LGM_REQUIRE(a_pitch % 4 == 0 && a_pitch >= gc && lgm_aligned16(a) && lgm_aligned16(u) && lgm_aligned16(out) &&
+              out_pitch % 4 == 0 && out_pitch >= oc && (!bias || lgm_aligned16(bias)),
+              "conv3x3_wino_partial: 16-byte aligned operands with pitch %% 4 == 0 expected");
+  LGM_REQUIRE(lgm_conv3x3_wino_fits(g, a_pitch, out_pitch, 0), "conv3x3_wino_partial: tensor too large for 32-bit offsets");
+  return lgm_wino_launch(g, yx, a, a_pitch, u, bias, nullptr, 0, out, out_pitch, workspace, workspace_bytes,
+                         (hipStream_t)stream, partial);
 }
 
 // =====================================================================================================
@@ -902,11 +969,11 @@ constexpr int YLD = 36;     // floats per output channel in a Y buffer (4 rows x
 constexpr int WXBUF = 64 * XLD, WYBUF = 64 * YLD, WBUF = WXBUF + WYBUF;
 
 template <int G, bool DBG = false>
-__global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WGArgs p) {
+__device__ __forceinline__ void wino_wgrad_body(const WGArgs& p, const int bidx) {
   int nstamp = 0;
   auto stamp = [&]() {
     if (DBG) {
-      if (threadIdx.x == 0 && nstamp < 62) p.dbg[blockIdx.x * 64 + 2 + nstamp] = (long long)__builtin_amdgcn_s_memtime();
+      if (threadIdx.x == 0 && nstamp < 62) p.dbg[bidx * 64 + 2 + nstamp] = (long long)__builtin_amdgcn_s_memtime();
       ++nstamp;
     }
   };
@@ -919,7 +986,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WGArgs p) {
   const int wa = wid & 1, wb = wid >> 1;            // input-channel half (A operand), output-channel half (B)
   const int lr = lane & 31, lh = lane >> 5;
 
-  int bid = blockIdx.x;
+  int bid = bidx;
   const int split = bid % p.splits;
   bid /= p.splits;
   const int tc = bid % p.tiles_c, tn = bid / p.tiles_c;
@@ -1243,7 +1310,24 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WGArgs p) {
     if (lh == 0) out[(long)p.Nw * 9 * p.Cw + n0 + wb * 32 + lr] = v;
   }
   stamp();
-  if (DBG && threadIdx.x == 0) p.dbg[blockIdx.x * 64] = nstamp;
+  if (DBG && threadIdx.x == 0) p.dbg[bidx * 64] = nstamp;
+}
+
+template <int G, bool DBG = false>
+__global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WGArgs p) {
+  wino_wgrad_body<G, DBG>(p, (int)blockIdx.x);
+}
+
+// Backward PAIR: the input gradient (blocks [0, nconv)) and the weight gradient (the rest) of ONE 3x3 layer in ONE
+// launch.  Both read the same output gradient and neither reads what the other writes.  At the per-GPU batches of a
+// strong-scaled run (16 ... 64 images) each of them fills a quarter to a half of the chip's 256 CUs and is bounded
+// by its own prologue / epilogue latency: side by side they take the time of one.  (Two streams or parallel graph
+// branches do not achieve this on this runtime - measured slower at every batch, DESIGN.md section 4 - a single
+// launch has no fork / join to pay for.)  Same code, same arithmetic as the separate kernels: bit-identical results.
+template <int G>
+__global__ __launch_bounds__(256, 1) void wino_bwd_pair_kernel(const Args pc, const WGArgs pw, const int nconv) {
+  if ((int)blockIdx.x < nconv) wino_conv_body<G, false, 0>(pc, (int)blockIdx.x, nconv);
+  else wino_wgrad_body<G, false>(pw, (int)blockIdx.x - nconv);
 }
 
 static bool wgrad_class(int H, int W, int* G, int* ipc) {
@@ -1294,16 +1378,22 @@ void lgm_wino_wgrad_plan(const LgmConvGeom* g, int* splits, int* cps, int* total
   *total_chunks = (int)chunks;
 }
 
-int lgm_wino_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch, float* out,
-                          int bias, long slab, int splits, int cps, int total_chunks, hipStream_t s) {
-  using namespace lgmwino;
-  WGArgs p{};
+static void wino_wgrad_prepare(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch, float* out,
+                               int bias, long slab, int splits, int cps, int total_chunks, lgmwino::WGArgs& p) {
+  p = lgmwino::WGArgs{};
   p.y = y; p.x = x; p.out = out; p.bias = bias; p.slab = slab; p.y_pitch = y_pitch; p.x_pitch = x_pitch;
   p.B = g->B; p.H = g->H; p.W = g->W; p.Nw = g->Nw; p.Cw = g->Cw;
   p.tiles_c = g->Cw / 64;
   p.splits = splits; p.cps = cps; p.total_chunks = total_chunks;
   p.rpn = g->H / 4;
   p.cgn = g->W >= 16 ? g->W / 16 : 1;
+}
+
+int lgm_wino_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch, float* out,
+                          int bias, long slab, int splits, int cps, int total_chunks, hipStream_t s) {
+  using namespace lgmwino;
+  WGArgs p;
+  wino_wgrad_prepare(g, y, y_pitch, x, x_pitch, out, bias, slab, splits, cps, total_chunks, p);
   int G, ipc;
   wgrad_class(g->H, g->W, &G, &ipc);
   const unsigned nblocks = (unsigned)((g->Nw / 64) * (g->Cw / 64) * splits);
@@ -1330,6 +1420,157 @@ int lgm_wino_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, co
   else if (G == 4) LGM_WGL(4);
   else LGM_WGL(2);
 #undef LGM_WGL
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// Joint plan of the backward pair.  Standing alone, each kernel splits its reduction until ITS grid fills the 256 CUs;
+// side by side that is two rounds again.  Here the two split counts are chosen together: the launch takes about
+//   max( (sum over both grids of blocks x time per block) / 256 CUs,  the longest single block )
+// in units of one phase / chunk (64 MFMAs per wave, ~2.1 us), plus what the splits cost afterwards: the input
+// gradient's partial planes (written, then read by the reducer or the consuming GroupNorm) and the weight gradient's
+// slabs (written by the kernel, read by the batched slab reducer).
+struct WinoPairPlan {
+  int csplits, wsplits, cps, total_chunks;
+};
+static WinoPairPlan wino_pair_plan_search(const LgmConvGeom* g, bool fused);
+WinoPairPlan lgm_wino_pair_plan(const LgmConvGeom* g, bool fused) {
+  // the search below costs ~1 ms: once per geometry and thread
+  struct Key {
+    int B, H, W, C, N, f;
+    bool operator==(const Key& o) const { return B == o.B && H == o.H && W == o.W && C == o.C && N == o.N && f == o.f; }
+  };
+  thread_local Key keys[64];
+  thread_local WinoPairPlan plans[64];
+  thread_local int n = 0;
+  const Key k{g->B, g->H, g->W, g->Cw, g->Nw, fused ? 1 : 0};
+  for (int i = 0; i < n; ++i)
+    if (keys[i] == k) return plans[i];
+  const WinoPairPlan p = wino_pair_plan_search(g, fused);
+  if (n < 64) {
+    keys[n] = k;
+    plans[n] = p;
+    ++n;
+  }
+  return p;
+}
+static WinoPairPlan wino_pair_plan_search(const LgmConvGeom* g, bool fused) {
+  using namespace lgmwino;
+  WinoPairPlan best{1, 2, 1, 2};
+  int TTH, TTW, NI, G, ipc;
+  plan_unit(g->H, g->W, &TTH, &TTW, &NI);
+  wgrad_class(g->H, g->W, &G, &ipc);
+  const int gc = g->Nw, oc = g->Cw;                       // input gradient: reduces over Nw, produces Cw
+  const long base = (long)(g->B / NI) * (g->H / (2 * TTH)) * (g->W / (2 * TTW)) * (oc / 64);
+  const int phases = gc / KC;
+  long cmax = phases / 2 < 32 ? phases / 2 : 32;
+  if (cmax < 1 || base >= 1024) cmax = 1;
+  const double per_split = (fused ? 6.0 : 8.0) * (double)g->B * g->H * g->W * oc / 3.0e12 / 2.1e-6;
+  const long chunks = (long)(g->B / ipc) * (g->H / 4) * (g->W >= 16 ? g->W / 16 : 1) * 2;
+  const long blocks = (long)(g->Nw / 64) * (g->Cw / 64);
+  long smax = chunks / 2 < 256 ? chunks / 2 : 256;
+  if (smax < 2) smax = 2;
+  // per slab: read back by the batched slab reducer at HBM rate (its write rides in the kernel's epilogue)
+  const double slab_cost = 4.0 * ((double)g->Nw * 9 * g->Cw + g->Nw) / 4.5e12 / 2.1e-6;
+  // makespan of n1 blocks of t1 followed by n2 blocks of t2 on 256 CUs, one block per CU, dispatched in order
+  auto makespan = [](long n1, double t1, long n2, double t2) {
+    const long P = 256;
+    const long r1 = n1 / P, m1 = n1 % P;
+    double ta = (double)r1 * t1;                 // the P - m1 CUs without a block of the last conv round
+    double tb = (double)(r1 + (m1 ? 1 : 0)) * t1;
+    const long ca = P - m1, cb = m1;
+    double end = tb > ta ? tb : ta;
+    if (n1 == 0) end = 0.0;
+    long left = n2;
+    while (left > 0) {                           // next free group takes blocks; merge of two arithmetic sequences
+      if (cb == 0 || ta <= tb) {
+        const long take = left < ca ? left : ca;
+        ta += t2;
+        left -= take;
+        if (ta > end) end = ta;
+      } else {
+        const long take = left < cb ? left : cb;
+        tb += t2;
+        left -= take;
+        if (tb > end) end = tb;
+      }
+    }
+    return end;
+  };
+  double bestc = 1e30;
+  for (long c = 1; c <= cmax; ++c) {
+    const long pps = (phases + c - 1) / c;
+    if ((phases + pps - 1) / pps != c) continue;
+    const double tc = (double)pps + 1.5;
+    const double conv_after = (c > 1 ? (fused ? 0.2 : 2.4) : 0.0) + per_split * (double)(c - 1);
+    for (long w = 2; w <= smax; ++w) {
+      const long per = (chunks + w - 1) / w;
+      if ((chunks + per - 1) / per != w) continue;
+      const double tw = (double)per + 3.0;
+      const double cost = makespan(base * c, tc, blocks * w, tw) + conv_after + slab_cost * (double)w;
+      if (cost < bestc - 1e-9) {
+        bestc = cost;
+        best = WinoPairPlan{(int)c, (int)w, (int)per, (int)chunks};
+      }
+    }
+  }
+  return best;
+}
+
+// One launch for the input gradient and the weight gradient of a 3x3 layer (wino_bwd_pair_kernel).  The split-K
+// reducer of the input gradient (when it split and the consumer does not sum the planes itself) follows as usual.
+// slab_stride = floats between two slabs; the slabs (lgm_wino_pair_plan(...).wsplits of them) go to `slabs`.
+int lgm_wino_pair_launch(const LgmConvGeom* g, const float* gy, long gy_pitch, const float* x, long x_pitch,
+                         const float* u_b, const float* res, long res_pitch, float* gx, long gx_pitch, void* dws,
+                         long dws_bytes, int64_t* partial, float* slabs, int bias, long slab, hipStream_t s) {
+  using namespace lgmwino;
+  const WinoPairPlan pl = lgm_wino_pair_plan(g, partial != nullptr);
+  Args pc;
+  unsigned nconv;
+  int TTW;
+  wino_prepare(g, 1, gy, gy_pitch, u_b, nullptr, res, res_pitch, gx, gx_pitch, dws, dws_bytes, partial != nullptr, pc,
+               &nconv, &TTW, pl.csplits);
+  pc.dbg = nullptr;
+  pc.dbg_mode = 0;
+  WGArgs pw;
+  wino_wgrad_prepare(g, gy, gy_pitch, x, x_pitch, slabs, bias, slab, pl.wsplits, pl.cps, pl.total_chunks, pw);
+  pw.dbg = nullptr;
+  int G, ipc;
+  wgrad_class(g->H, g->W, &G, &ipc);
+  if (G != TTW) {
+    lgm_set_error("wino_pair: map classes of the two kernels differ (%d vs %d)", G, TTW);
+    return LGM_ERR_UNSUPPORTED;
+  }
+  const unsigned nw = (unsigned)((g->Nw / 64) * (g->Cw / 64) * pl.wsplits);
+  const size_t smem_w = (size_t)3 * WBUF * sizeof(float);
+#define LGM_PAIR(GG)                                                                                             \
+  do {                                                                                                           \
+    auto kern = wino_bwd_pair_kernel<GG>;                                                                        \
+    size_t smem = ((size_t)12 * Geo<GG>::RPLANE) * sizeof(float);                                                \
+    if (smem_w > smem) smem = smem_w;                                                                            \
+    static bool attr = false;                                                                                    \
+    if (!attr) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)smem);                                                                      \
+      attr = true;                                                                                               \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kern, dim3(nconv + nw), dim3(256), smem, s, pc, pw, (int)nconv);                          \
+  } while (0)
+  lgm_note_kernel(G == 8 ? "lgmwino::wino_bwd_pair_kernel<8>" : G == 4 ? "lgmwino::wino_bwd_pair_kernel<4>"
+                                                                        : "lgmwino::wino_bwd_pair_kernel<2>");
+  if (G == 8) LGM_PAIR(8);
+  else if (G == 4) LGM_PAIR(4);
+  else LGM_PAIR(2);
+#undef LGM_PAIR
+  const long M = (long)g->B * g->H * g->W;
+  if (partial) {
+    partial[0] = pc.splits;
+    partial[1] = pc.ws_stride;
+    LGM_LAUNCH_CHECK();
+    return LGM_OK;
+  }
+  if (pc.splits > 1)
+    return lgm_splitk_reduce_launch(pc.ws, pc.ws_stride, pc.splits, nullptr, res, res_pitch, gx, gx_pitch, M, pc.N, s);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

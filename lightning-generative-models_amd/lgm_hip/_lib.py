@@ -56,6 +56,14 @@ def parse_header(path: str = HEADER_PATH):
     return protos
 
 
+def header_abi_version(path: str = HEADER_PATH) -> int:
+    m = re.search(r"#define\s+LGM_ABI_VERSION\s+(\d+)", open(path).read())
+    return int(m.group(1))
+
+
+ABI_VERSION = header_abi_version()
+
+
 class LgmError(RuntimeError):
     pass
 
@@ -72,6 +80,11 @@ class _Lib:
         import torch  # noqa: F401
         self._dll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
+        self._dll.lgm_abi_version.restype = ctypes.c_int
+        built = self._dll.lgm_abi_version()
+        if built != ABI_VERSION:      # a stale .so against a newer header: signatures would be mis-bound silently
+            raise ImportError(f"{LIB_PATH} was built for ABI {built}, include/lgm_hip.h declares {ABI_VERSION}: "
+                              "rebuild it (python __graft_entry__.py build)")
         self._dll.lgm_last_error.restype = ctypes.c_char_p
         self._dll.lgm_last_kernel.restype = ctypes.c_char_p
         for name, (res, args) in self.protos.items():

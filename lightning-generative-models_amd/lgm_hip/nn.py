@@ -85,6 +85,20 @@ class Conv2d(nn.Module):
         g = self.geom(B, H, W)
         return (B, g.Ho, g.Wo, _r4(self.cout))
 
+    def fwd_planes(self, x, groups: int):
+        """Forward for a consumer that is a GroupNorm(groups): returns (y, planes).  planes = None: y is complete;
+        else the convolution split its reduction and left its result as partial planes (ops.conv_xy partial=True) that
+        the GroupNorm sums itself (GroupNorm.fwd(..., planes=planes) also writes the finished y)."""
+        B, H, W, C = x.shape
+        assert C == _r4(self.cin), f"conv expects {_r4(self.cin)} (padded) channels, got {C}"
+        g = self.geom(B, H, W)
+        fp = _flat(self.weight)
+        y = ops.new((B, g.Ho, g.Wo, _r4(self.cout)), x)
+        ok = self.k == 3 and ops.gn_planes_ok(B, g.Ho * g.Wo, _r4(self.cout), groups)
+        pl = ops.conv_xy(g, x, fp.ptr(self.weight), fp.ptr(self.bias) if self.bias is not None else None, None, y,
+                         partial=ok)
+        return y, pl
+
     def fwd(self, x, out=None, res=None, stats=False):
         """stats=True (bias-free convolution feeding a train-mode BatchNorm): returns (y, (partials, tiles)) with the
         batch statistics of y left behind by the convolution's epilogue (tiles == 0: not for this geometry)."""
@@ -98,8 +112,10 @@ class Conv2d(nn.Module):
         ops.conv_xy(g, x, fp.ptr(self.weight), fp.ptr(self.bias) if self.bias is not None else None, res, y)
         return (y, (None, 0)) if stats else y
 
-    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None):
-        """gW, gb into flat grads; returns gx = dgrad(gy) (+ res) (+ existing gx when accumulate)."""
+    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None, planes_for_groups=0):
+        """gW, gb into flat grads; returns gx = dgrad(gy) (+ res) (+ existing gx when accumulate).
+        ``planes_for_groups`` = G > 0: the only reader of gx is the backward of a GroupNorm(G) - returns (gx, planes) as
+        ``fwd_planes`` does (planes given: gx itself is NOT written)."""
         B, H, W, _ = x.shape
         g = self.geom(B, H, W)
         fp = gc.flat
@@ -112,6 +128,17 @@ class Conv2d(nn.Module):
                 gb = fp.gptr(self.bias)              # bias gradient fused into the wgrad kernel
             else:
                 ops.colsum(gy, fp.gptr(self.bias), bb)
+        if need_gx and self.k == 3:
+            # 3x3 layers: input gradient and weight gradient side by side in ONE launch (ops.conv_bwd_pair)
+            if gx is None:
+                gx = ops.new(x.shape, x)
+                accumulate = False
+            pres = gx if accumulate else res
+            assert not (accumulate and res is not None)
+            ok_pl = bool(planes_for_groups) and pres is None and ops.gn_planes_ok(B, H * W, x.shape[-1], planes_for_groups)
+            r = ops.conv_bwd_pair(g, gy, x, fp.ptr(self.weight), fp.gptr(self.weight), bw, gb, dfr, pres, gx, partial=ok_pl)
+            if r is not False:
+                return (gx, r) if planes_for_groups else gx
         ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=dfr)
         if not need_gx:
             return None
@@ -121,6 +148,9 @@ class Conv2d(nn.Module):
         if accumulate:
             assert res is None
             res = gx
+        if planes_for_groups:
+            ok = self.k == 3 and res is None and ops.gn_planes_ok(B, H * W, x.shape[-1], planes_for_groups)
+            return gx, ops.conv_yx(g, gy, fp.ptr(self.weight), None, res, gx, fp.tptr(self.weight), partial=ok)
         ops.conv_yx(g, gy, fp.ptr(self.weight), None, res, gx, fp.tptr(self.weight))
         return gx
 
@@ -253,20 +283,23 @@ class GroupNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(channels))
         self.bias = nn.Parameter(torch.zeros(channels))
 
-    def fwd(self, x, ss, act, res, out=None):
+    def fwd(self, x, ss, act, res, out=None, planes=None):
+        """``planes`` (from Conv2d.fwd_planes): x arrives as split-K partial planes; summed, written to x and
+        normalised in one pass."""
         fp = _flat(self.weight)
         y = out if out is not None else ops.new(x.shape, x)
-        sv = ops.gn_fwd(x, self.groups, self.eps, fp.ptr(self.weight), fp.ptr(self.bias), ss, act, res, y)
+        sv = ops.gn_fwd(x, self.groups, self.eps, fp.ptr(self.weight), fp.ptr(self.bias), ss, act, res, y, planes=planes)
         return y, sv
 
-    def bwd(self, gc: GradCtx, x, gy, ss, act, sv, gss, gx=None, accumulate=False):
+    def bwd(self, gc: GradCtx, x, gy, ss, act, sv, gss, gx=None, accumulate=False, gy_planes=None):
         fp = gc.flat
         if gx is None:
             gx = ops.new(x.shape, x)
             accumulate = False
         dfr = gc.defer_for(self.weight)
         ops.gn_bwd(x, gy, self.groups, fp.ptr(self.weight), fp.ptr(self.bias), ss, act, sv, gx, accumulate,
-                   fp.gptr(self.weight), fp.gptr(self.bias), gc.beta(self.weight), gss, 0.0, defer=dfr)
+                   fp.gptr(self.weight), fp.gptr(self.bias), gc.beta(self.weight), gss, 0.0, defer=dfr,
+                   gy_planes=gy_planes)
         gc.beta(self.bias)
         return gx
 

@@ -216,18 +216,38 @@ def _wino_supported(g: ConvGeom, yx: int) -> bool:
     return v
 
 
-def _wino_call(yx: int, g: ConvGeom, a, u_ptr: int, bias_ptr, res, out) -> bool:
-    """Launch the Winograd kernel when the operands qualify (16-byte aligned, pitch % 4); False = not taken."""
+_WINO_FITS = {}
+
+
+def _wino_call(yx: int, g: ConvGeom, a, u_ptr: int, bias_ptr, res, out, partial: bool = False):
+    """Launch the Winograd kernel when the operands qualify (16-byte aligned, pitch % 4, 32-bit offsets); False = not
+    taken (the caller falls back to the direct kernel).  ``partial``: the split-K planes are left for the consumer
+    (GroupNorm) to sum - returns (planes address, plane stride in floats, planes) or, when the launch did not split,
+    True (``out`` complete)."""
     if a.data_ptr() % 16 or out.data_ptr() % 16 or pitch(a) % 4 or pitch(out) % 4 or (bias_ptr or 0) % 16:
         return False
     if res is not None and (res.data_ptr() % 16 or pitch(res) % 4):
         return False
-    key = (g.B, g.H, g.W, g.Cw, g.Nw, yx)
+    fkey = (g.B, g.H, g.W, pitch(a), pitch(out), pitch(res) if res is not None else 0)
+    fits = _WINO_FITS.get(fkey)
+    if fits is None:
+        fits = bool(lib().lgm_conv3x3_wino_fits(ctypes.byref(g), fkey[3], fkey[4], fkey[5]))
+        _WINO_FITS[fkey] = fits
+    if not fits:
+        return False
+    key = (g.B, g.H, g.W, g.Cw, g.Nw, yx, partial)
     n = _WINO_WS.get(key)
     if n is None:
-        n = lib().lgm_conv3x3_wino_workspace(ctypes.byref(g), yx)
+        n = (lib().lgm_conv3x3_wino_workspace_partial if partial else lib().lgm_conv3x3_wino_workspace)(ctypes.byref(g), yx)
         _WINO_WS[key] = n
     ws = workspace(n, a.device) if n > 0 else None
+    if partial:
+        assert res is None
+        part = (ctypes.c_int64 * 2)()
+        lib().lgm_conv3x3_wino_partial(yx, ctypes.byref(g), a.data_ptr(), pitch(a), u_ptr, bias_ptr, out.data_ptr(),
+                                       pitch(out), None if ws is None else ws.data_ptr(),
+                                       0 if ws is None else ws.numel() * 4, ctypes.addressof(part), stream())
+        return (ws.data_ptr(), int(part[1]), int(part[0])) if part[0] > 1 else True
     lib().lgm_conv3x3_wino(yx, ctypes.byref(g), a.data_ptr(), pitch(a), u_ptr, bias_ptr, _p(res),
                            pitch(res) if res is not None else 0, out.data_ptr(), pitch(out),
                            None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
@@ -243,15 +263,23 @@ def _conv_ws(g: ConvGeom, yx: int, device):
     return workspace(n, device) if n > 0 else None
 
 
-def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y):
+PLANES = _os.environ.get("LGM_NO_PLANES", "0") != "1"     # A/B switch: GroupNorm sums split-K partial planes itself
+
+
+def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y, partial: bool = False):
+    """``partial=True`` (the consumer is a GroupNorm that can sum split-K planes, see gn_fwd): returns
+    (planes address, plane stride, planes, bias address) when the convolution left its result in pieces - ``y`` is then
+    NOT written and the bias NOT applied - else None (``y`` complete)."""
     if TIMER is not None:
         TIMER.begin("igemm_xy", _conv_flops(g), _conv_bytes(g))
     if WINO and _WINO_FLATS and not B3 and _wino_supported(g, 0):
         u = _wino_u(w_ptr, False)
-        if u is not None and _wino_call(0, g, x, u, bias_ptr, res, y):
-            if TIMER is not None:
-                TIMER.end()
-            return
+        if u is not None:
+            r = _wino_call(0, g, x, u, bias_ptr, res, y, partial and PLANES and res is None)
+            if r:
+                if TIMER is not None:
+                    TIMER.end()
+                return None if r is True else r + (bias_ptr,)
     ws = _conv_ws(g, 0, x.device)
     pl = _b3_planes(w_ptr, False) if (B3 and _b3_supported(g, 0, pitch(x))) else None
     if pl is not None:
@@ -290,15 +318,19 @@ def conv_stats(yx: int, g: ConvGeom, a, w_ptr: int, out, wt_ptr: Optional[int] =
     return stats, int(nt.value)
 
 
-def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr: Optional[int] = None):
+def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr: Optional[int] = None,
+            partial: bool = False):
+    """``partial``: as conv_xy."""
     if TIMER is not None:
         TIMER.begin("igemm_yx", _conv_flops(g), _conv_bytes(g))
     if WINO and _WINO_FLATS and not B3 and _wino_supported(g, 1):
         u = _wino_u(w_ptr, True)
-        if u is not None and _wino_call(1, g, y, u, bias_ptr, res, x):
-            if TIMER is not None:
-                TIMER.end()
-            return
+        if u is not None:
+            r = _wino_call(1, g, y, u, bias_ptr, res, x, partial and PLANES and res is None)
+            if r:
+                if TIMER is not None:
+                    TIMER.end()
+                return None if r is True else r + (bias_ptr,)
     ws = _conv_ws(g, 1, y.device)
     pl = _b3_planes(wt_ptr, True) if (B3 and wt_ptr is not None and _b3_supported(g, 1, pitch(y))) else None
     if pl is not None:
@@ -345,6 +377,84 @@ def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[
         TIMER.end()
 
 
+_PAIR_OK = {}
+
+
+def conv_bwd_pair(g: ConvGeom, gy, x, w_ptr: int, gw_ptr: int, beta: float, gbias_ptr: Optional[int], defer, res, gx,
+                  partial: bool = False):
+    """Input gradient AND weight gradient of a 3x3 layer in ONE launch (lgm_conv3x3_wino_bwd): at small per-GPU batches
+    each of the two fills a fraction of the chip and is latency-bound; side by side they take the time of one.
+    Returns False when the pair kernel does not take this layer (the caller issues conv_wgrad + conv_yx), else None
+    or, with ``partial``, the planes tuple of conv_yx(partial=True)."""
+    if not (WINO and _WINO_FLATS and not B3) or g.KH != 3 or g.KW != 3:
+        return False
+    u = _wino_u(w_ptr, True)
+    if u is None:
+        return False
+    if gy.data_ptr() % 16 or x.data_ptr() % 16 or gx.data_ptr() % 16 or (gbias_ptr or 0) % 16 or gw_ptr % 16:
+        return False
+    if res is not None and res.data_ptr() % 16:
+        return False
+    key = (g.B, g.H, g.W, g.Cw, g.Nw, pitch(gy), pitch(x), pitch(gx), pitch(res) if res is not None else 0)
+    ok = _PAIR_OK.get(key)
+    if ok is None:
+        ok = bool(lib().lgm_conv3x3_wino_bwd_supported(ctypes.byref(g), key[5], key[6], key[7], key[8]))
+        _PAIR_OK[key] = ok
+    if not ok:
+        return False
+    L = lib()
+    partial = bool(partial and PLANES and res is None)
+    wkey = (g.B, g.H, g.W, g.Cw, g.Nw, "pair", partial)
+    sizes = _WINO_WS.get(wkey)
+    if sizes is None:
+        two = (ctypes.c_int64 * 2)()
+        L.lgm_conv3x3_wino_bwd_workspaces(ctypes.byref(g), 1 if partial else 0, ctypes.addressof(two))
+        sizes = (int(two[0]), int(two[1]))
+        _WINO_WS[wkey] = sizes
+    n, nbytes = sizes
+    dws = workspace(n, gy.device) if n > 0 else None
+    if TIMER is not None:
+        TIMER.begin("bwd_pair", 2.0 * _conv_flops(g), 2.0 * _conv_bytes(g))
+    if defer is None:
+        # the slabs must not share the generic workspace with the input gradient's split-K planes
+        wws = _pair_slabs(nbytes, gy.device)
+        desc = None
+    else:
+        k2 = (gw_ptr, nbytes)
+        wws = _WGRAD_WS.get(k2)
+        if wws is None:
+            wws = torch.empty(max(nbytes // 4 + 4, 16), dtype=torch.float32, device=gy.device)
+            _WGRAD_WS[k2] = wws
+        desc = (ctypes.c_int64 * 8)()
+    part = (ctypes.c_int64 * 2)() if partial else None
+    L.lgm_conv3x3_wino_bwd(ctypes.byref(g), gy.data_ptr(), pitch(gy), x.data_ptr(), pitch(x), u, _p(res),
+                           pitch(res) if res is not None else 0, gx.data_ptr(), pitch(gx),
+                           None if dws is None else dws.data_ptr(), 0 if dws is None else dws.numel() * 4,
+                           None if part is None else ctypes.addressof(part), gw_ptr, gbias_ptr, beta, wws.data_ptr(),
+                           wws.numel() * 4, None if desc is None else ctypes.addressof(desc), stream())
+    if TIMER is not None:
+        TIMER.end()
+    if desc is not None and desc[6] > 1:
+        defer.append(tuple(desc))
+    if part is not None and part[0] > 1:
+        return (dws.data_ptr(), int(part[1]), int(part[0]), None)
+    return None
+
+
+_PAIR_SLABS = {}
+
+
+def _pair_slabs(nbytes: int, device) -> torch.Tensor:
+    key = torch.device(device).index or 0
+    ws = _PAIR_SLABS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _WS_RETIRED.append(ws)
+        ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=device)
+        _PAIR_SLABS[key] = ws
+    return ws
+
+
 def wgrad_reduce_batch(rows, device):
     """One launch: fixed-order reduction of the partial slabs of every deferred weight gradient in ``rows``."""
     if not rows:
@@ -381,12 +491,49 @@ class GNSaved:
     __slots__ = ("mean", "rstd", "A", "Bc")
 
 
-def gn_fwd(x, G, eps, gamma_ptr, beta_ptr, ss, act: bool, res, y) -> GNSaved:
+_GN_PLANES_OK = {}
+
+
+def gn_planes_ok(B, HW, C, G) -> bool:
+    """The one-pass GroupNorm kernels (forward AND backward) exist for this shape: they can sum split-K planes."""
+    key = (B, HW, C, G)
+    v = _GN_PLANES_OK.get(key)
+    if v is None:
+        v = bool(lib().lgm_gn_planes_supported(B, HW, C, G))
+        _GN_PLANES_OK[key] = v
+    return v
+
+
+_GN_WS = {}
+
+
+def _gn_scratch(nfloats: int, device) -> torch.Tensor:
+    """GroupNorm-backward scratch (S1, S2, P, Q, R rows).  NOT the shared workspace: the split-K planes of the
+    producing convolution may still be sitting there when the backward kernel runs."""
+    key = torch.device(device).index or 0
+    ws = _GN_WS.get(key)
+    if ws is None or ws.numel() < nfloats:
+        if ws is not None:
+            _WS_RETIRED.append(ws)          # a captured graph may have its address baked in
+        ws = torch.empty(max(int(nfloats * 1.25) + 64, 1 << 16), dtype=torch.float32, device=device)
+        _GN_WS[key] = ws
+    return ws
+
+
+def gn_fwd(x, G, eps, gamma_ptr, beta_ptr, ss, act: bool, res, y, planes=None) -> GNSaved:
+    """``planes`` = (address, stride, count, conv bias address) from conv_xy(partial=True): x is summed from them,
+    WRITTEN to ``x`` and normalised in the same pass."""
     B, H, W, C = x.shape
     sv = GNSaved()
     stats = new((2, B, G), x)
     coef = new((2, B, C), x)
     sv.mean, sv.rstd, sv.A, sv.Bc = stats[0], stats[1], coef[0], coef[1]
+    if planes is not None:
+        lib().lgm_gn_fwd_planes(planes[0], planes[1], planes[2], planes[3], x.data_ptr(), pitch(x), B, H * W, C, G, eps,
+                                gamma_ptr, beta_ptr, _p(ss), pitch(ss) if ss is not None else 0, 1 if act else 0,
+                                _p(res), pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
+                                sv.mean.data_ptr(), sv.rstd.data_ptr(), sv.A.data_ptr(), sv.Bc.data_ptr(), stream())
+        return sv
     lib().lgm_gn_fwd(x.data_ptr(), pitch(x), B, H * W, C, G, eps, gamma_ptr, beta_ptr, _p(ss),
                      pitch(ss) if ss is not None else 0, 1 if act else 0, _p(res),
                      pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
@@ -395,9 +542,29 @@ def gn_fwd(x, G, eps, gamma_ptr, beta_ptr, ss, act: bool, res, y) -> GNSaved:
 
 
 def gn_bwd(x, gy, G, gamma_ptr, beta_ptr, ss, act: bool, sv: GNSaved, gx, accumulate: bool,
-           ggamma_ptr, gbeta_ptr, affine_beta: float, gss, gss_beta: float, defer=None):
+           ggamma_ptr, gbeta_ptr, affine_beta: float, gss, gss_beta: float, defer=None, gy_planes=None):
+    """``gy_planes`` = (address, stride, count, _) from conv_yx(partial=True): gy is summed from them (``gy`` unused)."""
     B, H, W, C = x.shape
-    ws = workspace(5 * B * C * 4, x.device)
+    ws = _gn_scratch(5 * B * C, x.device)
+    if gy_planes is not None:
+        rws, desc = None, None
+        if defer is not None and ggamma_ptr % 16 == 0 and gbeta_ptr % 16 == 0:
+            key = (ggamma_ptr, B * 2 * C)
+            rws = _WGRAD_WS.get(key)
+            if rws is None:
+                rws = torch.empty(B * 2 * C + 4, dtype=torch.float32, device=x.device)
+                _WGRAD_WS[key] = rws
+            desc = (ctypes.c_int64 * 8)()
+        lib().lgm_gn_bwd_planes(x.data_ptr(), pitch(x), gy_planes[0], gy_planes[1], gy_planes[2], B, H * W, C, G,
+                                gamma_ptr, beta_ptr, _p(ss), pitch(ss) if ss is not None else 0, 1 if act else 0,
+                                sv.mean.data_ptr(), sv.rstd.data_ptr(), sv.A.data_ptr(), sv.Bc.data_ptr(), gx.data_ptr(),
+                                pitch(gx), 1 if accumulate else 0, ggamma_ptr, gbeta_ptr, affine_beta, _p(gss),
+                                pitch(gss) if gss is not None else 0, gss_beta, ws.data_ptr(),
+                                None if rws is None else rws.data_ptr(), None if desc is None else ctypes.addressof(desc),
+                                stream())
+        if desc is not None and desc[6] > 0:
+            defer.append(tuple(desc))
+        return
     if defer is not None and ggamma_ptr % 16 == 0 and gbeta_ptr % 16 == 0:
         key = (ggamma_ptr, B * 2 * C)
         rws = _WGRAD_WS.get(key)

@@ -50,22 +50,25 @@ class ResnetBlock(nn.Module):
         self.res_conv = Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
 
     def fwd(self, x, ss, out, save: bool):
-        u1 = self.block1.proj.fwd(x)
-        h1, sv1 = self.block1.norm.fwd(u1, ss, True, None)
-        u2 = self.block2.proj.fwd(h1)
+        # a 3x3 convolution that splits its reduction (small maps, small batches) leaves partial planes; the
+        # GroupNorm behind it sums them while it computes its statistics: no reducer launch, one round trip less
+        G = self.block1.norm.groups
+        u1, p1 = self.block1.proj.fwd_planes(x, G)
+        h1, sv1 = self.block1.norm.fwd(u1, ss, True, None, planes=p1)
+        u2, p2 = self.block2.proj.fwd_planes(h1, G)
         if isinstance(self.res_conv, Conv2d):
-            h2, sv2 = self.block2.norm.fwd(u2, None, True, None)
+            h2, sv2 = self.block2.norm.fwd(u2, None, True, None, planes=p2)
             self.res_conv.fwd(x, out=out, res=h2)
         else:
-            _, sv2 = self.block2.norm.fwd(u2, None, True, x, out=out)
+            _, sv2 = self.block2.norm.fwd(u2, None, True, x, out=out, planes=p2)
         return (x, ss, u1, sv1, h1, u2, sv2) if save else None
 
     def bwd(self, gc: GradCtx, saved, gy, gss, gx, accumulate: bool):
         x, ss, u1, sv1, h1, u2, sv2 = saved
         gu2 = self.block2.norm.bwd(gc, u2, gy, None, True, sv2, None)
-        gh1 = self.block2.proj.bwd(gc, h1, gu2)
+        gh1, pg = self.block2.proj.bwd(gc, h1, gu2, planes_for_groups=self.block1.norm.groups)
         del gu2
-        gu1 = self.block1.norm.bwd(gc, u1, gh1, ss, True, sv1, gss)
+        gu1 = self.block1.norm.bwd(gc, u1, gh1, ss, True, sv1, gss, gy_planes=pg)
         del gh1
         if isinstance(self.res_conv, Conv2d):
             self.block1.proj.bwd(gc, x, gu1, gx, accumulate)

@@ -12,7 +12,8 @@ def test_header_parses_and_library_exports_all_symbols():
     protos = _lib.parse_header()
     assert len(protos) >= 30
     for must in ("lgm_conv_xy", "lgm_conv_yx", "lgm_conv_wgrad", "lgm_gn_fwd", "lgm_gn_bwd", "lgm_linattn_fwd",
-                 "lgm_attn_bwd", "lgm_adam_step", "lgm_ema_lerp", "lgm_sample_step", "lgm_qsample_target"):
+                 "lgm_attn_bwd", "lgm_adam_step", "lgm_ema_lerp", "lgm_sample_step", "lgm_qsample_target",
+                 "lgm_gn_fwd_planes", "lgm_gn_bwd_planes", "lgm_conv3x3_wino_partial", "lgm_conv3x3_wino_fits"):
         assert must in protos
     assert os.path.exists(_lib.LIB_PATH), "run `python __graft_entry__.py build` first"
     dll = ctypes.CDLL(_lib.LIB_PATH)
@@ -22,7 +23,7 @@ def test_header_parses_and_library_exports_all_symbols():
 
 def test_abi_version_and_error_string():
     L = _lib.lib()
-    assert L.lgm_abi_version() == 1
+    assert L.lgm_abi_version() == _lib.ABI_VERSION == 2        # the loader refuses a library built for another ABI
     # invalid-argument path works without a GPU: null geometry is rejected before any launch
     with pytest.raises(_lib.LgmError) as e:
         L.lgm_conv_xy(None, None, 0, None, None, None, 0, None, 0, None, 0, None)

@@ -153,3 +153,145 @@ def test_winograd_weight_transform_matches_definition(dev):
     got_b = ub.cpu().double().view(ci // 32, co // 8, 16, 2, 32, 4)                     # roles swapped: N = c, K = n
     exp_b = Ub.permute(0, 2, 1).reshape(16, ci // 32, 32, co // 8, 2, 4).permute(1, 3, 0, 4, 2, 5)
     assert float((got_b - exp_b).abs().max()) < 1e-6
+
+
+# (B, H, Cin, Cout): geometries whose partial launch splits (small maps / small batches) and one that does not
+PLANE_CASES = [(16, 4, 512, 512), (16, 8, 256, 256), (4, 16, 128, 128), (16, 32, 64, 64), (128, 4, 256, 256), (64, 32, 64, 64)]
+
+
+@pytest.mark.parametrize("case", PLANE_CASES)
+def test_groupnorm_sums_the_split_k_planes(dev, case, parity):
+    """Block.forward / its backward (ddpm.py:164-173) with the reducer folded into the consumer: the 3x3 convolution
+    leaves its split-K partial planes (lgm_conv3x3_wino_partial), GroupNorm sums them while it computes its statistics
+    (lgm_gn_fwd_planes: also writes the finished convolution output) / its backward sums the input-gradient planes
+    (lgm_gn_bwd_planes).  Against the two-step path of the same library - convolution with its own reducer, then
+    GroupNorm - every output must be IDENTICAL when the split counts agree and within fp32 reduction-order distance
+    otherwise; and against float64."""
+    from lgm_hip import ops
+    B, hw, ci, co = case
+    G = 8
+    L = ops.lib()
+    gen = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(B, hw, hw, ci, generator=gen).to(dev)
+    w = (torch.randn(co, 9, ci, generator=gen) / (3 * ci ** 0.5)).to(dev)
+    bias, gamma, beta = (torch.randn(co, generator=gen).to(dev) for _ in range(3))
+    ss = torch.randn(B, 2 * co, generator=gen).to(dev) * 0.3
+    res = torch.randn(B, hw, hw, co, generator=gen).to(dev)
+    uf, ub = wino_weights(w)
+    g = ops.make_geom(B, hw, hw, ci, co, 3, 3, 1, 1)
+    assert L.lgm_gn_planes_supported(B, hw * hw, co, G) == 1
+
+    def conv_partial(yx, a, u, b_, out):
+        n = L.lgm_conv3x3_wino_workspace_partial(ctypes.byref(g), yx)
+        ws = torch.empty(max(n // 4, 4), device=dev)
+        part = (ctypes.c_int64 * 2)()
+        L.lgm_conv3x3_wino_partial(yx, ctypes.byref(g), a.data_ptr(), ops.pitch(a), u.data_ptr(),
+                                   None if b_ is None else b_.data_ptr(), out.data_ptr(), ops.pitch(out), ws.data_ptr(),
+                                   ws.numel() * 4, ctypes.addressof(part), ops.stream())
+        return ws, int(part[0]), int(part[1])
+
+    # ---- forward: two-step reference of the same library
+    u_ref = torch.empty(B, hw, hw, co, device=dev)
+    wino(0, g, x, uf, bias, None, u_ref)
+    y_ref = torch.empty_like(u_ref)
+    sv_ref = ops.gn_fwd(u_ref, G, 1e-5, gamma.data_ptr(), beta.data_ptr(), ss, True, res, y_ref)
+    # ---- forward: planes
+    u_pl = torch.full((B, hw, hw, co), 3.0, device=dev)
+    ws, splits, stride = conv_partial(0, x, uf, bias, u_pl)
+    y_pl = torch.empty_like(u_ref)
+    if splits > 1:
+        sv = ops.gn_fwd(u_pl, G, 1e-5, gamma.data_ptr(), beta.data_ptr(), ss, True, res, y_pl,
+                        planes=(ws.data_ptr(), stride, splits, bias.data_ptr()))
+    else:
+        sv = ops.gn_fwd(u_pl, G, 1e-5, gamma.data_ptr(), beta.data_ptr(), ss, True, res, y_pl)
+    ref64 = F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), w.cpu().reshape(co, 3, 3, ci).permute(0, 3, 1, 2).double(),
+                     bias.cpu().double(), padding=1).permute(0, 2, 3, 1)
+    parity(f"conv output written by GroupNorm ({splits} planes) vs float64", maxerr(u_pl, ref64), 2e-6)
+    parity("conv output: planes path vs reducer path", maxerr(u_pl, u_ref.double().cpu()), 2e-6)
+    parity("GroupNorm output: planes path vs reducer path", maxerr(y_pl, y_ref.double().cpu()), 5e-6)
+    parity("GroupNorm mean / rstd: planes path vs reducer path",
+           max(maxerr(sv.mean, sv_ref.mean.double().cpu()), maxerr(sv.rstd, sv_ref.rstd.double().cpu())), 5e-6)
+
+    # ---- backward: gy of the GroupNorm = input gradient of a following convolution (co -> co here needs ci == co)
+    if ci != co:
+        return
+    gz = torch.randn(B, hw, hw, co, generator=gen).to(dev)
+    gy_ref = torch.empty(B, hw, hw, ci, device=dev)
+    wino(1, g, gz, ub, None, None, gy_ref)
+    gg = [torch.zeros(co, device=dev) for _ in range(4)]
+    gss = [torch.zeros(B, 2 * co, device=dev) for _ in range(2)]
+    gx_ref, gx_pl = torch.empty_like(u_ref), torch.empty_like(u_ref)
+    ops.gn_bwd(u_ref, gy_ref, G, gamma.data_ptr(), beta.data_ptr(), ss, True, sv_ref, gx_ref, False, gg[0].data_ptr(),
+               gg[1].data_ptr(), 0.0, gss[0], 0.0)
+    gy_dummy = torch.full((B, hw, hw, ci), float("nan"), device=dev)     # never read, never written with planes
+    ws, splits, stride = conv_partial(1, gz, ub, None, gy_dummy)
+    if splits > 1:
+        ops.gn_bwd(u_ref, gy_dummy, G, gamma.data_ptr(), beta.data_ptr(), ss, True, sv_ref, gx_pl, False, gg[2].data_ptr(),
+                   gg[3].data_ptr(), 0.0, gss[1], 0.0, gy_planes=(ws.data_ptr(), stride, splits, None))
+        assert bool(torch.isnan(gy_dummy).all())
+    else:
+        ops.gn_bwd(u_ref, gy_dummy, G, gamma.data_ptr(), beta.data_ptr(), ss, True, sv_ref, gx_pl, False, gg[2].data_ptr(),
+                   gg[3].data_ptr(), 0.0, gss[1], 0.0)
+    parity(f"GroupNorm input gradient from {splits} input-gradient planes vs reducer path", maxerr(gx_pl, gx_ref.double().cpu()), 5e-6)
+    parity("gamma / beta gradients", max(maxerr(gg[2], gg[0].double().cpu()), maxerr(gg[3], gg[1].double().cpu())), 5e-6)
+    parity("FiLM scale / shift gradients", maxerr(gss[1], gss[0].double().cpu()), 5e-6)
+
+
+@pytest.mark.parametrize("case", [(16, 4, 512, 512), (8, 8, 128, 64), (2, 16, 192, 128), (16, 32, 64, 64), (3, 32, 128, 64)])
+@pytest.mark.parametrize("variant", ["plain", "accumulate", "residual", "planes"])
+def test_backward_pair_launch_matches_separate_launches(dev, case, variant, parity):
+    """lgm_conv3x3_wino_bwd (input gradient + weight gradient of a 3x3 layer in ONE launch, the same kernels' code as
+    two block ranges of one grid, split counts planned jointly) against lgm_conv3x3_wino(yx = 1) + lgm_conv_wgrad: equal
+    within fp32 reduction-order distance for the input gradient
+    (with a residual / accumulated into an existing tensor / left as partial planes), the weight gradient and the bias
+    gradient - and against float64 autograd."""
+    from lgm_hip import ops
+    B, hw, ci, co = case
+    L = ops.lib()
+    gen = torch.Generator().manual_seed(sum(case) + 7)
+    xbuf = torch.randn(B, hw, hw, ci + 32, generator=gen).to(dev)          # pitched operands, as in the concat buffers
+    x = xbuf[..., 32:]
+    gy = torch.randn(B, hw, hw, co, generator=gen).to(dev)
+    w = (torch.randn(co, 9, ci, generator=gen) / (3 * ci ** 0.5)).to(dev)
+    res = torch.randn(B, hw, hw, ci, generator=gen).to(dev)
+    uf, ub = wino_weights(w)
+    g = ops.make_geom(B, hw, hw, ci, co, 3, 3, 1, 1)
+    assert L.lgm_conv3x3_wino_bwd_supported(ctypes.byref(g), co, ci + 32, ci, ci) == 1
+    # ---- separate launches
+    gx_ref = res.clone() if variant == "accumulate" else torch.empty(B, hw, hw, ci, device=dev)
+    r_ref = gx_ref if variant == "accumulate" else (res if variant == "residual" else None)
+    wino(1, g, gy, ub, None, r_ref, gx_ref)
+    gw_ref, gb_ref = torch.full((co, 9, ci), 0.5, device=dev), torch.full((co,), 0.25, device=dev)
+    nb = L.lgm_conv_wgrad_workspace(ctypes.byref(g))
+    wws = torch.empty(nb // 4 + 16, device=dev)
+    two = (ctypes.c_int64 * 2)()
+    L.lgm_conv3x3_wino_bwd_workspaces(ctypes.byref(g), 1 if variant == "planes" else 0, ctypes.addressof(two))
+    L.lgm_conv_wgrad(ctypes.byref(g), gy.data_ptr(), co, x.data_ptr(), ci + 32, gw_ref.data_ptr(), gb_ref.data_ptr(), 1.0,
+                     wws.data_ptr(), wws.numel() * 4, ops.stream())
+    # ---- the pair
+    gx = res.clone() if variant == "accumulate" else torch.full((B, hw, hw, ci), float("nan"), device=dev)
+    r = gx if variant == "accumulate" else (res if variant == "residual" else None)
+    gw, gb = torch.full((co, 9, ci), 0.5, device=dev), torch.full((co,), 0.25, device=dev)
+    partial = variant == "planes"
+    dws = torch.empty(max(two[0] // 4, 4), device=dev)
+    wws2 = torch.empty(two[1] // 4 + 16, device=dev)
+    part = (ctypes.c_int64 * 2)()
+    L.lgm_conv3x3_wino_bwd(ctypes.byref(g), gy.data_ptr(), co, x.data_ptr(), ci + 32, ub.data_ptr(),
+                           None if r is None else r.data_ptr(), 0 if r is None else ci, gx.data_ptr(), ci, dws.data_ptr(),
+                           dws.numel() * 4, ctypes.addressof(part) if partial else None, gw.data_ptr(), gb.data_ptr(), 1.0,
+                           wws2.data_ptr(), wws2.numel() * 4, None, ops.stream())
+    assert ops.lib()._dll.lgm_last_kernel().decode().startswith("lgmwino::wino_bwd_pair_kernel<")
+    if partial and part[0] > 1:
+        assert bool(torch.isnan(gx).all())                      # planes mode leaves gx alone ...
+        planes = dws[: part[0] * part[1]].view(part[0], -1)[:, : B * hw * hw * ci]
+        gx = planes.sum(0).view(B, hw, hw, ci)                 # ... its sum is the input gradient
+        parity(f"input gradient from {part[0]} planes vs separate launch", maxerr(gx, gx_ref.double().cpu()), 2e-6)
+    else:
+        parity("input gradient vs separate launch (split counts may differ)", maxerr(gx, gx_ref.double().cpu()), 2e-6)
+    parity("weight gradient vs separate launch", maxerr(gw, gw_ref.double().cpu()), 2e-6)
+    parity("bias gradient vs separate launch", maxerr(gb, gb_ref.double().cpu()), 2e-6)
+    w4 = w.cpu().reshape(co, 3, 3, ci).permute(0, 3, 1, 2).double().requires_grad_(True)
+    x64 = x.cpu().permute(0, 3, 1, 2).double()
+    y64 = F.conv2d(x64, w4, None, padding=1)
+    (gw64,) = torch.autograd.grad(y64, w4, gy.cpu().permute(0, 3, 1, 2).double())
+    parity("weight gradient vs float64 autograd", maxerr(gw - 0.5, gw64.permute(0, 2, 3, 1).reshape(co, 9, ci)), 5e-6)
