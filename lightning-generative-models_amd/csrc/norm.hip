@@ -197,7 +197,21 @@ __global__ __launch_bounds__(NT) void gn_fused_fwd_kernel(const float* __restric
     const float* pb = planes + ((long)b * HW) * C + c0 + q * 4;
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(pb + (long)(pl + k * ppb) * C);
-    for (int sidx = 1; sidx < splits; ++sidx) {
+    // two planes per round: 2 NV independent 16-byte loads in flight (one plane per round left the block waiting for
+    // `splits` dependent memory round trips); the ADDITIONS stay in plane order
+    int sidx = 1;
+    for (; sidx + 1 < splits; sidx += 2) {
+      const float* ps = pb + (long)sidx * pstride;
+      f32x4 t0[NV], t1[NV];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        t0[k] = *reinterpret_cast<const f32x4*>(ps + (long)(pl + k * ppb) * C);
+        t1[k] = *reinterpret_cast<const f32x4*>(ps + pstride + (long)(pl + k * ppb) * C);
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k] = (v[k] + t0[k]) + t1[k];
+    }
+    if (sidx < splits) {
       const float* ps = pb + (long)sidx * pstride;
 #pragma unroll
       for (int k = 0; k < NV; ++k) v[k] += *reinterpret_cast<const f32x4*>(ps + (long)(pl + k * ppb) * C);
@@ -480,7 +494,19 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
     const float* pb = planes + ((long)b * HW) * C + c;
 #pragma unroll
     for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const f32x4*>(pb + (long)(pl + k * ppb) * C);
-    for (int sidx = 1; sidx < splits; ++sidx) {
+    int sidx = 1;
+    for (; sidx + 1 < splits; sidx += 2) {       // two planes per round, additions in plane order (see the forward)
+      const float* ps = pb + (long)sidx * pstride;
+      f32x4 t0[NV], t1[NV];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        t0[k] = *reinterpret_cast<const f32x4*>(ps + (long)(pl + k * ppb) * C);
+        t1[k] = *reinterpret_cast<const f32x4*>(ps + pstride + (long)(pl + k * ppb) * C);
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) g[k] = (g[k] + t0[k]) + t1[k];
+    }
+    if (sidx < splits) {
       const float* ps = pb + (long)sidx * pstride;
 #pragma unroll
       for (int k = 0; k < NV; ++k) g[k] += *reinterpret_cast<const f32x4*>(ps + (long)(pl + k * ppb) * C);

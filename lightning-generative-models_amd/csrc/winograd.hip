@@ -30,6 +30,8 @@
 // holds all 16 xi of its (tile, channel) pairs); the four output positions leave through a wave-private
 // LDS transpose as 16-byte stores with bias / residual fused.  Split-K writes partial OUTPUTS (the output
 // transform is linear) that the existing fixed-order reducer sums.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "lgm_common.h"
@@ -1471,7 +1473,11 @@ static WinoPairPlan wino_pair_plan_search(const LgmConvGeom* g, bool fused) {
   long smax = chunks / 2 < 256 ? chunks / 2 : 256;
   if (smax < 2) smax = 2;
   // per slab: read back by the batched slab reducer at HBM rate (its write rides in the kernel's epilogue)
-  const double slab_cost = 4.0 * ((double)g->Nw * 9 * g->Cw + g->Nw) / 4.5e12 / 2.1e-6;
+  static const double k_slab = getenv("LGM_PLAN_SLAB") ? atof(getenv("LGM_PLAN_SLAB")) : 1.0;     // tuning knobs (A/B runs)
+  static const double k_tc = getenv("LGM_PLAN_TC") ? atof(getenv("LGM_PLAN_TC")) : 1.5;
+  static const double k_tw = getenv("LGM_PLAN_TW") ? atof(getenv("LGM_PLAN_TW")) : 3.0;
+  static const double k_wph = getenv("LGM_PLAN_WPH") ? atof(getenv("LGM_PLAN_WPH")) : 1.0;
+  const double slab_cost = k_slab * 4.0 * ((double)g->Nw * 9 * g->Cw + g->Nw) / 4.5e12 / 2.1e-6;
   // makespan of n1 blocks of t1 followed by n2 blocks of t2 on 256 CUs, one block per CU, dispatched in order
   auto makespan = [](long n1, double t1, long n2, double t2) {
     const long P = 256;
@@ -1501,12 +1507,12 @@ static WinoPairPlan wino_pair_plan_search(const LgmConvGeom* g, bool fused) {
   for (long c = 1; c <= cmax; ++c) {
     const long pps = (phases + c - 1) / c;
     if ((phases + pps - 1) / pps != c) continue;
-    const double tc = (double)pps + 1.5;
+    const double tc = (double)pps + k_tc;
     const double conv_after = (c > 1 ? (fused ? 0.2 : 2.4) : 0.0) + per_split * (double)(c - 1);
     for (long w = 2; w <= smax; ++w) {
       const long per = (chunks + w - 1) / w;
       if ((chunks + per - 1) / per != w) continue;
-      const double tw = (double)per + 3.0;
+      const double tw = k_wph * (double)per + k_tw;
       const double cost = makespan(base * c, tc, blocks * w, tw) + conv_after + slab_cost * (double)w;
       if (cost < bestc - 1e-9) {
         bestc = cost;
