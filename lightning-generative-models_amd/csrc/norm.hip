@@ -197,21 +197,24 @@ __global__ __launch_bounds__(NT) void gn_fused_fwd_kernel(const float* __restric
     const float* pb = planes + ((long)b * HW) * C + c0 + q * 4;
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(pb + (long)(pl + k * ppb) * C);
-    // two planes per round: 2 NV independent 16-byte loads in flight (one plane per round left the block waiting for
-    // `splits` dependent memory round trips); the ADDITIONS stay in plane order
+    // PR planes per round: PR x NV independent 16-byte loads in flight (one plane per round left the block waiting for
+    // `splits` dependent memory round trips - 16 of them on the 4x4 maps at small batches); the ADDITIONS stay in
+    // plane order, so the sum is the reducer's
+    constexpr int PR = NV >= 4 ? 2 : NV == 2 ? 4 : 8;
     int sidx = 1;
-    for (; sidx + 1 < splits; sidx += 2) {
+    for (; sidx + PR <= splits; sidx += PR) {
       const float* ps = pb + (long)sidx * pstride;
-      f32x4 t0[NV], t1[NV];
+      f32x4 t[PR][NV];
 #pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        t0[k] = *reinterpret_cast<const f32x4*>(ps + (long)(pl + k * ppb) * C);
-        t1[k] = *reinterpret_cast<const f32x4*>(ps + pstride + (long)(pl + k * ppb) * C);
-      }
+      for (int j = 0; j < PR; ++j)
 #pragma unroll
-      for (int k = 0; k < NV; ++k) v[k] = (v[k] + t0[k]) + t1[k];
+        for (int k = 0; k < NV; ++k) t[j][k] = *reinterpret_cast<const f32x4*>(ps + (long)j * pstride + (long)(pl + k * ppb) * C);
+#pragma unroll
+      for (int j = 0; j < PR; ++j)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] += t[j][k];
     }
-    if (sidx < splits) {
+    for (; sidx < splits; ++sidx) {
       const float* ps = pb + (long)sidx * pstride;
 #pragma unroll
       for (int k = 0; k < NV; ++k) v[k] += *reinterpret_cast<const f32x4*>(ps + (long)(pl + k * ppb) * C);
@@ -227,6 +230,24 @@ __global__ __launch_bounds__(NT) void gn_fused_fwd_kernel(const float* __restric
   } else {
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(xb + (long)(pl + k * ppb) * pitch);
+  }
+  // Everything else the block will need from memory is requested NOW, before the two reductions: the residual rows
+  // and this thread's gamma / beta / FiLM operands.  Issued where they are used they were three more dependent
+  // memory round trips on the critical path of a kernel that is pure latency at small batches.
+  f32x4 r[NV];
+  if (res) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      r[k] = *reinterpret_cast<const f32x4*>(res + ((long)b * HW + pl + k * ppb) * res_pitch + c0 + q * 4);
+  }
+  float pg = 0.f, pbeta = 0.f, psc = 1.f, psh = 0.f;
+  if (tid < CB) {
+    pg = gamma[c0 + tid];
+    pbeta = beta[c0 + tid];
+    if (ss) {
+      psc = ss[(long)b * ss_pitch + c0 + tid] + 1.f;
+      psh = ss[(long)b * ss_pitch + C + c0 + tid];
+    }
   }
   f32x4 s = v[0];
 #pragma unroll
@@ -252,13 +273,11 @@ __global__ __launch_bounds__(NT) void gn_fused_fwd_kernel(const float* __restric
   if (tid < CB) {      // z = x * A[b,c] + Bc[b,c]  (also kept for the backward pass)
     const int c = c0 + tid;
     const float m = gmean[tid / Cg], rs = grstd[tid / Cg];
-    float a = rs * gamma[c];
-    float bb = beta[c] - m * a;
+    float a = rs * pg;
+    float bb = pbeta - m * a;
     if (ss) {
-      const float sc = ss[(long)b * ss_pitch + c] + 1.f;
-      const float shf = ss[(long)b * ss_pitch + C + c];
-      a *= sc;
-      bb = bb * sc + shf;
+      a *= psc;
+      bb = bb * psc + psh;
     }
     A[(long)b * C + c] = a;
     Bc[(long)b * C + c] = bb;
@@ -268,12 +287,6 @@ __global__ __launch_bounds__(NT) void gn_fused_fwd_kernel(const float* __restric
   __syncthreads();
   const f32x4 a4 = *reinterpret_cast<const f32x4*>(&cA[q * 4]);
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(&cB[q * 4]);
-  f32x4 r[NV];
-  if (res) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k)
-      r[k] = *reinterpret_cast<const f32x4*>(res + ((long)b * HW + pl + k * ppb) * res_pitch + c0 + q * 4);
-  }
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     f32x4 z = v[k] * a4 + b4;
@@ -494,19 +507,21 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
     const float* pb = planes + ((long)b * HW) * C + c;
 #pragma unroll
     for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const f32x4*>(pb + (long)(pl + k * ppb) * C);
+    constexpr int PR = NV >= 4 ? 2 : NV == 2 ? 4 : 8;     // planes per round, additions in plane order (see the forward)
     int sidx = 1;
-    for (; sidx + 1 < splits; sidx += 2) {       // two planes per round, additions in plane order (see the forward)
+    for (; sidx + PR <= splits; sidx += PR) {
       const float* ps = pb + (long)sidx * pstride;
-      f32x4 t0[NV], t1[NV];
+      f32x4 t[PR][NV];
 #pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        t0[k] = *reinterpret_cast<const f32x4*>(ps + (long)(pl + k * ppb) * C);
-        t1[k] = *reinterpret_cast<const f32x4*>(ps + pstride + (long)(pl + k * ppb) * C);
-      }
+      for (int j = 0; j < PR; ++j)
 #pragma unroll
-      for (int k = 0; k < NV; ++k) g[k] = (g[k] + t0[k]) + t1[k];
+        for (int k = 0; k < NV; ++k) t[j][k] = *reinterpret_cast<const f32x4*>(ps + (long)j * pstride + (long)(pl + k * ppb) * C);
+#pragma unroll
+      for (int j = 0; j < PR; ++j)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) g[k] += t[j][k];
     }
-    if (sidx < splits) {
+    for (; sidx < splits; ++sidx) {
       const float* ps = pb + (long)sidx * pstride;
 #pragma unroll
       for (int k = 0; k < NV; ++k) g[k] += *reinterpret_cast<const f32x4*>(ps + (long)(pl + k * ppb) * C);
@@ -522,6 +537,20 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
   for (int k = 0; k < 4; ++k) {
     mu[k] = mean[b * G + (c + k) / Cg];
     rs[k] = rstd[b * G + (c + k) / Cg];
+  }
+  // the per-channel operands of the coefficient stage, requested before the reduction (see the forward kernel)
+  float pgam = 0.f, pbet = 0.f, pscv = 1.f, pm = 0.f, pr = 0.f, pgsc = 0.f, pgsh = 0.f;
+  if (tid < CB) {
+    const int cc = c0 + tid;
+    pgam = gamma[cc];
+    pbet = beta[cc];
+    pscv = ss ? ss[(long)b * ss_pitch + cc] + 1.f : 1.f;
+    pm = mean[b * G + cc / Cg];
+    pr = rstd[b * G + cc / Cg];
+    if (gss && gss_beta != 0.f) {
+      pgsc = gss[(long)b * gss_pitch + cc];
+      pgsh = gss[(long)b * gss_pitch + C + cc];
+    }
   }
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -547,8 +576,8 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
     const int cc = c0 + tid;
     S1[(long)b * C + cc] = a1;
     S2[(long)b * C + cc] = a2;
-    scv = ss ? ss[(long)b * ss_pitch + cc] + 1.f : 1.f;
-    const float w = gamma[cc] * scv;
+    scv = pscv;
+    const float w = pgam * scv;
     wa1[tid] = w * a1;
     wa2[tid] = w * a2;
     if (T) {   // deferred gamma/beta reduction: this image's row [sc*S2 | sc*S1] for lgm_wgrad_reduce_batch
@@ -568,17 +597,17 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
     const float inv_n = 1.f / ((float)Cg * (float)HW);
     m1 *= inv_n;
     m2 *= inv_n;
-    const float m = mean[b * G + cc / Cg], r = rstd[b * G + cc / Cg];
-    cP[tid] = r * gamma[cc] * scv;
+    const float m = pm, r = pr;
+    cP[tid] = r * pgam * scv;
     const float R = -r * m2;          // multiplies xhat
     cR[tid] = R * r;                  // multiplies x
     cQ[tid] = -r * m1 - m * r * R;
     if (gss) {
-      float gsc = gamma[cc] * a2 + beta[cc] * a1;
+      float gsc = pgam * a2 + pbet * a1;
       float gsh = a1;
       if (gss_beta != 0.f) {
-        gsc += gss_beta * gss[(long)b * gss_pitch + cc];
-        gsh += gss_beta * gss[(long)b * gss_pitch + C + cc];
+        gsc += gss_beta * pgsc;
+        gsh += gss_beta * pgsh;
       }
       gss[(long)b * gss_pitch + cc] = gsc;
       gss[(long)b * gss_pitch + C + cc] = gsh;
