@@ -45,12 +45,25 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ 
 
   // two-level fixed-order reduction of the per-thread partials in sh ([pixel lane][channel]):
   // one thread per channel over the pixel lanes, then one thread per group over its channels
+  // fixed-order reduction of the per-thread partials in sh ([pixel lane][channel]) in two levels: every thread sums
+  // the lanes pp = j, j + J, ... of one channel (J = NT / CB parts), then one thread per channel sums the J parts - a
+  // chain of ppb / J + J additions instead of ppb (128 dependent LDS reads by 8 ... 32 threads were ~3 us per
+  // reduction, twice per launch: a third of this kernel's time at small batches)
   auto group_reduce = [&](float* dst, bool second) {
     __syncthreads();
-    if (tid < CB) {
+    {
+      const int J = NT / CB, cch = tid % CB, j = tid / CB;
       float acc = 0.f;
-      for (int pp = 0; pp < ppb; ++pp) acc += sh[pp * CB + tid];
-      chs[tid] = acc;
+      if (j < J)
+        for (int pp = j; pp < ppb; pp += J) acc += sh[pp * CB + cch];
+      __syncthreads();                       // everyone has read its sh entries: sh is reused for the parts
+      if (j < J) sh[j * CB + cch] = acc;
+      __syncthreads();
+      if (tid < CB) {
+        float a2 = 0.f;
+        for (int jj = 0; jj < J; ++jj) a2 += sh[jj * CB + tid];
+        chs[tid] = a2;
+      }
     }
     __syncthreads();
     if (tid < ngl) {
@@ -173,12 +186,25 @@ __global__ __launch_bounds__(NT) void gn_fused_fwd_kernel(const float* __restric
   const int ngl = CB / Cg;
   const float inv_n = 1.f / ((float)Cg * (float)HW);
 
+  // fixed-order reduction of the per-thread partials in sh ([pixel lane][channel]) in two levels: every thread sums
+  // the lanes pp = j, j + J, ... of one channel (J = NT / CB parts), then one thread per channel sums the J parts - a
+  // chain of ppb / J + J additions instead of ppb (128 dependent LDS reads by 8 ... 32 threads were ~3 us per
+  // reduction, twice per launch: a third of this kernel's time at small batches)
   auto group_reduce = [&](float* dst, bool second) {
     __syncthreads();
-    if (tid < CB) {
+    {
+      const int J = NT / CB, cch = tid % CB, j = tid / CB;
       float acc = 0.f;
-      for (int pp = 0; pp < ppb; ++pp) acc += sh[pp * CB + tid];
-      chs[tid] = acc;
+      if (j < J)
+        for (int pp = j; pp < ppb; pp += J) acc += sh[pp * CB + cch];
+      __syncthreads();                       // everyone has read its sh entries: sh is reused for the parts
+      if (j < J) sh[j * CB + cch] = acc;
+      __syncthreads();
+      if (tid < CB) {
+        float a2 = 0.f;
+        for (int jj = 0; jj < J; ++jj) a2 += sh[jj * CB + tid];
+        chs[tid] = a2;
+      }
     }
     __syncthreads();
     if (tid < ngl) {
@@ -350,11 +376,26 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const float* __restri
   __syncthreads();
   __shared__ float wa1[256], wa2[256];
   float a1 = 0.f, a2 = 0.f, scv = 1.f;
-  if (tid < CB) {  // one thread per channel, fixed-order sum over pixel lanes
-    const int qq = tid / 4, k = tid % 4;
-    for (int pp = 0; pp < ppb; ++pp) {
-      a1 += sh[(pp * tq + qq) * 8 + k];
-      a2 += sh[(pp * tq + qq) * 8 + 4 + k];
+  {   // two-level fixed-order sum over the pixel lanes (see gn_fused_fwd_kernel): J parts per channel, then the parts
+    const int J = NT / CB, cch = tid % CB, j = tid / CB;
+    const int qq = cch / 4, k = cch % 4;
+    float p1 = 0.f, p2 = 0.f;
+    if (j < J)
+      for (int pp = j; pp < ppb; pp += J) {
+        p1 += sh[(pp * tq + qq) * 8 + k];
+        p2 += sh[(pp * tq + qq) * 8 + 4 + k];
+      }
+    __syncthreads();
+    if (j < J) {
+      sh[(j * CB + cch) * 2] = p1;
+      sh[(j * CB + cch) * 2 + 1] = p2;
+    }
+    __syncthreads();
+  }
+  if (tid < CB) {  // one thread per channel
+    for (int jj = 0; jj < NT / CB; ++jj) {
+      a1 += sh[(jj * CB + tid) * 2];
+      a2 += sh[(jj * CB + tid) * 2 + 1];
     }
     const int cc = c0 + tid;
     S1[(long)b * C + cc] = a1;
@@ -567,11 +608,26 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
   *reinterpret_cast<f32x4*>(&sh[tid * 8 + 4]) = s2;
   __syncthreads();
   float a1 = 0.f, a2 = 0.f, scv = 1.f;
-  if (tid < CB) {  // one thread per channel, fixed-order sum over pixel lanes
-    const int qq = tid / 4, k = tid % 4;
-    for (int pp = 0; pp < ppb; ++pp) {
-      a1 += sh[(pp * tq + qq) * 8 + k];
-      a2 += sh[(pp * tq + qq) * 8 + 4 + k];
+  {   // two-level fixed-order sum over the pixel lanes (see gn_fused_fwd_kernel): J parts per channel, then the parts
+    const int J = NT / CB, cch = tid % CB, j = tid / CB;
+    const int qq = cch / 4, k = cch % 4;
+    float p1 = 0.f, p2 = 0.f;
+    if (j < J)
+      for (int pp = j; pp < ppb; pp += J) {
+        p1 += sh[(pp * tq + qq) * 8 + k];
+        p2 += sh[(pp * tq + qq) * 8 + 4 + k];
+      }
+    __syncthreads();
+    if (j < J) {
+      sh[(j * CB + cch) * 2] = p1;
+      sh[(j * CB + cch) * 2 + 1] = p2;
+    }
+    __syncthreads();
+  }
+  if (tid < CB) {  // one thread per channel
+    for (int jj = 0; jj < NT / CB; ++jj) {
+      a1 += sh[(jj * CB + tid) * 2];
+      a2 += sh[(jj * CB + tid) * 2 + 1];
     }
     const int cc = c0 + tid;
     S1[(long)b * C + cc] = a1;
