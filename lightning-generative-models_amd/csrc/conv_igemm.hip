@@ -1453,8 +1453,17 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
     const bool fast = !no_fast && a.lWo >= 0 && a.lHo >= 0 && a.lW >= 0 && a.lH >= 0 &&
                       (long)a.B * a.H * a.W < (1L << 24) && x_pitch * 4 < (1L << 24) &&
                       (long)a.B * a.H * a.W * x_pitch * 4 < (1L << 31) && ((long)a.P + WBK) * y_pitch * 4 < (1L << 31);
-    lgm_note_kernel(fast ? "wgrad_kernel<64, 64, 1, 1, true>" : "wgrad_kernel<64, 64, 1, 1, false>");
-    if (fast)
+    // Opt-in (LGM_WGRAD_BIG=1), measured SLOWER on the WGAN-GP step (24,150 vs 24,760 images/s): 128 output channels
+    // per workgroup - two accumulators per wave, every gathered X fragment feeds two MFMAs - halves the workgroups,
+    // and these layers need the parallelism more than the operand reuse.
+    static const bool want_big = getenv("LGM_WGRAD_BIG") != nullptr;
+    const bool big = fast && want_big && a.Nw % 128 == 0 && (long)(a.Nw / 128) * a.tiles_n * a.splits >= 512;
+    lgm_note_kernel(big ? "wgrad_kernel<128, 64, 2, 1, true>"
+                        : fast ? "wgrad_kernel<64, 64, 1, 1, true>" : "wgrad_kernel<64, 64, 1, 1, false>");
+    if (big) {
+      a.tiles_m = a.Nw / 128;
+      hipLaunchKernelGGL((wgrad_kernel<128, 64, 2, 1, true>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
+    } else if (fast)
       hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1, true>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
     else
       hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1, false>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
