@@ -77,6 +77,26 @@ int lgm_transpose_weights(const float* src, float* dst, const int32_t* table, in
  * Passing NULL / too few bytes is legal (no split, slower on tiny feature maps). */
 int64_t lgm_conv_workspace(const LgmConvGeom* g, int yx);
 
+/* Post-op of a convolution's epilogue: out = act(conv + bias + res), then - backward passes - the ReLU / LeakyReLU
+ * mask of a SAVED activation m (its forward output): out *= (m > 0 ? 1 : mask_slope).  Replaces the separate
+ * activation launches around the reference's Conv2d -> ReLU pairs (vqvae.py:36-51,74-85, residual.py:14-20) and
+ * their autograd mirror images.  act: 0 none, 3 ReLU, 4 LeakyReLU(slope); mask NULL: none.  Applied inside the
+ * implicit-GEMM kernels' epilogue / split-K reducer; paths without an epilogue hook finish with one elementwise
+ * launch - the result is the same on every path. */
+typedef struct {
+  int32_t act;
+  float slope;
+  const float* mask;
+  int64_t mask_pitch;
+  float mask_slope;
+} LgmPostOp;
+int lgm_conv_xy_post(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w, const float* bias,
+                     const float* res, int64_t res_pitch, float* y, int64_t y_pitch, void* workspace,
+                     int64_t workspace_bytes, const LgmPostOp* post, void* stream);
+int lgm_conv_yx_post(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w, const float* w_t,
+                     const float* bias, const float* res, int64_t res_pitch, float* x, int64_t x_pitch,
+                     void* workspace, int64_t workspace_bytes, const LgmPostOp* post, void* stream);
+
 /* Weight gradient: gw[n][tap][c] = beta*gw + sum_{b,oh,ow} Y[b,oh,ow,n] * X[b,ih,iw,c].
  * (Conv2d: Y = grad_output, X = input;  ConvTranspose2d: Y = input, X = grad_output.)
  * Deterministic: split-K partials go to `workspace` and are reduced in a fixed order.
@@ -369,6 +389,11 @@ int lgm_fill_col(float* out, int64_t pitch, int64_t n, int ncols, int col, float
                  const float* vptr, void* stream);
 /* vals4 = (real, fake, gp, d_loss): d_loss = fake - real + gp (wgan.py:87,98) */
 int lgm_wgan_dloss(float* vals4, void* stream);
+/* VQVAE._common_step's scalar tail (vqvae.py:184-194) in one launch: vals4 = (recon * w_recon + vq * w_vq, recon, vq,
+ * perplexity) with out3 = (vq_loss, perplexity, .) as lgm_vq_gather_loss leaves it; and its mirror image for the
+ * backward pass: out2 = (g * w0, g * w1). */
+int lgm_vqvae_loss(const float* recon, const float* out3, float w_recon, float w_vq, float* vals4, void* stream);
+int lgm_scale_pair(const float* g, float w0, float w1, float* out2, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * OPT-IN split-precision 3x3 convolution (SURVEY.md "bf16x3 ... behind a flag, only if it holds 1e-4";

@@ -104,7 +104,18 @@ struct IgemmArgs {
   // (Chan's combination in the second reduction stage) takes it from there and the read pass over the
   // activation disappears.
   float* stats;
+  // post-op of the epilogue (lgm_conv_xy_post / lgm_conv_yx_post): v = act(acc + bias + res), then the ReLU /
+  // LeakyReLU backward mask of a SAVED activation m: v *= (m > 0 ? 1 : mask_slope)
+  int act;            // 0 none, 3 ReLU, 4 LeakyReLU(slope)
+  float slope;
+  const float* mask;
+  long mask_pitch;
+  float mask_slope;
 };
+
+__device__ __forceinline__ float lgm_post_act(float v, int act, float slope) {
+  return act == 0 ? v : (v > 0.f ? v : (act == 4 ? slope * v : 0.f));
+}
 
 template <int MODE, int BM, int BN, int TM, int TN, bool UNI>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
@@ -509,8 +520,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         lgm_tile_to_lds(acc[i][j], Ts, lane);
         lgm_wave_lds_sync();
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<f32x4*>(p.out + orow[q] * p.out_pitch + nc) = lgm_tile_row4(Ts, lane, q) + bv4 + rv4[q];
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v4 = lgm_tile_row4(Ts, lane, q) + bv4 + rv4[q];
+          if (p.act | (p.mask != nullptr)) {       // wave-uniform: the plain epilogue pays one scalar test
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = lgm_post_act(v4[e], p.act, p.slope);
+            if (p.mask) {
+              const f32x4 m4 = *reinterpret_cast<const f32x4*>(p.mask + orow[q] * p.mask_pitch + nc);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v4[e] *= m4[e] > 0.f ? 1.f : p.mask_slope;
+            }
+          }
+          *reinterpret_cast<f32x4*>(p.out + orow[q] * p.out_pitch + nc) = v4;
+        }
       }
     }
     return;
@@ -536,7 +558,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.M) p.out[out_row(m) * p.out_pitch + n] = acc[i][j][r] + bv + rv[r];
+        if (m < p.M) {
+          float v = lgm_post_act(acc[i][j][r] + bv + rv[r], p.act, p.slope);
+          if (p.mask) v *= p.mask[out_row(m) * p.mask_pitch + n] > 0.f ? 1.f : p.mask_slope;
+          p.out[out_row(m) * p.out_pitch + n] = v;
+        }
       }
     }
   }
@@ -597,6 +623,54 @@ int igemm_splits(long M, int N, int K, int* kchunk) {
   return lgm_cdiv(nk, per);
 }
 
+// ---- post-op plumbing (lgm_conv_xy_post / lgm_conv_yx_post) -----------------------------------------------------------
+// The entry points park the caller's post-op here for the duration of ONE call on this thread; the launch paths that
+// can apply it in their epilogue (implicit-GEMM kernels, their split-K reducer) take it and set `done`; for every
+// other path the entry point runs post_kernel over the finished output, so the result is the same either way.
+struct PostState {
+  const LgmPostOp* post;
+  bool done;
+};
+static thread_local PostState t_post = {nullptr, false};
+
+__global__ __launch_bounds__(256) void splitk_reduce_post_kernel(const float* __restrict__ ws, long ws_stride, int splits,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ res, long res_pitch,
+                                                                 float* __restrict__ out, long out_pitch, long M, int N,
+                                                                 int act, float slope, const float* __restrict__ mask,
+                                                                 long mask_pitch, float mask_slope) {
+  const int n4 = N / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * n4) return;
+  const long m = i / n4;
+  const int n = (int)(i % n4) * 4;
+  f32x4 s = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+  for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(ws + (long)k * ws_stride + m * N + n);
+  if (bias) s += *reinterpret_cast<const f32x4*>(bias + n);
+  if (res) s += *reinterpret_cast<const f32x4*>(res + m * res_pitch + n);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s[e] = lgm_post_act(s[e], act, slope);
+  if (mask) {
+    const f32x4 m4 = *reinterpret_cast<const f32x4*>(mask + m * mask_pitch + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] *= m4[e] > 0.f ? 1.f : mask_slope;
+  }
+  *reinterpret_cast<f32x4*>(out + m * out_pitch + n) = s;
+}
+
+// in-place post-op over a finished [M][N] output (paths without an epilogue hook)
+__global__ __launch_bounds__(256) void post_kernel(float* __restrict__ out, long out_pitch, long M, int N, int act,
+                                                   float slope, const float* __restrict__ mask, long mask_pitch,
+                                                   float mask_slope) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const long m = i / N;
+  const int n = (int)(i % N);
+  float v = lgm_post_act(out[m * out_pitch + n], act, slope);
+  if (mask) v *= mask[m * mask_pitch + n] > 0.f ? 1.f : mask_slope;
+  out[m * out_pitch + n] = v;
+}
+
 // stats / stats_tiles (optional): request the BatchNorm statistics of the output from the epilogue; *stats_tiles = the
 // number of row tiles written (0: this launch could not produce them - split-K, ragged tiles, bias / residual)
 template <int MODE>
@@ -606,6 +680,13 @@ int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool 
   a.phases = 1;
   a.KHs = a.KH;
   a.KWs = a.KW;
+  a.act = 0; a.slope = 0.f; a.mask = nullptr; a.mask_pitch = 0; a.mask_slope = 0.f;
+  const LgmPostOp* post = t_post.post;
+  if (post) {          // every launch of this dispatcher applies it: in the epilogue, or in the split-K reducer
+    a.act = post->act; a.slope = post->slope; a.mask = post->mask; a.mask_pitch = post->mask_pitch;
+    a.mask_slope = post->mask_slope;
+    t_post.done = true;
+  }
   if (MODE == MODE_YX && a.stride > 1 && a.KH % a.stride == 0 && a.KW % a.stride == 0 && a.H % a.stride == 0 &&
       a.W % a.stride == 0) {
     a.phases = a.stride * a.stride;
@@ -640,7 +721,15 @@ int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool 
     a.splits = splits;
     a.kchunk = kchunk;
     a.ws = (float*)workspace;
-    if (int rc = launch_igemm<MODE, 64, 64, 1, 1>(a, s)) return rc;
+    if (int rc = launch_igemm<MODE, 64, 64, 1, 1>(a, s)) return rc;      // partial products: the kernel skips the epilogue ops
+    if (post) {
+      const long items = (long)a.M * (a.N / 4);
+      hipLaunchKernelGGL(splitk_reduce_post_kernel, dim3((unsigned)lgm_cdiv(items, 256)), dim3(256), 0, s,
+                         (const float*)a.ws, (long)a.M * a.N, splits, a.bias, a.res, a.res_pitch, a.out, a.out_pitch,
+                         (long)a.M, a.N, a.act, a.slope, a.mask, a.mask_pitch, a.mask_slope);
+      LGM_LAUNCH_CHECK();
+      return LGM_OK;
+    }
     return lgm_splitk_reduce_launch(a.ws, (long)a.M * a.N, splits, a.bias, a.res, a.res_pitch, a.out, a.out_pitch, a.M,
                                     a.N, s);
   }
@@ -688,7 +777,8 @@ static int conv_xy_impl(const LgmConvGeom* g, const float* x, int64_t x_pitch, c
   LGM_REQUIRE(x_pitch % 4 == 0 && x_pitch >= g->Cw && lgm_aligned16(x) && lgm_aligned16(w),
               "conv_xy: x/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(y_pitch >= g->Nw && (!res || res_pitch >= g->Nw), "conv_xy: output pitch < Nw");
-  if (use_3x3() && wide_ok(y, y_pitch, res, res_pitch, bias) && lgm_conv3x3_supported(g, g->Cw, g->Nw) &&
+  static const bool post_3x3 = getenv("LGM_POST_VIA_3X3") != nullptr;   // A/B switch: direct 3x3 kernel + elementwise post-op
+  if (use_3x3() && (!t_post.post || post_3x3) && wide_ok(y, y_pitch, res, res_pitch, bias) && lgm_conv3x3_supported(g, g->Cw, g->Nw) &&
       ((long)g->B * g->H * g->W + g->W + 1) * x_pitch < (1L << 29))   // buffer offsets (bytes) below 2^31
     return lgm_conv3x3_launch(0, g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, workspace, workspace_bytes,
                               (hipStream_t)stream);
@@ -715,6 +805,40 @@ extern "C" int lgm_conv_xy(const LgmConvGeom* g, const float* x, int64_t x_pitch
                            int64_t y_pitch, void* workspace, int64_t workspace_bytes, void* stream) {
   return conv_xy_impl(g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, workspace, workspace_bytes, nullptr, nullptr,
                       stream);
+}
+
+static int post_check(const LgmPostOp* post, const char* who) {
+  LGM_REQUIRE(post && (post->act == 0 || post->act == 3 || post->act == 4), "%s: post-op activation must be none / ReLU / LeakyReLU", who);
+  LGM_REQUIRE(!post->mask || (lgm_aligned16(post->mask) && post->mask_pitch % 4 == 0), "%s: mask must be 16B aligned, pitch %% 4 == 0", who);
+  return LGM_OK;
+}
+
+// runs `call` with the post-op parked for the launch paths; applies it with one elementwise launch when the path
+// taken had no epilogue hook
+template <typename F>
+static int with_post(const LgmPostOp* post, float* out, int64_t out_pitch, long M, int N, void* stream, F call) {
+  t_post.post = post;
+  t_post.done = false;
+  const int rc = call();
+  const bool done = t_post.done;
+  t_post.post = nullptr;
+  t_post.done = false;
+  if (rc != LGM_OK || done || (post->act == 0 && !post->mask)) return rc;
+  hipLaunchKernelGGL(post_kernel, dim3((unsigned)lgm_cdiv(M * N, 256)), dim3(256), 0, (hipStream_t)stream, out,
+                     (long)out_pitch, M, N, post->act, post->slope, post->mask, (long)post->mask_pitch, post->mask_slope);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_conv_xy_post(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w,
+                                const float* bias, const float* res, int64_t res_pitch, float* y, int64_t y_pitch,
+                                void* workspace, int64_t workspace_bytes, const LgmPostOp* post, void* stream) {
+  if (int rc = post_check(post, "conv_xy_post")) return rc;
+  if (int rc = check_geom(g)) return rc;
+  return with_post(post, y, y_pitch, (long)g->B * g->Ho * g->Wo, g->Nw, stream, [&] {
+    return conv_xy_impl(g, x, x_pitch, w, bias, res, res_pitch, y, y_pitch, workspace, workspace_bytes, nullptr, nullptr,
+                        stream);
+  });
 }
 
 // lgm_conv_xy that also leaves the per-row-tile BatchNorm statistics of y in stats[tile][3][Nw] (see IgemmArgs::stats);
@@ -993,7 +1117,8 @@ static int conv_yx_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch, c
   LGM_REQUIRE(y_pitch % 4 == 0 && y_pitch >= g->Nw && lgm_aligned16(y) && lgm_aligned16(w),
               "conv_yx: y/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(x_pitch >= g->Cw && (!res || res_pitch >= g->Cw), "conv_yx: output pitch < Cw");
-  if (use_3x3() && wide_ok(x, x_pitch, res, res_pitch, bias) && lgm_conv3x3_supported(g, g->Nw, g->Cw) &&
+  static const bool post_3x3 = getenv("LGM_POST_VIA_3X3") != nullptr;   // A/B switch (see conv_xy_impl)
+  if (use_3x3() && (!t_post.post || post_3x3) && wide_ok(x, x_pitch, res, res_pitch, bias) && lgm_conv3x3_supported(g, g->Nw, g->Cw) &&
       ((long)g->B * g->H * g->W + g->W + 1) * y_pitch < (1L << 29))
     return lgm_conv3x3_launch(w_t ? 2 : 1, g, y, y_pitch, w_t ? w_t : w, bias, res, res_pitch, x, x_pitch, workspace,
                               workspace_bytes, (hipStream_t)stream);
@@ -1054,6 +1179,18 @@ extern "C" int lgm_conv_yx(const LgmConvGeom* g, const float* y, int64_t y_pitch
                            int64_t x_pitch, void* workspace, int64_t workspace_bytes, void* stream) {
   return conv_yx_impl(g, y, y_pitch, w, w_t, bias, res, res_pitch, x, x_pitch, workspace, workspace_bytes, nullptr,
                       nullptr, stream);
+}
+
+extern "C" int lgm_conv_yx_post(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w,
+                                const float* w_t, const float* bias, const float* res, int64_t res_pitch, float* x,
+                                int64_t x_pitch, void* workspace, int64_t workspace_bytes, const LgmPostOp* post,
+                                void* stream) {
+  if (int rc = post_check(post, "conv_yx_post")) return rc;
+  if (int rc = check_geom(g)) return rc;
+  return with_post(post, x, x_pitch, (long)g->B * g->H * g->W, g->Cw, stream, [&] {
+    return conv_yx_impl(g, y, y_pitch, w, w_t, bias, res, res_pitch, x, x_pitch, workspace, workspace_bytes, nullptr,
+                        nullptr, stream);
+  });
 }
 
 // the transposed convolution with the BatchNorm statistics of x left in stats (see lgm_conv_xy_stats)

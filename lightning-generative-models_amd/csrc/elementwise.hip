@@ -816,6 +816,35 @@ extern "C" int lgm_fill_col(float* out, int64_t pitch, int64_t n, int ncols, int
   return LGM_OK;
 }
 
+namespace {
+__global__ void vqvae_loss_kernel(const float* recon, const float* out3, float w_recon, float w_vq, float* vals4) {
+  const float r = recon[0], v = out3[0];
+  vals4[0] = r * w_recon + v * w_vq;
+  vals4[1] = r;
+  vals4[2] = v;
+  vals4[3] = out3[1];
+}
+__global__ void scale_pair_kernel(const float* g, float w0, float w1, float* out2) {
+  out2[0] = g[0] * w0;
+  out2[1] = g[0] * w1;
+}
+}  // namespace
+
+extern "C" int lgm_vqvae_loss(const float* recon, const float* out3, float w_recon, float w_vq, float* vals4,
+                              void* stream) {
+  LGM_REQUIRE(recon && out3 && vals4, "vqvae_loss: null pointer");
+  hipLaunchKernelGGL(vqvae_loss_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, recon, out3, w_recon, w_vq, vals4);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_scale_pair(const float* g, float w0, float w1, float* out2, void* stream) {
+  LGM_REQUIRE(g && out2, "scale_pair: null pointer");
+  hipLaunchKernelGGL(scale_pair_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, g, w0, w1, out2);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
 extern "C" int lgm_wgan_dloss(float* vals4, void* stream) {
   LGM_REQUIRE(vals4, "wgan_dloss: null pointer");
   hipLaunchKernelGGL(wgan_dloss_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, vals4);

@@ -99,9 +99,10 @@ class Conv2d(nn.Module):
                          partial=ok)
         return y, pl
 
-    def fwd(self, x, out=None, res=None, stats=False):
+    def fwd(self, x, out=None, res=None, stats=False, act=0, slope=0.0):
         """stats=True (bias-free convolution feeding a train-mode BatchNorm): returns (y, (partials, tiles)) with the
-        batch statistics of y left behind by the convolution's epilogue (tiles == 0: not for this geometry)."""
+        batch statistics of y left behind by the convolution's epilogue (tiles == 0: not for this geometry).
+        act (ReLU / LeakyReLU): y = act(conv(x) + bias + res), applied by the convolution's epilogue."""
         B, H, W, C = x.shape
         assert C == _r4(self.cin), f"conv expects {_r4(self.cin)} (padded) channels, got {C}"
         g = self.geom(B, H, W)
@@ -109,11 +110,15 @@ class Conv2d(nn.Module):
         y = out if out is not None else ops.new((B, g.Ho, g.Wo, _r4(self.cout)), x)
         if stats and self.bias is None and res is None:
             return y, ops.conv_stats(0, g, x, fp.ptr(self.weight), y)
-        ops.conv_xy(g, x, fp.ptr(self.weight), fp.ptr(self.bias) if self.bias is not None else None, res, y)
+        ops.conv_xy(g, x, fp.ptr(self.weight), fp.ptr(self.bias) if self.bias is not None else None, res, y,
+                    post=ops.make_post(act, slope))
         return (y, (None, 0)) if stats else y
 
-    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None, planes_for_groups=0):
+    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None, planes_for_groups=0,
+            mask=None, mask_slope=0.0):
         """gW, gb into flat grads; returns gx = dgrad(gy) (+ res) (+ existing gx when accumulate).
+        ``mask`` (a saved ReLU / LeakyReLU output): gx is multiplied by that activation's derivative in the input
+        gradient's epilogue - the backward of an activation that sat in front of this layer's input.
         ``planes_for_groups`` = G > 0: the only reader of gx is the backward of a GroupNorm(G) - returns (gx, planes) as
         ``fwd_planes`` does (planes given: gx itself is NOT written)."""
         B, H, W, _ = x.shape
@@ -128,7 +133,7 @@ class Conv2d(nn.Module):
                 gb = fp.gptr(self.bias)              # bias gradient fused into the wgrad kernel
             else:
                 ops.colsum(gy, fp.gptr(self.bias), bb)
-        if need_gx and self.k == 3:
+        if need_gx and self.k == 3 and mask is None:
             # 3x3 layers: input gradient and weight gradient side by side in ONE launch (ops.conv_bwd_pair)
             if gx is None:
                 gx = ops.new(x.shape, x)
@@ -151,7 +156,8 @@ class Conv2d(nn.Module):
         if planes_for_groups:
             ok = self.k == 3 and res is None and ops.gn_planes_ok(B, H * W, x.shape[-1], planes_for_groups)
             return gx, ops.conv_yx(g, gy, fp.ptr(self.weight), None, res, gx, fp.tptr(self.weight), partial=ok)
-        ops.conv_yx(g, gy, fp.ptr(self.weight), None, res, gx, fp.tptr(self.weight))
+        ops.conv_yx(g, gy, fp.ptr(self.weight), None, res, gx, fp.tptr(self.weight),
+                    post=ops.make_post(0, 0.0, mask, mask_slope), post_mask=mask)
         return gx
 
 
@@ -215,8 +221,9 @@ class ConvTranspose2d(nn.Module):
             self._geoms[key] = g
         return g
 
-    def fwd(self, x, out=None, res=None, stats=False):
-        """stats=True: as Conv2d.fwd - (y, (partials, tiles)) with the batch statistics of y from the epilogue."""
+    def fwd(self, x, out=None, res=None, stats=False, act=0, slope=0.0):
+        """stats=True: as Conv2d.fwd - (y, (partials, tiles)) with the batch statistics of y from the epilogue.
+        act: as Conv2d.fwd."""
         B, H, W, C = x.shape
         assert C == _r4(self.cin)
         g = self.geom(B, H, W)
@@ -224,10 +231,11 @@ class ConvTranspose2d(nn.Module):
         y = out if out is not None else ops.new((B, g.H, g.W, _r4(self.cout)), x)
         if stats and self.bias is None and res is None:
             return y, ops.conv_stats(1, g, x, fp.ptr(self.weight), y)
-        ops.conv_yx(g, x, fp.ptr(self.weight), fp.ptr(self.bias) if self.bias is not None else None, res, y)
+        ops.conv_yx(g, x, fp.ptr(self.weight), fp.ptr(self.bias) if self.bias is not None else None, res, y,
+                    post=ops.make_post(act, slope))
         return (y, (None, 0)) if stats else y
 
-    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None):
+    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None, mask=None, mask_slope=0.0):
         B, H, W, _ = x.shape
         g = self.geom(B, H, W)
         fp = gc.flat
@@ -242,7 +250,7 @@ class ConvTranspose2d(nn.Module):
         if accumulate:
             assert res is None
             res = gx
-        ops.conv_xy(g, gy, fp.ptr(self.weight), None, res, gx)
+        ops.conv_xy(g, gy, fp.ptr(self.weight), None, res, gx, post=ops.make_post(0, 0.0, mask, mask_slope), post_mask=mask)
         return gx
 
 

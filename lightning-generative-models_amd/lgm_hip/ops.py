@@ -264,14 +264,54 @@ def _conv_ws(g: ConvGeom, yx: int, device):
 
 
 PLANES = _os.environ.get("LGM_NO_PLANES", "0") != "1"     # A/B switch: GroupNorm sums split-K partial planes itself
+POSTOPS = _os.environ.get("LGM_NO_POSTOP", "0") != "1"    # A/B switch: activations / masks as separate launches
 
 
-def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y, partial: bool = False):
+class PostOp(ctypes.Structure):
+    """LgmPostOp (include/lgm_hip.h): out = act(conv + bias + res) * (mask > 0 ? 1 : mask_slope)"""
+    _fields_ = [("act", ctypes.c_int32), ("slope", ctypes.c_float), ("mask", ctypes.c_void_p),
+                ("mask_pitch", ctypes.c_int64), ("mask_slope", ctypes.c_float)]
+
+
+def make_post(act: int = 0, slope: float = 0.0, mask: Optional[torch.Tensor] = None, mask_slope: float = 0.0):
+    """None when there is nothing to do"""
+    if act == 0 and mask is None:
+        return None
+    assert act in (0, ACT_RELU, ACT_LRELU)
+    return PostOp(act, slope, None if mask is None else mask.data_ptr(), 0 if mask is None else pitch(mask), mask_slope)
+
+
+def _apply_post_separately(post: PostOp, out, mask):
+    """LGM_NO_POSTOP=1: the same arithmetic from the separate elementwise launches"""
+    if post.act:
+        act_fwd(out, None, None, out, post.act, post.slope)
+    if mask is not None:
+        act_bwd(mask, None, out, out, False, ACT_LRELU if post.mask_slope != 0.0 else ACT_RELU, post.mask_slope)
+
+
+def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y, partial: bool = False, post: Optional[PostOp] = None,
+            post_mask=None):
     """``partial=True`` (the consumer is a GroupNorm that can sum split-K planes, see gn_fwd): returns
     (planes address, plane stride, planes, bias address) when the convolution left its result in pieces - ``y`` is then
-    NOT written and the bias NOT applied - else None (``y`` complete)."""
+    NOT written and the bias NOT applied - else None (``y`` complete).
+    ``post`` (make_post): activation / backward mask applied by the convolution's epilogue (lgm_conv_xy_post)."""
     if TIMER is not None:
         TIMER.begin("igemm_xy", _conv_flops(g), _conv_bytes(g))
+    if post is not None:
+        ws = _conv_ws(g, 0, x.device)
+        if POSTOPS:
+            lib().lgm_conv_xy_post(ctypes.byref(g), x.data_ptr(), pitch(x), w_ptr, bias_ptr, _p(res),
+                                   pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
+                                   None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4,
+                                   ctypes.byref(post), stream())
+        else:
+            lib().lgm_conv_xy(ctypes.byref(g), x.data_ptr(), pitch(x), w_ptr, bias_ptr, _p(res),
+                              pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
+                              None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
+            _apply_post_separately(post, y, post_mask)
+        if TIMER is not None:
+            TIMER.end()
+        return None
     if WINO and _WINO_FLATS and not B3 and _wino_supported(g, 0):
         u = _wino_u(w_ptr, False)
         if u is not None:
@@ -319,10 +359,25 @@ def conv_stats(yx: int, g: ConvGeom, a, w_ptr: int, out, wt_ptr: Optional[int] =
 
 
 def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr: Optional[int] = None,
-            partial: bool = False):
-    """``partial``: as conv_xy."""
+            partial: bool = False, post: Optional[PostOp] = None, post_mask=None):
+    """``partial`` / ``post``: as conv_xy."""
     if TIMER is not None:
         TIMER.begin("igemm_yx", _conv_flops(g), _conv_bytes(g))
+    if post is not None:
+        ws = _conv_ws(g, 1, y.device)
+        if POSTOPS:
+            lib().lgm_conv_yx_post(ctypes.byref(g), y.data_ptr(), pitch(y), w_ptr, wt_ptr, bias_ptr, _p(res),
+                                   pitch(res) if res is not None else 0, x.data_ptr(), pitch(x),
+                                   None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4,
+                                   ctypes.byref(post), stream())
+        else:
+            lib().lgm_conv_yx(ctypes.byref(g), y.data_ptr(), pitch(y), w_ptr, wt_ptr, bias_ptr, _p(res),
+                              pitch(res) if res is not None else 0, x.data_ptr(), pitch(x),
+                              None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
+            _apply_post_separately(post, x, post_mask)
+        if TIMER is not None:
+            TIMER.end()
+        return None
     if WINO and _WINO_FLATS and not B3 and _wino_supported(g, 1):
         u = _wino_u(w_ptr, True)
         if u is not None:

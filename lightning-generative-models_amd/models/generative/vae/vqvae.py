@@ -39,25 +39,25 @@ class ResidualStack(nn.Module):
                                      for _ in range(num_residual_layers)])
 
     def fwd(self, cur, save):
+        """``cur`` arrives with the first block's (in-place) ReLU already applied by the epilogue of the convolution
+        that produced it; every ReLU in here rides in a convolution epilogue too (lgm_conv_xy_post):
+        y = relu(conv3x3(cur)), cur' = relu(conv1x1(y) + cur) - the next block's in-place ReLU, or the stack's final one."""
         tape = []
         for blk in self.layers:
-            ops.act_fwd(cur, None, None, cur, ops.ACT_RELU)          # in place: cur := relu(cur)
-            y = blk.block[1].fwd(cur)
-            ops.act_fwd(y, None, None, y, ops.ACT_RELU)
-            z = blk.block[3].fwd(y, res=cur)
+            y = blk.block[1].fwd(cur, act=ops.ACT_RELU)
+            z = blk.block[3].fwd(y, res=cur, act=ops.ACT_RELU)
             tape.append((cur, y))
             cur = z
-        ops.act_fwd(cur, None, None, cur, ops.ACT_RELU)
         return cur, (tape, cur)
 
     def bwd(self, gc, saved, g):
+        """``g`` arrives already multiplied by the final ReLU's mask (the consumer's input gradient applied it in its
+        epilogue, mask = the stack's output); returns the gradient w.r.t. the stack's (ReLU'd) input, again with that
+        ReLU's mask applied - every activation backward is an epilogue mask of the input gradient before it."""
         tape, out = saved
-        ops.act_bwd(out, None, g, g, False, ops.ACT_RELU)
         for blk, (r, y) in zip(reversed(self.layers), reversed(tape)):
-            gy = blk.block[3].bwd(gc, y, g)
-            ops.act_bwd(y, None, gy, gy, False, ops.ACT_RELU)
-            blk.block[1].bwd(gc, r, gy, g, True)                        # g (= residual path) += dgrad
-            ops.act_bwd(r, None, g, g, False, ops.ACT_RELU)
+            gy = blk.block[3].bwd(gc, y, g, mask=y)
+            blk.block[1].bwd(gc, r, gy, g, True, mask=r)                # g = (g + dgrad(gy)) * relu'(r)
         return g
 
 
@@ -80,10 +80,9 @@ class Encoder(nn.Module):
         acts = [x]
         cur = x
         for i in (0, 2, 4):
-            cur = L[i].fwd(cur)
-            ops.act_fwd(cur, None, None, cur, ops.ACT_RELU)
+            cur = L[i].fwd(cur, act=ops.ACT_RELU)                       # Conv2d -> ReLU: one launch
             acts.append(cur)
-        a3 = L[6].fwd(cur)
+        a3 = L[6].fwd(cur, act=ops.ACT_RELU)                            # the residual stack's first in-place ReLU
         s, st = L[7].fwd(a3, True)
         lat = L[8].fwd(s)
         return lat, (acts, st, s)
@@ -91,12 +90,11 @@ class Encoder(nn.Module):
     def bwd(self, gc, saved, glat):
         acts, st, s = saved
         L = self.layers
-        g = L[8].bwd(gc, s, glat)
+        g = L[8].bwd(gc, s, glat, mask=s)                               # * relu'(stack output)
         g = L[7].bwd(gc, st, g)
-        g = L[6].bwd(gc, acts[3], g)
+        g = L[6].bwd(gc, acts[3], g, mask=acts[3])
         for k, i in ((3, 4), (2, 2), (1, 0)):
-            ops.act_bwd(acts[k], None, g, g, False, ops.ACT_RELU)
-            g = L[i].bwd(gc, acts[k - 1], g, need_gx=(i != 0))
+            g = L[i].bwd(gc, acts[k - 1], g, need_gx=(i != 0), mask=(acts[k - 1] if i != 0 else None))
 
 
 class Decoder(nn.Module):
@@ -114,12 +112,10 @@ class Decoder(nn.Module):
 
     def fwd(self, q):
         L = self.layers
-        a0 = L[0].fwd(q)
+        a0 = L[0].fwd(q, act=ops.ACT_RELU)                              # the residual stack's first in-place ReLU
         s, st = L[1].fwd(a0, True)
-        u1 = L[2].fwd(s)
-        ops.act_fwd(u1, None, None, u1, ops.ACT_RELU)
-        u2 = L[4].fwd(u1)
-        ops.act_fwd(u2, None, None, u2, ops.ACT_RELU)
+        u1 = L[2].fwd(s, act=ops.ACT_RELU)
+        u2 = L[4].fwd(u1, act=ops.ACT_RELU)
         pre = L[6].fwd(u2)
         xh = ops.new(pre.shape, pre)
         ops.act_fwd(pre, None, None, xh, ops.ACT_TANH)
@@ -129,11 +125,9 @@ class Decoder(nn.Module):
         q, st, s, u1, u2, pre = saved
         L = self.layers
         ops.act_bwd(pre, None, gxh, gxh, False, ops.ACT_TANH)
-        g = L[6].bwd(gc, u2, gxh)
-        ops.act_bwd(u2, None, g, g, False, ops.ACT_RELU)
-        g = L[4].bwd(gc, u1, g)
-        ops.act_bwd(u1, None, g, g, False, ops.ACT_RELU)
-        g = L[2].bwd(gc, s, g)
+        g = L[6].bwd(gc, u2, gxh, mask=u2)
+        g = L[4].bwd(gc, u1, g, mask=u1)
+        g = L[2].bwd(gc, s, g, mask=s)
         g = L[1].bwd(gc, st, g)
         return L[0].bwd(gc, q, g)
 
@@ -327,20 +321,22 @@ class _VQVAEStepFn(torch.autograd.Function):
     def forward(ctx, anchor, m: VQVAE, x, w_recon, w_vq):
         save = bool(ctx.needs_input_grad[0])
         r, tape = m.run(x.detach().float(), save)
-        out3 = r["out3"]
-        loss = r["recon"] * w_recon + out3[0:1] * w_vq          # two scalar ops (plumbing)
+        vals = ops.new((4,), r["recon"])            # (loss, recon, vq, perplexity): one launch, no torch arithmetic
+        ops.lib().lgm_vqvae_loss(r["recon"].data_ptr(), r["out3"].data_ptr(), w_recon, w_vq, vals.data_ptr(), ops.stream())
         m.last = r
         ctx.stuff = (m, tape, w_recon, w_vq)
-        recon_o, vq_o, ppl_o = r["recon"].view(()).clone(), out3[0].clone(), out3[1].clone()
+        loss, recon_o, vq_o, ppl_o = vals[0], vals[1], vals[2], vals[3]
         ctx.mark_non_differentiable(recon_o, vq_o, ppl_o)
-        return loss.view(()), recon_o, vq_o, ppl_o
+        return loss, recon_o, vq_o, ppl_o
 
     @staticmethod
     def backward(ctx, gloss, *_unused):
         m, tape, w_recon, w_vq = ctx.stuff
         if tape is None:
             raise RuntimeError("VQVAE step ran without saving activations")
-        gl = gloss.detach().float().reshape(1)
-        m.backward_hip(tape, (gl * w_recon).contiguous(), (gl * w_vq).contiguous())
+        gl = gloss.detach().float().reshape(1).contiguous()
+        g2 = ops.new((2,), gl)
+        ops.lib().lgm_scale_pair(gl.data_ptr(), w_recon, w_vq, g2.data_ptr(), ops.stream())
+        m.backward_hip(tape, g2[0:1], g2[1:2])
         ctx.stuff = None
         return None, None, None, None, None

@@ -480,3 +480,48 @@ def test_attend_module_path(dev):
     (o * w.to(dev)).sum().backward()
     for a, r in ((qd, q2), (kd, k2), (vd, v2)):
         assert rel(a.grad, r.grad) < RTOL
+
+
+# (B, Cin, Cout, H, k, stride, pad): the paths behind lgm_conv_xy_post / lgm_conv_yx_post - implicit GEMM with and
+# without split-K, strided (phase-decomposed) input gradient, the 1x1 fast paths and the direct 3x3 kernel (no epilogue
+# hook there: the entry point finishes with the elementwise launch), ragged channel counts
+POST_CASES = [(8, 3, 32, 32, 4, 2, 1), (16, 32, 64, 16, 4, 2, 1), (64, 128, 128, 4, 3, 1, 1), (64, 128, 32, 4, 3, 1, 1),
+              (64, 32, 128, 4, 1, 1, 0), (4, 64, 128, 8, 4, 2, 1), (2, 20, 12, 8, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", POST_CASES)
+@pytest.mark.parametrize("act", ["relu", "lrelu"])
+def test_conv_epilogue_activation_and_mask(dev, case, act):
+    """Conv2d -> ReLU / LeakyReLU as ONE launch (reference vqvae.py:36-51,74-85, residual.py:14-20, dcgan.py) and its
+    autograd mirror image - the activation's backward as a mask in the epilogue of the input gradient that precedes
+    it: y = act(conv(x) + b + res);  gx = (dgrad(gy) + res') * act'(saved output).  Against torch on the CPU."""
+    from lgm_hip import ops
+    B, ci, co, hw, k, st, pd = case
+    gen = torch.Generator().manual_seed(sum(case))
+    slope = 0.2 if act == "lrelu" else 0.0
+    code = ops.ACT_LRELU if act == "lrelu" else ops.ACT_RELU
+    x = torch.randn(B, ci, hw, hw, generator=gen)
+    w = torch.randn(co, ci, k, k, generator=gen) / math.sqrt(ci * k * k)
+    b = torch.randn(co, generator=gen)
+    ho = (hw + 2 * pd - k) // st + 1
+    res = torch.randn(B, co, ho, ho, generator=gen)
+    f = (lambda t: F.leaky_relu(t, slope)) if act == "lrelu" else F.relu
+    y_ref = f(F.conv2d(x, w, b, stride=st, padding=pd) + res)
+    xd, wd, bd, rd = nhwc(x, dev), phys_weight(w, dev), vec(b, dev), nhwc(res, dev)
+    Cp, Np = xd.shape[-1], rd.shape[-1]
+    g = ops.make_geom(B, hw, hw, Cp, Np, k, k, st, pd)
+    y = torch.empty(B, ho, ho, Np, device=dev)
+    ops.conv_xy(g, xd, wd.data_ptr(), bd.data_ptr(), rd, y, post=ops.make_post(code, slope))
+    assert rel(nchw(y, co), y_ref) < 1e-5
+    # backward: gradient w.r.t. an input that is itself an activation output `xin` (saved), with a residual-path term
+    xin = f(torch.randn(B, ci, hw, hw, generator=gen))
+    gy = torch.randn(B, co, ho, ho, generator=gen)
+    gres = torch.randn(B, ci, hw, hw, generator=gen)
+    dg = torch.nn.grad.conv2d_input(x.shape, w, gy, stride=st, padding=pd)
+    gx_ref = (dg + gres) * torch.where(xin > 0, torch.ones_like(xin), torch.full_like(xin, slope))
+    gyd, xind = nhwc(gy, dev), nhwc(xin, dev)
+    gx = nhwc(gres, dev).contiguous()
+    wt = wd.permute(2, 1, 0).contiguous()
+    ops.conv_yx(g, gyd, wd.data_ptr(), None, gx, gx, wt.data_ptr(), post=ops.make_post(0, 0.0, xind, slope), post_mask=xind)
+    assert rel(nchw(gx, ci), gx_ref) < 1e-5
+    assert float(gx[..., ci:].abs().max()) == 0 if Cp > ci else True      # padding lanes stay zero
