@@ -182,11 +182,13 @@ class Discriminator(_Net):
                 tape.append((h, a, sv, hn))
                 h = hn
                 continue
-            a = blk[0].fwd(h)
             if not final:
-                hn = ops.new(a.shape, a)
-                ops.act_fwd(a, None, None, hn, ops.ACT_LRELU, SLOPE)
+                # Conv2d -> LeakyReLU without a BatchNorm between them (the critic's first layer): the activation rides
+                # in the convolution's epilogue; the backward passes only ever need its OUTPUT (sign of hn)
+                hn = blk[0].fwd(h, act=ops.ACT_LRELU, slope=SLOPE)
+                a = hn
             else:
+                a = blk[0].fwd(h)
                 hn = a
             tape.append((h, a, sv, hn))
             h = hn
