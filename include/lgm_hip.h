@@ -107,6 +107,16 @@ int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g);
 int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
                    int64_t x_pitch, float* gw, float* gbias, float beta, void* workspace,
                    int64_t workspace_bytes, void* stream);
+/* Backward of ANY convolution / linear layer in one call: weight / bias gradient (lgm_conv_wgrad, or its deferred form
+ * when desc != NULL) AND input gradient gx = W^T gy (+ res) (lgm_conv_yx).  When the dispatchers pick the two kernels
+ * that can share a grid - the 1x1 convolutions and linears of the UNet at small row counts (to_qkv / to_out
+ * ddpm.py:214-223, res_conv :184, Downsample :100-104) - both run in ONE launch (gemm_bwd_pair_kernel: same kernel
+ * bodies, bit-identical results); otherwise exactly the two separate calls.  dgrad_ws (lgm_conv_workspace(g, 1) bytes)
+ * and wgrad_ws (lgm_conv_wgrad_workspace(g) bytes) must not overlap. */
+int lgm_conv_bwd_pair(const LgmConvGeom* g, const float* gy, int64_t gy_pitch, const float* x, int64_t x_pitch,
+                      const float* w, const float* w_t, const float* res, int64_t res_pitch, float* gx,
+                      int64_t gx_pitch, void* dgrad_ws, int64_t dgrad_ws_bytes, float* gw, float* gbias, float beta,
+                      void* wgrad_ws, int64_t wgrad_ws_bytes, int64_t* desc, void* stream);
 /* Deferred form (same arithmetic): writes only the per-split partial slabs into `workspace` (which must then
  * stay untouched until the reduction) and fills desc[8] = {workspace, slab stride, gw, n_w, gbias, n_b, splits,
  * beta bits}; lgm_wgrad_reduce_batch then performs the fixed-order slab reductions of MANY layers in one

@@ -13,6 +13,7 @@
 // element s of that float4 from both operands (the k -> (half, step) assignment is arbitrary as
 // long as A and B agree; fp32 accumulation order inside a chunk is fixed => deterministic).
 #include <stdlib.h>
+#include <string.h>
 
 #include "lgm_common.h"
 
@@ -117,8 +118,10 @@ __device__ __forceinline__ float lgm_post_act(float v, int act, float slope) {
   return act == 0 ? v : (v > 0.f ? v : (act == 4 ? slope * v : 0.f));
 }
 
+// kernel body as a device function of (arguments, logical block id): its own launch (igemm_kernel) or the first block
+// range of gemm_bwd_pair_kernel (input gradient + weight gradient of one layer in ONE launch, see below)
 template <int MODE, int BM, int BN, int TM, int TN, bool UNI>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+__device__ __forceinline__ void igemm_body(const IgemmArgs& p, const int bidx) {
   static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 wave grid");
   constexpr int A_PER = BM / 32;  // float4 per thread per chunk
   constexpr int B_PER = BN / 32;
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   const int lr = lane & 31, lh = lane >> 5;
 
   // tile mapping: consecutive blocks walk N first (share the A tile through L2)
-  const int split = blockIdx.x % p.splits;
-  int tile = blockIdx.x / p.splits;
+  const int split = bidx % p.splits;
+  int tile = bidx / p.splits;
   const int per_phase = p.tiles_m * p.tiles_n;
   const int pc = tile / per_phase;               // residue class (0 when the decomposition is off)
   tile -= pc * per_phase;
@@ -569,6 +572,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 }
 
 template <int MODE, int BM, int BN, int TM, int TN, bool UNI>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+  igemm_body<MODE, BM, BN, TM, TN, UNI>(p, (int)blockIdx.x);
+}
+
+// ---- backward pair of the generic layers (1x1 convolutions, linears): lgm_conv_bwd_pair ---------------------------------
+// While the context is active, the two launch sites that can share a grid - the 64 x 64 uniform-tap input-gradient
+// GEMM and the generic weight-gradient kernel - RECORD their arguments instead of launching, and the reducers that would
+// follow them are stashed; lgm_conv_bwd_pair then issues ONE launch for both (or each alone when only one recorded) and
+// the stashed reducers after it.  Every other path launches as usual: whatever the dispatchers pick, nothing is lost.
+struct PairCtx {
+  bool active, rec_i, rec_w, red_i, red_w;
+  IgemmArgs ig;
+  size_t ig_smem;
+  unsigned ig_blocks, wg_blocks;
+  alignas(16) unsigned char wg[320];        // WgradArgs (defined below)
+  // stashed split-K reducer of the input gradient
+  const float* r_ws; long r_stride; int r_splits; const float* r_bias; const float* r_res; long r_res_pitch;
+  float* r_out; long r_out_pitch; long r_M; int r_N;
+  // stashed slab reducer of the weight gradient (non-deferred form)
+  const float* w_ws; long w_slab; float* w_gw; long w_nw; float* w_gb; long w_nb; int w_splits; float w_beta;
+};
+static thread_local PairCtx t_pair = {};
+
+template <int MODE, int BM, int BN, int TM, int TN, bool UNI>
 int launch_igemm_t(IgemmArgs& a, hipStream_t s) {
   a.tiles_m = lgm_cdiv(a.M, BM);
   a.tiles_n = lgm_cdiv(a.N, BN);
@@ -584,6 +611,13 @@ int launch_igemm_t(IgemmArgs& a, hipStream_t s) {
   static char name[64] = "";
   if (!name[0]) snprintf(name, sizeof(name), "igemm_kernel<%d, %d, %d, %d, %d, %s>", MODE, BM, BN, TM, TN, UNI ? "true" : "false");
   lgm_note_kernel(name);
+  if (MODE == MODE_YX && BM == 64 && BN == 64 && UNI && t_pair.active && !t_pair.rec_i && !a.stats) {
+    t_pair.ig = a;                                   // launched by lgm_conv_bwd_pair, together with the weight gradient
+    t_pair.ig_smem = smem;
+    t_pair.ig_blocks = (unsigned)(a.tiles_m * a.tiles_n * a.splits * a.phases);
+    t_pair.rec_i = true;
+    return LGM_OK;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits * a.phases)), dim3(256), smem, s, a);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
@@ -722,6 +756,13 @@ int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool 
     a.kchunk = kchunk;
     a.ws = (float*)workspace;
     if (int rc = launch_igemm<MODE, 64, 64, 1, 1>(a, s)) return rc;      // partial products: the kernel skips the epilogue ops
+    if (t_pair.active && t_pair.rec_i && !post && t_pair.ig.ws == a.ws) {   // recorded, not launched: reduce after the pair
+      t_pair.red_i = true;
+      t_pair.r_ws = a.ws; t_pair.r_stride = (long)a.M * a.N; t_pair.r_splits = splits; t_pair.r_bias = a.bias;
+      t_pair.r_res = a.res; t_pair.r_res_pitch = a.res_pitch; t_pair.r_out = a.out; t_pair.r_out_pitch = a.out_pitch;
+      t_pair.r_M = a.M; t_pair.r_N = a.N;
+      return LGM_OK;
+    }
     if (post) {
       const long items = (long)a.M * (a.N / 4);
       hipLaunchKernelGGL(splitk_reduce_post_kernel, dim3((unsigned)lgm_cdiv(items, 256)), dim3(256), 0, s,
@@ -1230,7 +1271,7 @@ struct WgradArgs {
 // instructions per gathered row instead of ~60 (two integer divisions each), which beside fp32 MFMAs is the
 // difference between a VALU-bound and an MFMA-bound loop (DESIGN finding 11).
 template <int BM, int BN, int TM, int TN, bool FAST>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bidx) {
   static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 wave grid");
   constexpr int A_TPR = BM / 4, A_RPP = 256 / A_TPR, A_PER = WBK / A_RPP > 0 ? WBK / A_RPP : 1;
   constexpr int B_TPR = BN / 4, B_RPP = 256 / B_TPR, B_PER = WBK / B_RPP > 0 ? WBK / B_RPP : 1;
@@ -1243,7 +1284,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
   const int wm = wid >> 1, wn = wid & 1;
   const int lr = lane & 31, lh = lane >> 5;
 
-  int bid = blockIdx.x;
+  int bid = bidx;
   const int split = bid % p.splits;
   bid /= p.splits;
   const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
@@ -1446,6 +1487,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
   }
 }
 
+template <int BM, int BN, int TM, int TN, bool FAST>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+  wgrad_body<BM, BN, TM, TN, FAST>(p, (int)blockIdx.x);
+}
+
+// Input gradient (blocks [0, n_ig): the 64 x 64 uniform-tap implicit GEMM) and weight gradient (the rest: the generic
+// 64 x 64 kernel) of ONE layer in ONE launch - the 1x1 convolutions and linears of the UNet (to_qkv / to_out
+// ddpm.py:214-223, res_conv :184, Downsample :100-104).  Same bodies as the separate kernels: bit-identical results.
+// At the per-GPU batches of a strong-scaled run each of the two is a ~9 us launch on a quarter of the chip.
+__global__ __launch_bounds__(256) void gemm_bwd_pair_kernel(const IgemmArgs pi, const WgradArgs pw, const int n_ig) {
+  if ((int)blockIdx.x < n_ig) igemm_body<MODE_YX, 64, 64, 1, 1, true>(pi, (int)blockIdx.x);
+  else wgrad_body<64, 64, 1, 1, true>(pw, (int)blockIdx.x - n_ig);
+}
+
 // Deterministic split-K reduction: out[i] = beta*out[i] + sum_s ws[s*slab + i] (fixed order:
 // 4 split lanes summed in LDS in lane order).  i < n_w -> gw, n_w <= i < n_w + n_b -> gbias.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, long slab,
@@ -1600,7 +1655,12 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
     const bool big = fast && want_big && a.Nw % 128 == 0 && (long)(a.Nw / 128) * a.tiles_n * a.splits >= 512;
     lgm_note_kernel(big ? "wgrad_kernel<128, 64, 2, 1, true>"
                         : fast ? "wgrad_kernel<64, 64, 1, 1, true>" : "wgrad_kernel<64, 64, 1, 1, false>");
-    if (big) {
+    static_assert(sizeof(WgradArgs) <= sizeof(t_pair.wg), "PairCtx::wg too small");
+    if (!big && fast && t_pair.active && !t_pair.rec_w) {       // launched by lgm_conv_bwd_pair, with the input gradient
+      memcpy(t_pair.wg, &a, sizeof(WgradArgs));
+      t_pair.wg_blocks = (unsigned)(a.tiles_m * a.tiles_n * a.splits);
+      t_pair.rec_w = true;
+    } else if (big) {
       a.tiles_m = a.Nw / 128;
       hipLaunchKernelGGL((wgrad_kernel<128, 64, 2, 1, true>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
     } else if (fast)
@@ -1619,6 +1679,12 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
     return LGM_OK;
   }
   if (a.splits > 1) {
+    if (t_pair.active && t_pair.rec_w) {          // the kernel has not run yet: reduce after the pair launch
+      t_pair.red_w = true;
+      t_pair.w_ws = (const float*)workspace; t_pair.w_slab = a.slab; t_pair.w_gw = gw; t_pair.w_nw = n_w;
+      t_pair.w_gb = gbias; t_pair.w_nb = n_b; t_pair.w_splits = a.splits; t_pair.w_beta = beta;
+      return LGM_OK;
+    }
     const long groups = (n_w + n_b + 3) / 4;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lgm_cdiv(groups, 64)), dim3(256), 0, s,
                        (const float*)workspace, a.slab, gw, n_w, gbias, n_b, a.splits, beta);
@@ -1697,6 +1763,66 @@ extern "C" int lgm_conv3x3_wino_bwd(const LgmConvGeom* g, const float* gy, int64
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lgm_cdiv(groups, 64)), dim3(256), 0, s, (const float*)wgrad_ws,
                      slab, gw, n_w, gbias, n_b, splits, beta);
   LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// Backward of a generic layer (any geometry): weight / bias gradient AND input gradient.  When the dispatchers pick
+// the two kernels that can share a grid (see PairCtx) both run in ONE launch; otherwise this is exactly
+// lgm_conv_wgrad[_deferred] followed by lgm_conv_yx.  dgrad_ws and wgrad_ws must not overlap (the kernels run side by side).
+extern "C" int lgm_conv_bwd_pair(const LgmConvGeom* g, const float* gy, int64_t gy_pitch, const float* x,
+                                 int64_t x_pitch, const float* w, const float* w_t, const float* res, int64_t res_pitch,
+                                 float* gx, int64_t gx_pitch, void* dgrad_ws, int64_t dgrad_ws_bytes, float* gw,
+                                 float* gbias, float beta, void* wgrad_ws, int64_t wgrad_ws_bytes, int64_t* desc,
+                                 void* stream) {
+  static const bool no_pair = getenv("LGM_NO_PAIR") != nullptr;   // A/B switch: separate launches
+  hipStream_t s = (hipStream_t)stream;
+  t_pair = PairCtx{};
+  t_pair.active = !no_pair;
+  int rc = conv_wgrad_impl(g, gy, gy_pitch, x, x_pitch, gw, gbias, beta, wgrad_ws, wgrad_ws_bytes, desc, stream);
+  if (rc == LGM_OK)
+    rc = conv_yx_impl(g, gy, gy_pitch, w, w_t, nullptr, res, res_pitch, gx, gx_pitch, dgrad_ws, dgrad_ws_bytes, nullptr,
+                      nullptr, stream);
+  const PairCtx c = t_pair;
+  t_pair = PairCtx{};
+  if (rc != LGM_OK) return rc;
+  WgradArgs wa;
+  memcpy(&wa, c.wg, sizeof(WgradArgs));
+  // one launch only while both grids fit the chip together (67 KB of LDS per workgroup: two per CU): large layers keep
+  // their own launches, where the input-gradient kernel alone gets four workgroups per CU (B = 128: 1 % slower paired)
+  static const unsigned pair_max = getenv("LGM_PAIR_MAX") ? (unsigned)atoi(getenv("LGM_PAIR_MAX")) : 512u;
+  const bool together = c.rec_i && c.rec_w && c.ig_blocks + c.wg_blocks <= pair_max;
+  if (together) {
+    static size_t attr = 0;
+    if (c.ig_smem > attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bwd_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)c.ig_smem);
+      attr = c.ig_smem;
+    }
+    lgm_note_kernel("gemm_bwd_pair_kernel");
+    hipLaunchKernelGGL(gemm_bwd_pair_kernel, dim3(c.ig_blocks + c.wg_blocks), dim3(256), c.ig_smem, s, c.ig, wa,
+                       (int)c.ig_blocks);
+  } else {
+    if (c.rec_w) {
+      lgm_note_kernel("wgrad_kernel<64, 64, 1, 1, true>");
+      hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1, true>), dim3(c.wg_blocks), dim3(256), 0, s, wa);
+    }
+    if (c.rec_i) {
+      IgemmArgs ia = c.ig;
+      t_pair = PairCtx{};                    // inactive: this time the launch site launches
+      if (int r2 = launch_igemm_t<MODE_YX, 64, 64, 1, 1, true>(ia, s)) return r2;
+    }
+  }
+  LGM_LAUNCH_CHECK();
+  if (c.red_i)
+    if (int r2 = lgm_splitk_reduce_launch(c.r_ws, c.r_stride, c.r_splits, c.r_bias, c.r_res, c.r_res_pitch, c.r_out,
+                                          c.r_out_pitch, c.r_M, c.r_N, s))
+      return r2;
+  if (c.red_w) {
+    const long groups = (c.w_nw + c.w_nb + 3) / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lgm_cdiv(groups, 64)), dim3(256), 0, s, c.w_ws, c.w_slab, c.w_gw,
+                       c.w_nw, c.w_gb, c.w_nb, c.w_splits, c.w_beta);
+    LGM_LAUNCH_CHECK();
+  }
   return LGM_OK;
 }
 

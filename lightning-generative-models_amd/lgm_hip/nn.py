@@ -144,6 +144,17 @@ class Conv2d(nn.Module):
             r = ops.conv_bwd_pair(g, gy, x, fp.ptr(self.weight), fp.gptr(self.weight), bw, gb, dfr, pres, gx, partial=ok_pl)
             if r is not False:
                 return (gx, r) if planes_for_groups else gx
+        if need_gx and self.k != 3 and mask is None and not planes_for_groups and not ops.B3:
+            # the other layers (1x1, 4x4 / stride 2, 7x7; a 3x3 layer the pair above did not take keeps its Winograd /
+            # direct input gradient below): both gradients through lgm_conv_bwd_pair - one launch when the kernels can
+            # share a grid
+            if gx is None:
+                gx = ops.new(x.shape, x)
+                accumulate = False
+            assert not (accumulate and res is not None)
+            ops.conv_bwd_generic(g, gy, x, fp.ptr(self.weight), fp.tptr(self.weight), fp.gptr(self.weight), bw, gb, dfr,
+                                 gx if accumulate else res, gx)
+            return gx
         ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=dfr)
         if not need_gx:
             return None

@@ -496,6 +496,35 @@ def conv_bwd_pair(g: ConvGeom, gy, x, w_ptr: int, gw_ptr: int, beta: float, gbia
     return None
 
 
+def conv_bwd_generic(g: ConvGeom, gy, x, w_ptr: int, wt_ptr: Optional[int], gw_ptr: int, beta: float,
+                     gbias_ptr: Optional[int], defer, res, gx):
+    """Weight / bias gradient and input gradient of any layer through lgm_conv_bwd_pair: ONE launch when the dispatchers
+    pick the two kernels that can share a grid (the 1x1 convolutions and linears at small row counts), else exactly
+    conv_wgrad + conv_yx."""
+    L = lib()
+    if TIMER is not None:
+        TIMER.begin("bwd_pair", 2.0 * _conv_flops(g), 2.0 * _conv_bytes(g))
+    dws = _conv_ws(g, 1, gy.device)
+    nbytes = L.lgm_conv_wgrad_workspace(ctypes.byref(g))
+    if defer is None:
+        wws, desc = _pair_slabs(nbytes, gy.device), None
+    else:
+        k2 = (gw_ptr, nbytes)
+        wws = _WGRAD_WS.get(k2)
+        if wws is None:
+            wws = torch.empty(max(nbytes // 4 + 4, 16), dtype=torch.float32, device=gy.device)
+            _WGRAD_WS[k2] = wws
+        desc = (ctypes.c_int64 * 8)()
+    L.lgm_conv_bwd_pair(ctypes.byref(g), gy.data_ptr(), pitch(gy), x.data_ptr(), pitch(x), w_ptr, wt_ptr, _p(res),
+                        pitch(res) if res is not None else 0, gx.data_ptr(), pitch(gx),
+                        None if dws is None else dws.data_ptr(), 0 if dws is None else dws.numel() * 4, gw_ptr, gbias_ptr,
+                        beta, wws.data_ptr(), wws.numel() * 4, None if desc is None else ctypes.addressof(desc), stream())
+    if TIMER is not None:
+        TIMER.end()
+    if desc is not None and desc[6] > 1:
+        defer.append(tuple(desc))
+
+
 _PAIR_SLABS = {}
 
 

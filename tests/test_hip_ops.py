@@ -525,3 +525,53 @@ def test_conv_epilogue_activation_and_mask(dev, case, act):
     ops.conv_yx(g, gyd, wd.data_ptr(), None, gx, gx, wt.data_ptr(), post=ops.make_post(0, 0.0, xind, slope), post_mask=xind)
     assert rel(nchw(gx, ci), gx_ref) < 1e-5
     assert float(gx[..., ci:].abs().max()) == 0 if Cp > ci else True      # padding lanes stay zero
+
+
+# (B, Cin, Cout, H, k): 1x1 layers of the UNet at small per-GPU batches (the pairable kernels), one with a residual, a
+# large one (other kernels are picked: the call must still equal the two separate calls) and a 3x3 without Winograd
+PAIR_CASES = [(16, 512, 384, 4, 1), (16, 128, 512, 4, 1), (16, 1024, 512, 4, 1), (8, 256, 384, 8, 1), (2, 96, 64, 16, 1),
+              (128, 64, 384, 32, 1), (4, 128, 32, 4, 3)]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+@pytest.mark.parametrize("variant", ["plain", "accumulate", "deferred"])
+def test_generic_backward_pair_equals_separate_calls(dev, case, variant):
+    """lgm_conv_bwd_pair (weight / bias gradient + input gradient of a layer, ONE launch when the dispatchers pick the two
+    kernels that can share a grid) against lgm_conv_wgrad + lgm_conv_yx: torch.equal - the same kernel bodies run either
+    way - and against torch on the CPU."""
+    import ctypes
+    from lgm_hip import ops
+    B, ci, co, hw, k = case
+    L = ops.lib()
+    gen = torch.Generator().manual_seed(sum(case) + 3)
+    x = torch.randn(B, ci, hw, hw, generator=gen)
+    gy = torch.randn(B, co, hw, hw, generator=gen)
+    w = torch.randn(co, ci, k, k, generator=gen) / math.sqrt(ci * k * k)
+    xd, gyd, wd = nhwc(x, dev), nhwc(gy, dev), phys_weight(w, dev)
+    wt = wd.permute(2, 1, 0).contiguous()
+    g = ops.make_geom(B, hw, hw, xd.shape[-1], gyd.shape[-1], k, k, 1, k // 2)
+    base = torch.randn(B, hw, hw, xd.shape[-1], generator=gen).to(dev)
+    # ---- separate calls
+    gw_ref, gb_ref = torch.zeros_like(wd), torch.zeros(gyd.shape[-1], device=dev)
+    ops.conv_wgrad(g, gyd, xd, gw_ref.data_ptr(), 0.0, gb_ref.data_ptr())
+    gx_ref = base.clone()
+    ops.conv_yx(g, gyd, wd.data_ptr(), None, gx_ref if variant == "accumulate" else None, gx_ref, wt.data_ptr())
+    # ---- one call
+    gw, gb = torch.zeros_like(wd), torch.zeros(gyd.shape[-1], device=dev)
+    gx = base.clone()
+    defer = [] if variant == "deferred" else None
+    ops.conv_bwd_generic(g, gyd, xd, wd.data_ptr(), wt.data_ptr(), gw.data_ptr(), 0.0, gb.data_ptr(), defer,
+                         gx if variant == "accumulate" else None, gx)
+    kern = L._dll.lgm_last_kernel().decode()
+    if defer:
+        ops.wgrad_reduce_batch(defer, dev)
+    assert torch.equal(gx, gx_ref), kern
+    assert torch.equal(gw, gw_ref) and torch.equal(gb, gb_ref), kern
+    if k == 1 and B * hw * hw <= 1024 and ci % 32 == 0 and co % 32 == 0:
+        assert kern == "gemm_bwd_pair_kernel", kern          # the small 1x1 layers do share a launch
+    dg = torch.nn.grad.conv2d_input(x.shape, w, gy, padding=k // 2)
+    ref = dg + (nchw(base, ci) if variant == "accumulate" else 0)
+    assert rel(nchw(gx, ci), ref) < 1e-5
+    assert rel(nchw(gw.permute(0, 2, 1).reshape(gw.shape[0], gw.shape[2], k, k).permute(0, 2, 3, 1), None)[:co, :ci] if False else
+               gw[:co, :, :ci].reshape(co, k, k, ci).permute(0, 3, 1, 2),
+               torch.nn.grad.conv2d_weight(x, w.shape, gy, padding=k // 2)) < 1e-5
