@@ -381,10 +381,11 @@ class Unet(nn.Module):
         ops.conv_yx(g, gss_all, fp.ptr(rbs[0].mlp[1].weight), None, None, gst)
         gtemb = ops.new(st.shape, st)
         ops.act_bwd(temb, None, gst, gtemb, False, ops.ACT_SILU)
-        ops.conv_wgrad(l2.geom(B), gtemb, h, fp.gptr(l2.weight), gc.beta(l2.weight), fp.gptr(l2.bias))
-        gc.beta(l2.bias)
         gh = ops.new(h.shape, h)
-        ops.conv_yx(l2.geom(B), gtemb, fp.ptr(l2.weight), None, None, gh)
+        # weight gradient and input gradient of the second time-MLP linear in one launch (lgm_conv_bwd_pair)
+        ops.conv_bwd_generic(l2.geom(B), gtemb, h, fp.ptr(l2.weight), fp.tptr(l2.weight), fp.gptr(l2.weight),
+                             gc.beta(l2.weight), fp.gptr(l2.bias), None, None, gh)
+        gc.beta(l2.bias)
         ga1 = ops.new(a1.shape, a1)
         ops.act_bwd(a1, None, gh, ga1, False, ops.ACT_GELU)
         ops.conv_wgrad(l1.geom(B), ga1, pe, fp.gptr(l1.weight), gc.beta(l1.weight), fp.gptr(l1.bias))
