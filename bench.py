@@ -15,6 +15,7 @@ Rank 0 prints ONE JSON line.  Its top level is the headline; on one GPU (and wit
                       ddpm64     config 5's network: DDPM UNet 64x64, B = 64 per GPU
                       wgan_gp64  config 3: WGAN-GP DCGAN G/D 64x64, B = 128, n_critic = 5 (one training_step = one D or G update)
                       vqvae / vqvae_ema   config 4: VQ-VAE 32x32, K = 512, B = 256 (plain / EMA codebook)
+                      ddpm64_sampling     config 5's sampling half: DDIM, 64 images 64x64, 250 steps, one graph replay per step
   "per_rank_proxy"  ms per step of the headline workload at the per-rank batches of 2 / 4 / 8 GPUs (64 / 32 / 16
                     images) on this one GPU: what a rank computes between its gradient exchanges under strong scaling.
 Objects of every workload:
@@ -465,6 +466,41 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
     return line
 
 
+def run_sampling(dev, steps=250, batch=64, img=64):
+    """Config 5's second half: DDIM sampling with the EMA network of a 64x64 DDPM (reference ddim_sample, ddpm.py:782-834),
+    ``batch`` images, ``steps`` sampling steps, each = one UNet forward + the fused update, replayed from ONE HIP graph per
+    step.  Random-init weights, device-side noise.  Step-level roofline: 14.594 GFLOP per image and UNet forward at 64x64
+    (SURVEY.md section 8a), against the fp32 MFMA peak (direct-convolution count) and against the Winograd-executed count."""
+    from lgm_hip import sampler
+    from models.generative.diffusion.ddpm import DDPM
+    torch.manual_seed(10)
+    m = DDPM(img_channels=3, img_size=img, dim=64, diffusion_timesteps=1000, sampling_timesteps=steps).to(dev)
+    m.sample_every = 0
+    m.prepare_hip(dev)
+    gd = m.ema.ema_model
+    gd.eval()
+    shape = (batch, 3, img, img)
+    sampler.ddim_sample(gd, shape)                   # capture + one whole chain as warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = sampler.ddim_sample(gd, shape)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fwd_flop = {32: 3.651e9, 64: 14.594e9}[img] * batch
+    wino_share = 0.879                                # share of the forward FLOPs in 3x3 layers that run as Winograd
+    exe = fwd_flop * (1.0 - wino_share * (1.0 - 1.0 / WINO_FACTOR))
+    per = dt / steps
+    return {"metric": f"DDIM sampling, {batch} images {img}x{img}, {steps} steps (UNet forward + update per step, one HIP "
+                      "graph replay each)", "value": round(batch * steps / dt, 1), "unit": "image-steps/s",
+            "ms_per_step": round(per * 1e3, 3), "seconds_per_chain": round(dt, 3), "finite": bool(torch.isfinite(out).all()),
+            "dtype": "f32", "config": {"workload": "configs/diffusion/ddpm_64.json EMA network, ddim_sample, eta = 0",
+                                       "batch": batch, "steps": steps},
+            "roofline": {"bound": "mfma", "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "step_algorithmic_frac_of_peak": round(fwd_flop / per / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "step_executed_frac_of_peak": round(exe / per / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "flop_per_step": round(fwd_flop)}}
+
+
 def _release():
     """between workloads: drop what the finished one allocated (models, graph pools, caches keyed by its buffers)"""
     import gc
@@ -542,6 +578,12 @@ def main():
             except Exception as e:      # a secondary leg must never take the headline line down with it
                 sec[wl] = {"error": f"{type(e).__name__}: {e}"}
                 print(f"[bench] secondary workload {wl} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        _release()
+        try:
+            sec["ddpm64_sampling"] = run_sampling(dev)
+        except Exception as e:
+            sec["ddpm64_sampling"] = {"error": f"{type(e).__name__}: {e}"}
+            print(f"[bench] sampling leg failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         line["secondary"] = sec
         proxy = {}
         for b in (64, 32, 16):
