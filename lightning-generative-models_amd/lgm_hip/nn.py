@@ -250,7 +250,8 @@ class ConvTranspose2d(nn.Module):
         B, H, W, _ = x.shape
         g = self.geom(B, H, W)
         fp = gc.flat
-        ops.conv_wgrad(g, x, gy, fp.gptr(self.weight), gc.beta(self.weight))  # Y side = input, X side = grad
+        dfr = gc.defer_for(self.weight)          # slab reduction batched with the other layers' when the pass defers
+        ops.conv_wgrad(g, x, gy, fp.gptr(self.weight), gc.beta(self.weight), defer=dfr)  # Y side = input, X side = grad
         if self.bias is not None:
             ops.colsum(gy, fp.gptr(self.bias), gc.beta(self.bias))
         if not need_gx:

@@ -95,6 +95,7 @@ class WGAN(DCGAN):
 class _CriticLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, D, x, x_hat, alpha, lam, with_gp):
+        ctx.set_materialize_grads(False)            # no zero tensors (fill launches) for the logged, non-differentiable outputs
         L = ops.lib()
         st = ops.stream()
         B = x.shape[0]

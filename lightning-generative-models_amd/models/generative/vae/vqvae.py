@@ -319,6 +319,7 @@ class VQVAE(LightningModule):
 class _VQVAEStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, m: VQVAE, x, w_recon, w_vq):
+        ctx.set_materialize_grads(False)            # no zero tensors (3 fill launches) for the logged, non-differentiable outputs
         save = bool(ctx.needs_input_grad[0])
         r, tape = m.run(x.detach().float(), save)
         vals = ops.new((4,), r["recon"])            # (loss, recon, vq, perplexity): one launch, no torch arithmetic
