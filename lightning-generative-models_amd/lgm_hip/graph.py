@@ -24,6 +24,11 @@ from . import ops
 from .lightning import multi_rank
 
 
+import os as _os
+
+_STEP_PIPELINE = _os.environ.get("LGM_STEP_PIPELINE", "0") == "1"   # opt-in: weight passes of a bucket on a side stream
+
+
 class _TrainingState:
     """Everything a warm-up / capture run of a training step may advance and a run that never tried to capture
     would not have: parameters and buffers (EMA codebooks, running statistics), the device random stream, the
@@ -93,15 +98,22 @@ class GraphedDDPMStep:
     step instead of being drawn inside graph 1.  Either way ``self.t`` / ``self.noise`` hold the values the
     last replay used.
 
-    One rank: two graphs (forward + backward phase 1 | backward phase 2).  With a gradient exchange (``sync``) the
-    backward is cut at every bucket boundary — four graphs — so that each bucket's all-reduce is issued the moment
-    its slice is final and runs beside everything that follows it:
+    One rank: two graphs (forward + backward phase 1 | backward phase 2), one Adam launch.  With a gradient exchange
+    (``sync``) the backward is cut at every bucket boundary - four graphs - so that each bucket's all-reduce is issued
+    the moment its slice is final and runs beside everything that follows it:
 
-        g1a  t, noise, q_sample, UNet forward, loss, backward of final block + up path   -> buckets [ups], [final]
-        g1b  backward of the middle blocks                                               -> bucket  [mid]
-        g2a  backward of the down path + init conv                                       -> bucket  [init, downs]
-        g2b  backward of the time MLP / FiLM projections                                 -> bucket  [FiLM, time]
-    """
+        g1a  t, noise, q_sample, UNet forward, loss, backward of final block + up path   -> bucket 0 [ups], [final]
+        g1b  backward of the middle blocks                                               -> bucket 1 [mid]
+        g2a  backward of the down path + init conv                                       -> bucket 2 [init, downs]
+        g2b  backward of the time MLP / FiLM projections                                 -> bucket 3 [FiLM, time]
+
+    ``LGM_STEP_PIPELINE=1`` (opt-in, measured SLOWER on one GPU: 11.69 vs 11.44 ms at B = 128, 4.77 vs 4.65 ms at
+    B = 16): four graphs on every rank count, and behind each of them on a SIDE stream the bucket's weight-sized passes -
+    batched slab reduction, all-reduce, ITS slice of the Adam update (a bucket's weights are not read again by the
+    backward once its gradients are final).  Bit-identical to the default (tested), but the streaming kernels' workgroups
+    delay the one-workgroup-per-CU convolutions more than the overlap returns, and two more graph boundaries plus five
+    Adam slices cost 0.2 ms by themselves.  Kept for multi-GPU experiments, where the Adam slices would run beside the
+    later buckets' all-reduces."""
 
     def __init__(self, model, opt, x: torch.Tensor, sync=None, warmup: int = 3, inject: bool = False):
         from models.generative.diffusion.ddpm import hip_loss_backward_phase1a, hip_loss_forward
@@ -115,7 +127,8 @@ class GraphedDDPMStep:
         net = self.net
         self.t = torch.zeros(x.shape[0], dtype=torch.long, device=x.device) if inject else None
         self.noise = torch.zeros_like(x) if inject else None
-        split = sync is not None
+        self.pipeline = _STEP_PIPELINE
+        split = sync is not None or self.pipeline
 
         def part1a():
             gd = self.gd
@@ -146,42 +159,77 @@ class GraphedDDPMStep:
                     whole()
             cur.wait_stream(side)
             torch.cuda.synchronize()
-            if split:
-                g1a, (self.loss, st), _ = _capture(part1a, 0)
-                pool = g1a.pool()
-                g1b, st, _ = _capture(lambda: net.backward_phase1b(st), 0, pool)
-                g2a, st, _ = _capture(lambda: net.backward_phase2a(st), 0, pool)
-                g2b, _, _ = _capture(lambda: net.backward_phase2b(st), 0, pool)
-                self.graphs = [g1a, g1b, g2a, g2b]
-            else:
-                def part1():
-                    loss, st1 = part1a()
-                    return loss, net.backward_phase1b(st1)
-                g1, (self.loss, st), _ = _capture(part1, 0)
-                g2, _, _ = _capture(lambda: net.backward_phase2(st), 0, g1.pool())
-                self.graphs = [g1, g2]
+            if self.pipeline:
+                net._flush_collect = {}              # the phases hand their reduction rows over instead of launching
+            try:
+                if split:
+                    g1a, (self.loss, st), _ = _capture(part1a, 0)
+                    pool = g1a.pool()
+                    g1b, st, _ = _capture(lambda: net.backward_phase1b(st), 0, pool)
+                    g2a, st, _ = _capture(lambda: net.backward_phase2a(st), 0, pool)
+                    g2b, _, _ = _capture(lambda: net.backward_phase2b(st), 0, pool)
+                    self.graphs = [g1a, g1b, g2a, g2b]
+                else:
+                    def part1():
+                        loss, st1 = part1a()
+                        return loss, net.backward_phase1b(st1)
+                    g1, (self.loss, st), _ = _capture(part1, 0)
+                    g2, _, _ = _capture(lambda: net.backward_phase2(st), 0, g1.pool())
+                    self.graphs = [g1, g2]
+                rows = net._flush_collect if self.pipeline else {}
+            finally:
+                net._flush_collect = None
+            self.ranges = net.bucket_ranges()
+            if self.pipeline:
+                self.reducers = [ops.make_reducer(rows.get(k), x.device) for k in range(4)]
+                self.side = torch.cuda.Stream()
+                self.events = [torch.cuda.Event() for _ in range(4)]
             self._st = st                            # keeps the captured buffers alive
         finally:
             torch.cuda.set_rng_state(rng_state, x.device)
 
     def step(self, batch_idx: int = 0):
-        net, sync = self.net, self.sync
+        if self.pipeline:
+            return self._step_pipelined(batch_idx)
+        sync = self.sync
         if sync is None:
             for g in self.graphs:
                 g.replay()
         else:
-            g1a, g1b, g2a, g2b = self.graphs
-            g1a.replay()
-            sync.ready(net._ups_start, net._mid_start)
-            sync.ready(net._final_start, net._flat.total)
-            g1b.replay()
-            sync.ready(net._mid_start, net._final_start)
-            g2a.replay()
-            sync.ready(net._head_end, net._ups_start)
-            g2b.replay()
-            sync.ready(0, net._head_end)
+            for k, g in enumerate(self.graphs):
+                g.replay()
+                for lo, hi in self.ranges[k]:
+                    sync.ready(lo, hi)               # asynchronous, on RCCL's stream, behind the replay just enqueued
             sync.finish()
         self.opt.step()
+        self.opt.zero_grad()                         # host flag only: the next backward overwrites
+        self.model.on_train_batch_end(None, None, batch_idx)
+        return self.loss
+
+    def _step_pipelined(self, batch_idx: int):
+        net, sync = self.net, self.sync
+        fp = net._flat
+        main, side = torch.cuda.current_stream(), self.side
+        inner = getattr(self.opt, "_opt", self.opt)
+        group, st = inner.begin_step(fp)
+        side.wait_stream(main)                       # whatever touched the weights / gradients before this step
+        for k, g in enumerate(self.graphs):
+            g.replay()
+            self.events[k].record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(self.events[k])
+                ops.launch_reducer(self.reducers[k])             # bucket k's gradients are final after this
+                hs = [sync.ready(lo, hi) for lo, hi in self.ranges[k]] if sync is not None else []
+                for h in hs:
+                    if h is not None:
+                        h.wait()                                 # the SIDE stream waits for the exchange, not the host
+                for lo, hi in self.ranges[k]:
+                    inner.step_slice(fp, group, st, lo, hi)
+        main.wait_stream(side)
+        if sync is not None:
+            sync.finish()
+        if hasattr(self.opt, "count_step"):
+            self.opt.count_step()                    # MiniTrainer's proxy: one optimizer step
         self.opt.zero_grad()                         # host flag only: the next backward overwrites
         self.model.on_train_batch_end(None, None, batch_idx)
         return self.loss
@@ -210,7 +258,8 @@ class DDPMFastStep:
     def _capture(self, x):
         try:
             self.graphed = GraphedDDPMStep(self.model, self.opt, x.clone(), self.sync)
-            self.mode = "hipGraph replay (2 graphs/step)"
+            self.mode = ("hipGraph replay (4 graphs/step, weight passes on a side stream)" if _STEP_PIPELINE else
+                         f"hipGraph replay ({4 if self.sync is not None else 2} graphs/step)")
         except Exception as e:  # capture is an optimisation: fall back to eager launches
             import sys
             print(f"[lgm_hip] HIP-graph capture unavailable ({type(e).__name__}: {e}); eager launches",

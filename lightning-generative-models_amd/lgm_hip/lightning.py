@@ -58,6 +58,10 @@ class _CountingOptimizer:
         self._owner._global_step += 1
         return r
 
+    def count_step(self):
+        """An optimizer step that was issued slice by slice (FusedAdam.begin_step / step_slice) counts as one."""
+        self._owner._global_step += 1
+
     def __getattr__(self, n):
         return getattr(self._opt, n)
 
@@ -195,10 +199,13 @@ class FlatGradSync:
         self.covered = 0
 
     def ready(self, lo: int, hi: int):
+        """-> the asynchronous work handle (None on one rank); ``finish()`` waits for whatever is still pending"""
         if self.world == 1 or hi <= lo:
-            return
-        self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True))
+            return None
+        h = dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True)
+        self.handles.append(h)
         self.covered += hi - lo
+        return h
 
     def finish(self):
         for h in self.handles:

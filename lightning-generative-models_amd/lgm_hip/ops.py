@@ -560,6 +560,23 @@ def wgrad_reduce_batch(rows, device):
     rows.clear()
 
 
+def make_reducer(rows, device):
+    """A reusable launcher for the batched slab / row reduction of ``rows`` (descriptor tuples collected by a deferred
+    backward pass whose buffers have fixed addresses, i.e. under graph capture): (device table, rows, blocks), or None."""
+    if not rows:
+        return None
+    tab, blk = [], 0
+    for r in rows:
+        tab.append(list(r) + [blk])
+        blk += (r[3] + r[5] + 255) // 256
+    return (torch.tensor(tab, dtype=torch.int64, device=device).contiguous(), len(rows), blk)
+
+
+def launch_reducer(ent):
+    if ent is not None:
+        lib().lgm_wgrad_reduce_batch(ent[0].data_ptr(), ent[1], ent[2], stream())
+
+
 def colsum(a, out_ptr: int, beta: float):
     """out[c] = beta*out[c] + sum over all leading dims of a[..., c]."""
     L = lib()

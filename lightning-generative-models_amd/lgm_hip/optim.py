@@ -54,6 +54,27 @@ class FusedAdam(torch.optim.Optimizer):
                               group["weight_decay"], st["step"], None, self.grad_scale, group["decoupled"])
         return loss
 
+    # ---- one step issued slice by slice (lgm_hip.graph: a bucket's slice as soon as ITS gradients are final) --------
+    def begin_step(self, fp: FlatParams):
+        """Advance the step count of ``fp``'s state once; returns (group, state) for ``step_slice``."""
+        for group in self.param_groups:
+            if any(f is fp for f in self._flats(group)):
+                st = self._flat_state.get(id(fp))
+                if st is None:
+                    st = dict(m=torch.zeros_like(fp.data), v=torch.zeros_like(fp.data), step=0, flat=fp)
+                    self._flat_state[id(fp)] = st
+                st["step"] += 1
+                return group, st
+        raise RuntimeError("begin_step: this optimizer does not own the flat buffer")
+
+    @torch.no_grad()
+    def step_slice(self, fp: FlatParams, group, st, lo: int, hi: int):
+        """The Adam update of elements [lo, hi) (multiples of 4) - same kernel, same arithmetic as step()."""
+        assert lo % 4 == 0 and hi % 4 == 0 and 0 <= lo < hi <= fp.total
+        b1, b2 = group["betas"]
+        ops.adam_step(fp.data[lo:hi], fp.grad[lo:hi], st["m"][lo:hi], st["v"][lo:hi], hi - lo, group["lr"], b1, b2,
+                      group["eps"], group["weight_decay"], st["step"], None, self.grad_scale, group["decoupled"])
+
     def zero_grad(self, set_to_none: bool = True):
         for group in self.param_groups:
             for fp in self._flats(group):

@@ -478,6 +478,26 @@ class Unet(nn.Module):
         st = self.backward_phase1(tape_all, gout)
         self.backward_phase2(st)
 
+    def _flush(self, gc: GradCtx, bucket: int):
+        """End of an exchange bucket (0: ups + final, 1: mid, 2: init + downs, 3: FiLM + time): the deferred slab / row
+        reductions of its layers.  Normally ONE batched launch right here.  While a step is being captured with
+        ``_flush_collect`` set (lgm_hip.graph.GraphedDDPMStep) the descriptor rows are handed to the step object
+        instead, which launches the reduction - and the bucket's all-reduce and Adam slice behind it - on a side stream
+        next to the following backward phase: weight-sized, HBM-bound passes beside MFMA-bound convolutions."""
+        col = getattr(self, "_flush_collect", None)
+        if col is None:
+            gc.flush()
+        else:
+            col[bucket] = list(gc.deferred or [])
+            if gc.deferred is not None:
+                gc.deferred.clear()
+
+    def bucket_ranges(self):
+        """Flat-buffer slices of the four exchange buckets, in backward completion order."""
+        t = self._flat.total
+        return [[(self._ups_start, self._mid_start), (self._final_start, t)], [(self._mid_start, self._final_start)],
+                [(self._head_end, self._ups_start)], [(0, self._head_end)]]
+
     def backward_phase1(self, tape_all, gout):
         """final conv -> final block -> up path -> middle.  After it the gradient slice
         [_ups_start, total) of the flat buffer is final (first exchange buckets)."""
@@ -525,7 +545,7 @@ class Unet(nn.Module):
             b1.bwd(gc, s1, _chan(gcat2, 0, co), gsl[k], gcat1, False); k -= 1
             gcats[s] = (gcat1, gcat2)
             g_next = _chan(gcat1, 0, co)
-        gc.flush()
+        self._flush(gc, 0)
         sync = getattr(self, "grad_sync", None)
         if sync is not None:
             sync.ready(self._ups_start, self._mid_start)
@@ -545,7 +565,7 @@ class Unet(nn.Module):
         gcur = ops.new(gm1.shape, x_in)
         self.mid_block1.bwd(gc, sm1, gm1, gsl[k], gcur, False); k -= 1
         del gm1
-        gc.flush()
+        self._flush(gc, 1)
         sync = getattr(self, "grad_sync", None)
         if sync is not None:
             sync.ready(self._mid_start, self._final_start)
@@ -589,7 +609,7 @@ class Unet(nn.Module):
                 gcur = gprev
         assert k == -1
         self.init_conv.bwd(gc, x_in, gcur, need_gx=False)
-        gc.flush()
+        self._flush(gc, 2)
         if sync is not None:
             sync.ready(self._head_end, self._ups_start)
         return st
@@ -599,7 +619,7 @@ class Unet(nn.Module):
         gc = st["gc"]
         sync = getattr(self, "grad_sync", None)
         self._time_bwd(gc, st["time_saved"], st["gss_all"])
-        gc.flush()
+        self._flush(gc, 3)
         if sync is not None:
             sync.ready(0, self._head_end)
         self._flat.bind_grad_views()

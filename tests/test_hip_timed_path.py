@@ -38,14 +38,19 @@ def _ddpm(dev, dim, S, seed=10, **kw):
     return m
 
 
-def test_graph_replay_is_bit_identical_to_eager_steps(dev):
-    """The timed path at the BASELINE configuration (dim 64, 32x32, B=128, configs/diffusion/ddpm.json's
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_graph_replay_is_bit_identical_to_eager_steps(dev, pipeline, monkeypatch):
+    """(pipeline=True: the opt-in LGM_STEP_PIPELINE structure - four graphs, each bucket's slab reduction and Adam slice
+    on a side stream - must give the same bits.)
+    The timed path at the BASELINE configuration (dim 64, 32x32, B=128, configs/diffusion/ddpm.json's
     optimiser): after ONE replay the loss and the WHOLE flat gradient buffer are torch.equal to an eager
     p_losses + backward on a twin with identical weights fed the (t, noise) the graph drew; after 12 replays
     the parameters, Adam moments and the EMA shadow are torch.equal to 12 eager steps fed the same draws
     (covers static-buffer aliasing across the two captures, RNG under capture, zero_grad-in-graph ordering,
     Adam's step count and the EMA update at step 10)."""
+    from lgm_hip import graph as lgm_graph
     from lgm_hip.graph import GraphedDDPMStep
+    monkeypatch.setattr(lgm_graph, "_STEP_PIPELINE", pipeline)
     kw = dict(lr=2e-5, betas=(0.9, 0.99), ema_update_every=10, ema_decay=0.995)
     a, b = _ddpm(dev, 64, 32, **kw), _ddpm(dev, 64, 32, **kw)
     fa, fb = a.ema.online_model.model._flat, b.ema.online_model.model._flat
