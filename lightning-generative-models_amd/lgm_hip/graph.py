@@ -26,6 +26,7 @@ from .lightning import multi_rank
 
 import os as _os
 
+_ONE_GRAPH = _os.environ.get("LGM_ONE_GRAPH", "1") == "1"           # one rank: the whole step in ONE graph (A/B switch)
 _STEP_PIPELINE = _os.environ.get("LGM_STEP_PIPELINE", "0") == "1"   # opt-in: weight passes of a bucket on a side stream
 
 
@@ -169,6 +170,14 @@ class GraphedDDPMStep:
                     g2a, st, _ = _capture(lambda: net.backward_phase2a(st), 0, pool)
                     g2b, _, _ = _capture(lambda: net.backward_phase2b(st), 0, pool)
                     self.graphs = [g1a, g1b, g2a, g2b]
+                elif _ONE_GRAPH:
+                    def everything():                # one rank: nothing has to happen between the phases
+                        loss, st1 = part1a()
+                        st2 = net.backward_phase1b(st1)
+                        net.backward_phase2(st2)
+                        return loss, st2
+                    g1, (self.loss, st), _ = _capture(everything, 0)
+                    self.graphs = [g1]
                 else:
                     def part1():
                         loss, st1 = part1a()
@@ -259,7 +268,7 @@ class DDPMFastStep:
         try:
             self.graphed = GraphedDDPMStep(self.model, self.opt, x.clone(), self.sync)
             self.mode = ("hipGraph replay (4 graphs/step, weight passes on a side stream)" if _STEP_PIPELINE else
-                         f"hipGraph replay ({4 if self.sync is not None else 2} graphs/step)")
+                         f"hipGraph replay ({len(self.graphed.graphs)} graph{'s' if len(self.graphed.graphs) > 1 else ''}/step)")
         except Exception as e:  # capture is an optimisation: fall back to eager launches
             import sys
             print(f"[lgm_hip] HIP-graph capture unavailable ({type(e).__name__}: {e}); eager launches",

@@ -572,6 +572,5 @@ def test_generic_backward_pair_equals_separate_calls(dev, case, variant):
     dg = torch.nn.grad.conv2d_input(x.shape, w, gy, padding=k // 2)
     ref = dg + (nchw(base, ci) if variant == "accumulate" else 0)
     assert rel(nchw(gx, ci), ref) < 1e-5
-    assert rel(nchw(gw.permute(0, 2, 1).reshape(gw.shape[0], gw.shape[2], k, k).permute(0, 2, 3, 1), None)[:co, :ci] if False else
-               gw[:co, :, :ci].reshape(co, k, k, ci).permute(0, 3, 1, 2),
-               torch.nn.grad.conv2d_weight(x, w.shape, gy, padding=k // 2)) < 1e-5
+    gw_oihw = gw[:co, :, :ci].reshape(co, k, k, ci).permute(0, 3, 1, 2)          # physical [N][T][C] -> OIHW
+    assert rel(gw_oihw, torch.nn.grad.conv2d_weight(x, w.shape, gy, padding=k // 2)) < 1e-5
