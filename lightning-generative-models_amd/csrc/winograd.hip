@@ -281,6 +281,57 @@ __device__ __forceinline__ void wino_conv_body(const Args& p, const int bidx, co
   };
   auto commit = [&](int j, float* rbuf) { *reinterpret_cast<u32x4*>(rbuf + plds[j]) = rp[j]; };
 
+  // ---- B fragments: U[n/32][c/8][xi][k-half][n%32][4]; lane (lr, lh) reads 16 bytes per xi.  Buffer loads:
+  // constant per-lane offset + wave-uniform (SALU) block offset, no 64-bit VALU address arithmetic per load.
+  const unsigned wlane = (unsigned)((lh * 32 + lr) * 4) * 4u;
+  const int wcb_s = __builtin_amdgcn_readfirstlane(wcb);
+  __amdgpu_buffer_rsrc_t rsrc_u;
+  {
+    const unsigned long long ub = reinterpret_cast<unsigned long long>(p.u);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ub);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
+    rsrc_u = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                               __builtin_amdgcn_readfirstlane((unsigned)((long)p.N * p.C * 16 * 4)),
+                                               0x00020000);
+  }
+  auto load_b = [&](const Phase& ph, int xi) -> f32x4 {
+    const unsigned soff = (unsigned)((((ph.n0 >> 5) + wcb_s) * ncc_total + ph.cc) * 16 + xi) * 1024u;
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, wlane, soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+  };
+
+  static_assert(NWQ == 16, "the prologue issues the whole weight ring for the first phase");
+  // ---- prologue ----
+  // Order matters here: ~850 scalar / vector instructions of set-up (four phase iterators with their integer divisions,
+  // the epilogue's addressing, buffer descriptors) used to run BEFORE the first load was issued, and then the workgroup
+  // waited ~1 us for that load (cycle stamps, mode 5: 2.0 k + 3.6 k cycles of set-up, 0.9 k of waiting).  Now the first
+  // unit's weight fragments and raw patch are requested as soon as ITS iterator is decoded, and everything else - the
+  // look-ahead iterators, the epilogue addressing - is computed under the shadow of those loads.
+  if (DBG && p.dbg_mode == 5) stamp();             // mode 5: the prologue in four parts (setup | fetch issue | landed + barrier | first transform)
+  Phase cur;
+  cur.valid = true;
+  decode(cur, L0);
+  f32x4 wq[NWQ];
+#pragma unroll
+  for (int x = 0; x < NWQ; ++x) wq[x] = load_b(cur, x);          // NWQ == 16: all of them belong to the first phase
+  unsigned poff[NJ];
+  u32x4 r0[NJ];
+  slot_offsets(cur, poff);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const unsigned soff0 = (unsigned)(cur.abase + (long)cur.cc * (KC * 4));
+    r0[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, poff[j], soff0, 0);
+  }
+  Phase nx1 = cur;
+  advance(nx1);
+  slot_offsets(nx1, poff);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) fetch_at(j, nx1, poff);
+  Phase nx2 = nx1;
+  advance(nx2);
+  Phase nx3 = nx2;
+  advance(nx3);
+
   // ---- input transform: every lane builds its OWN A fragments (tile = accumulator row lr, channel quad lh) in
   // registers straight from the raw patch -- the transformed tiles never go through LDS.  Raw element d[r][c] of
   // the lane's 4x4 input tile: plane lh*2 + (c & 1), row 2 ty + r, half-column tx + (c >> 1).
@@ -322,25 +373,6 @@ __device__ __forceinline__ void wino_conv_body(const Args& p, const int bidx, co
     Af[hrow][o] = v;
   };
 
-  // ---- B fragments: U[n/32][c/8][xi][k-half][n%32][4]; lane (lr, lh) reads 16 bytes per xi.  Buffer loads:
-  // constant per-lane offset + wave-uniform (SALU) block offset, no 64-bit VALU address arithmetic per load.
-  const unsigned wlane = (unsigned)((lh * 32 + lr) * 4) * 4u;
-  const int wcb_s = __builtin_amdgcn_readfirstlane(wcb);
-  __amdgpu_buffer_rsrc_t rsrc_u;
-  {
-    const unsigned long long ub = reinterpret_cast<unsigned long long>(p.u);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ub);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
-    rsrc_u = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
-                                               __builtin_amdgcn_readfirstlane((unsigned)((long)p.N * p.C * 16 * 4)),
-                                               0x00020000);
-  }
-  auto load_b = [&](const Phase& ph, int xi) -> f32x4 {
-    const unsigned soff = (unsigned)((((ph.n0 >> 5) + wcb_s) * ncc_total + ph.cc) * 16 + xi) * 1024u;
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, wlane, soff, 0);
-    return __builtin_bit_cast(f32x4, v);
-  };
-
   // ---- epilogue addressing (kernel constants): byte offset of (this lane's tile, first channel of its register group 0)
   // relative to the unit's first pixel / first channel, for the output, the split-K partial buffer and the residual
   unsigned evoff, evoff_w, evoff_r;
@@ -368,41 +400,15 @@ __device__ __forceinline__ void wino_conv_body(const Args& p, const int bidx, co
   const __amdgpu_buffer_rsrc_t rsrc_r = make_rsrc(p.res ? (const void*)p.res : (const void*)p.out,
                                                   p.res ? npix * p.res_pitch * 4 : 4);
 
-  // ---- prologue ----
-  if (DBG && p.dbg_mode == 5) stamp();             // mode 5: the prologue in four parts (setup | fetch issue | landed + barrier | first transform)
-  Phase cur;
-  cur.valid = true;
-  decode(cur, L0);
-  Phase nx1 = cur;
-  advance(nx1);
-  Phase nx2 = nx1;
-  advance(nx2);
-  Phase nx3 = nx2;
-  advance(nx3);
-  f32x4 wq[NWQ];
+  if (DBG && p.dbg_mode == 5) stamp();
 #pragma unroll
-  for (int x = 0; x < NWQ; ++x) wq[x] = x < 16 ? load_b(cur, x) : load_b(nx1, x - 16);
-  unsigned poff[NJ];
-  {
-    u32x4 r0[NJ];
-    slot_offsets(cur, poff);
+  for (int j = 0; j < NJ; ++j) *reinterpret_cast<u32x4*>(Rb + plds[j]) = r0[j];        // raw[cur] -> buffer 0
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) fetch_at(j, cur, poff);
+  for (int j = 0; j < NJ; ++j) commit(j, Rb + 4 * RPLANE);                              // raw[nx1] -> buffer 1
+  slot_offsets(nx2, poff);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) r0[j] = rp[j];
-    slot_offsets(nx1, poff);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) fetch_at(j, nx1, poff);
-    if (DBG && p.dbg_mode == 5) stamp();
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) *reinterpret_cast<u32x4*>(Rb + plds[j]) = r0[j];      // raw[cur] -> buffer 0
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) commit(j, Rb + 4 * RPLANE);                            // raw[nx1] -> buffer 1
-    slot_offsets(nx2, poff);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) fetch_at(j, nx2, poff);                                // raw[nx2] stays in registers
-    slot_offsets(nx3, poff);
-  }
+  for (int j = 0; j < NJ; ++j) fetch_at(j, nx2, poff);                                  // raw[nx2] stays in registers
+  slot_offsets(nx3, poff);
   __syncthreads();
   if (DBG && p.dbg_mode == 5) stamp();
 #pragma unroll
