@@ -212,7 +212,7 @@ def setup_ddpm(args, dev, world, rank, img, global_batch):
     g = torch.Generator(device="cpu").manual_seed(10 + rank)
     x = (torch.rand(per_gpu, 3, img, img, generator=g) * 2 - 1).to(dev)
     y = torch.zeros(per_gpu, dtype=torch.long, device=dev)
-    # the object MiniTrainer.fit drives for a DDPM module: overlapped bucketed all-reduce + two-graph replay
+    # the object MiniTrainer.fit drives for a DDPM module: overlapped bucketed all-reduce + graph replay
     fast = DDPMFastStep(model, opt, world, use_graph=not args.no_graph)
     eager = DDPMFastStep.__new__(DDPMFastStep)
     eager.__dict__.update(fast.__dict__)

@@ -1,18 +1,17 @@
-"""HIP-graph replay of the DDPM training step.
+"""HIP-graph replay of the training steps.
 
-At small per-GPU batches (strong scaling: 128 / N images per GPU) the ~640 kernel launches of a
-step are host-bound when issued from Python.  The step is therefore captured ONCE into two HIP
-graphs and replayed:
+At small per-GPU batches (strong scaling: 128 / N images per GPU) the ~400 kernel launches of a DDPM step are
+host-bound when issued from Python.  The step is therefore captured ONCE and replayed:
 
-    graph 1 : t ~ randint, noise ~ randn, q_sample, UNet forward, loss, loss gradient,
-              backward phase 1 (final -> up path -> middle)
-    eager   : async all-reduce of gradient bucket [ups, mid, final]        (N > 1)
-    graph 2 : backward phase 2 (down path, init conv, FiLM / time MLP)      -- overlaps the bucket above
-    eager   : all-reduce of the two remaining buckets, wait, fused Adam (1 kernel), EMA (every 10th step)
+    one rank : ONE graph - t ~ randint, noise ~ randn, q_sample, UNet forward, loss, the whole backward -
+               then fused Adam (1 eager kernel) and EMA (every 10th step)
+    N ranks  : FOUR graphs, cut where an exchange bucket of the flat gradient buffer becomes final
+               (GraphedDDPMStep), with the asynchronous all-reduce of each bucket issued between the replays
 
-Collectives are never captured (they are issued between the two replays), the optimiser's step
-count lives on the host (one eager kernel), and the RNG is torch's graph-safe Philox generator.
-The arithmetic is identical to the eager path (same kernels, same order).
+Collectives are never captured, the optimiser's step count lives on the host, and the RNG is torch's graph-safe
+Philox generator.  The arithmetic is identical to the eager path (same kernels, same order) - tested bit for bit.
+ModuleFastStep (VQ-VAE: one graph) and WGANFastStep (critic graph / generator graph) follow the same rules: warm-up and
+capture leave the training state untouched (_TrainingState), also when capture fails.
 """
 from __future__ import annotations
 
@@ -99,7 +98,8 @@ class GraphedDDPMStep:
     step instead of being drawn inside graph 1.  Either way ``self.t`` / ``self.noise`` hold the values the
     last replay used.
 
-    One rank: two graphs (forward + backward phase 1 | backward phase 2), one Adam launch.  With a gradient exchange
+    One rank: ONE graph for the whole forward + backward (``LGM_ONE_GRAPH=0``: two, forward + backward phase 1 | phase 2 -
+    no measurable difference), one Adam launch.  With a gradient exchange
     (``sync``) the backward is cut at every bucket boundary - four graphs - so that each bucket's all-reduce is issued
     the moment its slice is final and runs beside everything that follows it:
 
@@ -246,7 +246,7 @@ class GraphedDDPMStep:
 
 class DDPMFastStep:
     """What ``MiniTrainer.fit`` drives for a ``DDPM`` module (``DDPM.make_fast_step``): the bucketed gradient
-    exchange overlapped with the hand-written backward (``FlatGradSync``, N > 1) and the two-graph replay of
+    exchange overlapped with the hand-written backward (``FlatGradSync``, N > 1) and the graph replay of
     the step, captured lazily at the first batch.  When capture is not possible (or a batch has another shape)
     the same step runs from eager launches, in the same process, with the same overlapped exchange.
     Logging (``train_loss``) and the reference's periodic in-training sampling (ddpm.py:1017-1027) stay
