@@ -50,6 +50,12 @@ extern "C" int lgm_wino_set_debug_buffer(void* buf, int mode) {
   return LGM_OK;
 }
 
+// cache policy of the kernels' OUTPUT stores (experiment knob, -DLGM_STORE_AUX=n at build time): 0 default write-back,
+// 2 = nt (streaming), 17 = sc0 | sc1 (write-through to memory)
+#ifndef LGM_STORE_AUX
+#define LGM_STORE_AUX 0
+#endif
+
 namespace lgmwino {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -611,7 +617,7 @@ __device__ __forceinline__ void wino_conv_body(const Args& p, const int bidx, co
                 }
             }
             v = add4(v, rv[g & 1][2 * dy + dx]);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_d, eo + g * 32, sbase + spos, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_d, eo + g * 32, sbase + spos, LGM_STORE_AUX);
             // A store of more than 8 bytes must not have its data registers overwritten in the next 2 wait states;
             // hipcc pads that for its own instructions but the next writers here are inline asm (accumulator reads,
             // packed adds), which it does not see.  Without the pad: wrong second dwords in lanes 12-15 / 28-31 of
@@ -1306,7 +1312,7 @@ __device__ __forceinline__ void wino_wgrad_body(const WGArgs& p, const int bidx)
             float v = w[b][e];
             asm volatile("" : "+v"(v));
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_o, vo,
-                                                  (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes + (unsigned)((a * 3 + b) * p.Cw) * 4u, 0);
+                                                  (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes + (unsigned)((a * 3 + b) * p.Cw) * 4u, LGM_STORE_AUX);
           }
       }
     }

@@ -9,7 +9,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_PKG, "csrc", "liblgm_hip.so")
+# LGM_LIB=<path>: another build of the same library (A/B runs of compile-time experiment knobs); default: the in-tree one
+LIB_PATH = os.environ.get("LGM_LIB") or os.path.join(_PKG, "csrc", "liblgm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "lgm_hip.h")
 
 
