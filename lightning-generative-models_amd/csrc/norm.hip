@@ -746,8 +746,9 @@ static GnPlan gn_plan(int B, int HW, int C, int G, bool bwd) {
   const int Cg = C / G;
   int cb = gn_cb(C, G);
   static const bool wide_only = getenv("LGM_GN_WIDE") != nullptr;   // A/B switch: never narrow the blocks
+  static const int min_cb = getenv("LGM_GN_MINCB") ? atoi(getenv("LGM_GN_MINCB")) : 16;   // tuning knob
   if (!wide_only)
-    while ((long)B * (C / cb) < 256 && cb > Cg && (cb / 2) % Cg == 0 && (cb / 2) % 4 == 0) cb /= 2;
+    while ((long)B * (C / cb) < 256 && cb > Cg && cb / 2 >= min_cb && (cb / 2) % Cg == 0 && (cb / 2) % 4 == 0) cb /= 2;
   GnPlan p = gn_plan_cb(HW, cb, bwd);
   // (Large maps - 64 x 64 at 64 channels: 4096 pixels x 32 channels do not fit a block's registers - stay on the two-pass
   // kernels.  Narrowing the block to ONE group so that its slice fits was tried: one pass over x instead of two, but
