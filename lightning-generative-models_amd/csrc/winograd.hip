@@ -766,14 +766,16 @@ int lgm_wino_splits(const LgmConvGeom* g, int gather_channels, int out_channels,
   // cost in phase times (~2.1 us): rounds of 256 workgroups x (phases per unit + ~1.5 of prologue / epilogue) + the
   // partial sums every extra split writes and the reducer reads back (8 bytes per output element at ~3 TB/s) -
   // 1.3 phases per split on the 4x4 maps at B = 128, 0.16 at B = 16, where splitting deeper is what fills the chip
-  const double per_split = (fused ? 6.0 : 8.0) * (double)g->B * g->H * g->W * out_channels / 3.0e12 / 2.1e-6;
+  static const double k_ovh = getenv("LGM_FPLAN_OVH") ? atof(getenv("LGM_FPLAN_OVH")) : 1.5;       // tuning knobs (A/B runs)
+  static const double k_spl = getenv("LGM_FPLAN_SPLIT") ? atof(getenv("LGM_FPLAN_SPLIT")) : 1.0;
+  const double per_split = k_spl * (fused ? 6.0 : 8.0) * (double)g->B * g->H * g->W * out_channels / 3.0e12 / 2.1e-6;
   long s = 1;
   double best = 1e30;
   for (long c = 1; c <= smax; ++c) {
     const long pps = (phases + c - 1) / c;
     if ((phases + pps - 1) / pps != c) continue;
     const double rounds = (double)((base * c + 255) / 256);
-    const double cost = rounds * ((double)pps + 1.5) + (c > 1 ? (fused ? 0.2 : 2.4) : 0.0) + per_split * (double)(c - 1);
+    const double cost = rounds * ((double)pps + k_ovh) + (c > 1 ? (fused ? 0.2 : 2.4) : 0.0) + per_split * (double)(c - 1);
     if (cost < best - 1e-9) {
       best = cost;
       s = c;
