@@ -649,8 +649,12 @@ int igemm_splits(long M, int N, int K, int* kchunk) {
   // up to 256 tiles a launch leaves at most one wave per SIMD: nothing hides the load -> LDS -> barrier latency
   // of a chunk.  Split the reduction until ~4 workgroups share a CU (>= 8 chunks each).
   if (tiles > 256 || N % 4 != 0) return 1;
-  long s = tiles > 64 ? 1024 / tiles : 256 / tiles;
-  if (s > nk / (tiles > 64 ? 8 : 4)) s = nk / (tiles > 64 ? 8 : 4);
+  static const long t_big = getenv("LGM_IGEMM_TBIG") ? atol(getenv("LGM_IGEMM_TBIG")) : 1024;      // tuning knobs (A/B runs)
+  static const long t_small = getenv("LGM_IGEMM_TSMALL") ? atol(getenv("LGM_IGEMM_TSMALL")) : 256;
+  static const long c_min = getenv("LGM_IGEMM_CMIN") ? atol(getenv("LGM_IGEMM_CMIN")) : 0;          // 0: 8 / 4 chunks per split
+  long s = tiles > 64 ? t_big / tiles : t_small / tiles;
+  const long cmin = c_min > 0 ? c_min : (tiles > 64 ? 8 : 4);
+  if (s > nk / cmin) s = nk / cmin;
   if (s < 2) return 1;
   const int per = lgm_cdiv(nk, s);
   *kchunk = per * BK;
