@@ -12,7 +12,17 @@
 // MFMA kernels for the linear-attention contractions (linattn_mfma.hip)
 int lgm_linattn_ctx_launch(int mode, const float* qkv, long pitch, const float* mem_kv, const float* gout,
                            long gout_pitch, const float* ctx_in, int B, int n, int heads, int M, float scale,
-                           float* ctx_out, float* kmax, float* ksum, float* r_out, hipStream_t s);
+                           float* ctx_out, float* kmax, float* ksum, float* r_out, hipStream_t s,
+                           const float* kmax_in = nullptr, const float* ksum_in = nullptr,
+                           float* gmem_partial = nullptr);
+// fused backward tail (linattn_fused.hip) and the single-layer slab reducer (conv_igemm.hip)
+int lgm_linattn_bwd_fused_launch(const float* qkv, long pitch, const float* gout, long gout_pitch, const float* ctx,
+                                 const float* gctx, const float* kmax, const float* ksum, const float* rvec,
+                                 const float* xn, long xn_pitch, const float* w, int B, int n, int C, float scale,
+                                 float* gxn, long gxn_pitch, float* gqkv, long gq_pitch, float* slabs, int* blocks_out,
+                                 hipStream_t s);
+int lgm_wgrad_reduce_launch(const float* ws, long slab, float* gw, long n_w, float* gb, long n_b, int splits, float beta,
+                            hipStream_t s);
 int lgm_linattn_bwd_launch(const float* qkv, long pitch, const float* mem_kv, const float* gout, long gout_pitch,
                            const float* ctx, const float* gctx, const float* kmax, const float* ksum,
                            const float* rvec, int B, int n, int heads, int M, float scale, float* gqkv,
@@ -326,6 +336,80 @@ extern "C" int lgm_linattn_bwd(const float* qkv, int64_t qkv_pitch, const float*
                                       B, n, heads, M, scale, gqkv, (long)gqkv_pitch, part, s))
     return rc;
   if (M > 0) return lgm_colsum(part, ncols, B, ncols, gmem_kv, gmem_beta, cs_ws, stream);
+  return LGM_OK;
+}
+
+// Backward with the tail fused (linattn_fused.hip): gq / gk / gv never leave the chip - the kernel that computes them
+// also produces to_qkv's input gradient gxn = gqkv Wqkv and, for C = 64 input channels, to_qkv's weight gradient
+// (slabs + descriptor for the fixed-order reducer; C > 64: gqkv is written for lgm_conv_wgrad as before).  The memory
+// columns' gradient rides in the gctx launch.  `gw_desc` / `gmem_desc` (8 int64 each, rows of lgm_wgrad_reduce_batch):
+// non-null = deferred, the caller reduces later and `slabs` / `gmem_part` must stay untouched until then.
+extern "C" int64_t lgm_linattn_bwd_fused_workspace(int B, int heads, int dim_head) {
+  const int64_t bh = (int64_t)B * heads;
+  return (bh * dim_head * dim_head + bh * dim_head) * (int64_t)sizeof(float) + 64;
+}
+
+extern "C" int lgm_linattn_bwd_fused(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* gout,
+                                     int64_t gout_pitch, const float* ctx, const float* kmax, const float* ksum,
+                                     const float* xn, int64_t xn_pitch, const float* wqkv, int C, int B, int n,
+                                     int heads, int dim_head, int M, float* gxn, int64_t gxn_pitch, float* gqkv,
+                                     int64_t gqkv_pitch, float* gwqkv, float gw_beta, void* slabs, int64_t slab_bytes,
+                                     int64_t* gw_desc, float* gmem_kv, float gmem_beta, void* gmem_part,
+                                     int64_t* gmem_desc, void* workspace, void* stream) {
+  if (int rc = attn_check(B, n, heads, dim_head, M)) return rc;
+  LGM_REQUIRE(lgm_linattn_bwd_fused_supported(heads, dim_head, C), "linattn_bwd_fused: heads=%d dim_head=%d C=%d unsupported",
+              heads, dim_head, C);
+  LGM_REQUIRE(qkv && mem_kv && gout && ctx && kmax && ksum && wqkv && gxn && gmem_kv && gmem_part && workspace,
+              "linattn_bwd_fused: null pointer");
+  LGM_REQUIRE(qkv_pitch % 4 == 0 && gout_pitch % 4 == 0 && lgm_aligned16(qkv) && lgm_aligned16(gout) && lgm_aligned16(ctx) &&
+                  lgm_aligned16(kmax) && lgm_aligned16(ksum) && lgm_aligned16(wqkv) && lgm_aligned16(workspace) &&
+                  lgm_aligned16(gmem_kv) && lgm_aligned16(gmem_part),
+              "linattn_bwd_fused: 16-byte aligned operands required");
+  const bool fuse_dw = C == 64;
+  if (fuse_dw)
+    LGM_REQUIRE(xn && xn_pitch % 4 == 0 && lgm_aligned16(xn) && gwqkv && lgm_aligned16(gwqkv) && slabs && lgm_aligned16(slabs) &&
+                    slab_bytes >= lgm_linattn_bwd_fused_slabs(B, n, C),
+                "linattn_bwd_fused: xn / weight-gradient slabs missing, misaligned or too small");
+  else
+    LGM_REQUIRE(gqkv && gqkv_pitch % 4 == 0 && lgm_aligned16(gqkv), "linattn_bwd_fused: gqkv required for C=%d", C);
+  hipStream_t s = (hipStream_t)stream;
+  const float scale = 1.f / sqrtf((float)dim_head);
+  const long bh = (long)B * heads;
+  float* gctx = (float*)workspace;
+  float* rvec = gctx + bh * DH * DH;
+  const long ncols = 2L * heads * DH * M;
+  if (int rc = lgm_linattn_ctx_launch(1, qkv, (long)qkv_pitch, mem_kv, gout, (long)gout_pitch, ctx, B, n, heads, M, scale,
+                                      gctx, nullptr, nullptr, rvec, s, kmax, ksum, (float*)gmem_part))
+    return rc;
+  int blocks = 0;
+  if (int rc = lgm_linattn_bwd_fused_launch(qkv, (long)qkv_pitch, gout, (long)gout_pitch, ctx, gctx, kmax, ksum, rvec, xn,
+                                            (long)xn_pitch, wqkv, B, n, C, scale, gxn, (long)gxn_pitch, gqkv,
+                                            (long)gqkv_pitch, (float*)slabs, &blocks, s))
+    return rc;
+  union { float f; int64_t i; } bb;
+  if (M > 0) {
+    if (gmem_desc) {
+      bb.i = 0; bb.f = gmem_beta;
+      gmem_desc[0] = (int64_t)(uintptr_t)gmem_part; gmem_desc[1] = ncols; gmem_desc[2] = (int64_t)(uintptr_t)gmem_kv;
+      gmem_desc[3] = ncols; gmem_desc[4] = 0; gmem_desc[5] = 0; gmem_desc[6] = B; gmem_desc[7] = bb.i;
+    } else if (int rc = lgm_wgrad_reduce_launch((const float*)gmem_part, ncols, gmem_kv, ncols, nullptr, 0, B, gmem_beta, s)) {
+      return rc;
+    }
+  } else if (gmem_desc) {
+    gmem_desc[6] = 0;
+  }
+  if (fuse_dw) {
+    const long n_w = 3L * heads * DH * 64;
+    if (gw_desc) {
+      bb.i = 0; bb.f = gw_beta;
+      gw_desc[0] = (int64_t)(uintptr_t)slabs; gw_desc[1] = n_w; gw_desc[2] = (int64_t)(uintptr_t)gwqkv; gw_desc[3] = n_w;
+      gw_desc[4] = 0; gw_desc[5] = 0; gw_desc[6] = blocks; gw_desc[7] = bb.i;
+    } else if (int rc = lgm_wgrad_reduce_launch((const float*)slabs, n_w, gwqkv, n_w, nullptr, 0, blocks, gw_beta, s)) {
+      return rc;
+    }
+  } else if (gw_desc) {
+    gw_desc[6] = 0;
+  }
   return LGM_OK;
 }
 

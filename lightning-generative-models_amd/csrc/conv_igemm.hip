@@ -1697,6 +1697,16 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
   return LGM_OK;
 }
 
+// the single-layer slab reducer for other translation units (linattn_fused.hip)
+int lgm_wgrad_reduce_launch(const float* ws, long slab, float* gw, long n_w, float* gb, long n_b, int splits, float beta,
+                            hipStream_t s) {
+  const long groups = (n_w + n_b + 3) / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lgm_cdiv(groups, 64)), dim3(256), 0, s, ws, slab, gw, n_w, gb, n_b,
+                     splits, beta);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
 // ---- backward pair of a 3x3 layer: input gradient + weight gradient in ONE launch (csrc/winograd.hip) -------------
 bool lgm_wino_supported(const LgmConvGeom* g, int gather_channels, int out_channels);
 struct WinoPairPlan {

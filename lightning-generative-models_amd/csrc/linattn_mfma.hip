@@ -18,7 +18,9 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
                                                         const float* __restrict__ ctx_in, int n, int heads, int M,
                                                         float scale, float* __restrict__ ctx_out,
                                                         float* __restrict__ kmax_out, float* __restrict__ ksum_out,
-                                                        float* __restrict__ r_out) {
+                                                        float* __restrict__ r_out, const float* __restrict__ kmax_in,
+                                                        const float* __restrict__ ksum_in,
+                                                        float* __restrict__ gmem_partial) {
   __shared__ float Ws[TP * LDW];
   __shared__ __align__(16) float Us[TP * DH];
   __shared__ __align__(16) float Red[4][DH][DH];
@@ -173,6 +175,30 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
     r += __shfl_xor(r, 2, 64);
     r += __shfl_xor(r, 4, 64);
     if ((tid % 8) == 0) r_out[bh * DH + d_c] = r;
+    if (gmem_partial != nullptr && M > 0) {
+      // gradient of the M memory key / value columns (mem_kv, ddpm.py:211,226): they see the same gctx as the pixels -
+      // gk[d][j] = ks[d][j] (sum_e gctx[d][e] v[e][j] - r[d]),  gv[e][j] = sum_d ks[d][j] gctx[d][e]
+      __syncthreads();
+      *reinterpret_cast<f32x4*>(&Red[0][d_c][e0]) = cv;
+      if ((tid % 8) == 0) red32[0][d_c] = r;
+      for (int t = tid; t < DH * M; t += 256) {
+        const int d = t / M, j = t % M;
+        Red[1][d][j] = __expf(memk[d * M + j] - kmax_in[bh * DH + d]) * (1.f / ksum_in[bh * DH + d]);
+      }
+      __syncthreads();
+      float* gm = gmem_partial + (long)b * 2 * heads * DH * M;   // [B][2][heads][32][M]
+      for (int t = tid; t < 2 * DH * M; t += 256) {
+        const int which = t / (DH * M), c = (t % (DH * M)) / M, j = t % M;
+        float a = 0.f;
+        if (which == 0) {
+          for (int e = 0; e < DH; ++e) a += Red[0][c][e] * memv[e * M + j];
+          a = Red[1][c][j] * (a - red32[0][c]);
+        } else {
+          for (int d = 0; d < DH; ++d) a += Red[1][d][j] * Red[0][d][c];
+        }
+        gm[((long)(which * heads + h) * DH + c) * M + j] = a;
+      }
+    }
   }
 }
 
@@ -352,15 +378,16 @@ __global__ __launch_bounds__(256) void linattn_bwd_mfma(
 
 int lgm_linattn_ctx_launch(int mode, const float* qkv, long pitch, const float* mem_kv, const float* gout,
                            long gout_pitch, const float* ctx_in, int B, int n, int heads, int M, float scale,
-                           float* ctx_out, float* kmax, float* ksum, float* r_out, hipStream_t s) {
+                           float* ctx_out, float* kmax, float* ksum, float* r_out, hipStream_t s,
+                           const float* kmax_in, const float* ksum_in, float* gmem_partial) {
   LGM_REQUIRE(pitch % 4 == 0 && lgm_aligned16(qkv) && (mode == 0 || (gout_pitch % 4 == 0 && lgm_aligned16(gout))),
               "linattn_ctx: 16-byte aligned rows required");
   if (mode == 0)
     hipLaunchKernelGGL(linattn_ctx_mfma<0>, dim3(B * heads), dim3(256), 0, s, qkv, pitch, mem_kv, gout, gout_pitch,
-                       ctx_in, n, heads, M, scale, ctx_out, kmax, ksum, r_out);
+                       ctx_in, n, heads, M, scale, ctx_out, kmax, ksum, r_out, kmax_in, ksum_in, gmem_partial);
   else
     hipLaunchKernelGGL(linattn_ctx_mfma<1>, dim3(B * heads), dim3(256), 0, s, qkv, pitch, mem_kv, gout, gout_pitch,
-                       ctx_in, n, heads, M, scale, ctx_out, kmax, ksum, r_out);
+                       ctx_in, n, heads, M, scale, ctx_out, kmax, ksum, r_out, kmax_in, ksum_in, gmem_partial);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

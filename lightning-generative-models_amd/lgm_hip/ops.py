@@ -739,6 +739,67 @@ def linattn_bwd(qkv, mem_ptr, gout, ctx, kstat, heads, dim_head, M, gqkv, gmem_p
                       pitch(gqkv), gmem_ptr, gmem_beta, ws.data_ptr(), stream())
 
 
+# opt-in: the fused LinearAttention backward tail (csrc/linattn_fused.hip).  Correct (tested) but measured SLOWER than the
+# three launches it replaces (B = 128: 11.59 vs 11.50 ms / step, B = 16: 4.87 vs 4.63), see DESIGN.md 3.4
+LA_FUSED = _os.environ.get("LGM_LA_FUSED") is not None
+
+
+def linattn_bwd_fused_ok(heads, dim_head, C, qkv, gout, xn, w_ptr, gw_ptr, gmem_ptr) -> bool:
+    if not LA_FUSED or not lib().lgm_linattn_bwd_fused_supported(heads, dim_head, C):
+        return False
+    return not any(v % 16 for v in (qkv.data_ptr(), gout.data_ptr(), xn.data_ptr(), w_ptr, gw_ptr, gmem_ptr)) and \
+        pitch(qkv) % 4 == 0 and pitch(gout) % 4 == 0 and pitch(xn) % 4 == 0
+
+
+def _persistent(key, nbytes, device):
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = torch.empty(max(nbytes // 4 + 4, 16), dtype=torch.float32, device=device)
+        _WGRAD_WS[key] = ws
+    return ws
+
+
+def linattn_bwd_fused(qkv, mem_ptr, gout, ctx, kstat, xn, w_ptr, heads, dim_head, M, gxn, gw_ptr, gw_beta, gw_defer,
+                      gmem_ptr, gmem_beta, gmem_defer):
+    """LinearAttention backward with to_qkv's backward folded in (lgm_linattn_bwd_fused): writes gxn; to_qkv's weight
+    gradient too when it has 64 input channels (returns None), else returns gqkv for the caller's conv_wgrad.
+    ``gw_defer`` / ``gmem_defer``: deferred-reduction lists (GradCtx.defer_for) or None = reduce now."""
+    L = lib()
+    B, H, W, _ = qkv.shape
+    n, C = H * W, xn.shape[-1]
+    dev = qkv.device
+    wsb = L.lgm_linattn_bwd_fused_workspace(B, heads, dim_head)
+    slab_bytes = L.lgm_linattn_bwd_fused_slabs(B, n, C)
+    part_bytes = B * 2 * heads * dim_head * M * 4
+    # scratch that dies with the call: gctx / r; the partial buffers too when their reduction is not deferred
+    extra = (0 if gw_defer is not None else slab_bytes + 64) + (0 if gmem_defer is not None else part_bytes + 64)
+    ws = workspace(wsb + extra, dev)
+    off = (wsb + 63) // 64 * 64
+    if gmem_defer is not None:
+        part_ptr = _persistent((gmem_ptr, part_bytes), part_bytes, dev).data_ptr()
+    else:
+        part_ptr = ws.data_ptr() + off
+        off += (part_bytes + 63) // 64 * 64
+    slab_ptr = None
+    if slab_bytes:
+        slab_ptr = _persistent((gw_ptr, slab_bytes), slab_bytes, dev).data_ptr() if gw_defer is not None \
+            else ws.data_ptr() + off
+    gqkv = None if slab_bytes else new(qkv.shape, qkv)
+    d_w = (ctypes.c_int64 * 8)() if gw_defer is not None else None
+    d_m = (ctypes.c_int64 * 8)() if gmem_defer is not None else None
+    L.lgm_linattn_bwd_fused(qkv.data_ptr(), pitch(qkv), mem_ptr, gout.data_ptr(), pitch(gout), ctx.data_ptr(),
+                            kstat[0].data_ptr(), kstat[1].data_ptr(), xn.data_ptr(), pitch(xn), w_ptr, C, B, n, heads,
+                            dim_head, M, gxn.data_ptr(), pitch(gxn), None if gqkv is None else gqkv.data_ptr(),
+                            0 if gqkv is None else pitch(gqkv), gw_ptr, gw_beta, slab_ptr, slab_bytes,
+                            None if d_w is None else ctypes.addressof(d_w), gmem_ptr, gmem_beta, part_ptr,
+                            None if d_m is None else ctypes.addressof(d_m), ws.data_ptr(), stream())
+    if d_w is not None and d_w[6] > 0:
+        gw_defer.append(tuple(d_w))
+    if d_m is not None and d_m[6] > 0:
+        gmem_defer.append(tuple(d_m))
+    return gqkv
+
+
 def attn_fwd(qkv, mem_ptr, heads, dim_head, M, out):
     B, H, W, _ = qkv.shape
     lse = new((B, heads, H * W), qkv)
