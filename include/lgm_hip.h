@@ -216,22 +216,34 @@ int lgm_linattn_bwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, co
                     float* gmem_kv, float gmem_beta, void* workspace, void* stream);
 /* The same backward with its tail fused (autograd of ddpm.py:214-239, i.e. LinearAttention.to_qkv's backward folded
  * into the attention core's): gq / gk / gv of a pixel tile stay on the chip; the launch that computes them also produces
- * to_qkv's input gradient gxn[B n, C] = gqkv Wqkv and, for C = 64, to_qkv's weight gradient (per-workgroup slabs in
- * `slabs`, lgm_linattn_bwd_fused_slabs bytes, summed by the fixed-order reducer); for C = 128 / 256 gqkv is written for
- * lgm_conv_wgrad as before and `slabs` / `xn` / `gwqkv` may be null.  xn = the RMSNorm output to_qkv was applied to,
- * wqkv = to_qkv.weight [3*heads*32][C].  `gw_desc` / `gmem_desc` (8 int64, rows of lgm_wgrad_reduce_batch; [6] = 0: no
- * row): non-null = the reductions are left to the caller's batched reducer and `slabs` / `gmem_part`
- * (B*2*heads*32*M floats) must stay untouched until it has run; null = reduced here. */
+ * to_qkv's input gradient gxn[B n, C] = gqkv Wqkv and to_qkv's weight gradient (per-workgroup slabs in `slabs`,
+ * lgm_linattn_bwd_fused_slabs bytes, summed by the fixed-order reducer).  Built for C = 64 input channels
+ * (lgm_linattn_bwd_fused_supported).  xn = the RMSNorm output to_qkv was applied to, wqkv_t = to_qkv.weight transposed,
+ * [C][3*heads*32].  `gw_desc` / `gmem_desc` (8 int64, rows of lgm_wgrad_reduce_batch; [6] = 0: no row): non-null = the
+ * reductions are left to the caller's batched reducer and `slabs` / `gmem_part` (B*2*heads*32*M floats) must stay
+ * untouched until it has run; null = reduced here. */
 int64_t lgm_linattn_bwd_fused_supported(int heads, int dim_head, int C);
 int64_t lgm_linattn_bwd_fused_slabs(int B, int n, int C);
 int64_t lgm_linattn_bwd_fused_workspace(int B, int heads, int dim_head);
 int lgm_linattn_bwd_fused(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* gout,
                           int64_t gout_pitch, const float* ctx, const float* kmax, const float* ksum,
-                          const float* xn, int64_t xn_pitch, const float* wqkv, int C, int B, int n,
-                          int heads, int dim_head, int M, float* gxn, int64_t gxn_pitch, float* gqkv,
-                          int64_t gqkv_pitch, float* gwqkv, float gw_beta, void* slabs, int64_t slab_bytes,
-                          int64_t* gw_desc, float* gmem_kv, float gmem_beta, void* gmem_part,
-                          int64_t* gmem_desc, void* workspace, void* stream);
+                          const float* xn, int64_t xn_pitch, const float* wqkv_t, int C, int B, int n,
+                          int heads, int dim_head, int M, float* gxn, int64_t gxn_pitch, float* gwqkv,
+                          float gw_beta, void* slabs, int64_t slab_bytes, int64_t* gw_desc, float* gmem_kv,
+                          float gmem_beta, void* gmem_part, int64_t* gmem_desc, void* workspace, void* stream);
+/* Deferred forms of the two backward entry points: the per-image partial rows of the mem_kv gradient are left in
+ * `gmem_part` (B*2*heads*32*M floats; must stay untouched until the caller's lgm_wgrad_reduce_batch has run) and
+ * `gmem_desc` (8 int64) receives their reducer row ([6] = 0: no row) - one batched reduction per exchange bucket instead
+ * of a column-sum launch pair per attention block.  gmem_kv must be 16-byte aligned. */
+int lgm_linattn_bwd_deferred(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* gout,
+                             int64_t gout_pitch, const float* ctx, const float* kmax, const float* ksum,
+                             int B, int n, int heads, int dim_head, int M, float* gqkv, int64_t gqkv_pitch,
+                             float* gmem_kv, float gmem_beta, void* gmem_part, int64_t* gmem_desc,
+                             void* workspace, void* stream);
+int lgm_attn_bwd_deferred(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* out,
+                          int64_t out_pitch, const float* gout, int64_t gout_pitch, const float* lse, int B,
+                          int n, int heads, int dim_head, int M, float* gqkv, int64_t gqkv_pitch,
+                          float* gmem_kv, float gmem_beta, void* gmem_part, int64_t* gmem_desc, void* stream);
 int lgm_attn_fwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, int B, int n, int heads,
                  int dim_head, int M, float* out, int64_t out_pitch, float* lse, void* stream);
 int64_t lgm_attn_bwd_workspace(int B, int heads, int dim_head, int M);

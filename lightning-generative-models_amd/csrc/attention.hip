@@ -18,9 +18,8 @@ int lgm_linattn_ctx_launch(int mode, const float* qkv, long pitch, const float* 
 // fused backward tail (linattn_fused.hip) and the single-layer slab reducer (conv_igemm.hip)
 int lgm_linattn_bwd_fused_launch(const float* qkv, long pitch, const float* gout, long gout_pitch, const float* ctx,
                                  const float* gctx, const float* kmax, const float* ksum, const float* rvec,
-                                 const float* xn, long xn_pitch, const float* w, int B, int n, int C, float scale,
-                                 float* gxn, long gxn_pitch, float* gqkv, long gq_pitch, float* slabs, int* blocks_out,
-                                 hipStream_t s);
+                                 const float* xn, long xn_pitch, const float* wt, int B, int n, float scale,
+                                 float* gxn, long gxn_pitch, float* slabs, int* blocks_out, hipStream_t s);
 int lgm_wgrad_reduce_launch(const float* ws, long slab, float* gw, long n_w, float* gb, long n_b, int splits, float beta,
                             hipStream_t s);
 int lgm_linattn_bwd_launch(const float* qkv, long pitch, const float* mem_kv, const float* gout, long gout_pitch,
@@ -311,39 +310,80 @@ extern "C" int lgm_linattn_fwd(const float* qkv, int64_t qkv_pitch, const float*
 extern "C" int64_t lgm_linattn_bwd_workspace(int B, int heads, int dim_head, int M) {
   const int64_t bh = (int64_t)B * heads;
   const int64_t part = (int64_t)B * 2 * heads * dim_head * M;
-  return (bh * dim_head * dim_head + bh * dim_head + part) * (int64_t)sizeof(float) + lgm_colsum_workspace(B, 2 * heads * dim_head * M) + 64;
+  return (bh * dim_head * dim_head + bh * dim_head + part) * (int64_t)sizeof(float) +
+         lgm_colsum_workspace(B, 2 * heads * dim_head * M) + 64;
 }
 
-extern "C" int lgm_linattn_bwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* gout,
-                               int64_t gout_pitch, const float* ctx, const float* kmax, const float* ksum, int B,
-                               int n, int heads, int dim_head, int M, float* gqkv, int64_t gqkv_pitch,
-                               float* gmem_kv, float gmem_beta, void* workspace, void* stream) {
+namespace {
+// gmem_desc == nullptr: the per-image partial rows of the mem_kv gradient (in `part`) are summed here, else the row of
+// lgm_wgrad_reduce_batch that sums them is written to gmem_desc and `part` must outlive that launch
+int linattn_bwd_impl(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* gout, int64_t gout_pitch,
+                     const float* ctx, const float* kmax, const float* ksum, int B, int n, int heads, int dim_head, int M,
+                     float* gqkv, int64_t gqkv_pitch, float* gmem_kv, float gmem_beta, float* part, int64_t* gmem_desc,
+                     void* workspace, void* stream) {
   if (int rc = attn_check(B, n, heads, dim_head, M)) return rc;
-  LGM_REQUIRE(qkv && mem_kv && gout && ctx && kmax && ksum && gqkv && gmem_kv && workspace, "linattn_bwd: null pointer");
-  LGM_REQUIRE(lgm_aligned16(workspace), "linattn_bwd: workspace must be 16B aligned");
+  LGM_REQUIRE(qkv && mem_kv && gout && ctx && kmax && ksum && gqkv && gmem_kv && workspace && part, "linattn_bwd: null pointer");
+  LGM_REQUIRE(lgm_aligned16(workspace) && lgm_aligned16(part), "linattn_bwd: workspace must be 16B aligned");
   hipStream_t s = (hipStream_t)stream;
   const float scale = 1.f / sqrtf((float)dim_head);
   const long bh = (long)B * heads;
   float* gctx = (float*)workspace;
   float* rvec = gctx + bh * DH * DH;
-  float* part = rvec + bh * DH;
   const long ncols = 2L * heads * DH * M;
-  float* cs_ws = part + (long)B * ncols;
+  // the memory columns' gradient rides in the gctx launch when the fixed-order slab reducer can take it (16-byte rows)
+  const bool in_ctx = M > 0 && lgm_aligned16(gmem_kv) && ncols % 4 == 0;
   if (int rc = lgm_linattn_ctx_launch(1, qkv, (long)qkv_pitch, mem_kv, gout, (long)gout_pitch, ctx, B, n, heads, M, scale,
-                                      gctx, nullptr, nullptr, rvec, s))
+                                      gctx, nullptr, nullptr, rvec, s, kmax, ksum, in_ctx ? part : nullptr))
     return rc;
   if (int rc = lgm_linattn_bwd_launch(qkv, (long)qkv_pitch, mem_kv, gout, (long)gout_pitch, ctx, gctx, kmax, ksum, rvec,
-                                      B, n, heads, M, scale, gqkv, (long)gqkv_pitch, part, s))
+                                      B, n, heads, M, scale, gqkv, (long)gqkv_pitch, in_ctx ? nullptr : part, s))
     return rc;
-  if (M > 0) return lgm_colsum(part, ncols, B, ncols, gmem_kv, gmem_beta, cs_ws, stream);
-  return LGM_OK;
+  if (gmem_desc) gmem_desc[6] = 0;
+  if (M <= 0) return LGM_OK;
+  if (!in_ctx) {
+    LGM_REQUIRE(!gmem_desc, "linattn_bwd_deferred: mem_kv gradient must be 16-byte aligned");
+    return lgm_colsum(part, ncols, B, ncols, gmem_kv, gmem_beta, part + (long)B * ncols, stream);
+  }
+  if (gmem_desc) {
+    union { float f; int64_t i; } bb;
+    bb.i = 0; bb.f = gmem_beta;
+    gmem_desc[0] = (int64_t)(uintptr_t)part; gmem_desc[1] = ncols; gmem_desc[2] = (int64_t)(uintptr_t)gmem_kv;
+    gmem_desc[3] = ncols; gmem_desc[4] = 0; gmem_desc[5] = 0; gmem_desc[6] = B; gmem_desc[7] = bb.i;
+    return LGM_OK;
+  }
+  return lgm_wgrad_reduce_launch(part, ncols, gmem_kv, ncols, nullptr, 0, B, gmem_beta, s);
+}
+}  // namespace
+
+extern "C" int lgm_linattn_bwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* gout,
+                               int64_t gout_pitch, const float* ctx, const float* kmax, const float* ksum, int B,
+                               int n, int heads, int dim_head, int M, float* gqkv, int64_t gqkv_pitch,
+                               float* gmem_kv, float gmem_beta, void* workspace, void* stream) {
+  LGM_REQUIRE(workspace, "linattn_bwd: null pointer");
+  const long bh = (long)B * heads;
+  float* part = (float*)workspace + bh * DH * DH + bh * DH;
+  // (unaligned mem_kv gradients take the two-stage column sum, whose scratch follows the partial rows)
+  return linattn_bwd_impl(qkv, qkv_pitch, mem_kv, gout, gout_pitch, ctx, kmax, ksum, B, n, heads, dim_head, M, gqkv,
+                          gqkv_pitch, gmem_kv, gmem_beta, part, nullptr, workspace, stream);
+}
+
+// Deferred form: the partial rows of the mem_kv gradient are left in `gmem_part` (B*2*heads*32*M floats, must stay
+// untouched until the caller's lgm_wgrad_reduce_batch has run) with their reducer row in gmem_desc (8 int64).
+extern "C" int lgm_linattn_bwd_deferred(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* gout,
+                                        int64_t gout_pitch, const float* ctx, const float* kmax, const float* ksum,
+                                        int B, int n, int heads, int dim_head, int M, float* gqkv, int64_t gqkv_pitch,
+                                        float* gmem_kv, float gmem_beta, void* gmem_part, int64_t* gmem_desc,
+                                        void* workspace, void* stream) {
+  LGM_REQUIRE(gmem_desc && gmem_part && lgm_aligned16(gmem_kv), "linattn_bwd_deferred: descriptor / partial buffer / aligned gradient required");
+  return linattn_bwd_impl(qkv, qkv_pitch, mem_kv, gout, gout_pitch, ctx, kmax, ksum, B, n, heads, dim_head, M, gqkv,
+                          gqkv_pitch, gmem_kv, gmem_beta, (float*)gmem_part, gmem_desc, workspace, stream);
 }
 
 // Backward with the tail fused (linattn_fused.hip): gq / gk / gv never leave the chip - the kernel that computes them
-// also produces to_qkv's input gradient gxn = gqkv Wqkv and, for C = 64 input channels, to_qkv's weight gradient
-// (slabs + descriptor for the fixed-order reducer; C > 64: gqkv is written for lgm_conv_wgrad as before).  The memory
-// columns' gradient rides in the gctx launch.  `gw_desc` / `gmem_desc` (8 int64 each, rows of lgm_wgrad_reduce_batch):
-// non-null = deferred, the caller reduces later and `slabs` / `gmem_part` must stay untouched until then.
+// also produces to_qkv's input gradient gxn = gqkv Wqkv and to_qkv's weight gradient (slabs + descriptor for the
+// fixed-order reducer).  The memory columns' gradient rides in the gctx launch.  `gw_desc` / `gmem_desc` (8 int64 each,
+// rows of lgm_wgrad_reduce_batch): non-null = deferred, the caller reduces later and `slabs` / `gmem_part` must stay
+// untouched until then.
 extern "C" int64_t lgm_linattn_bwd_fused_workspace(int B, int heads, int dim_head) {
   const int64_t bh = (int64_t)B * heads;
   return (bh * dim_head * dim_head + bh * dim_head) * (int64_t)sizeof(float) + 64;
@@ -351,27 +391,22 @@ extern "C" int64_t lgm_linattn_bwd_fused_workspace(int B, int heads, int dim_hea
 
 extern "C" int lgm_linattn_bwd_fused(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* gout,
                                      int64_t gout_pitch, const float* ctx, const float* kmax, const float* ksum,
-                                     const float* xn, int64_t xn_pitch, const float* wqkv, int C, int B, int n,
-                                     int heads, int dim_head, int M, float* gxn, int64_t gxn_pitch, float* gqkv,
-                                     int64_t gqkv_pitch, float* gwqkv, float gw_beta, void* slabs, int64_t slab_bytes,
-                                     int64_t* gw_desc, float* gmem_kv, float gmem_beta, void* gmem_part,
-                                     int64_t* gmem_desc, void* workspace, void* stream) {
+                                     const float* xn, int64_t xn_pitch, const float* wqkv_t, int C, int B, int n,
+                                     int heads, int dim_head, int M, float* gxn, int64_t gxn_pitch, float* gwqkv,
+                                     float gw_beta, void* slabs, int64_t slab_bytes, int64_t* gw_desc, float* gmem_kv,
+                                     float gmem_beta, void* gmem_part, int64_t* gmem_desc, void* workspace,
+                                     void* stream) {
   if (int rc = attn_check(B, n, heads, dim_head, M)) return rc;
   LGM_REQUIRE(lgm_linattn_bwd_fused_supported(heads, dim_head, C), "linattn_bwd_fused: heads=%d dim_head=%d C=%d unsupported",
               heads, dim_head, C);
-  LGM_REQUIRE(qkv && mem_kv && gout && ctx && kmax && ksum && wqkv && gxn && gmem_kv && gmem_part && workspace,
-              "linattn_bwd_fused: null pointer");
-  LGM_REQUIRE(qkv_pitch % 4 == 0 && gout_pitch % 4 == 0 && lgm_aligned16(qkv) && lgm_aligned16(gout) && lgm_aligned16(ctx) &&
-                  lgm_aligned16(kmax) && lgm_aligned16(ksum) && lgm_aligned16(wqkv) && lgm_aligned16(workspace) &&
-                  lgm_aligned16(gmem_kv) && lgm_aligned16(gmem_part),
+  LGM_REQUIRE(qkv && mem_kv && gout && ctx && kmax && ksum && xn && wqkv_t && gxn && gwqkv && slabs && gmem_kv && gmem_part &&
+                  workspace, "linattn_bwd_fused: null pointer");
+  LGM_REQUIRE(qkv_pitch % 4 == 0 && gout_pitch % 4 == 0 && xn_pitch % 4 == 0 && gxn_pitch % 4 == 0 && lgm_aligned16(qkv) &&
+                  lgm_aligned16(gout) && lgm_aligned16(ctx) && lgm_aligned16(kmax) && lgm_aligned16(ksum) &&
+                  lgm_aligned16(xn) && lgm_aligned16(wqkv_t) && lgm_aligned16(gxn) && lgm_aligned16(gwqkv) &&
+                  lgm_aligned16(slabs) && lgm_aligned16(workspace) && lgm_aligned16(gmem_kv) && lgm_aligned16(gmem_part),
               "linattn_bwd_fused: 16-byte aligned operands required");
-  const bool fuse_dw = C == 64;
-  if (fuse_dw)
-    LGM_REQUIRE(xn && xn_pitch % 4 == 0 && lgm_aligned16(xn) && gwqkv && lgm_aligned16(gwqkv) && slabs && lgm_aligned16(slabs) &&
-                    slab_bytes >= lgm_linattn_bwd_fused_slabs(B, n, C),
-                "linattn_bwd_fused: xn / weight-gradient slabs missing, misaligned or too small");
-  else
-    LGM_REQUIRE(gqkv && gqkv_pitch % 4 == 0 && lgm_aligned16(gqkv), "linattn_bwd_fused: gqkv required for C=%d", C);
+  LGM_REQUIRE(slab_bytes >= lgm_linattn_bwd_fused_slabs(B, n, C), "linattn_bwd_fused: slab buffer too small");
   hipStream_t s = (hipStream_t)stream;
   const float scale = 1.f / sqrtf((float)dim_head);
   const long bh = (long)B * heads;
@@ -383,8 +418,8 @@ extern "C" int lgm_linattn_bwd_fused(const float* qkv, int64_t qkv_pitch, const 
     return rc;
   int blocks = 0;
   if (int rc = lgm_linattn_bwd_fused_launch(qkv, (long)qkv_pitch, gout, (long)gout_pitch, ctx, gctx, kmax, ksum, rvec, xn,
-                                            (long)xn_pitch, wqkv, B, n, C, scale, gxn, (long)gxn_pitch, gqkv,
-                                            (long)gqkv_pitch, (float*)slabs, &blocks, s))
+                                            (long)xn_pitch, wqkv_t, B, n, scale, gxn, (long)gxn_pitch, (float*)slabs,
+                                            &blocks, s))
     return rc;
   union { float f; int64_t i; } bb;
   if (M > 0) {
@@ -398,17 +433,13 @@ extern "C" int lgm_linattn_bwd_fused(const float* qkv, int64_t qkv_pitch, const 
   } else if (gmem_desc) {
     gmem_desc[6] = 0;
   }
-  if (fuse_dw) {
-    const long n_w = 3L * heads * DH * 64;
-    if (gw_desc) {
-      bb.i = 0; bb.f = gw_beta;
-      gw_desc[0] = (int64_t)(uintptr_t)slabs; gw_desc[1] = n_w; gw_desc[2] = (int64_t)(uintptr_t)gwqkv; gw_desc[3] = n_w;
-      gw_desc[4] = 0; gw_desc[5] = 0; gw_desc[6] = blocks; gw_desc[7] = bb.i;
-    } else if (int rc = lgm_wgrad_reduce_launch((const float*)slabs, n_w, gwqkv, n_w, nullptr, 0, blocks, gw_beta, s)) {
-      return rc;
-    }
-  } else if (gw_desc) {
-    gw_desc[6] = 0;
+  const long n_w = 3L * heads * DH * C;
+  if (gw_desc) {
+    bb.i = 0; bb.f = gw_beta;
+    gw_desc[0] = (int64_t)(uintptr_t)slabs; gw_desc[1] = n_w; gw_desc[2] = (int64_t)(uintptr_t)gwqkv; gw_desc[3] = n_w;
+    gw_desc[4] = 0; gw_desc[5] = 0; gw_desc[6] = blocks; gw_desc[7] = bb.i;
+  } else if (int rc = lgm_wgrad_reduce_launch((const float*)slabs, n_w, gwqkv, n_w, nullptr, 0, blocks, gw_beta, s)) {
+    return rc;
   }
   return LGM_OK;
 }
@@ -431,13 +462,14 @@ extern "C" int64_t lgm_attn_bwd_workspace(int B, int heads, int dim_head, int M)
   return (int64_t)B * ncols * (int64_t)sizeof(float) + lgm_colsum_workspace(B, ncols) + 64;
 }
 
-extern "C" int lgm_attn_bwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* out,
-                            int64_t out_pitch, const float* gout, int64_t gout_pitch, const float* lse, int B, int n,
-                            int heads, int dim_head, int M, float* gqkv, int64_t gqkv_pitch, float* gmem_kv,
-                            float gmem_beta, void* workspace, void* stream) {
+namespace {
+int attn_bwd_impl(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* out, int64_t out_pitch,
+                  const float* gout, int64_t gout_pitch, const float* lse, int B, int n, int heads, int dim_head, int M,
+                  float* gqkv, int64_t gqkv_pitch, float* gmem_kv, float gmem_beta, float* part, int64_t* gmem_desc,
+                  void* stream) {
   if (int rc = attn_check(B, n, heads, dim_head, M)) return rc;
   LGM_REQUIRE(n <= FA_MAXN, "attn_bwd: n=%d > %d query pixels unsupported", n, FA_MAXN);
-  LGM_REQUIRE(qkv && mem_kv && out && gout && lse && gqkv && gmem_kv && workspace, "attn_bwd: null pointer");
+  LGM_REQUIRE(qkv && mem_kv && out && gout && lse && gqkv && gmem_kv && part, "attn_bwd: null pointer");
   const size_t smem = ((size_t)2 * (n + M) * FA_LD + (size_t)2 * n * FA_LD + 2 * n) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -445,12 +477,40 @@ extern "C" int lgm_attn_bwd(const float* qkv, int64_t qkv_pitch, const float* me
                         (int)(((size_t)4 * (FA_MAXN + 16) * FA_LD + 2 * FA_MAXN) * sizeof(float)));
     attr_set = true;
   }
-  float* part = (float*)workspace;
   const long ncols = 2L * heads * M * DH;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(192), smem, (hipStream_t)stream, qkv, (long)qkv_pitch,
                      mem_kv, out, (long)out_pitch, gout, (long)gout_pitch, lse, n, heads, M,
                      1.f / sqrtf((float)dim_head), gqkv, (long)gqkv_pitch, part);
   LGM_LAUNCH_CHECK();
-  if (M > 0) return lgm_colsum(part, ncols, B, ncols, gmem_kv, gmem_beta, part + (long)B * ncols, stream);
-  return LGM_OK;
+  if (gmem_desc) gmem_desc[6] = 0;
+  if (M <= 0) return LGM_OK;
+  if (gmem_desc) {
+    union { float f; int64_t i; } bb;
+    bb.i = 0; bb.f = gmem_beta;
+    gmem_desc[0] = (int64_t)(uintptr_t)part; gmem_desc[1] = ncols; gmem_desc[2] = (int64_t)(uintptr_t)gmem_kv;
+    gmem_desc[3] = ncols; gmem_desc[4] = 0; gmem_desc[5] = 0; gmem_desc[6] = B; gmem_desc[7] = bb.i;
+    return LGM_OK;
+  }
+  return lgm_colsum(part, ncols, B, ncols, gmem_kv, gmem_beta, part + (long)B * ncols, stream);
+}
+}  // namespace
+
+extern "C" int lgm_attn_bwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* out,
+                            int64_t out_pitch, const float* gout, int64_t gout_pitch, const float* lse, int B, int n,
+                            int heads, int dim_head, int M, float* gqkv, int64_t gqkv_pitch, float* gmem_kv,
+                            float gmem_beta, void* workspace, void* stream) {
+  return attn_bwd_impl(qkv, qkv_pitch, mem_kv, out, out_pitch, gout, gout_pitch, lse, B, n, heads, dim_head, M, gqkv,
+                       gqkv_pitch, gmem_kv, gmem_beta, (float*)workspace, nullptr, stream);
+}
+
+// Deferred form (see lgm_linattn_bwd_deferred): gmem_part = B*2*heads*M*32 floats.
+extern "C" int lgm_attn_bwd_deferred(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* out,
+                                     int64_t out_pitch, const float* gout, int64_t gout_pitch, const float* lse, int B,
+                                     int n, int heads, int dim_head, int M, float* gqkv, int64_t gqkv_pitch,
+                                     float* gmem_kv, float gmem_beta, void* gmem_part, int64_t* gmem_desc,
+                                     void* stream) {
+  LGM_REQUIRE(gmem_desc && gmem_part && lgm_aligned16(gmem_part) && lgm_aligned16(gmem_kv),
+              "attn_bwd_deferred: descriptor / partial buffer / aligned gradient required");
+  return attn_bwd_impl(qkv, qkv_pitch, mem_kv, out, out_pitch, gout, gout_pitch, lse, B, n, heads, dim_head, M, gqkv,
+                       gqkv_pitch, gmem_kv, gmem_beta, (float*)gmem_part, gmem_desc, stream);
 }

@@ -6,9 +6,10 @@
 // dWqkv = gqkv^T xn (weight gradient).  All three launches are bound by that tensor's traffic.  Here the three
 // [128 x 32] gradient tiles of a (pixel tile, head) stay in LDS:
 //   * gxn[128 x C]  += [gq | gk | gv] Wqkv_h[96 x C]        accumulated over the four heads in registers,
-//   * dWqkv_h[96 x 64] += [gq | gk | gv]^T xn[128 x 64]      (C = 64 only) accumulated over the block's pixel tiles in
-//     registers and written once per block as a slab for the batched fixed-order reducer (lgm_wgrad_reduce_batch);
-//     for C > 64 the accumulators do not fit and gqkv is written for the separate weight-gradient kernel as before.
+//   * dWqkv_h[96 x 64] += [gq | gk | gv]^T xn[128 x 64]      accumulated over the block's pixel tiles in registers and
+//     written once per block as a slab for the batched fixed-order reducer (lgm_wgrad_reduce_batch).
+// Built for to_qkv layers with 64 input channels (the 32x32 and the down-path 16x16 attention blocks of the UNet, where
+// the gradient tensor is large); wider layers sit on small maps and keep the three-launch path.
 // One persistent workgroup per CU walks a contiguous range of (image, 128-pixel tile) items; the next head's operand
 // tiles are fetched into registers while the current head is multiplied.  Everything a wave needs between the staging
 // barrier and the weight-gradient step lives in ITS 32 rows of the LDS tiles (softmax passes use two lanes per row), so
@@ -25,39 +26,51 @@ namespace {
 constexpr int DH = 32;
 constexpr int HEADS = 4;
 constexpr int HID = HEADS * DH;
-constexpr int LDW = 33;    // row stride of the [pixel][channel] tiles: conflict-free 32x32x2 operand reads
+constexpr int C = 64;      // to_qkv's input channels (the weight-gradient accumulators are sized for this)
+constexpr int LD = 36;     // row stride of the [pixel][channel] tiles: 16-byte aligned rows; the 16 lanes one ds_read_b128
+                           // services together (rows 36 floats apart) cover all 64 banks exactly once
 constexpr int TP = 128;    // pixels per tile (32 per wave)
-constexpr int XLD = 80;    // row stride of the xn tile: the 4 pixel rows of a 16x16x4 operand read cover all banks twice
-constexpr int WLD = 64;    // row stride of the staged weight chunk [96][64]
+constexpr int XLD = 80;    // row stride of the xn tile: the 4 pixel rows of a 16x16x4 operand read cover all banks
+constexpr int WLD = 100;   // row stride of the staged weight rows [c][96]: 100 = 36 (mod 64), same property as LD
 
 struct FArgs {
   const float* qkv;  long pitch;
   const float* gout; long gout_pitch;
   const float* ctx; const float* gctx; const float* kmax; const float* ksum; const float* rvec;
   const float* xn;   long xn_pitch;
-  const float* w;                       // Wqkv [3 * HID][C]
+  const float* wt;                      // to_qkv's weight transposed: [C][3 * HID]
   float* gxn;        long gxn_pitch;
-  float* gqkv;       long gq_pitch;     // written when the weight gradient is not fused
-  float* slabs;                         // [blocks][3 * HID * 64] (FUSE_DW)
-  int n, tiles, items, per, C;
+  float* slabs;                         // [blocks][3 * HID * C]
+  int n, tiles, items, per;
   float scale;
 };
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
+// All contractions run with the reduction index dealt out as k = 16 * (lane >> 5) + step (any bijection of k works for a
+// sum): a lane's sixteen operand values of a 32 x 32 x 32 product are then CONSECUTIVE floats of one tile row = four
+// ds_read_b128 instead of sixteen ds_read_b32 (beside fp32 MFMAs every instruction of the wave costs MFMA issue time,
+// DESIGN.md finding 11).  Products are oriented D[channel][pixel] - the small matrices are the A operand - so that a lane
+// ends up with ONE pixel and groups of 4 consecutive channels: results go back into the [pixel][channel] tiles, and out
+// to memory, as 16-byte accesses.
+__device__ __forceinline__ void load16(const float* p, float (&v)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+    v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+  }
+}
 
-template <int NCH, bool FUSE_DW>
 __global__ __launch_bounds__(256, 1) void linattn_bwd_fused_kernel(const FArgs p) {
-  static_assert(!FUSE_DW || NCH == 1, "the weight-gradient accumulators fit for 64 input channels only");
   extern __shared__ __align__(16) float sm[];
-  float* Qs = sm;                    // q -> softmax_d(q) -> gq
-  float* Ks = Qs + TP * LDW;         // softmax_n(k) -> gk
-  float* Vs = Ks + TP * LDW;         // v -> T2 = V gctx^T -> gv
-  float* Gs = Vs + TP * LDW;         // gout -> T1 = G ctx^T
-  float* Cs = Gs + TP * LDW;         // ctx  [32][33]
-  float* GCs = Cs + DH * LDW;        // gctx [32][33]
-  float* rr = GCs + DH * LDW;        // r[d]
-  float* Ws = rr + DH;               // Wqkv rows of the head, one 64-column chunk: [96][64]
-  float* Xs = Ws + 3 * DH * WLD;     // xn tile [128][XLD] (FUSE_DW)
+  float* Qs = sm;                    // q -> gq
+  float* Ks = Qs + TP * LD;          // softmax_n(k) -> gk
+  float* Vs = Ks + TP * LD;          // v -> T2 = V gctx^T -> gv
+  float* Gs = Vs + TP * LD;          // gout -> T1 = G ctx^T
+  float* Cs = Gs + TP * LD;          // ctx  [d][e]
+  float* GCs = Cs + DH * LD;         // gctx [d][e]
+  float* GCt = GCs + DH * LD;        // gctx^T [e][d]
+  float* rr = GCt + DH * LD;         // r[d]
+  float* Ws = rr + DH;               // the head's weight rows, transposed: [c][part * 32 + d]
+  float* Xs = Ws + C * WLD;          // xn tile [128][XLD]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -66,6 +79,17 @@ __global__ __launch_bounds__(256, 1) void linattn_bwd_fused_kernel(const FArgs p
   const int srow = 32 * wid + (lane >> 1), spart = (lane & 1) * 16;   // softmax map: two lanes per row of the wave's rows
   const int it0 = blockIdx.x * p.per, it1 = min(p.items, it0 + p.per);
   if (it0 >= it1) return;
+
+  // weight staging map: element e = tid + 256 u of [c][part][8 x 16 bytes]
+  int w_src[6], w_dst[6];
+#pragma unroll
+  for (int u = 0; u < 6; ++u) {
+    const int e = tid + 256 * u;
+    const int c = e / 24, rem = e - 24 * c;
+    const int part = rem >> 3, j = rem & 7;
+    w_src[u] = c * (3 * HID) + part * HID + 4 * j;
+    w_dst[u] = c * WLD + part * DH + 4 * j;
+  }
 
   // ---- register-staged operands of the NEXT (item, head) ----
   f32x4 q4[4], k4[4], v4[4], g4[4], km4, ks4, cx4, gc4, w4[6];
@@ -89,43 +113,28 @@ __global__ __launch_bounds__(256, 1) void linattn_bwd_fused_kernel(const FArgs p
     cx4 = *reinterpret_cast<const f32x4*>(p.ctx + bh * DH * DH + tid * 4);
     gc4 = *reinterpret_cast<const f32x4*>(p.gctx + bh * DH * DH + tid * 4);
     if (tid < DH) rr1 = p.rvec[bh * DH + tid];
-    // weight chunk 0 of the head: rows part * HID + h * DH + d, 64 columns = 16 x 16 bytes; 1536 / 256 = 6 per thread
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int e = tid + 256 * u;
-      const int wr = e >> 4, wc = (e & 15) * 4;
-      w4[u] = *reinterpret_cast<const f32x4*>(p.w + (long)((wr >> 5) * HID + h * DH + (wr & 31)) * p.C + wc);
-    }
-  };
-  auto stage_w = [&](int h, int cc) {           // chunks after the first: straight from global memory (small maps only)
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int e = tid + 256 * u;
-      const int wr = e >> 4, wc = (e & 15) * 4;
-      *reinterpret_cast<f32x4*>(Ws + wr * WLD + wc) =
-          *reinterpret_cast<const f32x4*>(p.w + (long)((wr >> 5) * HID + h * DH + (wr & 31)) * p.C + cc * 64 + wc);
-    }
+    for (int u = 0; u < 6; ++u) w4[u] = *reinterpret_cast<const f32x4*>(p.wt + w_src[u] + h * DH);
   };
 
   // weight-gradient accumulators: wave w owns xn channels [16 w, 16 w + 16); per head 3 parts x 2 row blocks of 16
-  f32x4 dacc[FUSE_DW ? HEADS : 1][6];
-  if constexpr (FUSE_DW) {
+  f32x4 dacc[HEADS][6];
 #pragma unroll
-    for (int h = 0; h < HEADS; ++h)
+  for (int h = 0; h < HEADS; ++h)
 #pragma unroll
-      for (int t = 0; t < 6; ++t) dacc[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+    for (int t = 0; t < 6; ++t) dacc[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   issue(it0, 0);
   for (int it = it0; it < it1; ++it) {
     const int b = it / p.tiles, i0 = (it % p.tiles) * TP;
     const int rows = min(TP, p.n - i0);
-    f32x16 acc[2 * NCH];
+    f32x16 acc[2];                     // gxn^T: [channel block of 32][the wave's 32 pixels]
 #pragma unroll
-    for (int a = 0; a < 2 * NCH; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-    if constexpr (FUSE_DW) {
+    {
       // the item's xn tile: [128][64]; the previous item's weight-gradient step ended with a barrier
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void linattn_bwd_fused_kernel(const FArgs p
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           f32x4 xv = *reinterpret_cast<const f32x4*>(p.xn + row * p.xn_pitch + hf * 32 + c4);
-          if (r >= rows) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (r >= rows) xv = zero4;
           *reinterpret_cast<f32x4*>(Xs + r * XLD + hf * 32 + c4) = xv;
         }
       }
@@ -146,28 +155,24 @@ __global__ __launch_bounds__(256, 1) void linattn_bwd_fused_kernel(const FArgs p
       for (int u = 0; u < 4; ++u) {
         const int r = prow + 32 * u;
         const bool live = r < rows;
+        f32x4 kv;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          Qs[r * LDW + c4 + k] = live ? q4[u][k] : 0.f;
-          Ks[r * LDW + c4 + k] = live ? __expf(k4[u][k] - km4[k]) * (1.f / ks4[k]) : 0.f;
-          Vs[r * LDW + c4 + k] = live ? v4[u][k] : 0.f;
-          Gs[r * LDW + c4 + k] = live ? g4[u][k] : 0.f;
-        }
+        for (int k = 0; k < 4; ++k) kv[k] = __expf(k4[u][k] - km4[k]) * (1.f / ks4[k]);
+        *reinterpret_cast<f32x4*>(Qs + r * LD + c4) = live ? q4[u] : zero4;
+        *reinterpret_cast<f32x4*>(Ks + r * LD + c4) = live ? kv : zero4;
+        *reinterpret_cast<f32x4*>(Vs + r * LD + c4) = live ? v4[u] : zero4;
+        *reinterpret_cast<f32x4*>(Gs + r * LD + c4) = live ? g4[u] : zero4;
       }
       {
-        const int e = tid * 4;
+        const int d = tid >> 3, e0 = (tid & 7) * 4;
+        *reinterpret_cast<f32x4*>(Cs + d * LD + e0) = cx4;
+        *reinterpret_cast<f32x4*>(GCs + d * LD + e0) = gc4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          Cs[((e + k) >> 5) * LDW + ((e + k) & 31)] = cx4[k];
-          GCs[((e + k) >> 5) * LDW + ((e + k) & 31)] = gc4[k];
-        }
+        for (int k = 0; k < 4; ++k) GCt[(e0 + k) * LD + d] = gc4[k];
       }
       if (tid < DH) rr[tid] = rr1;
 #pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int e = tid + 256 * u;
-        *reinterpret_cast<f32x4*>(Ws + (e >> 4) * WLD + (e & 15) * 4) = w4[u];
-      }
+      for (int u = 0; u < 6; ++u) *reinterpret_cast<f32x4*>(Ws + w_dst[u]) = w4[u];
       __syncthreads();
       // ---- the next (item, head) into the registers just freed ----
       if (h + 1 < HEADS) issue(it, h + 1);
@@ -176,12 +181,10 @@ __global__ __launch_bounds__(256, 1) void linattn_bwd_fused_kernel(const FArgs p
       // ---- phase A: s = softmax_d(q) for this wave's rows, two lanes per row; kept in registers for phase C ----
       float sv[16];
       {
-        float mx = -INFINITY;
+        load16(Qs + srow * LD + spart, sv);
+        float mx = sv[0];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          sv[k] = Qs[srow * LDW + spart + k];
-          mx = fmaxf(mx, sv[k]);
-        }
+        for (int k = 1; k < 16; ++k) mx = fmaxf(mx, sv[k]);
         mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
         float sum = 0.f;
 #pragma unroll
@@ -194,94 +197,84 @@ __global__ __launch_bounds__(256, 1) void linattn_bwd_fused_kernel(const FArgs p
 #pragma unroll
         for (int k = 0; k < 16; ++k) sv[k] *= inv;
       }
-      // ---- phase B: T1 = G ctx^T, T2 = V gctx^T, gv = KS gctx for the wave's 32 rows ----
+      // ---- phase B: T1^T = ctx G^T, T2^T = gctx V^T, gv^T = gctx^T KS^T for the wave's 32 pixels ----
       f32x16 a1, a2, a3;
 #pragma unroll
       for (int r = 0; r < 16; ++r) a1[r] = a2[r] = a3[r] = 0.f;
       {
-        const float* gp = Gs + (32 * wid + lr) * LDW + lh;
-        const float* vp = Vs + (32 * wid + lr) * LDW + lh;
-        const float* kp = Ks + (32 * wid + lr) * LDW + lh;
-        const float* cT = Cs + lr * LDW + lh;      // B[k = e][j = d] = ctx[d][e]
-        const float* gT = GCs + lr * LDW + lh;     // B[k = e][j = d] = gctx[d][e]
-        const float* gN = GCs + lh * LDW + lr;     // B[k = d][j = e] = gctx[d][e]
+        float ca[16], ga[16], ta[16], gb[16], vb[16], kb[16];
+        load16(Cs + lr * LD + 16 * lh, ca);
+        load16(GCs + lr * LD + 16 * lh, ga);
+        load16(GCt + lr * LD + 16 * lh, ta);
+        load16(Gs + (32 * wid + lr) * LD + 16 * lh, gb);
+        load16(Vs + (32 * wid + lr) * LD + 16 * lh, vb);
+        load16(Ks + (32 * wid + lr) * LD + 16 * lh, kb);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-          a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[2 * s], cT[2 * s], a1, 0, 0, 0);
-          a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[2 * s], gT[2 * s], a2, 0, 0, 0);
-          a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], gN[2 * s * LDW], a3, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[s], gb[s], a1, 0, 0, 0);
+          a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s], vb[s], a2, 0, 0, 0);
+          a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[s], kb[s], a3, 0, 0, 0);
         }
       }
       lgm_wave_lds_sync();                          // the operand reads above precede the overwrites below
+      {
+        float* gp = Gs + (32 * wid + lr) * LD + 4 * lh;
+        float* vp = Vs + (32 * wid + lr) * LD + 4 * lh;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wid + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        Gs[row * LDW + lr] = a1[r];
-        Vs[row * LDW + lr] = a2[r];
+        for (int g = 0; g < 4; ++g) {
+          *reinterpret_cast<f32x4*>(gp + 8 * g) = f32x4{a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]};
+          *reinterpret_cast<f32x4*>(vp + 8 * g) = f32x4{a2[4 * g], a2[4 * g + 1], a2[4 * g + 2], a2[4 * g + 3]};
+        }
       }
       lgm_wave_lds_sync();
       // ---- phase C: gq = s (T1 scale - <s, T1 scale>), gk = ks (T2 - r); then gv replaces T2 ----
       {
-        float g1[16], dot = 0.f;
+        float g1[16], t2[16], kk[16], rv[16], dot = 0.f;
+        load16(Gs + srow * LD + spart, g1);
+        load16(Vs + srow * LD + spart, t2);
+        load16(Ks + srow * LD + spart, kk);
+        load16(rr + spart, rv);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          g1[k] = Gs[srow * LDW + spart + k] * p.scale;
+          g1[k] *= p.scale;
           dot += sv[k] * g1[k];
         }
         dot += __shfl_xor(dot, 1, 64);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          Qs[srow * LDW + spart + k] = sv[k] * (g1[k] - dot);
-          Ks[srow * LDW + spart + k] = Ks[srow * LDW + spart + k] * (Vs[srow * LDW + spart + k] - rr[spart + k]);
+        for (int q = 0; q < 4; ++q) {
+          f32x4 oq, ok;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            oq[k] = sv[4 * q + k] * (g1[4 * q + k] - dot);
+            ok[k] = kk[4 * q + k] * (t2[4 * q + k] - rv[4 * q + k]);
+          }
+          *reinterpret_cast<f32x4*>(Qs + srow * LD + spart + 4 * q) = oq;
+          *reinterpret_cast<f32x4*>(Ks + srow * LD + spart + 4 * q) = ok;
         }
       }
       lgm_wave_lds_sync();
+      {
+        float* vp = Vs + (32 * wid + lr) * LD + 4 * lh;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wid + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        Vs[row * LDW + lr] = a3[r];
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(vp + 8 * g) = f32x4{a3[4 * g], a3[4 * g + 1], a3[4 * g + 2], a3[4 * g + 3]};
       }
       lgm_wave_lds_sync();
-      if constexpr (!FUSE_DW) {
-        // gq | gk | gv of the wave's rows for the separate weight-gradient kernel: lane = (row, 16-channel half)
-        const int r = srow;
-        if (r < rows) {
-          float* o = p.gqkv + ((long)b * p.n + i0 + r) * p.gq_pitch + h * DH + spart;
+      // ---- phase D: gxn^T[c][pixels of the wave] += W_h^T[c][96] [gq | gk | gv]^T ----
 #pragma unroll
-          for (int part = 0; part < 3; ++part) {
-            const float* X = part == 0 ? Qs : part == 1 ? Ks : Vs;
+      for (int part = 0; part < 3; ++part) {
+        float xb[16], w0[16], w1[16];
+        load16((part == 0 ? Qs : part == 1 ? Ks : Vs) + (32 * wid + lr) * LD + 16 * lh, xb);
+        load16(Ws + lr * WLD + part * DH + 16 * lh, w0);
+        load16(Ws + (32 + lr) * WLD + part * DH + 16 * lh, w1);
 #pragma unroll
-            for (int k4i = 0; k4i < 4; ++k4i) {
-              f32x4 ov;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) ov[k] = X[r * LDW + spart + 4 * k4i + k];
-              *reinterpret_cast<f32x4*>(o + part * HID + 4 * k4i) = ov;
-            }
-          }
-        }
-      }
-      // ---- phase D: gxn[rows of the wave][C] += [gq | gk | gv] W_h ----
-#pragma unroll
-      for (int cc = 0; cc < NCH; ++cc) {
-        if (cc > 0) {
-          __syncthreads();
-          stage_w(h, cc);
-          __syncthreads();
-        }
-#pragma unroll
-        for (int part = 0; part < 3; ++part) {
-          const float* X = (part == 0 ? Qs : part == 1 ? Ks : Vs) + (32 * wid + lr) * LDW + lh;
-          const float* Wp = Ws + (part * DH + lh) * WLD + lr;
-#pragma unroll
-          for (int s = 0; s < 16; ++s) {
-            const float av = X[2 * s];
-            acc[2 * cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wp[2 * s * WLD], acc[2 * cc], 0, 0, 0);
-            acc[2 * cc + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wp[2 * s * WLD + 32], acc[2 * cc + 1], 0, 0, 0);
-          }
+        for (int s = 0; s < 16; ++s) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[s], xb[s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[s], xb[s], acc[1], 0, 0, 0);
         }
       }
       __syncthreads();
-      if constexpr (FUSE_DW) {
+      {
         // ---- phase E: dW_h[96][64] += [gq | gk | gv]^T xn over the tile's 128 pixels, on 16x16x4 tiles:
         // A[i = gradient channel][k = pixel], B[k = pixel][j = xn channel]; this wave's 16 xn channels
         const float* xb = Xs + lq * XLD + 16 * wid + l16;
@@ -290,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void linattn_bwd_fused_kernel(const FArgs p
           const float bv = xb[4 * s * XLD];
 #pragma unroll
           for (int part = 0; part < 3; ++part) {
-            const float* X = (part == 0 ? Qs : part == 1 ? Ks : Vs) + (4 * s + lq) * LDW + l16;
+            const float* X = (part == 0 ? Qs : part == 1 ? Ks : Vs) + (4 * s + lq) * LD + l16;
             dacc[h][2 * part] = __builtin_amdgcn_mfma_f32_16x16x4f32(X[0], bv, dacc[h][2 * part], 0, 0, 0);
             dacc[h][2 * part + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(X[16], bv, dacc[h][2 * part + 1], 0, 0, 0);
           }
@@ -302,17 +295,18 @@ __global__ __launch_bounds__(256, 1) void linattn_bwd_fused_kernel(const FArgs p
     head(std::integral_constant<int, 1>{});
     head(std::integral_constant<int, 2>{});
     head(std::integral_constant<int, 3>{});
-    // ---- the item's input gradient: rows of this wave, 32 consecutive channels per accumulator ----
+    // ---- the item's input gradient: this lane's pixel, groups of 4 consecutive channels ----
+    if (32 * wid + lr < rows) {
+      float* o = p.gxn + ((long)b * p.n + i0 + 32 * wid + lr) * p.gxn_pitch + 4 * lh;
 #pragma unroll
-    for (int a = 0; a < 2 * NCH; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wid + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < rows) p.gxn[((long)b * p.n + i0 + row) * p.gxn_pitch + a * 32 + lr] = acc[a][r];
-      }
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(o + 32 * a + 8 * g) = f32x4{acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]};
+    }
   }
-  if constexpr (FUSE_DW) {
-    float* sl = p.slabs + (long)blockIdx.x * (3 * HID * 64);
+  {
+    float* sl = p.slabs + (long)blockIdx.x * (3 * HID * C);
 #pragma unroll
     for (int h = 0; h < HEADS; ++h)
 #pragma unroll
@@ -320,28 +314,12 @@ __global__ __launch_bounds__(256, 1) void linattn_bwd_fused_kernel(const FArgs p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int wrow = (t >> 1) * HID + h * DH + (t & 1) * 16 + 4 * lq + r;
-          sl[(long)wrow * 64 + 16 * wid + l16] = dacc[h][t][r];
+          sl[(long)wrow * C + 16 * wid + l16] = dacc[h][t][r];
         }
   }
 }
 
-constexpr size_t smem_bytes(bool fuse) {
-  return ((size_t)4 * TP * LDW + 2 * DH * LDW + DH + 3 * DH * WLD + (fuse ? TP * XLD : 0)) * sizeof(float);
-}
-
-template <int NCH, bool FUSE_DW>
-int launch(const FArgs& a, int blocks, hipStream_t s) {
-  const size_t smem = smem_bytes(FUSE_DW);
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_bwd_fused_kernel<NCH, FUSE_DW>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr = true;
-  }
-  hipLaunchKernelGGL((linattn_bwd_fused_kernel<NCH, FUSE_DW>), dim3(blocks), dim3(256), smem, s, a);
-  LGM_LAUNCH_CHECK();
-  return LGM_OK;
-}
+constexpr size_t kSmem = ((size_t)4 * TP * LD + 3 * DH * LD + DH + C * WLD + TP * XLD) * sizeof(float);
 
 int plan_blocks(int B, int n, int* tiles, int* items, int* per) {
   *tiles = lgm_cdiv(n, TP);
@@ -353,33 +331,37 @@ int plan_blocks(int B, int n, int* tiles, int* items, int* per) {
 
 }  // namespace
 
-extern "C" int64_t lgm_linattn_bwd_fused_supported(int heads, int dim_head, int C) {
-  return heads == HEADS && dim_head == DH && (C == 64 || C == 128 || C == 256) ? 1 : 0;
+extern "C" int64_t lgm_linattn_bwd_fused_supported(int heads, int dim_head, int Cin) {
+  return heads == HEADS && dim_head == DH && Cin == C ? 1 : 0;
 }
 
-// bytes of the weight-gradient slab buffer (0: the weight gradient is not fused for this C)
-extern "C" int64_t lgm_linattn_bwd_fused_slabs(int B, int n, int C) {
-  if (C != 64) return 0;
+// bytes of the weight-gradient slab buffer
+extern "C" int64_t lgm_linattn_bwd_fused_slabs(int B, int n, int Cin) {
+  if (Cin != C) return 0;
   int tiles, items, per;
   const int blocks = plan_blocks(B, n, &tiles, &items, &per);
-  return (int64_t)blocks * 3 * HID * 64 * (int64_t)sizeof(float);
+  return (int64_t)blocks * 3 * HID * C * (int64_t)sizeof(float);
 }
 
 int lgm_linattn_bwd_fused_launch(const float* qkv, long pitch, const float* gout, long gout_pitch, const float* ctx,
                                  const float* gctx, const float* kmax, const float* ksum, const float* rvec,
-                                 const float* xn, long xn_pitch, const float* w, int B, int n, int C, float scale,
-                                 float* gxn, long gxn_pitch, float* gqkv, long gq_pitch, float* slabs, int* blocks_out,
-                                 hipStream_t s) {
+                                 const float* xn, long xn_pitch, const float* wt, int B, int n, float scale,
+                                 float* gxn, long gxn_pitch, float* slabs, int* blocks_out, hipStream_t s) {
   FArgs a;
   a.qkv = qkv; a.pitch = pitch; a.gout = gout; a.gout_pitch = gout_pitch;
   a.ctx = ctx; a.gctx = gctx; a.kmax = kmax; a.ksum = ksum; a.rvec = rvec;
-  a.xn = xn; a.xn_pitch = xn_pitch; a.w = w; a.gxn = gxn; a.gxn_pitch = gxn_pitch; a.gqkv = gqkv; a.gq_pitch = gq_pitch;
-  a.slabs = slabs; a.n = n; a.C = C; a.scale = scale;
+  a.xn = xn; a.xn_pitch = xn_pitch; a.wt = wt; a.gxn = gxn; a.gxn_pitch = gxn_pitch;
+  a.slabs = slabs; a.n = n; a.scale = scale;
   const int blocks = plan_blocks(B, n, &a.tiles, &a.items, &a.per);
   *blocks_out = blocks;
-  lgm_note_kernel(C == 64 ? "linattn_bwd_fused_kernel<1, true>" : C == 128 ? "linattn_bwd_fused_kernel<2, false>"
-                                                                            : "linattn_bwd_fused_kernel<4, false>");
-  if (C == 64) return launch<1, true>(a, blocks, s);
-  if (C == 128) return launch<2, false>(a, blocks, s);
-  return launch<4, false>(a, blocks, s);
+  lgm_note_kernel("linattn_bwd_fused_kernel");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_bwd_fused_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem);
+    attr = true;
+  }
+  hipLaunchKernelGGL(linattn_bwd_fused_kernel, dim3(blocks), dim3(256), kSmem, s, a);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
 }

@@ -406,7 +406,8 @@ int lgm_linattn_bwd_launch(const float* qkv, long pitch, const float* mem_kv, co
                         (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL(linattn_bwd_mfma, dim3(B * heads, lgm_cdiv(n, TP) + (M > 0 ? 1 : 0)), dim3(256), smem, s, qkv,
+  // gmem_partial == nullptr: the memory columns' gradient came out of the gctx launch (linattn_ctx_mfma<1>'s epilogue)
+  hipLaunchKernelGGL(linattn_bwd_mfma, dim3(B * heads, lgm_cdiv(n, TP) + (M > 0 && gmem_partial ? 1 : 0)), dim3(256), smem, s, qkv,
                      pitch, mem_kv, gout, gout_pitch, ctx, gctx, kmax, ksum, rvec, n, heads, M, scale, gqkv, gq_pitch,
                      gmem_partial);
   LGM_LAUNCH_CHECK();

@@ -730,25 +730,25 @@ def linattn_fwd(qkv, mem_ptr, heads, dim_head, M, out):
     return ctx, kstat
 
 
-def linattn_bwd(qkv, mem_ptr, gout, ctx, kstat, heads, dim_head, M, gqkv, gmem_ptr, gmem_beta):
+def linattn_bwd(qkv, mem_ptr, gout, ctx, kstat, heads, dim_head, M, gqkv, gmem_ptr, gmem_beta, defer=None):
+    """``defer`` (GradCtx.defer_for(mem_kv)): the mem_kv gradient's partial rows join the bucket's batched reduction."""
     L = lib()
     B, H, W, _ = qkv.shape
     ws = workspace(L.lgm_linattn_bwd_workspace(B, heads, dim_head, M), qkv.device)
-    L.lgm_linattn_bwd(qkv.data_ptr(), pitch(qkv), mem_ptr, gout.data_ptr(), pitch(gout), ctx.data_ptr(),
-                      kstat[0].data_ptr(), kstat[1].data_ptr(), B, H * W, heads, dim_head, M, gqkv.data_ptr(),
-                      pitch(gqkv), gmem_ptr, gmem_beta, ws.data_ptr(), stream())
-
-
-# opt-in: the fused LinearAttention backward tail (csrc/linattn_fused.hip).  Correct (tested) but measured SLOWER than the
-# three launches it replaces (B = 128: 11.59 vs 11.50 ms / step, B = 16: 4.87 vs 4.63), see DESIGN.md 3.4
-LA_FUSED = _os.environ.get("LGM_LA_FUSED") is not None
-
-
-def linattn_bwd_fused_ok(heads, dim_head, C, qkv, gout, xn, w_ptr, gw_ptr, gmem_ptr) -> bool:
-    if not LA_FUSED or not lib().lgm_linattn_bwd_fused_supported(heads, dim_head, C):
-        return False
-    return not any(v % 16 for v in (qkv.data_ptr(), gout.data_ptr(), xn.data_ptr(), w_ptr, gw_ptr, gmem_ptr)) and \
-        pitch(qkv) % 4 == 0 and pitch(gout) % 4 == 0 and pitch(xn) % 4 == 0
+    if defer is None or gmem_ptr % 16 or M <= 0:
+        L.lgm_linattn_bwd(qkv.data_ptr(), pitch(qkv), mem_ptr, gout.data_ptr(), pitch(gout), ctx.data_ptr(),
+                          kstat[0].data_ptr(), kstat[1].data_ptr(), B, H * W, heads, dim_head, M, gqkv.data_ptr(),
+                          pitch(gqkv), gmem_ptr, gmem_beta, ws.data_ptr(), stream())
+        return
+    nb = B * 2 * heads * dim_head * M * 4
+    part = _persistent((gmem_ptr, nb), nb, qkv.device)
+    desc = (ctypes.c_int64 * 8)()
+    L.lgm_linattn_bwd_deferred(qkv.data_ptr(), pitch(qkv), mem_ptr, gout.data_ptr(), pitch(gout), ctx.data_ptr(),
+                               kstat[0].data_ptr(), kstat[1].data_ptr(), B, H * W, heads, dim_head, M, gqkv.data_ptr(),
+                               pitch(gqkv), gmem_ptr, gmem_beta, part.data_ptr(), ctypes.addressof(desc), ws.data_ptr(),
+                               stream())
+    if desc[6] > 0:
+        defer.append(tuple(desc))
 
 
 def _persistent(key, nbytes, device):
@@ -759,10 +759,27 @@ def _persistent(key, nbytes, device):
     return ws
 
 
-def linattn_bwd_fused(qkv, mem_ptr, gout, ctx, kstat, xn, w_ptr, heads, dim_head, M, gxn, gw_ptr, gw_beta, gw_defer,
+# The fused LinearAttention backward tail (csrc/linattn_fused.hip) for layers with at least this many (image, 128-pixel
+# tile) work items: one item is four heads in a row on ONE CU (55 us), so below a full round of the chip the three
+# separate launches - which spread over more workgroups - are faster (measured).  LGM_NO_LA_FUSED=1: off.
+LA_FUSED = _os.environ.get("LGM_NO_LA_FUSED") is None
+LA_FUSED_MIN_ITEMS = int(_os.environ.get("LGM_LA_FUSED_MIN_ITEMS", "256"))
+
+
+def linattn_bwd_fused_ok(heads, dim_head, C, qkv, gout, xn, wt_ptr, gw_ptr, gmem_ptr) -> bool:
+    if not LA_FUSED or not wt_ptr or not lib().lgm_linattn_bwd_fused_supported(heads, dim_head, C):
+        return False
+    B, H, W, _ = qkv.shape
+    if B * ((H * W + 127) // 128) < LA_FUSED_MIN_ITEMS:
+        return False
+    return not any(v % 16 for v in (qkv.data_ptr(), gout.data_ptr(), xn.data_ptr(), wt_ptr, gw_ptr, gmem_ptr)) and \
+        pitch(qkv) % 4 == 0 and pitch(gout) % 4 == 0 and pitch(xn) % 4 == 0
+
+
+def linattn_bwd_fused(qkv, mem_ptr, gout, ctx, kstat, xn, wt_ptr, heads, dim_head, M, gxn, gw_ptr, gw_beta, gw_defer,
                       gmem_ptr, gmem_beta, gmem_defer):
-    """LinearAttention backward with to_qkv's backward folded in (lgm_linattn_bwd_fused): writes gxn; to_qkv's weight
-    gradient too when it has 64 input channels (returns None), else returns gqkv for the caller's conv_wgrad.
+    """LinearAttention backward with to_qkv's backward folded in (lgm_linattn_bwd_fused): writes gxn and to_qkv's weight
+    gradient (``wt_ptr``: the weight's transposed copy, [C][3 * hidden]).
     ``gw_defer`` / ``gmem_defer``: deferred-reduction lists (GradCtx.defer_for) or None = reduce now."""
     L = lib()
     B, H, W, _ = qkv.shape
@@ -773,31 +790,26 @@ def linattn_bwd_fused(qkv, mem_ptr, gout, ctx, kstat, xn, w_ptr, heads, dim_head
     part_bytes = B * 2 * heads * dim_head * M * 4
     # scratch that dies with the call: gctx / r; the partial buffers too when their reduction is not deferred
     extra = (0 if gw_defer is not None else slab_bytes + 64) + (0 if gmem_defer is not None else part_bytes + 64)
-    ws = workspace(wsb + extra, dev)
+    ws = workspace(wsb + extra + 64, dev)
     off = (wsb + 63) // 64 * 64
     if gmem_defer is not None:
         part_ptr = _persistent((gmem_ptr, part_bytes), part_bytes, dev).data_ptr()
     else:
         part_ptr = ws.data_ptr() + off
         off += (part_bytes + 63) // 64 * 64
-    slab_ptr = None
-    if slab_bytes:
-        slab_ptr = _persistent((gw_ptr, slab_bytes), slab_bytes, dev).data_ptr() if gw_defer is not None \
-            else ws.data_ptr() + off
-    gqkv = None if slab_bytes else new(qkv.shape, qkv)
+    slab_ptr = _persistent((gw_ptr, slab_bytes), slab_bytes, dev).data_ptr() if gw_defer is not None \
+        else ws.data_ptr() + off
     d_w = (ctypes.c_int64 * 8)() if gw_defer is not None else None
     d_m = (ctypes.c_int64 * 8)() if gmem_defer is not None else None
     L.lgm_linattn_bwd_fused(qkv.data_ptr(), pitch(qkv), mem_ptr, gout.data_ptr(), pitch(gout), ctx.data_ptr(),
-                            kstat[0].data_ptr(), kstat[1].data_ptr(), xn.data_ptr(), pitch(xn), w_ptr, C, B, n, heads,
-                            dim_head, M, gxn.data_ptr(), pitch(gxn), None if gqkv is None else gqkv.data_ptr(),
-                            0 if gqkv is None else pitch(gqkv), gw_ptr, gw_beta, slab_ptr, slab_bytes,
+                            kstat[0].data_ptr(), kstat[1].data_ptr(), xn.data_ptr(), pitch(xn), wt_ptr, C, B, n, heads,
+                            dim_head, M, gxn.data_ptr(), pitch(gxn), gw_ptr, gw_beta, slab_ptr, slab_bytes,
                             None if d_w is None else ctypes.addressof(d_w), gmem_ptr, gmem_beta, part_ptr,
                             None if d_m is None else ctypes.addressof(d_m), ws.data_ptr(), stream())
     if d_w is not None and d_w[6] > 0:
         gw_defer.append(tuple(d_w))
     if d_m is not None and d_m[6] > 0:
         gmem_defer.append(tuple(d_m))
-    return gqkv
 
 
 def attn_fwd(qkv, mem_ptr, heads, dim_head, M, out):
@@ -808,13 +820,23 @@ def attn_fwd(qkv, mem_ptr, heads, dim_head, M, out):
     return lse
 
 
-def attn_bwd(qkv, mem_ptr, out, gout, lse, heads, dim_head, M, gqkv, gmem_ptr, gmem_beta):
+def attn_bwd(qkv, mem_ptr, out, gout, lse, heads, dim_head, M, gqkv, gmem_ptr, gmem_beta, defer=None):
     L = lib()
     B, H, W, _ = qkv.shape
-    ws = workspace(L.lgm_attn_bwd_workspace(B, heads, dim_head, M), qkv.device)
-    L.lgm_attn_bwd(qkv.data_ptr(), pitch(qkv), mem_ptr, out.data_ptr(), pitch(out), gout.data_ptr(),
-                   pitch(gout), lse.data_ptr(), B, H * W, heads, dim_head, M, gqkv.data_ptr(), pitch(gqkv),
-                   gmem_ptr, gmem_beta, ws.data_ptr(), stream())
+    if defer is None or gmem_ptr % 16 or M <= 0:
+        ws = workspace(L.lgm_attn_bwd_workspace(B, heads, dim_head, M), qkv.device)
+        L.lgm_attn_bwd(qkv.data_ptr(), pitch(qkv), mem_ptr, out.data_ptr(), pitch(out), gout.data_ptr(),
+                       pitch(gout), lse.data_ptr(), B, H * W, heads, dim_head, M, gqkv.data_ptr(), pitch(gqkv),
+                       gmem_ptr, gmem_beta, ws.data_ptr(), stream())
+        return
+    nb = B * 2 * heads * dim_head * M * 4
+    part = _persistent((gmem_ptr, nb), nb, qkv.device)
+    desc = (ctypes.c_int64 * 8)()
+    L.lgm_attn_bwd_deferred(qkv.data_ptr(), pitch(qkv), mem_ptr, out.data_ptr(), pitch(out), gout.data_ptr(),
+                            pitch(gout), lse.data_ptr(), B, H * W, heads, dim_head, M, gqkv.data_ptr(), pitch(gqkv),
+                            gmem_ptr, gmem_beta, part.data_ptr(), ctypes.addressof(desc), stream())
+    if desc[6] > 0:
+        defer.append(tuple(desc))
 
 
 # ----------------------------------------------------------------------------------------

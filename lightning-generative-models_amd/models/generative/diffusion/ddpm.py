@@ -112,22 +112,21 @@ class LinearAttention(nn.Module):
         gao = self.to_out[0].bwd(gc, ao, go2)
         del go2
         w = self.to_qkv.weight
-        if ops.linattn_bwd_fused_ok(self.heads, self.dim_head, xn.shape[-1], qkv, gao, xn, fp.ptr(w), fp.gptr(w),
+        gqkv = None
+        if ops.linattn_bwd_fused_ok(self.heads, self.dim_head, xn.shape[-1], qkv, gao, xn, fp.tptr(w), fp.gptr(w),
                                     fp.gptr(self.mem_kv)):
-            # gq / gk / gv never reach memory: the kernel that computes them also multiplies them with to_qkv's weight
-            # (input gradient) and, for 64 input channels, with xn (weight gradient)
+            # large maps: gq / gk / gv never reach memory - the kernel that computes them also multiplies them
+            # with to_qkv's weight (input gradient) and with xn (weight gradient)
             dw, dm = gc.defer_for(w), gc.defer_for(self.mem_kv)
             bw, bm = gc.beta(w), gc.beta(self.mem_kv)
             gxn = ops.new(xn.shape, xn)
-            gqkv = ops.linattn_bwd_fused(qkv, fp.ptr(self.mem_kv), gao, ctx, kstat, xn, fp.ptr(w), self.heads,
-                                         self.dim_head, self.M, gxn, fp.gptr(w), bw, dw, fp.gptr(self.mem_kv), bm, dm)
-            if gqkv is not None:
-                B, H, W, _ = xn.shape
-                ops.conv_wgrad(self.to_qkv.geom(B, H, W), gqkv, xn, fp.gptr(w), bw, None, defer=dw)
+            ops.linattn_bwd_fused(qkv, fp.ptr(self.mem_kv), gao, ctx, kstat, xn, fp.tptr(w), self.heads, self.dim_head,
+                                  self.M, gxn, fp.gptr(w), bw, dw, fp.gptr(self.mem_kv), bm, dm)
         else:
             gqkv = ops.new(qkv.shape, qkv)
+            dm = gc.defer_for(self.mem_kv)
             ops.linattn_bwd(qkv, fp.ptr(self.mem_kv), gao, ctx, kstat, self.heads, self.dim_head, self.M, gqkv,
-                            fp.gptr(self.mem_kv), gc.beta(self.mem_kv))
+                            fp.gptr(self.mem_kv), gc.beta(self.mem_kv), defer=dm)
             gxn = self.to_qkv.bwd(gc, xn, gqkv)
         del gqkv, gao
         # gx (+)= d norm / dx + gy: the residual branch's gradient rides in the RMSNorm backward pass
@@ -162,8 +161,9 @@ class Attention(nn.Module):
         fp = gc.flat
         gao = self.to_out.bwd(gc, ao, gy)
         gqkv = ops.new(qkv.shape, qkv)
+        dm = gc.defer_for(self.mem_kv)
         ops.attn_bwd(qkv, fp.ptr(self.mem_kv), ao, gao, lse, self.heads, self.dim_head, self.M, gqkv,
-                     fp.gptr(self.mem_kv), gc.beta(self.mem_kv))
+                     fp.gptr(self.mem_kv), gc.beta(self.mem_kv), defer=dm)
         gxn = self.to_qkv.bwd(gc, xn, gqkv)
         del gqkv, gao
         # gx (+)= d norm / dx + gy: the residual branch's gradient rides in the RMSNorm backward pass
