@@ -209,6 +209,16 @@ int lgm_rmsnorm_bwd_deferred(const float* x, int64_t x_pitch, const float* gy, i
 int lgm_linattn_fwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, int B, int n,
                     int heads, int dim_head, int M, float* out, int64_t out_pitch, float* ctx,
                     float* kmax, float* ksum, void* stream);
+/* Forward with its tail fused (ddpm.py:229-239 + the residual around the block): after the context launch ONE launch
+ * computes out = softmax_d(q) scale ctx, o2 = to_out[0](out) (wout [Cout][heads*32], bout [Cout]) and
+ * y = RMSNorm_g(o2) + x.  `out` and `o2` are written for the backward pass.  Cout in {64, 128, 256}
+ * (lgm_linattn_fwd_fused_supported: 0 = not built, 1 = built, 2 = built and faster than the separate launches). */
+int64_t lgm_linattn_fwd_fused_supported(int heads, int dim_head, int Cout);
+int lgm_linattn_fwd_fused(const float* qkv, int64_t qkv_pitch, const float* mem_kv, int B, int n, int heads,
+                          int dim_head, int M, const float* wout, const float* bout, const float* g, int Cout,
+                          const float* x, int64_t x_pitch, float* out, int64_t out_pitch, float* o2,
+                          int64_t o2_pitch, float* y, int64_t y_pitch, float* ctx, float* kmax, float* ksum,
+                          void* stream);
 int64_t lgm_linattn_bwd_workspace(int B, int heads, int dim_head, int M);
 int lgm_linattn_bwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, const float* gout,
                     int64_t gout_pitch, const float* ctx, const float* kmax, const float* ksum,

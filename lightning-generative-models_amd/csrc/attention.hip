@@ -22,6 +22,9 @@ int lgm_linattn_bwd_fused_launch(const float* qkv, long pitch, const float* gout
                                  float* gxn, long gxn_pitch, float* slabs, int* blocks_out, hipStream_t s);
 int lgm_wgrad_reduce_launch(const float* ws, long slab, float* gw, long n_w, float* gb, long n_b, int splits, float beta,
                             hipStream_t s);
+int lgm_linattn_out_fused_launch(const float* qkv, long pitch, const float* ctx, const float* wout, const float* bout,
+                                 const float* g, const float* x, long x_pitch, float* ao, long ao_pitch, float* o2,
+                                 long o2_pitch, float* y, long y_pitch, int B, int n, int Cout, float scale, hipStream_t s);
 int lgm_linattn_bwd_launch(const float* qkv, long pitch, const float* mem_kv, const float* gout, long gout_pitch,
                            const float* ctx, const float* gctx, const float* kmax, const float* ksum,
                            const float* rvec, int B, int n, int heads, int M, float scale, float* gqkv,
@@ -305,6 +308,31 @@ extern "C" int lgm_linattn_fwd(const float* qkv, int64_t qkv_pitch, const float*
                      (const float*)ctx, n, heads, scale, out, (long)out_pitch);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
+}
+
+// Forward with its tail fused (linattn_fused.hip): the context launch, then ONE launch for softmax_d(q), out = q ctx,
+// to_out[0] (1x1 convolution + bias), to_out[1] (RMSNorm) and the residual: y = RMSNorm(to_out(out)) + x.  `out` and
+// o2 = to_out[0](out) are written for the backward pass but not read back.
+extern "C" int lgm_linattn_fwd_fused(const float* qkv, int64_t qkv_pitch, const float* mem_kv, int B, int n, int heads,
+                                     int dim_head, int M, const float* wout, const float* bout, const float* g, int Cout,
+                                     const float* x, int64_t x_pitch, float* out, int64_t out_pitch, float* o2,
+                                     int64_t o2_pitch, float* y, int64_t y_pitch, float* ctx, float* kmax, float* ksum,
+                                     void* stream) {
+  if (int rc = attn_check(B, n, heads, dim_head, M)) return rc;
+  LGM_REQUIRE(lgm_linattn_fwd_fused_supported(heads, dim_head, Cout), "linattn_fwd_fused: heads=%d dim_head=%d C=%d unsupported",
+              heads, dim_head, Cout);
+  LGM_REQUIRE(qkv && mem_kv && wout && bout && g && x && out && o2 && y && ctx && kmax && ksum, "linattn_fwd_fused: null pointer");
+  LGM_REQUIRE(qkv_pitch % 4 == 0 && x_pitch % 4 == 0 && out_pitch % 4 == 0 && o2_pitch % 4 == 0 && y_pitch % 4 == 0 &&
+                  lgm_aligned16(qkv) && lgm_aligned16(wout) && lgm_aligned16(bout) && lgm_aligned16(g) && lgm_aligned16(x) &&
+                  lgm_aligned16(out) && lgm_aligned16(o2) && lgm_aligned16(y) && lgm_aligned16(ctx),
+              "linattn_fwd_fused: 16-byte aligned operands required");
+  hipStream_t s = (hipStream_t)stream;
+  const float scale = 1.f / sqrtf((float)dim_head);
+  if (int rc = lgm_linattn_ctx_launch(0, qkv, (long)qkv_pitch, mem_kv, nullptr, 0L, nullptr, B, n, heads, M, scale, ctx,
+                                      kmax, ksum, nullptr, s))
+    return rc;
+  return lgm_linattn_out_fused_launch(qkv, (long)qkv_pitch, ctx, wout, bout, g, x, (long)x_pitch, out, (long)out_pitch, o2,
+                                      (long)o2_pitch, y, (long)y_pitch, B, n, Cout, scale, s);
 }
 
 extern "C" int64_t lgm_linattn_bwd_workspace(int B, int heads, int dim_head, int M) {

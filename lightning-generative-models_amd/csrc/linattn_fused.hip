@@ -365,3 +365,216 @@ int lgm_linattn_bwd_fused_launch(const float* qkv, long pitch, const float* gout
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
+
+// =====================================================================================================================
+// Fused tail of the LinearAttention FORWARD (ddpm.py:229-239 + the Residual around the block): for a 128-pixel tile,
+//   qs = softmax_d(q) scale;  out[:, h] = qs ctx_h  (four heads);  o2 = to_out[0](out) + bias;  y = RMSNorm(o2) + x
+// in ONE launch instead of three (linattn_out_kernel, the to_out GEMM, rmsnorm_fwd) and two round trips of `out` / o2
+// through memory.  Products are oriented D[channel][pixel], so a lane owns ONE pixel: its query row comes straight from
+// global memory into the lane's operand registers (no LDS staging), its softmax needs one exchange with lane ^ 32, and
+// the RMSNorm over the produced channels is lane-local plus that same exchange.  The out^T accumulators of a head ARE
+// the B operand of to_out's product: the MFMA contracts over k in whatever order the two operands agree on, and the
+// weight fragments are read in the order the accumulator layout dictates (lane half lh, register 4 g + j <-> channel
+// h 32 + 8 g + 4 lh + j), so `out` never goes through LDS either.  `out` (needed by to_out's weight gradient) and o2
+// (needed by the RMSNorm backward) are still written, but never read back.  LDS holds only to_out's weight and the
+// image's four ctx^T; waves are independent between the two barriers of an image change.
+namespace {
+
+constexpr int OTP = 128;    // pixels per block item (32 per wave)
+constexpr int ALD = 132;    // row stride of the staged weight [c][128]: 132 = 4 (mod 64) -> conflict-free 16-byte rows
+
+struct OArgs {
+  const float* qkv;  long pitch;
+  const float* ctx;
+  const float* wout; const float* bout; const float* g;
+  const float* x;    long x_pitch;
+  float* ao;         long ao_pitch;
+  float* o2;         long o2_pitch;
+  float* y;          long y_pitch;
+  int n, tiles, items, per;
+  float scale;
+};
+
+template <int NC>       // produced channels / 32
+__global__ __launch_bounds__(256, NC == 2 ? 3 : 1) void linattn_out_fused_kernel(const OArgs p) {
+  constexpr int CO = 32 * NC;
+  extern __shared__ __align__(16) float sm[];
+  float* Ws = sm;                        // to_out[0].weight [CO][128], row stride ALD
+  float* Ct = Ws + CO * ALD;             // ctx^T of the image's four heads: [h][e][d], row stride LD
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int it0 = blockIdx.x * p.per, it1 = min(p.items, it0 + p.per);
+  if (it0 >= it1) return;
+  const float sqrtc = sqrtf((float)CO);
+
+  f32x4 qn[4];
+  auto issue_q = [&](int it, int h) {
+    const int b = it / p.tiles, i0 = (it % p.tiles) * OTP;
+    const int pix = min(i0 + 32 * wid + lr, p.n - 1);
+    const float* qp = p.qkv + ((long)b * p.n + pix) * p.pitch + h * DH + 16 * lh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qn[j] = *reinterpret_cast<const f32x4*>(qp + 4 * j);
+  };
+  issue_q(it0, 0);
+#pragma unroll
+  for (int u = 0; u < NC * 4; ++u) {      // CO x 128 floats = CO * 32 16-byte pieces
+    const int e = tid + 256 * u;
+    const int c = e >> 5, k4 = (e & 31) * 4;
+    *reinterpret_cast<f32x4*>(Ws + c * ALD + k4) = *reinterpret_cast<const f32x4*>(p.wout + (long)c * HID + k4);
+  }
+  int b_staged = -1;
+  for (int it = it0; it < it1; ++it) {
+    const int b = it / p.tiles, i0 = (it % p.tiles) * OTP;
+    const int pix = i0 + 32 * wid + lr;
+    const bool live = pix < p.n;
+    const long row = (long)b * p.n + min(pix, p.n - 1);
+    if (b != b_staged) {
+      __syncthreads();                 // everybody is done with the previous image's ctx
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = (tid + 256 * u) * 4;             // flat index into [head][d][e]
+        const int h = e >> 10, d = (e >> 5) & 31, e0 = e & 31;
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(p.ctx + (long)b * HEADS * DH * DH + e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Ct[h * (DH * LD) + (e0 + k) * LD + d] = cv[k];
+      }
+      __syncthreads();
+      b_staged = b;
+    }
+    // the residual rows of the lane's pixel: fetched a whole item ahead of their use
+    f32x4 xres[NC <= 4 ? NC * 4 : 1];
+    if constexpr (NC <= 4) {
+#pragma unroll
+      for (int a = 0; a < NC; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          xres[a * 4 + g] = *reinterpret_cast<const f32x4*>(p.x + row * p.x_pitch + a * 32 + 8 * g + 4 * lh);
+    }
+    f32x16 acc[NC];
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+      float qs[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        qs[4 * j] = qn[j][0]; qs[4 * j + 1] = qn[j][1]; qs[4 * j + 2] = qn[j][2]; qs[4 * j + 3] = qn[j][3];
+      }
+      if (h + 1 < HEADS) issue_q(it, h + 1);
+      else if (it + 1 < it1) issue_q(it + 1, 0);
+      float mx = qs[0];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) mx = fmaxf(mx, qs[k]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        qs[k] = __expf(qs[k] - mx);
+        sum += qs[k];
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = p.scale / sum;
+      float ca[16];
+      load16(Ct + h * (DH * LD) + lr * LD + 16 * lh, ca);
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[s], qs[s] * inv, o, 0, 0, 0);
+      // out^T[e][pixel]: this lane's pixel, register 4 g + j = channel h * 32 + 8 g + 4 lh + j
+      if (live) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(p.ao + row * p.ao_pitch + h * DH + 8 * g + 4 * lh) =
+              f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+      }
+      // o2^T[c][pixel] += Wout[c][k] out^T[k][pixel] over the head's 32 k, in the accumulators' own order
+#pragma unroll
+      for (int a = 0; a < NC; ++a) {
+        const float* wp = Ws + (a * 32 + lr) * ALD + h * DH + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], o[4 * g + j], acc[a], 0, 0, 0);
+        }
+      }
+    }
+    // ---- bias, RMSNorm over the CO channels of the lane's pixel (the other half sits in lane ^ 32), residual ----
+    float ss = 0.f;
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bout + a * 32 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[a][4 * g + k] += bv[k];
+          ss += acc[a][4 * g + k] * acc[a][4 * g + k];
+        }
+      }
+    ss += __shfl_xor(ss, 32, 64);
+    const float rinv = sqrtc / fmaxf(sqrtf(ss), 1e-12f);
+    if (live) {
+#pragma unroll
+      for (int a = 0; a < NC; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = a * 32 + 8 * g + 4 * lh;
+          const f32x4 v = {acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]};
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(p.g + c);
+          f32x4 xv;
+          if constexpr (NC <= 4) xv = xres[a * 4 + g];
+          else xv = *reinterpret_cast<const f32x4*>(p.x + row * p.x_pitch + c);
+          *reinterpret_cast<f32x4*>(p.o2 + row * p.o2_pitch + c) = v;
+          *reinterpret_cast<f32x4*>(p.y + row * p.y_pitch + c) = v * gv * rinv + xv;
+        }
+    }
+  }
+}
+
+template <int NC>
+int launch_out(const OArgs& a, int blocks, hipStream_t s) {
+  const size_t smem = ((size_t)32 * NC * ALD + HEADS * DH * LD) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_out_fused_kernel<NC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  hipLaunchKernelGGL(linattn_out_fused_kernel<NC>, dim3(blocks), dim3(256), smem, s, a);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+}  // namespace
+
+// 1: built for this layer; 2: built AND measured faster than the three separate launches (256 produced channels sit on
+// 8 x 8 maps, where a 128-pixel item is half empty and the 128 KB weight is staged per block: 35 vs 30 us)
+extern "C" int64_t lgm_linattn_fwd_fused_supported(int heads, int dim_head, int Cout) {
+  if (heads != HEADS || dim_head != DH) return 0;
+  return Cout == 64 || Cout == 128 ? 2 : Cout == 256 ? 1 : 0;
+}
+
+int lgm_linattn_out_fused_launch(const float* qkv, long pitch, const float* ctx, const float* wout, const float* bout,
+                                 const float* g, const float* x, long x_pitch, float* ao, long ao_pitch, float* o2,
+                                 long o2_pitch, float* y, long y_pitch, int B, int n, int Cout, float scale, hipStream_t s) {
+  OArgs a;
+  a.qkv = qkv; a.pitch = pitch; a.ctx = ctx; a.wout = wout; a.bout = bout; a.g = g; a.x = x; a.x_pitch = x_pitch;
+  a.ao = ao; a.ao_pitch = ao_pitch; a.o2 = o2; a.o2_pitch = o2_pitch; a.y = y; a.y_pitch = y_pitch;
+  a.n = n; a.scale = scale;
+  a.tiles = lgm_cdiv(n, OTP);
+  a.items = B * a.tiles;
+  const int slots = Cout == 64 ? 768 : 256;
+  const int nb = a.items < slots ? a.items : slots;
+  a.per = lgm_cdiv(a.items, nb);
+  const int blocks = lgm_cdiv(a.items, a.per);
+  lgm_note_kernel(Cout == 64 ? "linattn_out_fused_kernel<2>" : Cout == 128 ? "linattn_out_fused_kernel<4>"
+                                                                             : "linattn_out_fused_kernel<8>");
+  if (Cout == 64) return launch_out<2>(a, blocks, s);
+  if (Cout == 128) return launch_out<4>(a, blocks, s);
+  return launch_out<8>(a, blocks, s);
+}

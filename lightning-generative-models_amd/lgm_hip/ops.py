@@ -730,6 +730,29 @@ def linattn_fwd(qkv, mem_ptr, heads, dim_head, M, out):
     return ctx, kstat
 
 
+LA_FWD_FUSED = _os.environ.get("LGM_NO_LA_FWD_FUSED") is None     # A/B switch: the fused LinearAttention forward tail
+
+
+def linattn_fwd_fused_ok(heads, dim_head, Cout, qkv, x, wout_ptr, bout_ptr, g_ptr, any_size=False) -> bool:
+    """``any_size``: every layer the kernel is built for, not only those it was measured faster on."""
+    if not LA_FWD_FUSED or lib().lgm_linattn_fwd_fused_supported(heads, dim_head, Cout) < (1 if any_size else 2):
+        return False
+    return not any(v % 16 for v in (qkv.data_ptr(), x.data_ptr(), wout_ptr, bout_ptr, g_ptr)) and \
+        pitch(qkv) % 4 == 0 and pitch(x) % 4 == 0
+
+
+def linattn_fwd_fused(qkv, mem_ptr, heads, dim_head, M, wout_ptr, bout_ptr, g_ptr, x, out, o2, y):
+    """ctx launch + ONE launch for softmax_d(q) ctx -> to_out[0] -> RMSNorm -> + x (lgm_linattn_fwd_fused)."""
+    B, H, W, _ = qkv.shape
+    ctx = new((B, heads, dim_head, dim_head), qkv)
+    kstat = new((2, B, heads, dim_head), qkv)
+    lib().lgm_linattn_fwd_fused(qkv.data_ptr(), pitch(qkv), mem_ptr, B, H * W, heads, dim_head, M, wout_ptr, bout_ptr,
+                                g_ptr, x.shape[-1], x.data_ptr(), pitch(x), out.data_ptr(), pitch(out), o2.data_ptr(),
+                                pitch(o2), y.data_ptr(), pitch(y), ctx.data_ptr(), kstat[0].data_ptr(),
+                                kstat[1].data_ptr(), stream())
+    return ctx, kstat
+
+
 def linattn_bwd(qkv, mem_ptr, gout, ctx, kstat, heads, dim_head, M, gqkv, gmem_ptr, gmem_beta, defer=None):
     """``defer`` (GradCtx.defer_for(mem_kv)): the mem_kv gradient's partial rows join the bucket's batched reduction."""
     L = lib()

@@ -100,9 +100,17 @@ class LinearAttention(nn.Module):
         qkv = self.to_qkv.fwd(xn)
         ao = ops.new((B, H, W, self.heads * self.dim_head), x)
         fp = self.mem_kv._lgm_flat
-        ctx, kstat = ops.linattn_fwd(qkv, fp.ptr(self.mem_kv), self.heads, self.dim_head, self.M, ao)
-        o2 = self.to_out[0].fwd(ao)
-        self.to_out[1].fwd(o2, res=x, out=out)
+        conv, norm = self.to_out[0], self.to_out[1]
+        if ops.linattn_fwd_fused_ok(self.heads, self.dim_head, C, qkv, x, fp.ptr(conv.weight), fp.ptr(conv.bias),
+                                    fp.ptr(norm.g)) and out.data_ptr() % 16 == 0 and ops.pitch(out) % 4 == 0:
+            # softmax_d(q) ctx -> to_out[0] -> RMSNorm -> + x in one launch behind the context launch
+            o2 = ops.new((B, H, W, C), x)
+            ctx, kstat = ops.linattn_fwd_fused(qkv, fp.ptr(self.mem_kv), self.heads, self.dim_head, self.M,
+                                               fp.ptr(conv.weight), fp.ptr(conv.bias), fp.ptr(norm.g), x, ao, o2, out)
+        else:
+            ctx, kstat = ops.linattn_fwd(qkv, fp.ptr(self.mem_kv), self.heads, self.dim_head, self.M, ao)
+            o2 = conv.fwd(ao)
+            norm.fwd(o2, res=x, out=out)
         return (x, xn, qkv, ao, ctx, kstat, o2) if save else None
 
     def bwd(self, gc: GradCtx, saved, gy, gx, accumulate: bool):

@@ -299,6 +299,43 @@ def test_linear_attention_core(dev, shape):
     assert rel(gm, mem.grad.reshape(-1)) < RTOL
 
 
+@pytest.mark.parametrize("case", [(2, 64, 16, 16), (3, 64, 20, 20), (2, 128, 8, 8), (1, 256, 5, 7), (5, 64, 32, 32),
+                                  (70, 128, 16, 16)])
+def test_linear_attention_forward_with_fused_tail(dev, case):
+    """lgm_linattn_fwd_fused: softmax_d(q) ctx -> to_out[0] -> RMSNorm -> + x in one launch, against the reference's
+    arithmetic (ddpm.py:229-239: to_out = Sequential(Conv2d(hidden, dim, 1), RMSNorm(dim)); RMSNorm :115-121)."""
+    from lgm_hip import ops
+    B, C, H, W = case
+    heads, d, M, n = 4, 32, 4, H * W
+    hidden = heads * d
+    g = torch.Generator().manual_seed(77 * C + n + B)
+    qkv = torch.randn(B, 3 * hidden, H, W, generator=g) * 1.5
+    mem = torch.randn(2, heads, d, M, generator=g)
+    x = torch.randn(B, C, H, W, generator=g)
+    wout = torch.randn(C, hidden, generator=g) / math.sqrt(hidden)
+    bout = torch.randn(C, generator=g) * 0.1
+    gn = 1.0 + 0.2 * torch.randn(C, generator=g)
+    q, k, v = (t.reshape(B, heads, d, n) for t in qkv.chunk(3, dim=1))
+    out_ref = _lin_attn_core(q, k, v, mem, d ** -0.5).reshape(B, hidden, H, W)
+    o2_ref = torch.einsum("ck,bkhw->bchw", wout, out_ref) + bout.view(1, C, 1, 1)
+    y_ref = F.normalize(o2_ref, dim=1) * gn.view(1, C, 1, 1) * C ** 0.5 + x
+    qd, xd = nhwc(qkv, dev), nhwc(x, dev, extra=4)
+    memd, wd, bd, gd = vec(mem, dev), wout.contiguous().to(dev), vec(bout, dev), vec(gn, dev)
+    assert ops.linattn_fwd_fused_ok(heads, d, C, qd, xd, wd.data_ptr(), bd.data_ptr(), gd.data_ptr(), any_size=True)
+    ao = torch.full((B, H, W, hidden), float("nan"), device=dev)
+    o2 = torch.full((B, H, W, C), float("nan"), device=dev)
+    y = torch.full((B, H, W, C + 4), float("nan"), device=dev)[..., :C]
+    ctx, kstat = ops.linattn_fwd_fused(qd, memd.data_ptr(), heads, d, M, wd.data_ptr(), bd.data_ptr(), gd.data_ptr(), xd,
+                                       ao, o2, y)
+    assert rel(nchw(ao), out_ref) < RTOL
+    assert rel(nchw(o2), o2_ref) < RTOL
+    assert rel(nchw(y), y_ref) < RTOL
+    # the saved context is what the unfused forward leaves (the backward pass reads it)
+    od = torch.empty(B, H, W, hidden, device=dev)
+    ctx2, kstat2 = ops.linattn_fwd(qd, memd.data_ptr(), heads, d, M, od)
+    assert torch.equal(ctx, ctx2) and torch.equal(kstat, kstat2)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 16, 16, False), (3, 64, 20, 20, True), (2, 64, 8, 8, True), (5, 64, 32, 32, True),
                                   (1, 64, 20, 12, False), (130, 64, 16, 16, True)])
 def test_linear_attention_backward_with_fused_tail(dev, case, monkeypatch):
