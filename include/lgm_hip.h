@@ -96,6 +96,15 @@ int lgm_conv_xy_post(const LgmConvGeom* g, const float* x, int64_t x_pitch, cons
 int lgm_conv_yx_post(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* w, const float* w_t,
                      const float* bias, const float* res, int64_t res_pitch, float* x, int64_t x_pitch,
                      void* workspace, int64_t workspace_bytes, const LgmPostOp* post, void* stream);
+/* lgm_conv_bwd_pair with lgm_conv_yx_post's post-op on the INPUT gradient (the backward mask of an activation that sat in
+ * front of this layer's input - VQ-VAE residual.py:14-20, vqvae.py:36-51): gx = post(W^T gy + res).  Keeps masked layers
+ * on the one-launch path. */
+int lgm_conv_bwd_pair_post(const LgmConvGeom* g, const float* gy, int64_t gy_pitch, const float* x, int64_t x_pitch,
+                           const float* w, const float* w_t, const float* res, int64_t res_pitch, float* gx,
+                           int64_t gx_pitch, void* dgrad_ws, int64_t dgrad_ws_bytes, float* gw, float* gbias,
+                           float beta, void* wgrad_ws, int64_t wgrad_ws_bytes, int64_t* desc, const LgmPostOp* post,
+                           void* stream);
+
 
 /* Weight gradient: gw[n][tap][c] = beta*gw + sum_{b,oh,ow} Y[b,oh,ow,n] * X[b,ih,iw,c].
  * (Conv2d: Y = grad_output, X = input;  ConvTranspose2d: Y = input, X = grad_output.)
@@ -133,6 +142,11 @@ int lgm_wgrad_reduce_batch(const int64_t* table, int n_entries, int64_t total_bl
 int64_t lgm_colsum_workspace(int64_t rows, int64_t cols);
 int lgm_colsum(const float* a, int64_t pitch, int64_t rows, int64_t cols, float* out, float beta,
                void* workspace, void* stream);
+/* Deferred form: the first stage's partial rows stay in `workspace` (must then stay untouched until the reduction) and
+ * desc[8] receives their row for lgm_wgrad_reduce_batch - the bias gradients of transposed convolutions join the
+ * bucket's one reduction launch.  cols % 4 == 0 and a 16-byte aligned `out` required. */
+int lgm_colsum_deferred(const float* a, int64_t pitch, int64_t rows, int64_t cols, float* out, float beta,
+                        void* workspace, int64_t* desc, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * GroupNorm(+FiLM scale/shift)(+SiLU)(+residual)   — Block.forward ddpm.py:164-173
@@ -443,6 +457,17 @@ int lgm_wgan_dloss(float* vals4, void* stream);
  * perplexity) with out3 = (vq_loss, perplexity, .) as lgm_vq_gather_loss leaves it; and its mirror image for the
  * backward pass: out2 = (g * w0, g * w1). */
 int lgm_vqvae_loss(const float* recon, const float* out3, float w_recon, float w_vq, float* vals4, void* stream);
+/* The same from the per-sample reconstruction terms lgm_weighted_mse_fwd leaves (its `loss` may be NULL: no mean launch):
+ * their mean is taken here, in mean_kernel's order. */
+int lgm_vqvae_loss_samples(const float* per_sample, int n, const float* out3, float w_recon, float w_vq, float* vals4,
+                           void* stream);
+/* VQ-VAE decoder end (vqvae.py:85-88, :130): x_hat = tanh(pre) and the per-sample reconstruction terms in one pass; and
+ * its backward with the loss weights folded in - gpre = d loss / d pre for loss = w_recon mse + ..., g2 = (gloss w_recon,
+ * gloss w_vq) left for the quantiser's backward (lgm_vq_bwd's g_vq_loss = g2 + 1). */
+int lgm_tanh_mse_fwd(const float* pre, const float* target, int64_t pitch, int B, int C, int HW, int Cpad, float* xh,
+                     float* per_sample, void* stream);
+int lgm_tanh_mse_bwd(const float* xh, const float* target, int64_t pitch, const float* gloss, float w_recon, float w_vq,
+                     int B, int C, int HW, int Cpad, float* gpre, float* g2, void* stream);
 int lgm_scale_pair(const float* g, float w0, float w1, float* out2, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -590,6 +590,7 @@ struct PairCtx {
   // stashed split-K reducer of the input gradient
   const float* r_ws; long r_stride; int r_splits; const float* r_bias; const float* r_res; long r_res_pitch;
   float* r_out; long r_out_pitch; long r_M; int r_N;
+  bool r_post; int r_act; float r_slope; const float* r_mask; long r_mask_pitch; float r_mask_slope;
   // stashed slab reducer of the weight gradient (non-deferred form)
   const float* w_ws; long w_slab; float* w_gw; long w_nw; float* w_gb; long w_nb; int w_splits; float w_beta;
 };
@@ -760,11 +761,13 @@ int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool 
     a.kchunk = kchunk;
     a.ws = (float*)workspace;
     if (int rc = launch_igemm<MODE, 64, 64, 1, 1>(a, s)) return rc;      // partial products: the kernel skips the epilogue ops
-    if (t_pair.active && t_pair.rec_i && !post && t_pair.ig.ws == a.ws) {   // recorded, not launched: reduce after the pair
+    if (t_pair.active && t_pair.rec_i && t_pair.ig.ws == a.ws) {   // recorded, not launched: reduce after the pair
       t_pair.red_i = true;
       t_pair.r_ws = a.ws; t_pair.r_stride = (long)a.M * a.N; t_pair.r_splits = splits; t_pair.r_bias = a.bias;
       t_pair.r_res = a.res; t_pair.r_res_pitch = a.res_pitch; t_pair.r_out = a.out; t_pair.r_out_pitch = a.out_pitch;
       t_pair.r_M = a.M; t_pair.r_N = a.N;
+      t_pair.r_post = post != nullptr; t_pair.r_act = a.act; t_pair.r_slope = a.slope; t_pair.r_mask = a.mask;
+      t_pair.r_mask_pitch = a.mask_pitch; t_pair.r_mask_slope = a.mask_slope;
       return LGM_OK;
     }
     if (post) {
@@ -1783,19 +1786,27 @@ extern "C" int lgm_conv3x3_wino_bwd(const LgmConvGeom* g, const float* gy, int64
 // Backward of a generic layer (any geometry): weight / bias gradient AND input gradient.  When the dispatchers pick
 // the two kernels that can share a grid (see PairCtx) both run in ONE launch; otherwise this is exactly
 // lgm_conv_wgrad[_deferred] followed by lgm_conv_yx.  dgrad_ws and wgrad_ws must not overlap (the kernels run side by side).
-extern "C" int lgm_conv_bwd_pair(const LgmConvGeom* g, const float* gy, int64_t gy_pitch, const float* x,
-                                 int64_t x_pitch, const float* w, const float* w_t, const float* res, int64_t res_pitch,
-                                 float* gx, int64_t gx_pitch, void* dgrad_ws, int64_t dgrad_ws_bytes, float* gw,
-                                 float* gbias, float beta, void* wgrad_ws, int64_t wgrad_ws_bytes, int64_t* desc,
-                                 void* stream) {
+static int conv_bwd_pair_impl(const LgmConvGeom* g, const float* gy, int64_t gy_pitch, const float* x,
+                              int64_t x_pitch, const float* w, const float* w_t, const float* res, int64_t res_pitch,
+                              float* gx, int64_t gx_pitch, void* dgrad_ws, int64_t dgrad_ws_bytes, float* gw,
+                              float* gbias, float beta, void* wgrad_ws, int64_t wgrad_ws_bytes, int64_t* desc,
+                              const LgmPostOp* post, void* stream) {
   static const bool no_pair = getenv("LGM_NO_PAIR") != nullptr;   // A/B switch: separate launches
   hipStream_t s = (hipStream_t)stream;
   t_pair = PairCtx{};
   t_pair.active = !no_pair;
   int rc = conv_wgrad_impl(g, gy, gy_pitch, x, x_pitch, gw, gbias, beta, wgrad_ws, wgrad_ws_bytes, desc, stream);
-  if (rc == LGM_OK)
+  bool post_done = true;
+  if (rc == LGM_OK) {
+    // the post-op belongs to the input gradient only: parked for the duration of ITS dispatch (see with_post)
+    t_post.post = post;
+    t_post.done = false;
     rc = conv_yx_impl(g, gy, gy_pitch, w, w_t, nullptr, res, res_pitch, gx, gx_pitch, dgrad_ws, dgrad_ws_bytes, nullptr,
                       nullptr, stream);
+    post_done = post == nullptr || t_post.done;
+    t_post.post = nullptr;
+    t_post.done = false;
+  }
   const PairCtx c = t_pair;
   t_pair = PairCtx{};
   if (rc != LGM_OK) return rc;
@@ -1827,17 +1838,53 @@ extern "C" int lgm_conv_bwd_pair(const LgmConvGeom* g, const float* gy, int64_t 
     }
   }
   LGM_LAUNCH_CHECK();
-  if (c.red_i)
-    if (int r2 = lgm_splitk_reduce_launch(c.r_ws, c.r_stride, c.r_splits, c.r_bias, c.r_res, c.r_res_pitch, c.r_out,
-                                          c.r_out_pitch, c.r_M, c.r_N, s))
+  if (c.red_i) {
+    if (c.r_post) {
+      const long items = c.r_M * (c.r_N / 4);
+      hipLaunchKernelGGL(splitk_reduce_post_kernel, dim3((unsigned)lgm_cdiv(items, 256)), dim3(256), 0, s, c.r_ws,
+                         c.r_stride, c.r_splits, c.r_bias, c.r_res, c.r_res_pitch, c.r_out, c.r_out_pitch, c.r_M, c.r_N,
+                         c.r_act, c.r_slope, c.r_mask, c.r_mask_pitch, c.r_mask_slope);
+      LGM_LAUNCH_CHECK();
+    } else if (int r2 = lgm_splitk_reduce_launch(c.r_ws, c.r_stride, c.r_splits, c.r_bias, c.r_res, c.r_res_pitch, c.r_out,
+                                                 c.r_out_pitch, c.r_M, c.r_N, s)) {
       return r2;
+    }
+  }
   if (c.red_w) {
     const long groups = (c.w_nw + c.w_nb + 3) / 4;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lgm_cdiv(groups, 64)), dim3(256), 0, s, c.w_ws, c.w_slab, c.w_gw,
                        c.w_nw, c.w_gb, c.w_nb, c.w_splits, c.w_beta);
     LGM_LAUNCH_CHECK();
   }
+  if (!post_done) {        // the input gradient took a path without an epilogue hook: one elementwise pass
+    const long M = (long)g->B * g->H * g->W;
+    hipLaunchKernelGGL(post_kernel, dim3((unsigned)lgm_cdiv(M * g->Cw, 256)), dim3(256), 0, s, gx, (long)gx_pitch, M, g->Cw,
+                       post->act, post->slope, post->mask, (long)post->mask_pitch, post->mask_slope);
+    LGM_LAUNCH_CHECK();
+  }
   return LGM_OK;
+}
+
+extern "C" int lgm_conv_bwd_pair(const LgmConvGeom* g, const float* gy, int64_t gy_pitch, const float* x,
+                                 int64_t x_pitch, const float* w, const float* w_t, const float* res, int64_t res_pitch,
+                                 float* gx, int64_t gx_pitch, void* dgrad_ws, int64_t dgrad_ws_bytes, float* gw,
+                                 float* gbias, float beta, void* wgrad_ws, int64_t wgrad_ws_bytes, int64_t* desc,
+                                 void* stream) {
+  return conv_bwd_pair_impl(g, gy, gy_pitch, x, x_pitch, w, w_t, res, res_pitch, gx, gx_pitch, dgrad_ws, dgrad_ws_bytes, gw,
+                            gbias, beta, wgrad_ws, wgrad_ws_bytes, desc, nullptr, stream);
+}
+
+// The same with a post-op on the INPUT gradient (lgm_conv_yx_post's: the backward mask of an activation that sat in
+// front of this layer's input): gx = post(conv_yx(gy) + res).
+extern "C" int lgm_conv_bwd_pair_post(const LgmConvGeom* g, const float* gy, int64_t gy_pitch, const float* x,
+                                      int64_t x_pitch, const float* w, const float* w_t, const float* res,
+                                      int64_t res_pitch, float* gx, int64_t gx_pitch, void* dgrad_ws,
+                                      int64_t dgrad_ws_bytes, float* gw, float* gbias, float beta, void* wgrad_ws,
+                                      int64_t wgrad_ws_bytes, int64_t* desc, const LgmPostOp* post, void* stream) {
+  if (int rc = post_check(post, "conv_bwd_pair_post")) return rc;
+  if (int rc = check_geom(g)) return rc;
+  return conv_bwd_pair_impl(g, gy, gy_pitch, x, x_pitch, w, w_t, res, res_pitch, gx, gx_pitch, dgrad_ws, dgrad_ws_bytes, gw,
+                            gbias, beta, wgrad_ws, wgrad_ws_bytes, desc, post, stream);
 }
 
 extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,

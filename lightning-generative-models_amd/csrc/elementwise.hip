@@ -92,6 +92,25 @@ extern "C" int lgm_colsum(const float* a, int64_t pitch, int64_t rows, int64_t c
   return LGM_OK;
 }
 
+extern "C" int lgm_colsum_deferred(const float* a, int64_t pitch, int64_t rows, int64_t cols, float* out, float beta,
+                                   void* workspace, int64_t* desc, void* stream) {
+  LGM_REQUIRE(a && out && workspace && desc && rows > 0 && cols > 0, "colsum_deferred: bad arguments");
+  LGM_REQUIRE(cols % 4 == 0 && lgm_aligned16(out) && lgm_aligned16(workspace),
+              "colsum_deferred: cols %% 4 == 0 and 16-byte aligned out / workspace required");
+  const long rpb = cs_rows(rows);
+  const int ns = lgm_cdiv(rows, rpb);
+  int lg = 2;
+  while (lg < 6 && (1L << lg) < cols) ++lg;
+  hipLaunchKernelGGL(colsum_stage, dim3(lgm_cdiv(cols, 1 << lg), ns), dim3(256), 0, (hipStream_t)stream, a, (long)pitch,
+                     (long)rows, (long)cols, rpb, (float*)workspace, (long)cols, 0.f, lg);
+  LGM_LAUNCH_CHECK();
+  union { float f; int64_t i; } bb;
+  bb.i = 0; bb.f = beta;
+  desc[0] = (int64_t)(uintptr_t)workspace; desc[1] = cols; desc[2] = (int64_t)(uintptr_t)out; desc[3] = cols;
+  desc[4] = 0; desc[5] = 0; desc[6] = ns; desc[7] = bb.i;
+  return LGM_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // Sinusoidal position embedding  (ddpm.py:125-132): emb[b] = cat(sin(t*f), cos(t*f)).  The frequency
 // table f[i] = exp(i * -(ln(theta)/(half-1))) is computed by the CALLER on the host exactly as the
@@ -589,14 +608,82 @@ extern "C" int lgm_qsample_target(const float* img, const float* noise, const in
   return LGM_OK;
 }
 
+namespace {
+// x_hat = tanh(pre) and the per-sample reconstruction term mean_{chw} (x_hat - target)^2 in one pass (VQ-VAE decoder end,
+// vqvae.py:85-88 + the recon loss :130): one block per sample, like mse_sample_kernel
+__global__ __launch_bounds__(256) void tanh_mse_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ target,
+                                                           long pitch, int C, int HW, int Cpad, float* __restrict__ xh,
+                                                           float* __restrict__ per_sample) {
+  __shared__ float sh[16];
+  const int b = blockIdx.x;
+  const long n = (long)HW * Cpad;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const long pix = (long)b * HW + i / Cpad;
+    const float t = tanhf(pre[pix * pitch + c]);
+    xh[pix * pitch + c] = t;
+    if (c < C) {
+      const float d = t - target[pix * pitch + c];
+      s += d * d;
+    }
+  }
+  s = lgm_block_sum(s, sh);
+  if (threadIdx.x == 0) per_sample[b] = s / ((float)C * (float)HW);
+}
+// its backward, with the loss weights folded in: gpre = (gloss w_recon) 2 (x_hat - target) / (C HW B) (1 - x_hat^2);
+// g2[0] = gloss w_recon, g2[1] = gloss w_vq for the quantiser's backward later in the stream
+__global__ __launch_bounds__(256) void tanh_mse_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ target,
+                                                           long pitch, const float* __restrict__ gloss, float w_recon,
+                                                           float w_vq, int B, int C, int HW, int Cpad,
+                                                           float* __restrict__ gpre, float* __restrict__ g2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * HW * Cpad;
+  const float gr = gloss[0] * w_recon;
+  if (i == 0) {
+    g2[0] = gr;
+    g2[1] = gloss[0] * w_vq;
+  }
+  if (i >= total) return;
+  const int c = (int)(i % Cpad);
+  const long pix = i / Cpad;
+  float g = 0.f;
+  if (c < C) {
+    const float t = xh[pix * pitch + c];
+    const float scale = gr * 2.f * 1.f / ((float)C * (float)HW * (float)B);
+    g = scale * (t - target[pix * pitch + c]);
+    g = g * (1.f - t * t);
+  }
+  gpre[pix * pitch + c] = g;
+}
+}  // namespace
+
+extern "C" int lgm_tanh_mse_fwd(const float* pre, const float* target, int64_t pitch, int B, int C, int HW, int Cpad,
+                                float* xh, float* per_sample, void* stream) {
+  LGM_REQUIRE(pre && target && xh && per_sample && B > 0, "tanh_mse_fwd: bad arguments");
+  hipLaunchKernelGGL(tanh_mse_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pre, target, (long)pitch, C, HW, Cpad,
+                     xh, per_sample);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_tanh_mse_bwd(const float* xh, const float* target, int64_t pitch, const float* gloss, float w_recon,
+                                float w_vq, int B, int C, int HW, int Cpad, float* gpre, float* g2, void* stream) {
+  LGM_REQUIRE(xh && target && gloss && gpre && g2 && B > 0, "tanh_mse_bwd: bad arguments");
+  hipLaunchKernelGGL(tanh_mse_bwd_kernel, dim3(lgm_cdiv((long)B * HW * Cpad, 256)), dim3(256), 0, (hipStream_t)stream, xh,
+                     target, (long)pitch, gloss, w_recon, w_vq, B, C, HW, Cpad, gpre, g2);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
 extern "C" int lgm_weighted_mse_fwd(const float* out, const float* target, int64_t pitch, const int64_t* t,
                                     const float* loss_weight, int B, int C, int HW, int Cpad, float* per_sample,
                                     float* loss, void* stream) {
-  LGM_REQUIRE(out && target && per_sample && loss && B > 0 && (!loss_weight || t), "weighted_mse_fwd: bad arguments");
+  LGM_REQUIRE(out && target && per_sample && B > 0 && (!loss_weight || t), "weighted_mse_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(mse_sample_kernel, dim3(B), dim3(256), 0, s, out, target, (long)pitch, t, loss_weight, C, HW, Cpad,
                      per_sample);
-  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, (const float*)per_sample, B, loss);
+  if (loss) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, (const float*)per_sample, B, loss);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
@@ -824,6 +911,21 @@ __global__ void vqvae_loss_kernel(const float* recon, const float* out3, float w
   vals4[2] = v;
   vals4[3] = out3[1];
 }
+// the same with the reconstruction term still as per-sample values: their mean (mean_kernel's arithmetic) is taken here
+__global__ __launch_bounds__(256) void vqvae_loss_mean_kernel(const float* per_sample, int n, const float* out3, float w_recon,
+                                                              float w_vq, float* vals4) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += per_sample[i];
+  s = lgm_block_sum(s, sh);
+  if (threadIdx.x == 0) {
+    const float r = s / (float)n, v = out3[0];
+    vals4[0] = r * w_recon + v * w_vq;
+    vals4[1] = r;
+    vals4[2] = v;
+    vals4[3] = out3[1];
+  }
+}
 __global__ void scale_pair_kernel(const float* g, float w0, float w1, float* out2) {
   out2[0] = g[0] * w0;
   out2[1] = g[0] * w1;
@@ -834,6 +936,15 @@ extern "C" int lgm_vqvae_loss(const float* recon, const float* out3, float w_rec
                               void* stream) {
   LGM_REQUIRE(recon && out3 && vals4, "vqvae_loss: null pointer");
   hipLaunchKernelGGL(vqvae_loss_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, recon, out3, w_recon, w_vq, vals4);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_vqvae_loss_samples(const float* per_sample, int n, const float* out3, float w_recon, float w_vq,
+                                      float* vals4, void* stream) {
+  LGM_REQUIRE(per_sample && out3 && vals4 && n > 0, "vqvae_loss_samples: bad arguments");
+  hipLaunchKernelGGL(vqvae_loss_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, per_sample, n, out3, w_recon, w_vq,
+                     vals4);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

@@ -144,7 +144,7 @@ class Conv2d(nn.Module):
             r = ops.conv_bwd_pair(g, gy, x, fp.ptr(self.weight), fp.gptr(self.weight), bw, gb, dfr, pres, gx, partial=ok_pl)
             if r is not False:
                 return (gx, r) if planes_for_groups else gx
-        if need_gx and self.k != 3 and mask is None and not planes_for_groups and not ops.B3:
+        if need_gx and (self.k != 3 or mask is not None) and not planes_for_groups and not ops.B3:
             # the other layers (1x1, 4x4 / stride 2, 7x7; a 3x3 layer the pair above did not take keeps its Winograd /
             # direct input gradient below): both gradients through lgm_conv_bwd_pair - one launch when the kernels can
             # share a grid
@@ -153,7 +153,8 @@ class Conv2d(nn.Module):
                 accumulate = False
             assert not (accumulate and res is not None)
             ops.conv_bwd_generic(g, gy, x, fp.ptr(self.weight), fp.tptr(self.weight), fp.gptr(self.weight), bw, gb, dfr,
-                                 gx if accumulate else res, gx)
+                                 gx if accumulate else res, gx, post=ops.make_post(0, 0.0, mask, mask_slope),
+                                 post_mask=mask)
             return gx
         ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=dfr)
         if not need_gx:
@@ -253,7 +254,8 @@ class ConvTranspose2d(nn.Module):
         dfr = gc.defer_for(self.weight)          # slab reduction batched with the other layers' when the pass defers
         ops.conv_wgrad(g, x, gy, fp.gptr(self.weight), gc.beta(self.weight), defer=dfr)  # Y side = input, X side = grad
         if self.bias is not None:
-            ops.colsum(gy, fp.gptr(self.bias), gc.beta(self.bias))
+            dfb = gc.defer_for(self.bias)
+            ops.colsum(gy, fp.gptr(self.bias), gc.beta(self.bias), defer=dfb)
         if not need_gx:
             return None
         if gx is None:

@@ -497,7 +497,7 @@ def conv_bwd_pair(g: ConvGeom, gy, x, w_ptr: int, gw_ptr: int, beta: float, gbia
 
 
 def conv_bwd_generic(g: ConvGeom, gy, x, w_ptr: int, wt_ptr: Optional[int], gw_ptr: int, beta: float,
-                     gbias_ptr: Optional[int], defer, res, gx):
+                     gbias_ptr: Optional[int], defer, res, gx, post=None, post_mask=None):
     """Weight / bias gradient and input gradient of any layer through lgm_conv_bwd_pair: ONE launch when the dispatchers
     pick the two kernels that can share a grid (the 1x1 convolutions and linears at small row counts), else exactly
     conv_wgrad + conv_yx."""
@@ -515,10 +515,16 @@ def conv_bwd_generic(g: ConvGeom, gy, x, w_ptr: int, wt_ptr: Optional[int], gw_p
             wws = torch.empty(max(nbytes // 4 + 4, 16), dtype=torch.float32, device=gy.device)
             _WGRAD_WS[k2] = wws
         desc = (ctypes.c_int64 * 8)()
-    L.lgm_conv_bwd_pair(ctypes.byref(g), gy.data_ptr(), pitch(gy), x.data_ptr(), pitch(x), w_ptr, wt_ptr, _p(res),
-                        pitch(res) if res is not None else 0, gx.data_ptr(), pitch(gx),
-                        None if dws is None else dws.data_ptr(), 0 if dws is None else dws.numel() * 4, gw_ptr, gbias_ptr,
-                        beta, wws.data_ptr(), wws.numel() * 4, None if desc is None else ctypes.addressof(desc), stream())
+    args = (ctypes.byref(g), gy.data_ptr(), pitch(gy), x.data_ptr(), pitch(x), w_ptr, wt_ptr, _p(res),
+            pitch(res) if res is not None else 0, gx.data_ptr(), pitch(gx),
+            None if dws is None else dws.data_ptr(), 0 if dws is None else dws.numel() * 4, gw_ptr, gbias_ptr,
+            beta, wws.data_ptr(), wws.numel() * 4, None if desc is None else ctypes.addressof(desc))
+    if post is None or not POSTOPS:
+        L.lgm_conv_bwd_pair(*args, stream())
+        if post is not None:
+            _apply_post_separately(post, gx, post_mask)
+    else:                # ``post_mask`` only keeps the mask tensor alive for the duration of the call
+        L.lgm_conv_bwd_pair_post(*args, ctypes.byref(post), stream())
     if TIMER is not None:
         TIMER.end()
     if desc is not None and desc[6] > 1:
@@ -577,10 +583,18 @@ def launch_reducer(ent):
         lib().lgm_wgrad_reduce_batch(ent[0].data_ptr(), ent[1], ent[2], stream())
 
 
-def colsum(a, out_ptr: int, beta: float):
-    """out[c] = beta*out[c] + sum over all leading dims of a[..., c]."""
+def colsum(a, out_ptr: int, beta: float, defer=None):
+    """out[c] = beta*out[c] + sum over all leading dims of a[..., c].  ``defer``: a deferred-reduction list - the second
+    stage joins the caller's batched reduction (wgrad_reduce_batch)."""
     L = lib()
     r, c = rows(a), a.shape[-1]
+    if defer is not None and c % 4 == 0 and out_ptr % 16 == 0:
+        nb = L.lgm_colsum_workspace(r, c)
+        ws = _persistent((out_ptr, nb, "colsum"), nb, a.device)
+        desc = (ctypes.c_int64 * 8)()
+        L.lgm_colsum_deferred(a.data_ptr(), pitch(a), r, c, out_ptr, beta, ws.data_ptr(), ctypes.addressof(desc), stream())
+        defer.append(tuple(desc))
+        return
     ws = workspace(L.lgm_colsum_workspace(r, c), a.device)
     L.lgm_colsum(a.data_ptr(), pitch(a), r, c, out_ptr, beta, ws.data_ptr(), stream())
 

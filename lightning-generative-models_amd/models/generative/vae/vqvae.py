@@ -116,16 +116,14 @@ class Decoder(nn.Module):
         s, st = L[1].fwd(a0, True)
         u1 = L[2].fwd(s, act=ops.ACT_RELU)
         u2 = L[4].fwd(u1, act=ops.ACT_RELU)
-        pre = L[6].fwd(u2)
-        xh = ops.new(pre.shape, pre)
-        ops.act_fwd(pre, None, None, xh, ops.ACT_TANH)
-        return xh, (q, st, s, u1, u2, pre)
+        pre = L[6].fwd(u2)          # the Tanh behind it is applied by the caller together with the reconstruction loss
+        return pre, (q, st, s, u1, u2)
 
-    def bwd(self, gc, saved, gxh):
-        q, st, s, u1, u2, pre = saved
+    def bwd(self, gc, saved, gpre):
+        """gpre: gradient w.r.t. the last layer's output BEFORE the Tanh"""
+        q, st, s, u1, u2 = saved
         L = self.layers
-        ops.act_bwd(pre, None, gxh, gxh, False, ops.ACT_TANH)
-        g = L[6].bwd(gc, u2, gxh, mask=u2)
+        g = L[6].bwd(gc, u2, gpre, mask=u2)
         g = L[4].bwd(gc, u1, g, mask=u1)
         g = L[2].bwd(gc, s, g, mask=s)
         g = L[1].bwd(gc, st, g)
@@ -255,24 +253,26 @@ class VQVAE(LightningModule):
         ops.nchw_to_nhwc(x.contiguous(), x4)
         lat, enc_saved = self.encoder.fwd(x4)
         q, out3, vq_saved = self.vector_quantizer.fwd(lat, self.training)
-        xh, dec_saved = self.decoder.fwd(q)
-        per = ops.new((B,), x)
-        recon = ops.new((1,), x)
-        ops.lib().lgm_weighted_mse_fwd(xh.data_ptr(), x4.data_ptr(), Cp, None, None, B, C, H * W, Cp,
-                                       per.data_ptr(), recon.data_ptr(), ops.stream())
+        pre, dec_saved = self.decoder.fwd(q)
+        xh = ops.new(pre.shape, pre)
+        per = ops.new((B,), x)      # per-sample reconstruction terms; their mean is taken by the loss kernel (_VQVAEStepFn)
+        ops.lib().lgm_tanh_mse_fwd(pre.data_ptr(), x4.data_ptr(), Cp, B, C, H * W, Cp, xh.data_ptr(), per.data_ptr(),
+                                   ops.stream())
         tape = (x4, enc_saved, vq_saved, dec_saved, xh) if save else None
-        return dict(recon=recon, out3=out3, x_hat=xh, indices=vq_saved[2], latents=lat), tape
+        return dict(recon_samples=per, out3=out3, x_hat=xh, indices=vq_saved[2], latents=lat), tape
 
-    def backward_hip(self, tape, g_recon, g_vq):
+    def backward_hip(self, tape, gloss, w_recon: float, w_vq: float):
+        """gloss: device scalar d L / d loss for loss = w_recon * recon + w_vq * vq"""
         x4, enc_saved, vq_saved, dec_saved, xh = tape
         B, H, W, Cp = x4.shape
         C = self.hparams.img_channels
         gc = GradCtx(self._flat, defer=True)     # weight-gradient slabs of all layers reduced by ONE launch (flush)
-        gxh = ops.new(xh.shape, xh)
-        ops.lib().lgm_weighted_mse_bwd(xh.data_ptr(), x4.data_ptr(), Cp, None, None, g_recon.data_ptr(), B, C, H * W,
-                                       Cp, gxh.data_ptr(), ops.stream())
-        gq = self.decoder.bwd(gc, dec_saved, gxh)
-        glat = self.vector_quantizer.bwd(gc, vq_saved, gq, g_vq)
+        gpre = ops.new(xh.shape, xh)
+        g2 = ops.new((2,), xh)                   # (gloss w_recon, gloss w_vq)
+        ops.lib().lgm_tanh_mse_bwd(xh.data_ptr(), x4.data_ptr(), Cp, gloss.data_ptr(), w_recon, w_vq, B, C, H * W, Cp,
+                                   gpre.data_ptr(), g2.data_ptr(), ops.stream())
+        gq = self.decoder.bwd(gc, dec_saved, gpre)
+        glat = self.vector_quantizer.bwd(gc, vq_saved, gq, g2[1:2])
         self.encoder.bwd(gc, enc_saved, glat)
         gc.flush()
         self._flat.bind_grad_views()
@@ -322,8 +322,10 @@ class _VQVAEStepFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)            # no zero tensors (3 fill launches) for the logged, non-differentiable outputs
         save = bool(ctx.needs_input_grad[0])
         r, tape = m.run(x.detach().float(), save)
-        vals = ops.new((4,), r["recon"])            # (loss, recon, vq, perplexity): one launch, no torch arithmetic
-        ops.lib().lgm_vqvae_loss(r["recon"].data_ptr(), r["out3"].data_ptr(), w_recon, w_vq, vals.data_ptr(), ops.stream())
+        per = r["recon_samples"]
+        vals = ops.new((4,), per)                   # (loss, recon, vq, perplexity): one launch, no torch arithmetic
+        ops.lib().lgm_vqvae_loss_samples(per.data_ptr(), per.numel(), r["out3"].data_ptr(), w_recon, w_vq, vals.data_ptr(),
+                                         ops.stream())
         m.last = r
         ctx.stuff = (m, tape, w_recon, w_vq)
         loss, recon_o, vq_o, ppl_o = vals[0], vals[1], vals[2], vals[3]
@@ -336,8 +338,6 @@ class _VQVAEStepFn(torch.autograd.Function):
         if tape is None:
             raise RuntimeError("VQVAE step ran without saving activations")
         gl = gloss.detach().float().reshape(1).contiguous()
-        g2 = ops.new((2,), gl)
-        ops.lib().lgm_scale_pair(gl.data_ptr(), w_recon, w_vq, g2.data_ptr(), ops.stream())
-        m.backward_hip(tape, g2[0:1], g2[1:2])
+        m.backward_hip(tape, gl, w_recon, w_vq)
         ctx.stuff = None
         return None, None, None, None, None
