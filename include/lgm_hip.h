@@ -223,6 +223,13 @@ int lgm_rmsnorm_bwd_deferred(const float* x, int64_t x_pitch, const float* gy, i
 int lgm_linattn_fwd(const float* qkv, int64_t qkv_pitch, const float* mem_kv, int B, int n,
                     int heads, int dim_head, int M, float* out, int64_t out_pitch, float* ctx,
                     float* kmax, float* ksum, void* stream);
+/* Head of the attention blocks' forward in one launch (ddpm.py:224-225, :262-263): xn = RMSNorm_g(x) (ddpm.py:115-121)
+ * and qkv = to_qkv(xn), a bias-free 1x1 convolution with weight w [N][C]; N = 384, C in {64, 128, 256}
+ * (lgm_rms_qkv_fused_supported: 0 = not built, 1 = built, 2 = built and faster than the two separate launches).  xn is
+ * written for the weight gradient. */
+int64_t lgm_rms_qkv_fused_supported(int C, int N);
+int lgm_rms_qkv_fused(const float* x, int64_t x_pitch, const float* g, const float* w, int C, int N, int64_t npix,
+                      float* xn, int64_t xn_pitch, float* qkv, int64_t qkv_pitch, void* stream);
 /* Forward with its tail fused (ddpm.py:229-239 + the residual around the block): after the context launch ONE launch
  * computes out = softmax_d(q) scale ctx, o2 = to_out[0](out) (wout [Cout][heads*32], bout [Cout]) and
  * y = RMSNorm_g(o2) + x.  `out` and `o2` are written for the backward pass.  Cout in {64, 128, 256}

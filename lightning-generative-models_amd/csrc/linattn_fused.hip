@@ -578,3 +578,150 @@ int lgm_linattn_out_fused_launch(const float* qkv, long pitch, const float* ctx,
   if (Cout == 128) return launch_out<4>(a, blocks, s);
   return launch_out<8>(a, blocks, s);
 }
+
+// =====================================================================================================================
+// Fused head of the attention blocks' forward (ddpm.py:224-225, :262-263): xn = RMSNorm(x), qkv = to_qkv(xn) (1x1
+// convolution, no bias) in one launch.  Per-pixel work with the same conventions as above: a lane owns one pixel, its
+// 16-byte pieces of the row arrive straight in registers, the norm is lane-local plus one exchange with lane ^ 32, and
+// the normalised values ARE the B operand of the product (k dealt out as a 32 + 8 g + 4 lh + j, the weight fragments read
+// in that order).  The 384 produced channels are split into three slices of 128 (q | k | v) over blockIdx.y so that a
+// block's weight slice fits LDS several times per CU; every slice recomputes the norm of its pixels (x comes from L2 the
+// second and third time), slice 0 writes xn (the weight gradient needs it).
+namespace {
+
+struct QArgs {
+  const float* x;  long x_pitch;
+  const float* g;
+  const float* w;                 // [3 * HID][C]
+  float* xn;       long xn_pitch;
+  float* qkv;      long q_pitch;
+  long P;                         // pixel rows
+  int items, per;
+};
+
+template <int NCI>      // input channels / 32
+__global__ __launch_bounds__(256, NCI == 2 ? 3 : NCI == 4 ? 2 : 1) void rms_qkv_fused_kernel(const QArgs p) {
+  constexpr int CI = 32 * NCI;
+  constexpr int WL = CI + 4;          // = 4 (mod 64): conflict-free 16-byte rows
+  extern __shared__ __align__(16) float sm[];
+  float* Ws = sm;                     // the slice's weight rows [128][WL]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int slice = blockIdx.y;
+  const int it0 = blockIdx.x * p.per, it1 = min(p.items, it0 + p.per);
+  if (it0 >= it1) return;
+  const float sqrtc = sqrtf((float)CI);
+  f32x4 xr[NCI * 4];
+  auto issue_x = [&](int it) {
+    const long pix = (long)it * 128 + 32 * wid + lr;
+    const long row = pix < p.P ? pix : p.P - 1;
+#pragma unroll
+    for (int a = 0; a < NCI; ++a)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        xr[a * 4 + g] = *reinterpret_cast<const f32x4*>(p.x + row * p.x_pitch + a * 32 + 8 * g + 4 * lh);
+  };
+  issue_x(it0);
+#pragma unroll
+  for (int u = 0; u < NCI * 4; ++u) {        // 128 rows x CI floats = 128 * CI / 4 16-byte pieces
+    const int e = tid + 256 * u;
+    const int r = e / (CI / 4), c4 = (e % (CI / 4)) * 4;
+    *reinterpret_cast<f32x4*>(Ws + r * WL + c4) = *reinterpret_cast<const f32x4*>(p.w + (long)(slice * 128 + r) * CI + c4);
+  }
+  __syncthreads();
+  for (int it = it0; it < it1; ++it) {
+    const long pix = (long)it * 128 + 32 * wid + lr;
+    const bool live = pix < p.P;
+    const long row = live ? pix : p.P - 1;
+    f32x4 xn[NCI * 4];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCI * 4; ++k) {
+      xn[k] = xr[k];
+      ss += xn[k][0] * xn[k][0] + xn[k][1] * xn[k][1] + xn[k][2] * xn[k][2] + xn[k][3] * xn[k][3];
+    }
+    if (NCI <= 4 && it + 1 < it1) issue_x(it + 1);
+    ss += __shfl_xor(ss, 32, 64);
+    const float inv = sqrtc / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int a = 0; a < NCI; ++a)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(p.g + a * 32 + 8 * g + 4 * lh);
+        xn[a * 4 + g] = xn[a * 4 + g] * gv * inv;
+        if (slice == 0 && live)
+          *reinterpret_cast<f32x4*>(p.xn + row * p.xn_pitch + a * 32 + 8 * g + 4 * lh) = xn[a * 4 + g];
+      }
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {        // one output tile at a time: the operand fragments of all four would not fit
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* wp = Ws + (t * 32 + lr) * WL + 4 * lh;
+#pragma unroll
+      for (int a = 0; a < NCI; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + a * 32 + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], xn[a * 4 + g][j], acc, 0, 0, 0);
+        }
+      // (D[pixel][channel] with dword stores that cover full 128-byte row segments was measured SLOWER here - 90 vs 77 us
+      // at 32 x 32 maps, B = 128: sixteen store instructions per tile instead of four)
+      if (live) {
+        float* o = p.qkv + row * p.q_pitch + slice * 128 + t * 32 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(o + 8 * g) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      }
+    }
+    if (NCI > 4 && it + 1 < it1) issue_x(it + 1);      // wide layers: no register room for a row in flight
+  }
+}
+
+template <int NCI>
+int launch_qkv(const QArgs& a, int blocks, hipStream_t s) {
+  const size_t smem = (size_t)128 * (32 * NCI + 4) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rms_qkv_fused_kernel<NCI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  hipLaunchKernelGGL(rms_qkv_fused_kernel<NCI>, dim3(blocks, 3), dim3(256), smem, s, a);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+}  // namespace
+
+// 1: built for this layer; 2: built and measured faster than RMSNorm + GEMM as two launches (64 channels, where the
+// GEMM is bound by its 6x larger output: 77 vs 87 us at 131 k pixel rows; wider layers sit on small maps: 50 vs 33 us)
+extern "C" int64_t lgm_rms_qkv_fused_supported(int C, int N) {
+  if (N != 3 * HID) return 0;
+  return C == 64 ? 2 : C == 128 || C == 256 ? 1 : 0;
+}
+
+// xn = RMSNorm_g(x) (ddpm.py:115-121), qkv = xn W^T  (W = to_qkv.weight [384][C], no bias)
+extern "C" int lgm_rms_qkv_fused(const float* x, int64_t x_pitch, const float* g, const float* w, int C, int N,
+                                 int64_t npix, float* xn, int64_t xn_pitch, float* qkv, int64_t qkv_pitch, void* stream) {
+  LGM_REQUIRE(lgm_rms_qkv_fused_supported(C, N), "rms_qkv_fused: C=%d N=%d unsupported", C, N);
+  LGM_REQUIRE(x && g && w && xn && qkv && npix > 0, "rms_qkv_fused: null pointer / empty");
+  LGM_REQUIRE(x_pitch % 4 == 0 && xn_pitch % 4 == 0 && qkv_pitch % 4 == 0 && lgm_aligned16(x) && lgm_aligned16(g) &&
+                  lgm_aligned16(w) && lgm_aligned16(xn) && lgm_aligned16(qkv),
+              "rms_qkv_fused: 16-byte aligned operands required");
+  QArgs a;
+  a.x = x; a.x_pitch = x_pitch; a.g = g; a.w = w; a.xn = xn; a.xn_pitch = xn_pitch; a.qkv = qkv; a.q_pitch = qkv_pitch;
+  a.P = npix;
+  a.items = lgm_cdiv(npix, 128);
+  const int slots = C == 64 ? 256 : C == 128 ? 170 : 85;      // x 3 slices: 3 / 2 / 1 blocks per CU
+  const int nb = a.items < slots ? a.items : slots;
+  a.per = lgm_cdiv(a.items, nb);
+  const int blocks = lgm_cdiv(a.items, a.per);
+  lgm_note_kernel(C == 64 ? "rms_qkv_fused_kernel<2>" : C == 128 ? "rms_qkv_fused_kernel<4>" : "rms_qkv_fused_kernel<8>");
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 64) return launch_qkv<2>(a, blocks, s);
+  if (C == 128) return launch_qkv<4>(a, blocks, s);
+  return launch_qkv<8>(a, blocks, s);
+}

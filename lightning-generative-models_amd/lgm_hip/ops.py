@@ -744,6 +744,28 @@ def linattn_fwd(qkv, mem_ptr, heads, dim_head, M, out):
     return ctx, kstat
 
 
+RMS_QKV_FUSED = _os.environ.get("LGM_NO_RMS_QKV_FUSED") is None     # A/B switch: RMSNorm + to_qkv in one launch
+
+
+RMS_QKV_MIN_ROWS = int(_os.environ.get("LGM_RMS_QKV_MIN_ROWS", "65536"))
+
+
+def rms_qkv_fused(x, g_ptr, w_ptr, N, any_size=False):
+    """(xn, qkv) = (RMSNorm_g(x), to_qkv(xn)) in one launch (lgm_rms_qkv_fused), or None when the layer is not taken:
+    by default only where it was measured faster (64 channels, at least RMS_QKV_MIN_ROWS pixel rows)."""
+    C = x.shape[-1]
+    lvl = lib().lgm_rms_qkv_fused_supported(C, N)
+    if not RMS_QKV_FUSED or lvl < (1 if any_size else 2) or x.data_ptr() % 16 or pitch(x) % 4 or g_ptr % 16 or w_ptr % 16:
+        return None
+    if not any_size and rows(x) < RMS_QKV_MIN_ROWS:
+        return None
+    xn = new(x.shape, x)
+    qkv = new(tuple(x.shape[:-1]) + (N,), x)
+    lib().lgm_rms_qkv_fused(x.data_ptr(), pitch(x), g_ptr, w_ptr, C, N, rows(x), xn.data_ptr(), pitch(xn), qkv.data_ptr(),
+                            pitch(qkv), stream())
+    return xn, qkv
+
+
 LA_FWD_FUSED = _os.environ.get("LGM_NO_LA_FWD_FUSED") is None     # A/B switch: the fused LinearAttention forward tail
 
 

@@ -96,10 +96,14 @@ class LinearAttention(nn.Module):
     def fwd(self, x, out, save: bool):
         """out = attn(x) + x"""
         B, H, W, C = x.shape
-        xn = self.norm.fwd(x)
-        qkv = self.to_qkv.fwd(xn)
-        ao = ops.new((B, H, W, self.heads * self.dim_head), x)
         fp = self.mem_kv._lgm_flat
+        r = ops.rms_qkv_fused(x, fp.ptr(self.norm.g), fp.ptr(self.to_qkv.weight), 3 * self.heads * self.dim_head)
+        if r is not None:
+            xn, qkv = r                                  # RMSNorm + to_qkv in one launch
+        else:
+            xn = self.norm.fwd(x)
+            qkv = self.to_qkv.fwd(xn)
+        ao = ops.new((B, H, W, self.heads * self.dim_head), x)
         conv, norm = self.to_out[0], self.to_out[1]
         if ops.linattn_fwd_fused_ok(self.heads, self.dim_head, C, qkv, x, fp.ptr(conv.weight), fp.ptr(conv.bias),
                                     fp.ptr(norm.g)) and out.data_ptr() % 16 == 0 and ops.pitch(out) % 4 == 0:
@@ -156,10 +160,14 @@ class Attention(nn.Module):
 
     def fwd(self, x, out, save: bool):
         B, H, W, C = x.shape
-        xn = self.norm.fwd(x)
-        qkv = self.to_qkv.fwd(xn)
-        ao = ops.new((B, H, W, self.heads * self.dim_head), x)
         fp = self.mem_kv._lgm_flat
+        r = ops.rms_qkv_fused(x, fp.ptr(self.norm.g), fp.ptr(self.to_qkv.weight), 3 * self.heads * self.dim_head)
+        if r is not None:
+            xn, qkv = r                                  # RMSNorm + to_qkv in one launch
+        else:
+            xn = self.norm.fwd(x)
+            qkv = self.to_qkv.fwd(xn)
+        ao = ops.new((B, H, W, self.heads * self.dim_head), x)
         lse = ops.attn_fwd(qkv, fp.ptr(self.mem_kv), self.heads, self.dim_head, self.M, ao)
         self.to_out.fwd(ao, out=out, res=x)
         return (x, xn, qkv, ao, lse) if save else None

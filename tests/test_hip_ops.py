@@ -299,6 +299,32 @@ def test_linear_attention_core(dev, shape):
     assert rel(gm, mem.grad.reshape(-1)) < RTOL
 
 
+@pytest.mark.parametrize("case", [(2, 64, 16, 16), (3, 64, 5, 7), (2, 128, 8, 8), (1, 256, 4, 4), (40, 64, 32, 32),
+                                  (300, 256, 4, 4)])
+def test_rmsnorm_and_to_qkv_in_one_launch(dev, case):
+    """lgm_rms_qkv_fused against F.normalize(x, dim=1) * g * sqrt(C) -> bias-free 1x1 convolution (ddpm.py:115-121,
+    :224-225)."""
+    from lgm_hip import ops
+    B, C, H, W = case
+    N = 384
+    g = torch.Generator().manual_seed(31 * C + H * W + B)
+    x = torch.randn(B, C, H, W, generator=g) * 2.0
+    gn = 1.0 + 0.3 * torch.randn(C, generator=g)
+    w = torch.randn(N, C, generator=g) / math.sqrt(C)
+    xn_ref = F.normalize(x, dim=1) * gn.view(1, C, 1, 1) * C ** 0.5
+    qkv_ref = torch.einsum("oc,bchw->bohw", w, xn_ref)
+    xd, gd, wd = nhwc(x, dev, extra=4), vec(gn, dev), w.contiguous().to(dev)
+    r = ops.rms_qkv_fused(xd, gd.data_ptr(), wd.data_ptr(), N, any_size=True)
+    assert r is not None
+    xn, qkv = r
+    assert rel(nchw(xn), xn_ref) < RTOL
+    assert rel(nchw(qkv), qkv_ref) < RTOL
+    # against the separate RMSNorm launch: the same arithmetic, only the channel sum of squares in another order
+    y = torch.empty_like(xn)
+    ops.rmsnorm_fwd(xd, gd.data_ptr(), None, y)
+    assert rel(xn, y) < 1e-6
+
+
 @pytest.mark.parametrize("case", [(2, 64, 16, 16), (3, 64, 20, 20), (2, 128, 8, 8), (1, 256, 5, 7), (5, 64, 32, 32),
                                   (70, 128, 16, 16)])
 def test_linear_attention_forward_with_fused_tail(dev, case):

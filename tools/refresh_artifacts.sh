@@ -14,6 +14,7 @@ for b in 64 32 16; do GRAPH=1 bash tools/prof_workload.sh ddpm32 ${R}_bench_b$b 
 for w in ddpm64 wgan_gp64 vqvae vqvae_ema; do GRAPH=1 bash tools/prof_workload.sh $w ${R}_bench_$w > /dev/null; done
 bash tools/prof_launches.sh ddpm32 ${R}_b128 > /dev/null
 bash tools/prof_launches.sh ddpm32 ${R}_b16 --batch 16 > /dev/null
+bash tools/prof_launches.sh vqvae ${R}_vqvae > /dev/null
 echo "kernel traces done"
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $c | cut -d' ' -f1)
