@@ -183,15 +183,17 @@ def _conv_linear(self, x, out=None):
     return y
 
 
-def _conv_dgrad(self, gy, in_shape, gx=None, accumulate=False):
-    """W^T * gy (input gradient only, no parameter gradients)."""
+def _conv_dgrad(self, gy, in_shape, gx=None, accumulate=False, mask=None, mask_slope=0.0):
+    """W^T * gy (input gradient only, no parameter gradients).  ``mask``: as Conv2d.bwd - the derivative of the
+    activation that produced this layer's input, applied in the epilogue."""
     B, H, W, _ = in_shape
     g = self.geom(B, H, W)
     fp = _flat(self.weight)
     if gx is None:
         gx = ops.new(tuple(in_shape), gy)
         accumulate = False
-    ops.conv_yx(g, gy, fp.ptr(self.weight), None, gx if accumulate else None, gx)
+    ops.conv_yx(g, gy, fp.ptr(self.weight), None, gx if accumulate else None, gx,
+                post=ops.make_post(0, 0.0, mask, mask_slope), post_mask=mask)
     return gx
 
 

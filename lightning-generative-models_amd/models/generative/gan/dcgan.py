@@ -117,9 +117,10 @@ class Generator(_Net):
                 ga = ops.new(g.shape, g)
                 ops.act_bwd(sv, None, g, ga, False, ops.ACT_TANH)        # sv = pre-activation here
             else:
-                ops.act_bwd(hn, None, g, g, False, ops.ACT_RELU)
-                ga, _ = blk[1].apply_T(sv, g, gc)
-            g = blk[0].bwd(gc, h_in, ga, need_gx=(i > 0))
+                ga, _ = blk[1].apply_T(sv, g, gc)                        # g arrives with relu'(hn) applied (below)
+            # the ReLU in front of this layer's input (h_in = the previous block's output): its backward mask rides in
+            # the input gradient's epilogue
+            g = blk[0].bwd(gc, h_in, ga, need_gx=(i > 0), mask=(h_in if i > 0 else None))
         self._flat.bind_grad_views()
 
     def forward(self, z: torch.Tensor) -> torch.Tensor:
@@ -202,17 +203,14 @@ class Discriminator(_Net):
             blk = self.model[i]
             ci, co, k, s, p, bn, final = self.spec[i]
             h_in, a, sv, hn = tape[i]
-            if not final:
-                gn = ops.new(g.shape, g)
-                ops.act_bwd(hn, None, g, gn, False, ops.ACT_LRELU, SLOPE)
-            else:
-                gn = g
+            gn = g          # below the head g arrives with lrelu'(hn) applied: the mask rides in the producer's epilogue
             ga = blk[1].apply_T(sv, gn, gc)[0] if bn else gn
             last = i == 0
+            mk = None if last else h_in                  # h_in = the previous block's LeakyReLU output
             if gc is not None:
-                g = blk[0].bwd(gc, h_in, ga, need_gx=(not last) or need_gx)
+                g = blk[0].bwd(gc, h_in, ga, need_gx=(not last) or need_gx, mask=mk, mask_slope=SLOPE)
             else:
-                g = blk[0].dgrad(ga, h_in.shape) if ((not last) or need_gx) else None
+                g = blk[0].dgrad(ga, h_in.shape, mask=mk, mask_slope=SLOPE) if ((not last) or need_gx) else None
         return g
 
     # ---- engine: gradient penalty with its second-order backward (wgan.py:117-156) ---------------
@@ -232,18 +230,14 @@ class Discriminator(_Net):
             blk = self.model[i]
             ci, co, k, s, p, bn, final = self.spec[i]
             h_in, a, sv, hn = tape[i]
-            if not final:
-                gn = ops.new(g.shape, g)
-                ops.act_bwd(hn, None, g, gn, False, ops.ACT_LRELU, SLOPE)
-            else:
-                gn = g
+            gn = g          # already multiplied by lrelu'(hn) in the epilogue of the layer above
             mvec = None
             if bn:
                 ga, mvec = blk[1].apply_T(sv, gn, None, want_m=True)
             else:
                 ga = gn
             first[i] = (gn, ga, mvec)
-            g = blk[0].dgrad(ga, h_in.shape)
+            g = blk[0].dgrad(ga, h_in.shape, mask=(h_in if i > 0 else None), mask_slope=SLOPE)
         Bx, H, W, Cp = x4.shape
         pen = ops.new((1,), x4)
         ws = ops.workspace(L.lgm_gp_penalty_workspace(Bx * H * W), x4.device)
@@ -297,9 +291,8 @@ class Discriminator(_Net):
             n_bar = None
             if i < n - 1 and a_bar is not None:
                 nxt = self.model[i + 1]
-                h_bar = nxt[0].dgrad(a_bar, hn.shape)    # a_{i+1} = W_{i+1} h_i
+                h_bar = nxt[0].dgrad(a_bar, hn.shape, mask=hn, mask_slope=SLOPE)    # a_{i+1} = W_{i+1} h_i, h_i = lrelu(n_i)
                 nxt[0].wgrad(gc, a_bar, hn)
-                ops.act_bwd(hn, None, h_bar, h_bar, False, ops.ACT_LRELU, SLOPE)
                 n_bar = h_bar
             if bn:
                 cur = a_extra[i]
