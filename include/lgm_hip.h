@@ -475,6 +475,15 @@ int lgm_tanh_mse_fwd(const float* pre, const float* target, int64_t pitch, int B
                      float* per_sample, void* stream);
 int lgm_tanh_mse_bwd(const float* xh, const float* target, int64_t pitch, const float* gloss, float w_recon, float w_vq,
                      int B, int C, int HW, int Cpad, float* gpre, float* g2, void* stream);
+
+/* The VQ-VAE's ResidualStack forward in ONE launch (models/modules/residual.py:5-43; vqvae.py:45-47, :71-73): per layer
+ * y = relu(conv3x3(cur)), cur' = relu(conv1x1(y) + cur).  x [B,H,W,Cin] arrives with the first in-place ReLU applied;
+ * w3[l] [Rh][9][Cin], w1[l] [hidden][1][Rh] (the flat parameter layouts, no bias); y[l] [B,H,W,Rh] and z[l]
+ * [B,H,W,hidden] (contiguous) receive every layer's two activations (the backward pass reads them).  Built for 4 x 4
+ * maps, Cin = hidden = 128, Rh = 32, <= 4 layers (lgm_resstack_fwd_supported). */
+int64_t lgm_resstack_fwd_supported(int H, int W, int Cin, int hidden, int Rh, int layers);
+int lgm_resstack_fwd(const float* x, int64_t x_pitch, int B, int H, int W, int Cin, int hidden, int Rh, int layers,
+                     const float* const* w3, const float* const* w1, float* const* y, float* const* z, void* stream);
 int lgm_scale_pair(const float* g, float w0, float w1, float* out2, void* stream);
 
 /* ---------------------------------------------------------------------------------------

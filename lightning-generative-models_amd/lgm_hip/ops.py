@@ -599,6 +599,25 @@ def colsum(a, out_ptr: int, beta: float, defer=None):
     L.lgm_colsum(a.data_ptr(), pitch(a), r, c, out_ptr, beta, ws.data_ptr(), stream())
 
 
+RESSTACK_FUSED = _os.environ.get("LGM_NO_RESSTACK_FUSED") is None     # A/B switch: the VQ-VAE ResidualStack forward in one launch
+
+
+def resstack_fwd(x, w3_ptrs, w1_ptrs, R: int):
+    """The whole ResidualStack forward in one launch (lgm_resstack_fwd): returns ([y_l], [z_l]) or None when the
+    geometry is not the one the kernel is built for."""
+    B, H, W, C = x.shape
+    n = len(w3_ptrs)
+    if not RESSTACK_FUSED or not lib().lgm_resstack_fwd_supported(H, W, C, C, R, n) or x.data_ptr() % 16 or pitch(x) % 4 \
+            or any(v % 16 for v in list(w3_ptrs) + list(w1_ptrs)):
+        return None
+    ys = [new((B, H, W, R), x) for _ in range(n)]
+    zs = [new((B, H, W, C), x) for _ in range(n)]
+    arr = ctypes.c_void_p * n
+    lib().lgm_resstack_fwd(x.data_ptr(), pitch(x), B, H, W, C, C, R, n, arr(*w3_ptrs), arr(*w1_ptrs),
+                           arr(*[t.data_ptr() for t in ys]), arr(*[t.data_ptr() for t in zs]), stream())
+    return ys, zs
+
+
 # ----------------------------------------------------------------------------------------
 # norms
 # ----------------------------------------------------------------------------------------

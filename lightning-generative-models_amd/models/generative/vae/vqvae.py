@@ -43,6 +43,16 @@ class ResidualStack(nn.Module):
         that produced it; every ReLU in here rides in a convolution epilogue too (lgm_conv_xy_post):
         y = relu(conv3x3(cur)), cur' = relu(conv1x1(y) + cur) - the next block's in-place ReLU, or the stack's final one."""
         tape = []
+        c3 = self.layers[0].block[1]
+        if c3.weight.shape[1] == cur.shape[-1] and c3.weight.shape[1] == self.layers[0].block[3].weight.shape[0]:
+            fp = c3.weight._lgm_flat
+            r = ops.resstack_fwd(cur, [fp.ptr(b.block[1].weight) for b in self.layers],
+                                 [fp.ptr(b.block[3].weight) for b in self.layers], c3.weight.shape[0])
+            if r is not None:                     # the whole stack in one launch (4 x 4 maps of the 32 x 32 configuration)
+                for y, z in zip(*r):
+                    tape.append((cur, y))
+                    cur = z
+                return cur, (tape, cur)
         for blk in self.layers:
             y = blk.block[1].fwd(cur, act=ops.ACT_RELU)
             z = blk.block[3].fwd(y, res=cur, act=ops.ACT_RELU)

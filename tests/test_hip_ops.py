@@ -677,3 +677,30 @@ def test_generic_backward_pair_equals_separate_calls(dev, case, variant):
     assert rel(nchw(gx, ci), ref) < 1e-5
     gw_oihw = gw[:co, :, :ci].reshape(co, k, k, ci).permute(0, 3, 1, 2)          # physical [N][T][C] -> OIHW
     assert rel(gw_oihw, torch.nn.grad.conv2d_weight(x, w.shape, gy, padding=k // 2)) < 1e-5
+
+
+@pytest.mark.parametrize("B,layers", [(5, 2), (256, 2), (2, 4)])
+def test_vqvae_residual_stack_forward_in_one_launch(dev, B, layers):
+    """lgm_resstack_fwd against the reference arithmetic (residual.py:5-43): per layer y = relu(conv3x3(cur)),
+    cur' = relu(conv1x1(y) + cur), with cur = relu(x) on entry."""
+    from lgm_hip import ops
+    C, R, H, W = 128, 32, 4, 4
+    g = torch.Generator().manual_seed(B + layers)
+    x = torch.relu(torch.randn(B, C, H, W, generator=g))
+    w3 = [torch.randn(R, C, 3, 3, generator=g) / math.sqrt(9 * C) for _ in range(layers)]
+    w1 = [torch.randn(C, R, 1, 1, generator=g) / math.sqrt(R) for _ in range(layers)]
+    cur = x.double()
+    ys, zs = [], []
+    for a, b in zip(w3, w1):
+        y = torch.relu(F.conv2d(cur, a.double(), padding=1))
+        cur = torch.relu(F.conv2d(y, b.double()) + cur)
+        ys.append(y)
+        zs.append(cur)
+    xd = nhwc(x, dev, extra=4)
+    w3d = [a.permute(0, 2, 3, 1).reshape(R, 9, C).contiguous().to(dev) for a in w3]       # [Np][taps][Cp]
+    w1d = [b.reshape(C, R).contiguous().to(dev) for b in w1]
+    r = ops.resstack_fwd(xd, [t.data_ptr() for t in w3d], [t.data_ptr() for t in w1d], R)
+    assert r is not None
+    for l in range(layers):
+        assert rel(nchw(r[0][l]), ys[l]) < 2e-5, l
+        assert rel(nchw(r[1][l]), zs[l]) < 2e-5, l
