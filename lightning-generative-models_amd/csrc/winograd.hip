@@ -160,8 +160,12 @@ struct Geo {
   // ds_read_b128 group (two tile rows of 8 tiles) hit all 64 banks; 2 * PWh = 4 (mod 16) does it for the
   // 4 x 4-tile images of the 8 x 8 maps (four tile rows of 4 tiles)
   static constexpr int PWh = G == 8 ? 12 : G == 4 ? 10 : 3;
+  // positions per image of a plane.  G == 2 (16 images of 2 x 2 tiles): the 16 lanes one ds_read_b128 services together
+  // are 4 images x 4 tiles at position offsets {0, 1, 6, 7} + image stride; 18 positions per image put two of the four
+  // images on the same banks (conflict share 0.50, SQ_LDS_BANK_CONFLICT), 20 = 4 (mod 16) puts all 16 on different ones
+  static constexpr int IMGS = PH * PWh + (G == 2 ? 2 : 0);
   static constexpr int NP = NI * PH * PWr;
-  static constexpr int RPLANE = NI * PH * PWh * 4 + 16;
+  static constexpr int RPLANE = NI * IMGS * 4 + 16;
   static constexpr int NJ = (2 * NP + 255) / 256;
 };
 
@@ -172,7 +176,7 @@ template <int G, bool DBG, int EXP = 0>
 __device__ __forceinline__ void wino_conv_body(const Args& p, const int bidx, const int nblk) {
   using GE = Geo<G>;
   constexpr int TTW = GE::TTW, TTH = GE::TTH, NI = GE::NI, lgTTW = GE::lgTTW, lgTT = GE::lgTT, PH = GE::PH,
-                PWr = GE::PWr, PWh = GE::PWh, NP = GE::NP, RPLANE = GE::RPLANE, NJ = GE::NJ;
+                PWr = GE::PWr, PWh = GE::PWh, NP = GE::NP, RPLANE = GE::RPLANE, NJ = GE::NJ, IMGS = GE::IMGS;
   extern __shared__ __align__(16) float smem[];
   int nstamp = 0;
   auto stamp = [&]() {
@@ -271,14 +275,14 @@ __device__ __forceinline__ void wino_conv_body(const Args& p, const int bidx, co
     const int pos = s >> 1, q = s & 1;
     // a slot that does not exist fetches "nothing" (out-of-range offset) and commits it to the pad floats
     // at the end of a plane: no predication anywhere in the phase body
-    unsigned d = 0, f = 16u, l = (unsigned)(q * 2 * RPLANE + NI * PH * PWh * 4);
+    unsigned d = 0, f = 16u, l = (unsigned)(q * 2 * RPLANE + NI * IMGS * 4);
     if (pos < NP) {
       const int img = pos / (PH * PWr);
       const int rem = pos - img * (PH * PWr);
       const int py = rem / PWr, px = rem - py * PWr;
       d = (unsigned)(((img * p.H + py) * p.W + px) * (int)p.a_pitch + q * 4) * 4u;
       f = (py == 0 ? 1u : 0u) | (py == PH - 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == PWr - 1 ? 8u : 0u);
-      l = (unsigned)((q * 2 + (px & 1)) * RPLANE + ((img * PH + py) * PWh + (px >> 1)) * 4);
+      l = (unsigned)((q * 2 + (px & 1)) * RPLANE + (img * IMGS + py * PWh + (px >> 1)) * 4);
     }
     pdelta[j] = d;
     plds[j] = l;
@@ -368,7 +372,7 @@ __device__ __forceinline__ void wino_conv_body(const Args& p, const int bidx, co
     const int t = wtb * 32 + tile_of_lane(lr);
     const int img = t >> lgTT, rr = t & ((1 << lgTT) - 1);
     const int ty = rr >> lgTTW, tx = rr & (TTW - 1);
-    trd = lh * 2 * RPLANE + ((img * PH + 2 * ty) * PWh + tx) * 4;
+    trd = lh * 2 * RPLANE + (img * IMGS + 2 * ty * PWh + tx) * 4;
   }
   auto rd = [&](const float* rbuf, int r, int c) -> f32x4 {
     if (EXP & 2) return f32x4{1.f, 2.f, (float)r, (float)c};
