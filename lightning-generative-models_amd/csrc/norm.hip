@@ -16,6 +16,17 @@ __device__ __forceinline__ float silu_grad(float z) {
   return s * (1.f + z * (1.f - s));
 }
 
+// Blocks narrower than a 128-byte row (CB < 32 channels) share every cache line of x with their 32 / CB - 1 siblings.
+// Consecutive block ids go to different XCDs, i.e. different L2s: every line was fetched from memory once per sibling
+// (64 x 64 maps, B = 64: 268 MB instead of 134 MB per two-pass statistics launch, 44 us).  This map puts the siblings on
+// consecutive slots of ONE XCD (block id = xcd + 8 slot), where the second reader hits the line the first one fetched.
+__device__ __forceinline__ int gn_sibling_map(int bid, int total, int CB) {
+  const int shr = 32 / CB;
+  if (shr < 2 || total % (8 * shr)) return bid;
+  const int xcd = bid & 7, slot = bid >> 3;
+  return ((slot / shr) * 8 + xcd) * shr + slot % shr;
+}
+
 // ---------------------------------------------------------------------------------------
 // GN statistics: one block per (image, channel block of CB channels); two in-kernel passes
 // (mean, then centred second moment) so the variance does not suffer cancellation.
@@ -31,7 +42,8 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ 
   __shared__ float chs[256];
   __shared__ float gmean[64], grstd[64];
   const int nb = C / CB;
-  const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
+  const int bid = gn_sibling_map((int)blockIdx.x, (int)gridDim.x, CB);
+  const int b = bid / nb, cb = bid % nb;
   const int c0 = cb * CB;
   const int Cg = C / G;
   const int tq = CB / 4;              // threads per pixel
@@ -77,6 +89,14 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ 
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (active) {
     int p = pl;
+    // large maps (64 x 64: 16 pixels per thread and pass): eight independent 16-byte loads in flight - with four, a block
+    // of 1024 threads streamed its 256 KB slice at 3.2 TB/s chip-wide (two dependent round trips per pass more)
+    for (; p + 7 * ppb < HW; p += 8 * ppb) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(xb + (long)(p + u * ppb) * pitch);
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
     for (; p + 3 * ppb < HW; p += 4 * ppb) {     // four independent loads in flight
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long)p * pitch);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + (long)(p + ppb) * pitch);
@@ -94,6 +114,12 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ 
   f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
   if (active) {
     int p = pl;
+    for (; p + 7 * ppb < HW; p += 8 * ppb) {
+      f32x4 d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d[u] = *reinterpret_cast<const f32x4*>(xb + (long)(p + u * ppb) * pitch) - mu;
+      s2 += ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) + ((d[4] * d[4] + d[5] * d[5]) + (d[6] * d[6] + d[7] * d[7]));
+    }
     for (; p + 3 * ppb < HW; p += 4 * ppb) {
       const f32x4 d0 = *reinterpret_cast<const f32x4*>(xb + (long)p * pitch) - mu;
       const f32x4 d1 = *reinterpret_cast<const f32x4*>(xb + (long)(p + ppb) * pitch) - mu;
@@ -175,7 +201,8 @@ __global__ __launch_bounds__(NT) void gn_fused_fwd_kernel(const float* __restric
   __shared__ float gmean[64], grstd[64];
   __shared__ __align__(16) float cA[256], cB[256];
   const int nb = C / CB;
-  const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
+  const int bid = gn_sibling_map((int)blockIdx.x, (int)gridDim.x, CB);
+  const int b = bid / nb, cb = bid % nb;
   const int c0 = cb * CB;
   const int Cg = C / G;
   const int tq = CB / 4;              // threads per pixel
@@ -340,7 +367,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const float* __restri
                                                             float* __restrict__ Rc) {
   __shared__ float sh[NT * 8];
   const int nb = C / CB;
-  const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
+  const int bid = gn_sibling_map((int)blockIdx.x, (int)gridDim.x, CB);
+  const int b = bid / nb, cb = bid % nb;
   const int c0 = cb * CB;
   const int Cg = C / G;
   const int tq = CB / 4, ppb = NT / tq;
@@ -359,8 +387,27 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const float* __restri
     rs[k] = rstd[b * G + (c + k) / Cg];
   }
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-  if (active)
-    for (int p = pl; p < HW; p += ppb) {
+  if (active) {
+    int p = pl;
+    for (; p + 3 * ppb < HW; p += 4 * ppb) {       // four pixels = eight independent 16-byte loads in flight
+      f32x4 xv[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = *reinterpret_cast<const f32x4*>(xb + (long)(p + u * ppb) * x_pitch);
+        g[u] = *reinterpret_cast<const f32x4*>(gb + (long)(p + u * ppb) * gy_pitch);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (act) {
+          const f32x4 z = xv[u] * a + bc;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g[u][k] *= silu_grad(z[k]);
+        }
+        s1 += g[u];
+        s2 += g[u] * ((xv[u] - mu) * rs);
+      }
+    }
+    for (; p < HW; p += ppb) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)p * x_pitch);
       f32x4 g = *reinterpret_cast<const f32x4*>(gb + (long)p * gy_pitch);
       if (act) {
@@ -371,6 +418,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const float* __restri
       s1 += g;
       s2 += g * ((xv - mu) * rs);
     }
+  }
   *reinterpret_cast<f32x4*>(&sh[tid * 8]) = s1;
   *reinterpret_cast<f32x4*>(&sh[tid * 8 + 4]) = s2;
   __syncthreads();
@@ -530,7 +578,8 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
   __shared__ float wa1[256], wa2[256];
   __shared__ __align__(16) float cP[256], cQ[256], cR[256];
   const int nb = C / CB;
-  const int b = blockIdx.x / nb, cb = blockIdx.x % nb;
+  const int bid = gn_sibling_map((int)blockIdx.x, (int)gridDim.x, CB);
+  const int b = bid / nb, cb = bid % nb;
   const int c0 = cb * CB;
   const int Cg = C / G;
   const int tq = CB / 4, ppb = NT / tq;     // HW == NV * ppb (checked by the host)
