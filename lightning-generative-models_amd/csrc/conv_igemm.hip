@@ -80,6 +80,16 @@ constexpr int LDA = BK + 4;  // floats; 16B-aligned rows, conflict-free b128 rea
 
 enum { MODE_XY = 0, MODE_YX = 1 };
 
+__device__ __forceinline__ int lgm_xcd_swizzle(int bid, int nb) {
+  return (nb % 8 == 0) ? (bid % 8) * (nb / 8) + bid / 8 : bid;
+}
+// opt-in (LGM_XCD_SWZ=1): measured 0.3 % SLOWER on the WGAN-GP and DDPM steps - the N-siblings' A tiles are served by the
+// Infinity Cache already, and the contiguous ranges cost some balance at the tail
+static int swz_on() {
+  static const int on = getenv("LGM_XCD_SWZ") != nullptr;
+  return on;
+}
+
 struct IgemmArgs {
   const float* a;     // gathered activations (X for XY, Y for YX)
   const float* w;     // [Nw][T][Cw]
@@ -99,6 +109,7 @@ struct IgemmArgs {
   // the products multiplied by zero.  phases = s*s (or 1 = off); then M, K, tiles_m describe ONE class.
   int phases, KHs, KWs;
   int wide;           // output / residual / bias are 16-byte aligned with pitches % 4 == 0 (wide epilogue allowed)
+  int swz;            // stand-alone launches: XCD-aware block order (igemm_kernel)
   // BatchNorm statistics of the OUTPUT folded into the epilogue (full tiles, no bias / residual / split-K): every
   // workgroup adds, per output column, the sum of its BM rows and their squared deviations from the tile's own mean
   // to stats[row tile][3][N] = (sum, M2, BM) - exactly what bn_stats_stage1 writes, so lgm_bn_stats_from_tiles
@@ -573,7 +584,10 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, const int bidx) {
 
 template <int MODE, int BM, int BN, int TM, int TN, bool UNI>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
-  igemm_body<MODE, BM, BN, TM, TN, UNI>(p, (int)blockIdx.x);
+  // "consecutive blocks walk N first (share the A tile through L2)" holds per XCD only: hardware deals consecutive block
+  // ids out to the 8 XCDs round-robin, each with its own L2.  With the swizzle XCD x runs the CONTIGUOUS logical range
+  // [x nb / 8, (x + 1) nb / 8): the N-siblings of a row tile (and the splits of a tile) meet in one L2.
+  igemm_body<MODE, BM, BN, TM, TN, UNI>(p, p.swz ? lgm_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);
 }
 
 // ---- backward pair of the generic layers (1x1 convolutions, linears): lgm_conv_bwd_pair ---------------------------------
@@ -619,6 +633,7 @@ int launch_igemm_t(IgemmArgs& a, hipStream_t s) {
     t_pair.rec_i = true;
     return LGM_OK;
   }
+  a.swz = swz_on();
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits * a.phases)), dim3(256), smem, s, a);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
@@ -1270,6 +1285,7 @@ struct WgradArgs {
   int B, H, W, Cw, Ho, Wo, Nw, KH, KW, stride, pad;
   int P, Q;        // pixels, T*Cw
   int tiles_m, tiles_n, splits, chunk;  // chunk = pixels per split (multiple of WBK)
+  int swz;         // stand-alone launches: XCD-aware block order (wgrad_kernel)
   int lWo, lHo, lW, lH;                 // FAST: log2 of the (power-of-two) map sizes
 };
 
@@ -1496,7 +1512,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bidx) {
 
 template <int BM, int BN, int TM, int TN, bool FAST>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
-  wgrad_body<BM, BN, TM, TN, FAST>(p, (int)blockIdx.x);
+  wgrad_body<BM, BN, TM, TN, FAST>(p, p.swz ? lgm_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);
 }
 
 // Input gradient (blocks [0, n_ig): the 64 x 64 uniform-tap implicit GEMM) and weight gradient (the rest: the generic
@@ -1663,6 +1679,7 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
     lgm_note_kernel(big ? "wgrad_kernel<128, 64, 2, 1, true>"
                         : fast ? "wgrad_kernel<64, 64, 1, 1, true>" : "wgrad_kernel<64, 64, 1, 1, false>");
     static_assert(sizeof(WgradArgs) <= sizeof(t_pair.wg), "PairCtx::wg too small");
+    a.swz = swz_on();
     if (!big && fast && t_pair.active && !t_pair.rec_w) {       // launched by lgm_conv_bwd_pair, with the input gradient
       memcpy(t_pair.wg, &a, sizeof(WgradArgs));
       t_pair.wg_blocks = (unsigned)(a.tiles_m * a.tiles_n * a.splits);

@@ -608,8 +608,21 @@ __global__ __launch_bounds__(256, NCI == 2 ? 3 : NCI == 4 ? 2 : 1) void rms_qkv_
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int slice = blockIdx.y;
-  const int it0 = blockIdx.x * p.per, it1 = min(p.items, it0 + p.per);
+  // the three slices of an item range read the same rows of x: on consecutive slots of ONE XCD (block id = xcd + 8 slot),
+  // so that the second and third reader find them in that XCD's L2 (consecutive ids sit on different XCDs)
+  int blk, slice;
+  {
+    const int nblk = (int)gridDim.x / 3, bid = (int)blockIdx.x;
+    if (nblk % 8 == 0) {
+      const int xcd = bid & 7, slot = bid >> 3;
+      blk = (slot / 3) * 8 + xcd;
+      slice = slot % 3;
+    } else {
+      blk = bid / 3;
+      slice = bid % 3;
+    }
+  }
+  const int it0 = blk * p.per, it1 = min(p.items, it0 + p.per);
   if (it0 >= it1) return;
   const float sqrtc = sqrtf((float)CI);
   f32x4 xr[NCI * 4];
@@ -689,7 +702,7 @@ int launch_qkv(const QArgs& a, int blocks, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL(rms_qkv_fused_kernel<NCI>, dim3(blocks, 3), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(rms_qkv_fused_kernel<NCI>, dim3(blocks * 3), dim3(256), smem, s, a);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
