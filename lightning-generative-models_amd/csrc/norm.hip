@@ -795,7 +795,9 @@ static GnPlan gn_plan(int B, int HW, int C, int G, bool bwd) {
   const int Cg = C / G;
   int cb = gn_cb(C, G);
   static const bool wide_only = getenv("LGM_GN_WIDE") != nullptr;   // A/B switch: never narrow the blocks
-  static const int min_cb = getenv("LGM_GN_MINCB") ? atoi(getenv("LGM_GN_MINCB")) : 16;   // tuning knob
+  // tuning knob.  8-channel (one group, 32-byte row) blocks were 2 % slower at B = 32 while their siblings sat in
+  // different L2s; with gn_sibling_map they are 0.3 % faster at B = 16 / 32 and neutral at B = 64
+  static const int min_cb = getenv("LGM_GN_MINCB") ? atoi(getenv("LGM_GN_MINCB")) : 8;
   if (!wide_only)
     while ((long)B * (C / cb) < 256 && cb > Cg && cb / 2 >= min_cb && (cb / 2) % Cg == 0 && (cb / 2) % 4 == 0) cb /= 2;
   GnPlan p = gn_plan_cb(HW, cb, bwd);
