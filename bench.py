@@ -3,6 +3,10 @@
     python bench.py --gpus N --steps K --warmup W [--workload ddpm32|ddpm64|wgan_gp64|vqvae] [--only]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Without a launcher in the environment ``--gpus N`` (N > 1) makes this process the parent of N ranks (lgm_hip/launch.py:
+one torch.distributed.run child, started before any GPU call; rank 0's line is relayed, the exit code is the ranks').
+Under a launcher WORLD_SIZE must equal --gpus; the line's n_gpus is always the number of ranks that ran.
+
 One "step" = the full optimiser step of the reference loop on a synthetic batch already
 resident in HBM.  Default workload (the headline, BASELINE config 2): DDPM.training_step (t ~ randint,
 noise ~ randn on device, q_sample, UNet fwd, weighted MSE) -> hand-written HIP backward -> gradient all-reduce
@@ -16,6 +20,7 @@ Rank 0 prints ONE JSON line.  Its top level is the headline; on one GPU (and wit
                       wgan_gp64  config 3: WGAN-GP DCGAN G/D 64x64, B = 128, n_critic = 5 (one training_step = one D or G update)
                       vqvae / vqvae_ema   config 4: VQ-VAE 32x32, K = 512, B = 256 (plain / EMA codebook)
                       ddpm64_sampling     config 5's sampling half: DDIM, 64 images 64x64, 250 steps, one graph replay per step
+                      ddpm64_sampling_1000  the same at its stated length: sample() -> 1000-step ancestral chain (p_sample_loop)
   "per_rank_proxy"  ms per step of the headline workload at the per-rank batches of 2 / 4 / 8 GPUs (64 / 32 / 16
                     images) on this one GPU: what a rank computes between its gradient exchanges under strong scaling.
 Objects of every workload:
@@ -466,11 +471,7 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
     return line
 
 
-def run_sampling(dev, steps=250, batch=64, img=64):
-    """Config 5's second half: DDIM sampling with the EMA network of a 64x64 DDPM (reference ddim_sample, ddpm.py:782-834),
-    ``batch`` images, ``steps`` sampling steps, each = one UNet forward + the fused update, replayed from ONE HIP graph per
-    step.  Random-init weights, device-side noise.  Step-level roofline: 14.594 GFLOP per image and UNet forward at 64x64
-    (SURVEY.md section 8a), against the fp32 MFMA peak (direct-convolution count) and against the Winograd-executed count."""
+def _sampling_leg(dev, kind, steps, batch, img):
     from lgm_hip import sampler
     from models.generative.diffusion.ddpm import DDPM
     torch.manual_seed(10)
@@ -480,25 +481,53 @@ def run_sampling(dev, steps=250, batch=64, img=64):
     gd = m.ema.ema_model
     gd.eval()
     shape = (batch, 3, img, img)
-    sampler.ddim_sample(gd, shape)                   # capture + one whole chain as warm-up
+    if kind == "ddim":
+        assert gd.is_ddim_sampling
+        chain = lambda: sampler.ddim_sample(gd, shape)
+        chain()                                      # capture + one whole chain as warm-up
+    else:
+        # T = 1000 sampling steps == T diffusion steps: ``sample()`` dispatches to the ancestral p_sample_loop
+        # (reference ddpm.py:836-845).  Warm-up: the capture plus a short chain on the same graph
+        # would need another schedule object, so the one warm-up here is the capture itself + 20 replays.
+        assert not gd.is_ddim_sampling and gd.num_timesteps == steps
+        chain = lambda: sampler.p_sample_loop(gd, shape)
+        sampler.warm_chain(gd, shape, replays=20)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = sampler.ddim_sample(gd, shape)
+    out = chain()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fwd_flop = {32: 3.651e9, 64: 14.594e9}[img] * batch
     wino_share = 0.879                                # share of the forward FLOPs in 3x3 layers that run as Winograd
     exe = fwd_flop * (1.0 - wino_share * (1.0 - 1.0 / WINO_FACTOR))
     per = dt / steps
-    return {"metric": f"DDIM sampling, {batch} images {img}x{img}, {steps} steps (UNet forward + update per step, one HIP "
+    name = "DDIM" if kind == "ddim" else "ancestral (p_sample_loop)"
+    return {"metric": f"{name} sampling, {batch} images {img}x{img}, {steps} steps (UNet forward + update per step, one HIP "
                       "graph replay each)", "value": round(batch * steps / dt, 1), "unit": "image-steps/s",
             "ms_per_step": round(per * 1e3, 3), "seconds_per_chain": round(dt, 3), "finite": bool(torch.isfinite(out).all()),
-            "dtype": "f32", "config": {"workload": "configs/diffusion/ddpm_64.json EMA network, ddim_sample, eta = 0",
+            "dtype": "f32", "config": {"workload": "configs/diffusion/ddpm_64.json EMA network, "
+                                       + ("ddim_sample, eta = 0" if kind == "ddim" else "sample() -> p_sample_loop, T = 1000"),
                                        "batch": batch, "steps": steps},
             "roofline": {"bound": "mfma", "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "step_algorithmic_frac_of_peak": round(fwd_flop / per / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                          "step_executed_frac_of_peak": round(exe / per / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                          "flop_per_step": round(fwd_flop)}}
+
+
+def run_sampling(dev, steps=250, batch=64, img=64):
+    """Config 5's second half, DDIM form: sampling with the EMA network of a 64x64 DDPM (reference ddim_sample,
+    ddpm.py:782-834), ``batch`` images, ``steps`` sampling steps, each = one UNet forward + the fused update, replayed from ONE
+    HIP graph per step.  Random-init weights, device-side noise.  Step-level roofline: 14.594 GFLOP per image and UNet
+    forward at 64x64, against the fp32 MFMA peak (direct-convolution count) and against the
+    Winograd-executed count."""
+    return _sampling_leg(dev, "ddim", steps, batch, img)
+
+
+def run_sampling_ancestral(dev, steps=1000, batch=64, img=64):
+    """Config 5's sampling half AT ITS STATED LENGTH: the 1000-step chain ``sample()`` runs when sampling_timesteps ==
+    timesteps (reference ddpm.py:759-780, 836-845): 64 images 64x64, 1000 x (UNet forward + posterior step with fresh
+    noise), one graph replay per step, no host synchronisation inside the chain."""
+    return _sampling_leg(dev, "ancestral", steps, batch, img)
 
 
 def _release():
@@ -528,10 +557,26 @@ def main():
     if args.vq_ema and args.workload == "vqvae":
         args.workload = "vqvae_ema"
 
+    from lgm_hip import launch
+    if not launch.launched():
+        if args.gpus > 1:
+            # no launcher in the environment: this process becomes the PARENT of --gpus ranks (what the reference's
+            # Trainer does for ``python train.py`` on a multi-GPU node).  Nothing above touched the GPU; the children
+            # are started as a child process, rank 0's JSON line goes straight to our stdout, their exit code is ours.
+            backend = os.environ.get("LGM_DIST_BACKEND", "nccl")
+            ndev = launch.visible_gpu_count()
+            if backend == "nccl" and ndev < args.gpus:
+                print(f"[bench] --gpus {args.gpus} but {ndev} GPU(s) are visible (LGM_DIST_BACKEND=gloo rehearses the "
+                      "N>1 path with several ranks on one GPU)", file=sys.stderr, flush=True)
+                sys.exit(2)
+            sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "--gpus must equal WORLD_SIZE under torch.distributed.run"
+    if world != args.gpus:
+        # --gpus N must never report another rank count: the driver computes scaling from n_gpus
+        print(f"[bench] --gpus {args.gpus} but the launcher set WORLD_SIZE={world}", file=sys.stderr, flush=True)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     ndev = torch.cuda.device_count()
     backend = os.environ.get("LGM_DIST_BACKEND", "nccl")     # "gloo": rehearse the N>1 path on one GPU
@@ -565,40 +610,64 @@ def main():
 
     single = world == 1 and not args.only and args.workload == "ddpm32" and args.batch is None
     line = run_workload(args.workload, args, dev, world, rank, args.steps, args.warmup, batch=args.batch)
+    rc = 0
     if single and rank == 0:
+        # The headline exists now: put it on record (stderr + gpurun_out/) BEFORE any secondary leg runs, so that a hard
+        # fault, abort or hang in one of them cannot lose it; stdout still gets exactly ONE line, at the end.
+        print("[bench] headline: " + json.dumps(line), file=sys.stderr, flush=True)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_headline.json"), "w") as f:
+                f.write(json.dumps(line) + "\n")
+        except OSError:
+            pass
+        from lgm_hip.lightning import is_device_error
+        faulted = None          # name of the leg after which the GPU must not be used any more
+
+        def leg(name, fn):
+            """A secondary leg never takes the headline down with it.  A Python-level error is recorded and the next leg
+            runs; a DEVICE error (hipError from the library, torch.AcceleratorError, RCCL) ends all GPU work of this
+            process: the remaining legs are recorded as skipped and the run exits non-zero after printing its line."""
+            nonlocal faulted
+            if faulted is not None:
+                return {"skipped": f"device error in leg '{faulted}'"}
+            try:
+                _release()
+                return fn()
+            except Exception as e:
+                print(f"[bench] leg {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                if is_device_error(e):
+                    faulted = name
+                return {"error": f"{type(e).__name__}: {e}", "device_error": bool(is_device_error(e))}
+
         # ---- BASELINE's secondary configs, each measured the same way, then the per-rank batches of the
         # strong-scaled headline on this one GPU
         sec = {}
         for wl, st, wu in (("ddpm64", 15, 3), ("wgan_gp64", 60, 12), ("vqvae", 100, 10), ("vqvae_ema", 100, 10)):
-            _release()
-            try:
+            def run(wl=wl, st=st, wu=wu):
                 r = run_workload(wl, args, dev, 1, 0, st, wu)
-                sec[wl] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
-                                             "roofline", "cpu_baseline") if k in r}
-            except Exception as e:      # a secondary leg must never take the headline line down with it
-                sec[wl] = {"error": f"{type(e).__name__}: {e}"}
-                print(f"[bench] secondary workload {wl} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-        _release()
-        try:
-            sec["ddpm64_sampling"] = run_sampling(dev)
-        except Exception as e:
-            sec["ddpm64_sampling"] = {"error": f"{type(e).__name__}: {e}"}
-            print(f"[bench] sampling leg failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                return {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
+                                          "roofline", "cpu_baseline") if k in r}
+            sec[wl] = leg(wl, run)
+        sec["ddpm64_sampling"] = leg("ddpm64_sampling", lambda: run_sampling(dev))
+        sec["ddpm64_sampling_1000"] = leg("ddpm64_sampling_1000", lambda: run_sampling_ancestral(dev))
         line["secondary"] = sec
         proxy = {}
         for b in (64, 32, 16):
-            _release()
-            try:
-                r = run_workload("ddpm32", args, dev, 1, 0, 20, 5, batch=b, roofline=False, cpu=False)
-                proxy[f"b{b}"] = r["ms_per_step"]
-            except Exception as e:
-                proxy[f"b{b}"] = None
-                print(f"[bench] per-rank proxy B={b} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            r = leg(f"proxy_b{b}", lambda b=b: run_workload("ddpm32", args, dev, 1, 0, 20, 5, batch=b, roofline=False,
+                                                             cpu=False))
+            proxy[f"b{b}"] = r.get("ms_per_step") if isinstance(r, dict) else None
         proxy["note"] = ("ms per step of the headline workload on ONE GPU at the per-rank batch of 2 / 4 / 8 GPUs "
                          "(global batch 128): compute between the gradient exchanges under strong scaling")
         line["per_rank_proxy"] = proxy
+        if faulted is not None:
+            line["device_error_in"] = faulted
+            rc = 4
     if rank == 0:
         print(json.dumps(line), flush=True)
+    if rc != 0:
+        sys.stdout.flush()
+        os._exit(rc)             # after a device error: no destructors, no further GPU calls
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

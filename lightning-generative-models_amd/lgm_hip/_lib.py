@@ -66,7 +66,17 @@ ABI_VERSION = header_abi_version()
 
 
 class LgmError(RuntimeError):
-    pass
+    """A C-ABI entry point returned non-zero.  The convention of include/lgm_hip.h: rc < 0 = the HOST rejected the
+    call (argument / geometry / unsupported shape: nothing was launched, the device is fine), rc > 0 = a hipError_t
+    from a launch or the runtime (the device state is suspect)."""
+
+
+class LgmArgumentError(LgmError):
+    """rc < 0: rejected on the host before any launch."""
+
+
+class LgmDeviceError(LgmError):
+    """rc > 0: a hipError_t; callers must not keep using the device (no state_dict(), no further launches)."""
 
 
 class _Lib:
@@ -103,7 +113,7 @@ class _Lib:
         def call(*a):
             rc = fn(*a)
             if rc != 0:
-                raise LgmError(f"{name} failed (rc={rc}): {last_error().decode()}")
+                raise (LgmDeviceError if rc > 0 else LgmArgumentError)(f"{name} failed (rc={rc}): {last_error().decode()}")
         call.__name__ = name
         return call
 

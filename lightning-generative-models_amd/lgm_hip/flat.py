@@ -16,8 +16,13 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import weakref
+
 import torch
 from torch import nn
+
+# every FlatParams alive in this process (weak): ops.forget_dead_flats() keeps the workspaces of the live ones
+ALL_FLATS: "weakref.WeakSet" = weakref.WeakSet()
 
 
 def _r4(n: int) -> int:
@@ -74,6 +79,7 @@ class FlatParams:
         self.total = off
         self.data = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        ALL_FLATS.add(self)
         self.by_param: Dict[int, ParamSlot] = {}
         self.fresh = True        # next backward overwrites (beta = 0) instead of accumulating
         self.written = False     # a backward pass wrote this buffer since the flag was last cleared

@@ -74,7 +74,7 @@ class MiniLightningModule(nn.Module):
         self.automatic_optimization = True
         self.logged: Dict[str, Any] = {}
         self._sync_dist_names = set()
-        self._grads_prescaled = False       # True: the optimizers fold 1/world into their kernels (grad_scale)
+        self._grads_prescaled = False       # informational only: the exchange decides from the optimizers' grad_scale
         self._optimizers: List[Any] = []
         self.trainer = None
         self.logger = None
@@ -122,20 +122,52 @@ class MiniLightningModule(nn.Module):
 
     def synced_logs(self) -> Dict[str, float]:
         """Host floats of everything logged so far; names logged with ``sync_dist=True`` are averaged over the
-        ranks with one all-reduce of the stacked scalars.  Collective when world > 1: every rank must call it at
-        the same step (the trainer does, on its logging interval)."""
+        ranks that logged them.  Collective when world > 1: every rank must call it at the same step (the trainer
+        does, on its logging interval).  Shape-safe: the exchanged tensor has a fixed (sum, count) pair per REGISTERED
+        name, whether or not this rank logged it this interval, and the ranks first agree on the name list itself
+        (a hash, one tiny all-reduce): a scalar logged with ``sync_dist=True`` under a rank-dependent condition raises
+        the same error on every rank instead of hanging the job in mismatched collectives."""
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         vals = {k: v for k, v in self.logged.items() if torch.is_tensor(v) and v.numel() == 1 or isinstance(v, (int, float))}
-        names = sorted(n for n in self._sync_dist_names if n in vals)
-        out = {k: float(v) for k, v in vals.items() if k not in names}
-        if names:
-            dev = self.device
-            t = torch.stack([torch.as_tensor(vals[n], dtype=torch.float32).detach().reshape(()).to(dev) for n in names])
+        names = sorted(self._sync_dist_names)
+        out = {k: float(v) for k, v in vals.items() if k not in self._sync_dist_names}
+        if not names and world == 1:
+            return out
+        dev = self.device
+        CAP = self._SYNC_SLOTS
+        # ONE fixed-size float64 all-reduce: [h1, h1^2, h2, h2^2 | (sum, count) x CAP slots].  h1, h2 = 24-bit hashes of
+        # the name list: every rank holds the same list  <=>  world * sum(h^2) == (sum h)^2 for both (exact in float64).
+        import hashlib
+        dg = hashlib.sha256("\n".join(names).encode()).digest()
+        h1, h2 = float(int.from_bytes(dg[:3], "big")), float(int.from_bytes(dg[3:6], "big"))
+
+        def pack(sub):
+            row = []
+            for n in sub:
+                v = vals.get(n)
+                row += [float(v), 1.0] if v is not None else [0.0, 0.0]
+            return row
+        head = [h1, h1 * h1, h2, h2 * h2] + pack(names[:CAP]) + [0.0, 0.0] * max(0, CAP - len(names))
+        t = torch.tensor(head, dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t)
+        r = t.tolist()
+        if world * r[1] != r[0] * r[0] or world * r[3] != r[2] * r[2]:
+            raise RuntimeError("log(..., sync_dist=True) was called with different names on different ranks "
+                               f"(this rank: {names}); log such scalars unconditionally on every rank")
+        rest = r[4:]
+        if len(names) > CAP:                         # the lists are known to be equal now: a second, sized exchange
+            t2 = torch.tensor(pack(names[CAP:]), dtype=torch.float64, device=dev)
             if world > 1:
-                dist.all_reduce(t)
-                t = t / world
-            out.update(zip(names, t.tolist()))
+                dist.all_reduce(t2)
+            rest = rest + t2.tolist()
+        for i, n in enumerate(names):
+            sm, cnt = rest[2 * i], rest[2 * i + 1]
+            if cnt > 0:
+                out[n] = sm / cnt
         return out
+
+    _SYNC_SLOTS = 32
 
     def optimizers(self):
         if len(self._optimizers) == 1:
@@ -154,7 +186,7 @@ class MiniLightningModule(nn.Module):
             for fp in flats:
                 if fp.written:
                     dist.all_reduce(fp.grad)
-                    if not self._grads_prescaled:    # else the fused optimizer multiplies by 1/world (grad_scale)
+                    if not _prescaled(self, world):  # else the fused optimizers multiply by 1/world (grad_scale)
                         fp.grad.div_(world)
                     fp.written = False
             for p in self.parameters():
@@ -221,6 +253,22 @@ class FlatGradSync:
         return 1.0 / self.world
 
 
+def _prescaled(module, world: int) -> bool:
+    """True when the 1/world average of a SUM all-reduce is applied by the optimizers that will consume the gradients
+    (``grad_scale`` folded into the fused kernels).  Decided from the optimizers the module holds NOW, not from a
+    sticky module flag: fresh optimizers (grad_scale = 1) on a module that once trained through a prescaled path must
+    get averaged gradients, not summed ones."""
+    opts = getattr(module, "_optimizers", None) or []
+    if not opts:
+        return False
+    want = 1.0 / world
+    for o in opts:
+        gs = getattr(o, "grad_scale", None)          # _CountingOptimizer forwards to the wrapped optimizer
+        if gs is None or abs(gs - want) > 1e-12 * want:
+            return False
+    return True
+
+
 class BufferSync:
     """DDP's ``broadcast_buffers=True`` for this engine (reference: DDPStrategy, utils/lightning_utils.py:37-43 —
     torch DDP re-broadcasts rank 0's module buffers at the start of every training forward, so BatchNorm running
@@ -256,18 +304,32 @@ class BufferSync:
         self._owners = []
         if not tg:
             self.flat = None
+            self.flats = []
             return
-        dev = tg[0][2].device
-        n = sum((b.numel() + 3) // 4 * 4 for _, _, b in tg)
-        flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
+        # one flat tensor per dtype (a buffer keeps its dtype); a buffer registered in two modules stays ONE tensor
+        by_dtype: Dict[torch.dtype, list] = {}
+        seen = {}
         for mod, name, b in tg:
-            v = flat[off:off + b.numel()].view(b.shape)
-            v.copy_(b.detach().to(torch.float32))
+            if id(b) not in seen:
+                seen[id(b)] = None
+                by_dtype.setdefault(b.dtype, []).append(b)
+        self.flats = []
+        for dt, bufs in by_dtype.items():
+            dev = bufs[0].device
+            n = sum((b.numel() + 3) // 4 * 4 for b in bufs)
+            flat = torch.zeros(n, dtype=dt, device=dev)
+            off = 0
+            for b in bufs:
+                v = flat[off:off + b.numel()].view(b.shape)
+                v.copy_(b.detach())
+                seen[id(b)] = v
+                off += (b.numel() + 3) // 4 * 4
+            self.flats.append(flat)
+        for mod, name, b in tg:
+            v = seen[id(b)]
             mod._buffers[name] = v
             self._owners.append((mod, name, v.data_ptr()))
-            off += (b.numel() + 3) // 4 * 4
-        self.flat = flat
+        self.flat = self.flats[0]
 
     def still_packed(self) -> bool:
         return all(mod._buffers[name] is not None and mod._buffers[name].data_ptr() == p for mod, name, p in self._owners)
@@ -278,8 +340,32 @@ class BufferSync:
             return
         if not self.still_packed():                  # module.to() / load with assign=True replaced the tensors
             self.pack()
-        dist.broadcast(self.flat, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
-                       group=self.group)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        for flat in self.flats:                      # one collective per dtype (fp32 only in every in-repo module)
+            dist.broadcast(flat, src=src, group=self.group)
+
+
+def is_device_error(e: BaseException) -> bool:
+    """A launch / runtime / collective failure after which the GPU must not be used again (no state_dict(), no more
+    launches).  By class where the class says it: ``LgmDeviceError`` (a C-ABI call returned a hipError_t; host-side
+    argument rejections are ``LgmArgumentError`` and are NOT device errors), ``torch.AcceleratorError``,
+    ``DistBackendError``; by message only for what torch raises as a plain RuntimeError."""
+    from ._lib import LgmArgumentError, LgmDeviceError
+    if isinstance(e, LgmArgumentError):
+        return False
+    if isinstance(e, LgmDeviceError):
+        return True
+    acc = getattr(torch, "AcceleratorError", None)
+    if acc is not None and isinstance(e, acc):
+        return True
+    dbe = getattr(dist, "DistBackendError", None)
+    if dbe is not None and isinstance(e, dbe):
+        return True
+    if isinstance(e, RuntimeError):
+        msg = str(e)
+        return any(s in msg for s in ("HIP error", "hipError", "CUDA error", "NCCL", "RCCL", "device-side assert",
+                                      "an illegal memory access", "hipErrorLaunchFailure"))
+    return False
 
 
 def save_checkpoint(model, optimizers, path: str, epoch: int = 0):
@@ -329,7 +415,7 @@ class MiniTrainer:
             return
         for fp in _flat_grads_of(module):
             dist.all_reduce(fp.grad)
-            if not getattr(module, "_grads_prescaled", False):   # else 1/world is folded into the fused optimizer
+            if not _prescaled(module, self.world):   # else 1/world is folded into the fused optimizers
                 fp.grad.div_(self.world)
         # parameters that are not flat-bound (CPU plumbing models)
         for p in module.parameters():
@@ -484,8 +570,7 @@ class MiniTrainer:
             # Ctrl-C / SIGTERM-as-exception / a host-side error: keep the progress made so far.  NOT after a device
             # error: state_dict() copies from the GPU, and after a fault or a hang that can block for ever instead of
             # letting the process exit non-zero.
-            device_error = isinstance(e, (torch.AcceleratorError if hasattr(torch, "AcceleratorError") else ())) or \
-                any(s in f"{type(e).__name__}: {e}" for s in ("HIP error", "hipError", "CUDA error", "LgmError", "NCCL", "RCCL"))
+            device_error = is_device_error(e)
             if isinstance(e, (KeyboardInterrupt, SystemExit)) or not device_error:
                 try:
                     self._save_last(model, epoch)

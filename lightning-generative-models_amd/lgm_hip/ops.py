@@ -142,12 +142,25 @@ def register_b3_flat(fp):
 
 
 def forget_dead_flats():
-    """Drop the registrations of flat buffers that no longer exist and every per-weight workspace (slab buffers keyed
-    by gradient address, reducer tables).  Only safe when no live HIP graph was captured against those workspaces:
-    bench.py calls it BETWEEN workloads, after the previous workload's models and graphs are gone."""
+    """Drop the registrations of flat buffers that no longer exist and the per-weight workspaces (slab buffers keyed by
+    gradient address, reducer tables) that belonged to them.  Workspaces of flat buffers that are still ALIVE stay: a
+    captured HIP graph of a live model has their addresses baked in (deferred descriptors), so clearing them
+    unconditionally would let a replay run against freed memory.  bench.py calls this between workloads."""
+    from .flat import ALL_FLATS
     _WINO_FLATS[:] = [r for r in _WINO_FLATS if r() is not None]
-    _WGRAD_WS.clear()
-    _WGRAD_TABLES.clear()
+    live = []
+    for fp in list(ALL_FLATS):
+        g = getattr(fp, "grad", None)
+        if g is not None:
+            live.append((g.data_ptr(), g.data_ptr() + 4 * g.numel()))
+
+    def alive(addr) -> bool:
+        return isinstance(addr, int) and any(lo <= addr < hi for lo, hi in live)
+
+    for key in [k for k in _WGRAD_WS if not alive(k[0])]:
+        del _WGRAD_WS[key]
+    for key in [k for k in _WGRAD_TABLES if not any(alive(v) for row in k for v in row)]:
+        del _WGRAD_TABLES[key]
 
 
 def _b3_planes(ptr: Optional[int], transposed: bool):

@@ -256,6 +256,18 @@ def ddim_step(chain: _Chain, t: int, t_next: int, noise: Optional[torch.Tensor],
 
 
 @torch.no_grad()
+def warm_chain(gd, shape, replays: int = 20) -> bool:
+    """Capture the ancestral chain's per-step graph for (network, shape) and run ``replays`` steps of it on noise
+    (benchmarks: warm-up without paying a whole 1000-step chain).  False when graph replay is unavailable."""
+    gc = _graph_chain(gd, shape, True)
+    if gc is None:
+        return False
+    ts = list(reversed(range(gd.num_timesteps)))[:replays]
+    gc.run(_Chain(gd, shape, None).x, ts, [_p_sample_coeffs(gd, t) for t in ts], None)
+    return True
+
+
+@torch.no_grad()
 def p_sample_loop(gd, shape, return_all_timesteps=False, init_noise=None, noises: Optional[List[torch.Tensor]] = None):
     chain = _Chain(gd, shape, init_noise)
     dev = chain.x.device

@@ -3,7 +3,10 @@
     python train.py --config_path configs/diffusion/ddpm.json [--max_steps N] [--max_epochs N]
                     [--accumulate_grad_batches K] [--ckpt_path last.ckpt] [--strategy ddp|auto]
 
-One process per GPU: under ``python -m torch.distributed.run --nproc-per-node N train.py ...`` every
+One process per GPU.  Like the reference (``--strategy`` defaults to DDP when the node shows more than one
+GPU, and Lightning starts the ranks), a plain ``python train.py ...`` on a multi-GPU node becomes the parent of one rank
+per visible GPU (``--devices N`` overrides the count; ``maybe_spawn`` below, before any GPU call); under an external
+``python -m torch.distributed.run --nproc-per-node N train.py ...`` it is one of the ranks.  Every
 rank binds to its LOCAL_RANK device, joins a torch.distributed group (backend "nccl" = RCCL over
 xGMI on ROCm, "gloo" on CPU) and averages the flat gradient buffers once per optimizer step.
 The loop is ALWAYS the in-repo MiniTrainer (lgm_hip/lightning.py) — also where pytorch_lightning is
@@ -55,6 +58,8 @@ def setup_arguments(argv=None, print_args=True, save_args=True):
     p.add_argument("--resume", action="store_true")
     p.add_argument("--id", type=str, default=None)
     p.add_argument("--accelerator", type=str, default="auto", help="auto | cpu | gpu")
+    p.add_argument("--devices", type=str, default="auto",
+                   help="ranks to run as (Lightning's Trainer(devices=...)): auto = every visible GPU, like the reference")
     args = p.parse_args(argv)
     args.config = load_config(args.config_path)
     args.experiment_dir = os.path.join(EXPERIMENT_DIR, args.config["model"]["name"], args.experiment_name)
@@ -79,7 +84,38 @@ def init_distributed(use_gpu: bool):
     return dist.get_rank(), world
 
 
+def maybe_spawn(argv):
+    """The reference's ``python train.py`` on a multi-GPU node trains on ALL its GPUs (``--strategy`` defaults to
+    ``configure_strategy()`` = DDP when ``device_count() > 1``, reference train.py:38, utils/lightning_utils.py:37-43, and
+    Lightning starts the ranks).  Same here: with no launcher in the environment, decide from the command line and the
+    visible devices - WITHOUT touching the GPU - whether this process is the parent of N ranks; if so start them
+    (lgm_hip/launch.py) and return their exit code, else return None and run as the one rank."""
+    from lgm_hip import launch
+    if launch.launched():
+        return None
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--strategy", type=str, default="auto")
+    pre.add_argument("--accelerator", type=str, default="auto")
+    pre.add_argument("--devices", type=str, default="auto")
+    a, _ = pre.parse_known_args(argv)
+    use_gpu = a.accelerator != "cpu" and launch.visible_gpu_count() > 0
+    n = launch.ranks_wanted(a.strategy, a.devices, use_gpu)
+    if n <= 1:
+        return None
+    if use_gpu:
+        assert n <= launch.visible_gpu_count(), f"--devices {n} but {launch.visible_gpu_count()} GPUs are visible"
+    child_argv = list(sys.argv[1:] if argv is None else argv)
+    if not any(x == "--experiment_name" or x.startswith("--experiment_name=") for x in child_argv):
+        child_argv += ["--experiment_name", EXPERIMENT_TIME]     # one experiment directory for all ranks
+    return launch.spawn_ranks(os.path.abspath(__file__), child_argv, n)
+
+
 def main(argv=None):
+    rc = maybe_spawn(argv)
+    if rc is not None:
+        if rc != 0:
+            sys.exit(rc)
+        return None
     args = setup_arguments(argv, print_args=int(os.environ.get("RANK", "0")) == 0)
     use_gpu = args.accelerator != "cpu" and torch.cuda.is_available()
     rank, world = init_distributed(use_gpu)

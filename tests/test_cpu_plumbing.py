@@ -308,3 +308,110 @@ def test_max_steps_mid_epoch_is_not_a_completed_epoch(tmp_path):
     sd = torch.load(os.path.join(str(tmp_path), "last.ckpt"), map_location="cpu")
     assert sd["global_step"] == 7 and sd["epoch"] == 1        # epoch 0 complete (5 steps), epoch 1 cut after 2
     assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+
+
+def _no_launcher_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(extra)
+    return env
+
+
+def test_train_entry_starts_its_own_ranks_cpu():
+    """``python train.py --strategy ddp --devices 2`` with NO launcher in the environment becomes the parent of two ranks
+    (gloo on the CPU accelerator) - what Lightning does for the reference's ``python train.py`` on a multi-GPU node
+    (reference train.py:38,124-141, utils/lightning_utils.py:37-43).  Both ranks train, rank 0 writes last.ckpt."""
+    r = subprocess.run([sys.executable, os.path.join(PKG, "train.py"), "--config_path",
+                        os.path.join(PKG, "configs", "vae", "vae.json"), "--max_steps", "6", "--accelerator", "cpu",
+                        "--strategy", "ddp", "--devices", "2", "--experiment_name", "pytest_cpu_spawn2"],
+                       capture_output=True, text=True, timeout=600, env=_no_launcher_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "[launch] starting 2 ranks" in r.stderr
+    sd = torch.load(os.path.join(PKG, "experiments", "VAE", "pytest_cpu_spawn2", "last.ckpt"), map_location="cpu")
+    assert sd["global_step"] == 6
+    # one rank by default on the CPU accelerator (the reference's SingleDeviceStrategy branch), no launcher involved
+    r1 = subprocess.run([sys.executable, os.path.join(PKG, "train.py"), "--config_path",
+                         os.path.join(PKG, "configs", "vae", "vae.json"), "--max_steps", "2", "--accelerator", "cpu",
+                         "--experiment_name", "pytest_cpu_spawn1"], capture_output=True, text=True, timeout=300,
+                        env=_no_launcher_env())
+    assert r1.returncode == 0 and "[launch]" not in r1.stderr, r1.stderr[-2000:]
+
+
+_WORKER_DIES = r'''
+import os, sys, time
+rank = int(os.environ["RANK"])
+assert int(os.environ["WORLD_SIZE"]) == 2
+if rank == 1:
+    sys.exit(7)              # a rank that dies ...
+time.sleep(600)              # ... while the other would wait for ever
+'''
+
+_WORKER_LOG_MISMATCH = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from lgm_hip.lightning import MiniLightningModule
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+m = MiniLightningModule()
+m.log("loss", torch.tensor(1.0 + rank), sync_dist=True)
+out = m.synced_logs()
+assert abs(out["loss"] - 1.5) < 1e-9, out
+m.log("loss", torch.tensor(3.0), sync_dist=True)
+if rank == 0:
+    m.log("only_rank0", torch.tensor(1.0), sync_dist=True)      # rank-dependent name: must fail on BOTH ranks, not hang
+try:
+    m.synced_logs()
+    print(f"RANK{rank} no-error", flush=True)
+except RuntimeError as e:
+    print(f"RANK{rank} raised: {str(e)[:60]}", flush=True)
+# a name registered everywhere but not logged this interval on one rank: mean over the ranks that logged it
+m2 = MiniLightningModule()
+m2._sync_dist_names.update(["a", "b"])
+m2.logged["a"] = float(rank)
+if rank == 1:
+    m2.logged["b"] = 10.0
+o2 = m2.synced_logs()
+print(f"RANK{rank} a={o2['a']} b={o2['b']}", flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_launcher_counts_devices_without_touching_them_and_reports_a_dead_rank(tmp_path, monkeypatch):
+    from lgm_hip import launch
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1,2,3")
+    assert launch.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert launch.visible_gpu_count() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    assert launch.ranks_wanted("auto", "auto", use_gpu=False) == 1
+    assert launch.ranks_wanted("ddp", "4", use_gpu=True) == 4
+    assert launch.ranks_wanted("single_device", "auto", use_gpu=True) == 1
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    script = tmp_path / "dies.py"
+    script.write_text(_WORKER_DIES)
+    import time
+    t0 = time.time()
+    rc = launch.spawn_ranks(str(script), [], 2, timeout=120)
+    assert rc != 0 and time.time() - t0 < 100          # the surviving rank is stopped by the launcher, not waited for
+    slow = tmp_path / "slow.py"
+    slow.write_text("import time\ntime.sleep(600)\n")
+    t0 = time.time()
+    assert launch.spawn_ranks(str(slow), [], 2, timeout=8) == 124 and time.time() - t0 < 60
+
+
+def test_sync_dist_logging_is_shape_safe_gloo_world2(tmp_path):
+    """ADVICE r3: a scalar logged with sync_dist=True under a rank-dependent condition must not leave the ranks in
+    mismatched collectives: every rank raises the same error; names registered but not logged on a rank average over
+    the ranks that did log them."""
+    script = tmp_path / "worker_log.py"
+    script.write_text(_WORKER_LOG_MISMATCH)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29549", str(script), PKG],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "RANK0 raised" in r.stdout and "RANK1 raised" in r.stdout, r.stdout
+    assert "RANK0 a=0.5 b=10.0" in r.stdout and "RANK1 a=0.5 b=10.0" in r.stdout, r.stdout

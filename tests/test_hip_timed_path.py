@@ -78,7 +78,6 @@ def test_graph_replay_is_bit_identical_to_eager_steps(dev, pipeline, monkeypatch
     assert sa["step"] == sb["step"] == 12 and torch.equal(sa["m"], sb["m"]) and torch.equal(sa["v"], sb["v"])
     ea, eb = a.ema.ema_model.model._flat, b.ema.ema_model.model._flat
     assert torch.equal(ea.data, eb.data) and not torch.equal(ea.data, fa.data)   # shadow = weights at step 10
-    assert not torch.equal(step.t, t) or True
     # consecutive replays draw fresh (t, noise)
     t0 = step.t.clone()
     step.step(12)
@@ -560,3 +559,26 @@ def test_two_rank_wgan_step(dev, tmp_path, mode, parity):
         assert res["mode"].startswith("hipGraph"), res
     parity(f"2-rank WGAN parameters + running statistics vs one-process emulation ({res['mode']})",
            res["rel_err_vs_emulation"], 1e-5)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with NO launcher in the environment: the process becomes the parent of two ranks
+    (lgm_hip/launch.py; here gloo ranks sharing the box's one GPU) and relays rank 0's line, whose n_gpus is 2.  The
+    reference's ``python train.py`` does the same through Lightning's DDPStrategy (train.py:38, lightning_utils.py:37-43)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LGM_DIST_BACKEND="gloo", LGM_DIST_TIMEOUT="240")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--only", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and "[launch] starting 2 ranks" in r.stderr
+    # under a launcher that disagrees with --gpus the run is refused; it never prints a line with another rank count
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--only", "--steps", "1", "--warmup", "0",
+                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env2)
+    assert r2.returncode != 0 and not [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]

@@ -233,6 +233,39 @@ def test_graph_replayed_sampling_is_bit_identical_to_eager_launches(dev, golden_
     assert torch.isfinite(a).all() and not torch.equal(a, b)
 
 
+def test_config5_ancestral_chain_64x64_graph_equals_eager(dev, monkeypatch):
+    """BASELINE config 5's sampling half on its own network size: the dim-64 UNet at 64x64 (ddpm_64.json), the
+    ancestral chain ``sample()`` dispatches to when sampling_timesteps == timesteps (reference ddpm.py:759-780, 836-845).
+    24 steps with injected noise: graph replay is torch.equal to eager launches, the result is finite, and a second
+    replayed chain reproduces it bit for bit.  (The 1000-step chain itself is bench.py's ``ddpm64_sampling_1000`` leg.)"""
+    from lgm_hip import sampler
+    from models.generative.diffusion.ddpm import DDPM
+    from oracle import diffusion as OD
+    torch.manual_seed(3)
+    m = DDPM(img_channels=3, img_size=64, dim=64, diffusion_timesteps=24).to(dev)
+    m.sample_every = 0
+    m.prepare_hip(dev)
+    gd = m.ema.ema_model
+    gd.eval()
+    assert not gd.is_ddim_sampling and gd.num_timesteps == 24
+    shape = (4, 3, 64, 64)
+    init, nz = OD.draw_loop_noise(11, shape, 23)
+    nzd = [n.to(dev) for n in nz] + [None]
+    outs = {}
+    for mode in ("graph", "eager", "graph2"):
+        monkeypatch.setenv("LGM_NO_SAMPLER_GRAPH", "1" if mode == "eager" else "0")
+        outs[mode] = sampler.p_sample_loop(gd, shape, init_noise=init.to(dev), noises=nzd).clone()
+    ents = [e for e in sampler._GRAPHS[gd.model].values()]
+    assert ents and all(isinstance(e, sampler._GraphedChain) for e in ents), "graph capture did not happen"
+    assert torch.isfinite(outs["graph"]).all() and float(outs["graph"].std()) > 0
+    assert torch.equal(outs["graph"], outs["eager"])
+    assert torch.equal(outs["graph"], outs["graph2"])
+    # the public entry takes the same route
+    monkeypatch.setenv("LGM_NO_SAMPLER_GRAPH", "0")
+    img = gd.sample(batch_size=4)
+    assert img.shape == shape and torch.isfinite(img).all()
+
+
 def test_ddpm_module_training_steps(dev, parity):
     """LightningModule surface: training_step -> backward -> FusedAdam.step -> EMA, 3 steps,
     against the oracle + torch.optim.Adam on CPU."""
