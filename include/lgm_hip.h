@@ -555,6 +555,32 @@ int lgm_conv3x3_wino(int yx, const LgmConvGeom* g, const float* a, int64_t a_pit
                      void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Winograd F(4x4, 3x3) convolution in fp32 (csrc/winograd4.hip): the same layers and the same contract as
+ * lgm_conv3x3_wino on the LARGE maps (16 x 16, or H % 16 == 0 and W % 32 == 0; reduction channels % 32, produced
+ * channels % 64): 2.25 multiplies per output instead of 4, 1.78x fewer MFMA FLOPs than F(2x2, 3x3) (reference ops:
+ * Block.proj ddpm.py:157-173 and its input gradient).  fp32 throughout; error against float64 a few 1e-6 of the output
+ * scale (interpolation points 0, +-1, +-2, inf).  Weights are passed TRANSFORMED by lgm_wino4_weights:
+ *   table rows as lgm_wino_weights; forward operand Np*Cp*36 floats, layout [Np/64][Cp/8][36][2][2][32][4]; input-gradient
+ *   operand with mirrored taps and the roles of Np / Cp swapped; one block per 32 x 32 (n, c) tile.
+ * ------------------------------------------------------------------------------------- */
+int64_t lgm_conv3x3_wino4_supported(const LgmConvGeom* g, int yx);
+int64_t lgm_conv3x3_wino4_workspace(const LgmConvGeom* g, int yx);   /* split-K partial outputs (bytes) */
+/* 1 when this layer is expected to run faster here than through lgm_conv3x3_wino (measured table: enough units to fill
+ * the chip without deep split-K); callers take F(4x4) only then */
+int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx);
+/* partial form, as lgm_conv3x3_wino_partial (same workspace size as lgm_conv3x3_wino4_workspace) */
+int lgm_conv3x3_wino4_partial(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,
+                              const float* bias, float* out, int64_t out_pitch, void* workspace,
+                              int64_t workspace_bytes, int64_t* partial, void* stream);
+int lgm_wino4_weights(const float* src, float* dst_f, float* dst_b, const int64_t* table, int n_slots,
+                      int64_t total_blocks, void* stream);
+/* diagnostic only: buf != NULL makes lgm_conv3x3_wino4 run its cycle-stamped build (32 int64 per workgroup) */
+int lgm_wino4_set_debug_buffer(void* buf, int exp);   /* exp: attribution build (drops parts of the phase: wrong results) */
+int lgm_conv3x3_wino4(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,
+                      const float* bias, const float* res, int64_t res_pitch, float* out, int64_t out_pitch,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimiser kernels on flat storage.
  * torch.optim.Adam (coupled L2; decoupled=1 gives AdamW) — ddpm.py:1053-1059, vqvae.py:207-214,
  * wgan.py:183-195.  step: 1-based count (host value, or read from step_dev when non-NULL).

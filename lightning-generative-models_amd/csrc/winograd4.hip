@@ -1,0 +1,698 @@
+// Winograd F(4x4, 3x3) convolution in fp32 on v_mfma_f32_32x32x2_f32 — the 3x3 / stride 1 / pad 1 layers of the DDPM UNet
+// on the LARGE feature maps (16x16, 32x32, 64x64; reference Block.proj ddpm.py:160-171 and the 3x3 convolutions of the
+// up path :93-97,377,413), forward and input gradient.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 6x6 input tile d -> 4x4 output tile Y,  36 products per 16 outputs
+//
+// i.e. 2.25 multiplies per output instead of 4 (F(2x2,3x3), winograd.hip) or 9 (direct): 1.78x fewer MFMA FLOPs than the
+// F(2x2) kernels for a comparable number of transform operations per output.  Interpolation points 0, +-1, +-2, inf; all
+// arithmetic fp32 with fp32 accumulation (error against float64 a few 1e-6 of the output scale: tests/test_hip_winograd.py).
+//
+// Work decomposition.  UNIT = 32 tiles (4 x 8 tiles = 16 x 32 output pixels of one image; on 16 x 16 maps 4 x 4 tiles of two
+// images) x 64 output channels x one split of the reduction; PHASE = 8 reduction channels.  512 threads = 8 waves, two
+// per SIMD, 144 accumulator registers each:
+//   * transform role: thread = (tile, reduction channel, half of the 6 rows of V): reads its 6x6 raw values from the
+//     channel-planar LDS patch (plane stride = 1 mod 32 floats: conflict-free), computes 18 elements of V = B^T d B and
+//     writes them to LDS as V[xi][k-half][tile][4] — every (tile, channel) is transformed ONCE per workgroup and serves
+//     all 64 output channels;
+//   * MFMA role: wave = (9 of the 36 xi) x (32 of the 64 output channels): per xi one ds_read_b128 of V (B operand,
+//     tiles on the lanes), one 16-byte load of the transformed weights U straight from L2 (A operand, fragment order),
+//     4 MFMAs into one 32x32 accumulator;
+//   * the raw patch of phase p+2 is fetched into registers while phase p runs (out-of-range buffer offsets are the zero
+//     padding), phase p+1's patch is transformed under phase p's MFMAs; ONE barrier per phase.
+// Epilogue: the 36 xi of a (tile, channel) sit in four different waves, so the accumulators go through LDS (two passes
+// of 32 output channels, 147 KB each, XOR-swizzled: conflict-free 16-byte writes and reads); thread = (tile, channel
+// quad, output row pair) applies A^T . A and stores full 128-byte segments with bias / residual fused.  Split-K writes
+// partial OUTPUT planes (the output transform is linear) for the fixed-order reducer or the plane-summing GroupNorm.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "lgm_common.h"
+
+int lgm_splitk_reduce_launch(const float* ws, long ws_stride, int splits, const float* bias, const float* res,
+                             long res_pitch, float* out, long out_pitch, long M, int N, hipStream_t s);
+
+// diagnostic: when set (lgm_wino4_set_debug_buffer), the convolution runs its stamped build and writes, per workgroup,
+// 32 int64: [0] stamp count, [1..] s_memtime (entry, set-up done, prologue done, every phase, both epilogue passes),
+// [31] s_memrealtime at exit.  Never set on the product path.
+static void* lgm_wino4_debug_buffer = nullptr;
+static int lgm_wino4_debug_exp = 0;
+extern "C" int lgm_wino4_set_debug_buffer(void* buf, int exp) {
+  lgm_wino4_debug_buffer = buf;
+  lgm_wino4_debug_exp = exp;
+  return LGM_OK;
+}
+
+namespace lgmwino4 {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KC = 8;              // reduction channels per phase
+constexpr int NXI = 36;
+constexpr int VBUF = NXI * 256;    // floats per V buffer: [xi][k-half][tile 32][4]
+constexpr int MBUF = NXI * 32 * 32;   // floats of the epilogue exchange: [xi][tile 32][8 quads (swizzled)][4]
+
+template <int CLS>
+struct Geo;
+template <>
+struct Geo<0> {   // maps >= 16 x 32: 4 x 8 tiles of one image
+  static constexpr int NI = 1, TTH = 4, TTW = 8, PH = 18, PW = 34, RS = 34, IMG = PH * RS, PLANE = 641;
+};
+template <>
+struct Geo<1> {   // 16 x 16 maps: 4 x 4 tiles of two images; 4 RS = 16 (mod 32) spreads the two tile rows of a wave
+  static constexpr int NI = 2, TTH = 4, TTW = 4, PH = 18, PW = 18, RS = 20, IMG = PH * RS, PLANE = 737;
+};
+
+struct Args {
+  const float* a;      // gathered activations, NHWC
+  const float* u;      // transformed weights [N/64][C/8][36][2][2][32][4]
+  const float* bias;
+  const float* res;
+  float* out;
+  long a_pitch, res_pitch, out_pitch;
+  int B, H, W;
+  int C;               // reduction channels
+  int N;               // produced channels
+  int tb_h, tb_w, tiles_n, nbg;
+  int splits, pps, units;
+  float* ws;
+  long ws_stride;
+  long long* dbg;      // diagnostic build only (wino4_conv_kernel<CLS, true>): per-workgroup cycle stamps
+};
+
+__device__ __forceinline__ f32x4 add4(const f32x4 a, const f32x4 b) { return a + b; }
+// hipcc emits four v_sub_f32 for a vector subtraction (the neg modifiers of v_pk_add_f32 are not selected)
+__device__ __forceinline__ f32x4 sub4(const f32x4 a, const f32x4 b) {
+  f32x2 lo, hi;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+      : "=v"(lo)
+      : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+      : "=v"(hi)
+      : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 fma4(const float c, const f32x4 a, const f32x4 b) {   // c * a + b
+  return __builtin_elementwise_fma(f32x4{c, c, c, c}, a, b);
+}
+__device__ __forceinline__ f32x2 fma2(const float c, const f32x2 a, const f32x2 b) {
+  return __builtin_elementwise_fma(f32x2{c, c}, a, b);
+}
+
+// EXP (diagnostic builds only): bit 0 drops the transform, bit 1 the patch fetch / commit, bit 2 the U loads, bit 3 the V
+// reads of the phase loop -- wrong results, used to attribute the phase time.
+template <int CLS, bool DBG = false, int EXP = 0>
+__global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
+  using GE = Geo<CLS>;
+  int nstamp = 0;
+  auto stamp = [&]() {
+    if (DBG) {
+      if (threadIdx.x == 0 && nstamp < 30) p.dbg[blockIdx.x * 32 + 1 + nstamp] = (long long)__builtin_amdgcn_s_memtime();
+      ++nstamp;
+    }
+  };
+  stamp();
+  constexpr int NI = GE::NI, PH = GE::PH, PW = GE::PW, RS = GE::RS, IMG = GE::IMG, PLANE = GE::PLANE;
+  constexpr int RBUF = 8 * PLANE;
+  constexpr int NPIX = NI * PH * PW;
+  constexpr int NJ = (2 * NPIX + 511) / 512;
+  extern __shared__ __align__(16) float smem[];
+  float* const Rb = smem;                   // [2][8 planes][PLANE]
+  float* const Vb = smem + 2 * RBUF;        // [2][VBUF]
+  float* const Mb = smem;                   // epilogue: aliases everything
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // ---- unit ----
+  int L = blockIdx.x;
+  const int tn = L % p.tiles_n;
+  L /= p.tiles_n;
+  const int split = L % p.splits;
+  L /= p.splits;
+  const int twi = L % p.tb_w;
+  L /= p.tb_w;
+  const int thi = L % p.tb_h;
+  const int bg = L / p.tb_h;
+  const int n0 = tn * 64;
+  const int h0 = thi * (4 * GE::TTH), w0 = twi * (4 * GE::TTW), b0 = bg * NI;
+  const int ncc = p.C / KC;
+  const int cc0 = split * p.pps;
+  const int cc1 = min(ncc, cc0 + p.pps);
+  const int nph = cc1 - cc0;
+
+  // ---- raw patch slots: s = tid + 512 j -> pixel s >> 1 of the patch, channel quad s & 1 ----
+  const unsigned nrec_a = (unsigned)((long)p.B * p.H * p.W * p.a_pitch * 4);
+  __amdgpu_buffer_rsrc_t rsrc_a;
+  {
+    const unsigned long long ab = reinterpret_cast<unsigned long long>(p.a);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ab);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ab >> 32));
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                               __builtin_amdgcn_readfirstlane(nrec_a), 0x00020000);
+  }
+  unsigned goff[NJ], plds[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int s = tid + 512 * j;
+    const int pix = s >> 1, q = s & 1;
+    unsigned g = nrec_a, l = (unsigned)(q * 4 * PLANE + NI * IMG);      // nothing -> zeros into the plane's pad
+    if (pix < NPIX) {
+      const int img = pix / (PH * PW);
+      const int rem = pix - img * (PH * PW);
+      const int py = rem / PW, px = rem - py * PW;
+      const int gy = h0 - 1 + py, gx = w0 - 1 + px;
+      l = (unsigned)(q * 4 * PLANE + img * IMG + py * RS + px);
+      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+        g = (unsigned)((((long)(b0 + img) * p.H + gy) * p.W + gx) * p.a_pitch + q * 4) * 4u;
+    }
+    goff[j] = g;
+    plds[j] = l;
+  }
+  u32x4 rp[NJ];
+  auto fetch = [&](int ph) {       // phase index relative to cc0; beyond the unit's range: zeros
+    const unsigned soff = (unsigned)((cc0 + ph) * (KC * 4));
+    const bool ok = ph < nph;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rp[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? goff[j] : nrec_a, soff, 0);
+  };
+  auto commit = [&](float* rbuf) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float* d = rbuf + plds[j];
+      const f32x4 f = __builtin_bit_cast(f32x4, rp[j]);     // cast the whole vector first (hipcc, DESIGN finding 14)
+      d[0] = f[0];
+      d[PLANE] = f[1];
+      d[2 * PLANE] = f[2];
+      d[3 * PLANE] = f[3];
+    }
+  };
+
+  // ---- transform role ----
+  int t_tile, t_img, t_ty, t_tx;
+  const int half = wid >> 2;                          // V rows 0-2 / 3-5; also the output row pair of the epilogue
+  const int tk = (lane & 3) + 4 * (lane >> 5);        // reduction channel of the phase
+  if (CLS == 0) {
+    t_img = 0;
+    t_ty = wid & 3;
+    t_tx = (lane >> 2) & 7;
+    t_tile = t_ty * 8 + t_tx;
+  } else {
+    t_img = (wid >> 1) & 1;
+    t_ty = 2 * (wid & 1) + ((lane >> 4) & 1);
+    t_tx = (lane >> 2) & 3;
+    t_tile = t_img * 16 + t_ty * 4 + t_tx;
+  }
+  const int trd = tk * PLANE + t_img * IMG + 4 * t_ty * RS + 4 * t_tx;
+  const int vwr = (tk >> 2) * 128 + t_tile * 4 + (tk & 3) + half * (18 * 256);
+
+  // ---- MFMA role ----
+  const int xg = wid & 3, ch = wid >> 2;
+  const int vrd = xg * (9 * 256) + lh * 128 + lr * 4;
+  __amdgpu_buffer_rsrc_t rsrc_u;
+  {
+    const unsigned long long ub = reinterpret_cast<unsigned long long>(p.u);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ub);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
+    rsrc_u = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                               __builtin_amdgcn_readfirstlane((unsigned)((long)p.N * p.C * NXI * 4)),
+                                               0x00020000);
+  }
+  const unsigned ulane = (unsigned)((ch * 64 + lane) * 16);
+  const unsigned ubase = (unsigned)((tn * ncc + cc0) * NXI + xg * 9) * 2048u;
+  auto load_u = [&](int ph, int e) -> f32x4 {        // phases past the unit's range are never consumed
+    const unsigned soff = ubase + (unsigned)(ph * NXI + e) * 2048u;
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, ulane, soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+  };
+
+  // Everything from here on is instantiated twice, for the two halves of the workgroup (waves 0-3 / 4-7): the halves
+  // differ in which three rows of V they build and which two output rows they finish, and a wave-uniform branch INSIDE
+  // a phase would split its scheduling region (DESIGN finding 12) - so the branch is taken once, here.
+  auto body = [&](auto half_c) {
+    constexpr int HALF = decltype(half_c)::value;
+    f32x16 acc[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+    f32x2 T[3][3];                                    // T[i][cp] = rows (3 HALF + i) of B^T d, columns 2cp, 2cp + 1
+    // the two raw buffers' per-thread read bases, opaque to constant folding: a raw read is then base + immediate
+    // (ds_read2_b32 offsets are 8-bit dword counts; folded into one base + a large constant the compiler spent a
+    // v_add per read)
+    int roff0 = trd, roff1 = RBUF + trd;             // (offsets, not pointers: the LDS address space must survive)
+    asm volatile("" : "+v"(roff0));
+    asm volatile("" : "+v"(roff1));
+    auto stage1 = [&](int nxt, int cp) {
+      const float* r = smem + (nxt ? roff1 : roff0);
+      f32x2 d[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr)
+        if (rr != (HALF ? 0 : 5)) d[rr] = f32x2{r[rr * RS + 2 * cp], r[rr * RS + 2 * cp + 1]};
+      if (HALF == 0) {
+        // row0 = 4 d0 - 5 d2 + d4;  row1 = (d4 - 4 d2) + (d3 - 4 d1);  row2 = (d4 - 4 d2) - (d3 - 4 d1)
+        T[0][cp] = fma2(4.f, d[0], fma2(-5.f, d[2], d[4]));
+        const f32x2 a = fma2(-4.f, d[2], d[4]), b = fma2(-4.f, d[1], d[3]);
+        T[1][cp] = a + b;
+        T[2][cp] = a - b;
+      } else {
+        // row3 = (d4 - d2) + 2 (d3 - d1);  row4 = (d4 - d2) - 2 (d3 - d1);  row5 = 4 d1 - 5 d3 + d5
+        const f32x2 c = d[4] - d[2], f = d[3] - d[1];
+        T[0][cp] = fma2(2.f, f, c);
+        T[1][cp] = fma2(-2.f, f, c);
+        T[2][cp] = fma2(4.f, d[1], fma2(-5.f, d[3], d[5]));
+      }
+    };
+    auto stage2 = [&](float* vbuf, int i, int part) {  // row i of the half, columns 0-2 (part 0) / 3-5 (part 1)
+      float* v = vbuf + vwr + i * (6 * 256);
+      const float t0 = T[i][0][0], t1 = T[i][0][1], t2 = T[i][1][0], t3 = T[i][1][1], t4 = T[i][2][0], t5 = T[i][2][1];
+      if (part == 0) {
+        const float a = __builtin_fmaf(-4.f, t2, t4), b = __builtin_fmaf(-4.f, t1, t3);
+        v[0 * 256] = __builtin_fmaf(4.f, t0, __builtin_fmaf(-5.f, t2, t4));
+        v[1 * 256] = a + b;
+        v[2 * 256] = a - b;
+      } else {
+        const float c = t4 - t2, f = t3 - t1;
+        v[3 * 256] = __builtin_fmaf(2.f, f, c);
+        v[4 * 256] = __builtin_fmaf(-2.f, f, c);
+        v[5 * 256] = __builtin_fmaf(4.f, t1, __builtin_fmaf(-5.f, t3, t5));
+      }
+    };
+    auto commit1 = [&](float* rbuf, int j) {
+      float* d = rbuf + plds[j];
+      const f32x4 f = __builtin_bit_cast(f32x4, rp[j]);     // cast the whole vector first (hipcc, DESIGN finding 14)
+      d[0] = f[0];
+      d[PLANE] = f[1];
+      d[2 * PLANE] = f[2];
+      d[3 * PLANE] = f[3];
+    };
+
+    // ---- prologue ----
+    stamp();
+    f32x4 uq[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) uq[e] = load_u(0, e);
+    {   // both patches of the first two phases are requested before either is waited for
+      u32x4 r1[NJ];
+      fetch(1);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) r1[j] = rp[j];
+      fetch(0);
+      commit(Rb);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) rp[j] = r1[j];
+      commit(Rb + RBUF);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cp = 0; cp < 3; ++cp) stage1(0, cp);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      stage2(Vb, i, 0);
+      stage2(Vb, i, 1);
+    }
+    __syncthreads();
+    stamp();
+
+    // ---- phase: nine steps of 4 MFMAs (one xi each), the side work dealt out over them; nothing crosses a step
+    // boundary (sched_barrier), so the U fragment loaded at the end of step e for step e + 3 IS three steps ahead ----
+    auto phase = [&](int ph, auto cur_c) {
+      constexpr int cur = decltype(cur_c)::value;
+      float* const rcur = Rb + cur * RBUF;
+      float* const vcur = Vb + cur * VBUF;
+      float* const vnxt = Vb + (cur ^ 1) * VBUF;
+      f32x4 vf = *reinterpret_cast<const f32x4*>(vcur + vrd);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        f32x4 vfn = vf;
+        if (e < 8 && !(EXP & 8)) vfn = *reinterpret_cast<const f32x4*>(vcur + vrd + (e + 1) * 256);
+        const f32x4 uf = uq[e % 3];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s], vf[s], acc[e], 0, 0, 0);
+        if (!(EXP & 4)) uq[e % 3] = (e + 3 < 9) ? load_u(ph, e + 3) : load_u(ph + 1, e + 3 - 9);
+        if (e == 0 && !(EXP & 2)) fetch(ph + 2);
+        if (!(EXP & 1)) {
+          if (e < 3) stage1(cur ^ 1, e);
+          else stage2(vnxt, (e - 3) >> 1, (e - 3) & 1);
+        }
+        if (e >= 6 && !(EXP & 2)) commit1(rcur, e - 6);
+        vf = vfn;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      static_assert(NJ == 3, "the commit is dealt out over steps 6..8");
+      __syncthreads();
+      stamp();
+    };
+    for (int ph = 0; ph < nph; ph += 2) {
+      phase(ph, std::integral_constant<int, 0>{});
+      if (ph + 1 < nph) phase(ph + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue addressing (computed here: no registers held across the phases) ----
+    const int eq = tid & 7, et = (tid >> 3) & 31;
+    int e_img, e_ty, e_tx;
+    if (CLS == 0) {
+      e_img = 0;
+      e_ty = et >> 3;
+      e_tx = et & 7;
+    } else {
+      e_img = et >> 4;
+      e_ty = (et >> 2) & 3;
+      e_tx = et & 3;
+    }
+    const long opix = ((long)(b0 + e_img) * p.H + h0 + 4 * e_ty) * p.W + w0 + 4 * e_tx;
+    const bool partial = p.splits > 1;
+    float* const obase = partial ? p.ws + (long)split * p.ws_stride + opix * p.N + n0 + eq * 4
+                                 : p.out + opix * p.out_pitch + n0 + eq * 4;
+    const long opitch = partial ? (long)p.N : p.out_pitch;
+    const bool has_res = !partial && p.res != nullptr;           // kernel argument: a scalar branch
+    const float* const rbase = p.res + opix * p.res_pitch + n0 + eq * 4;
+    const int mrd = (et * 8 + (eq ^ (et & 7))) * 4;
+
+    // ---- epilogue: two passes of 32 output channels through LDS; this half finishes output rows HALF, HALF + 2 ----
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      // pass c: the waves that hold output channels 32 c .. 32 c + 31 (ch == HALF == c) hand their accumulators to LDS
+      // and - their registers now free - finish one (tile, channel quad) each: all four output rows, 36 reads.  The other
+      // half waits (pass 0: its accumulators are still live, 144 + the transform's ~120 registers would spill); per SIMD
+      // the instruction count is the same as with the work spread over both of its waves.
+      if (HALF == c) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(Mb + (((xg * 9 + e) * 32 + lr) * 8 + ((2 * g + lh) ^ (lr & 7))) * 4) = v;
+          }
+      }
+      __syncthreads();
+      if (HALF == c) {
+        f32x4 X[4][6];                                 // A^T m: output row x xi column
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          auto m = [&](int i) -> f32x4 { return *reinterpret_cast<const f32x4*>(Mb + (i * 6 + j) * 1024 + mrd); };
+          const f32x4 m1 = m(1), m2 = m(2), m3 = m(3), m4 = m(4);
+          const f32x4 s1 = add4(m1, m2), d1 = sub4(m1, m2), s2 = add4(m3, m4), d2 = sub4(m3, m4);
+          X[0][j] = add4(add4(m(0), s1), s2);
+          X[1][j] = fma4(2.f, d2, d1);
+          X[2][j] = fma4(4.f, s2, s1);
+          X[3][j] = add4(fma4(8.f, d2, d1), m(5));
+        }
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (!partial && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c * 32 + eq * 4);
+#pragma unroll
+        for (int oi = 0; oi < 4; ++oi) {
+          const f32x4 s1 = add4(X[oi][1], X[oi][2]), d1 = sub4(X[oi][1], X[oi][2]);
+          const f32x4 s2 = add4(X[oi][3], X[oi][4]), d2 = sub4(X[oi][3], X[oi][4]);
+          f32x4 y[4];
+          y[0] = add4(add4(X[oi][0], s1), s2);
+          y[1] = fma4(2.f, d2, d1);
+          y[2] = fma4(4.f, s2, s1);
+          y[3] = add4(fma4(8.f, d2, d1), X[oi][5]);
+          if (has_res) {
+#pragma unroll
+            for (int oj = 0; oj < 4; ++oj)
+              y[oj] = add4(y[oj], *reinterpret_cast<const f32x4*>(rbase + ((long)oi * p.W + oj) * p.res_pitch + c * 32));
+          }
+#pragma unroll
+          for (int oj = 0; oj < 4; ++oj)
+            *reinterpret_cast<f32x4*>(obase + ((long)oi * p.W + oj) * opitch + c * 32) = add4(y[oj], bv);
+        }
+      }
+      if (c == 0) __syncthreads();
+      stamp();
+    }
+    if (DBG && threadIdx.x == 0) {
+      p.dbg[blockIdx.x * 32] = nstamp;
+      p.dbg[blockIdx.x * 32 + 31] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+  };
+  if (half == 0) body(std::integral_constant<int, 0>{});
+  else body(std::integral_constant<int, 1>{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// U = G g G^T for 3x3 weight slots of a flat buffer (weights [Np][9][Cp]), computed in float64, stored in the fragment
+// order the convolution kernel reads.  table rows: [src offset, Np, Cp, dst_f offset, dst_b offset, first block]
+//   forward operand  Uf[n/64][c/8][xi][(n%64)/32][(c%8)/4][n%32][c%4],  g[a][b] = w[n][3a+b][c]
+//   input-gradient   Ub[c/64][n/8][xi][(c%64)/32][(n%8)/4][c%32][n%4],  g'[a][b] = w[n][3(2-a)+(2-b)][c]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ggt36(const float (&g)[9], float (&u)[36]) {
+  double t[6][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const double g0 = g[b], g1 = g[3 + b], g2 = g[6 + b];
+    t[0][b] = g0 * 0.25;
+    t[1][b] = -(g0 + g1 + g2) * (1.0 / 6.0);
+    t[2][b] = -(g0 - g1 + g2) * (1.0 / 6.0);
+    t[3][b] = g0 * (1.0 / 24.0) + g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0);
+    t[4][b] = g0 * (1.0 / 24.0) - g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0);
+    t[5][b] = g2;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double g0 = t[i][0], g1 = t[i][1], g2 = t[i][2];
+    u[i * 6 + 0] = (float)(g0 * 0.25);
+    u[i * 6 + 1] = (float)(-(g0 + g1 + g2) * (1.0 / 6.0));
+    u[i * 6 + 2] = (float)(-(g0 - g1 + g2) * (1.0 / 6.0));
+    u[i * 6 + 3] = (float)(g0 * (1.0 / 24.0) + g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0));
+    u[i * 6 + 4] = (float)(g0 * (1.0 / 24.0) - g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0));
+    u[i * 6 + 5] = (float)g2;
+  }
+}
+
+__global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restrict__ src, float* __restrict__ dst_f,
+                                                            float* __restrict__ dst_b, const long* __restrict__ table,
+                                                            int n_slots) {
+  __shared__ float wt[32 * 9 * 36];               // [n][tap][c (+4 pad)]
+  int lo = 0, hi = n_slots - 1;
+  const long bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 6 + 5] <= bid) lo = mid;
+    else hi = mid - 1;
+  }
+  const long* row = table + lo * 6;
+  const long soff = row[0];
+  const int Np = (int)row[1], Cp = (int)row[2];
+  const long lb = bid - row[5];
+  const int cblocks = Cp / 32;
+  const int nb = (int)(lb / cblocks), cb = (int)(lb % cblocks);
+  const float* w = src + soff + ((long)nb * 32 * 9) * Cp + cb * 32;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 288 * 8; i += 256) {
+    const int r = i >> 3, c4 = (i & 7) * 4;
+    *reinterpret_cast<f32x4*>(wt + r * 36 + c4) = *reinterpret_cast<const f32x4*>(w + (long)r * Cp + c4);
+  }
+  __syncthreads();
+  if (dst_f) {      // thread = (n, c quad)
+    const int n = tid & 31, cq = tid >> 5;
+    f32x4 uu[36];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float g[9], u[36];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t] = wt[(n * 9 + t) * 36 + cq * 4 + s];
+      ggt36(g, u);
+#pragma unroll
+      for (int x = 0; x < 36; ++x) uu[x][s] = u[x];
+    }
+    // [(nb >> 1)][ph = cb * 4 + (cq >> 1)][xi][nb & 1][cq & 1][n][4]
+    float* d = dst_f + row[3] + (((long)(nb >> 1) * (Cp / 8) + cb * 4 + (cq >> 1)) * NXI) * 512 +
+               (((nb & 1) * 2 + (cq & 1)) * 32 + n) * 4;
+#pragma unroll
+    for (int x = 0; x < 36; ++x) *reinterpret_cast<f32x4*>(d + x * 512) = uu[x];
+  }
+  if (dst_b) {      // thread = (c, n quad)
+    const int c = tid & 31, nq = tid >> 5;
+    f32x4 uu[36];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float g[9], u[36];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[8 - t] = wt[((nq * 4 + s) * 9 + t) * 36 + c];      // mirrored taps
+      ggt36(g, u);
+#pragma unroll
+      for (int x = 0; x < 36; ++x) uu[x][s] = u[x];
+    }
+    float* d = dst_b + row[4] + (((long)(cb >> 1) * (Np / 8) + nb * 4 + (nq >> 1)) * NXI) * 512 +
+               (((cb & 1) * 2 + (nq & 1)) * 32 + c) * 4;
+#pragma unroll
+    for (int x = 0; x < 36; ++x) *reinterpret_cast<f32x4*>(d + x * 512) = uu[x];
+  }
+}
+
+static int unit_class(int H, int W) {
+  if (H == 16 && W == 16) return 1;
+  if (H >= 16 && W >= 32 && H % 16 == 0 && W % 32 == 0) return 0;
+  return -1;
+}
+
+}  // namespace lgmwino4
+
+bool lgm_wino4_supported(const LgmConvGeom* g, int gather_channels, int out_channels) {
+  using namespace lgmwino4;
+  if (!(g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1)) return false;
+  if (gather_channels % 8 != 0 || out_channels % 64 != 0 || gather_channels % 32 != 0) return false;
+  const int cls = unit_class(g->H, g->W);
+  if (cls < 0) return false;
+  const long pix = (long)g->B * g->H * g->W + g->W + 1;
+  if (pix * gather_channels >= (1L << 29) || pix * out_channels >= (1L << 29)) return false;
+  if ((long)gather_channels * out_channels * 36 >= (1L << 29)) return false;
+  return g->B % (cls == 1 ? 2 : 1) == 0;
+}
+
+int lgm_wino4_splits(const LgmConvGeom* g, int gather_channels, int out_channels) {
+  using namespace lgmwino4;
+  const int cls = unit_class(g->H, g->W);
+  if (cls < 0) return 1;
+  const long base = cls == 1 ? (long)(g->B / 2) * (out_channels / 64)
+                             : (long)g->B * (g->H / 16) * (g->W / 32) * (out_channels / 64);
+  static const int forced = getenv("LGM_WINO4_SPLITS") ? atoi(getenv("LGM_WINO4_SPLITS")) : 0;
+  const int phases = gather_channels / KC;
+  int smax = phases / 2 < 16 ? phases / 2 : 16;
+  if (smax < 1) smax = 1;
+  if (forced > 0) return forced < smax ? forced : smax;
+  if (base >= 192) return 1;
+  int s = (int)((256 + base - 1) / base);
+  if (s > smax) s = smax;
+  return s;
+}
+
+// partial (optional, int64 x 2): as lgm_wino_launch - the caller's consumer sums the split-K planes itself
+int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, const float* u, const float* bias,
+                     const float* res, long res_pitch, float* out, long out_pitch, void* workspace, long workspace_bytes,
+                     hipStream_t s, int64_t* partial = nullptr) {
+  using namespace lgmwino4;
+  Args p{};
+  p.a = a; p.u = u; p.bias = bias; p.res = res; p.out = out;
+  p.a_pitch = a_pitch; p.res_pitch = res_pitch; p.out_pitch = out_pitch;
+  p.B = g->B; p.H = g->H; p.W = g->W;
+  p.C = yx ? g->Nw : g->Cw;
+  p.N = yx ? g->Cw : g->Nw;
+  const int cls = unit_class(g->H, g->W);
+  p.tb_h = cls == 1 ? 1 : g->H / 16;
+  p.tb_w = cls == 1 ? 1 : g->W / 32;
+  p.nbg = cls == 1 ? g->B / 2 : g->B;
+  p.tiles_n = p.N / 64;
+  const long M = (long)g->B * g->H * g->W;
+  p.splits = lgm_wino4_splits(g, p.C, p.N);
+  if (p.splits > 1) {
+    const long need = (long)p.splits * M * p.N * (long)sizeof(float);
+    if (!workspace || workspace_bytes < need || !lgm_aligned16(workspace)) p.splits = 1;
+  }
+  p.ws = (float*)workspace;
+  p.ws_stride = M * p.N;
+  p.pps = lgm_cdiv(p.C / KC, p.splits);
+  p.splits = lgm_cdiv(p.C / KC, p.pps);
+  p.units = (int)((long)p.nbg * p.tb_h * p.tb_w * p.tiles_n * p.splits);
+  const size_t smem = (size_t)MBUF * sizeof(float);
+  p.dbg = (long long*)lgm_wino4_debug_buffer;
+#define LGM_W4LAUNCH(CC, DD, EE)                                                                                \
+  do {                                                                                                          \
+    auto kern = wino4_conv_kernel<CC, DD, EE>;                                                                        \
+    static bool attr = false;                                                                                   \
+    if (!attr) {                                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)smem);                                                                     \
+      attr = true;                                                                                              \
+    }                                                                                                           \
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(512), smem, s, p);                                   \
+  } while (0)
+  lgm_note_kernel(cls == 0 ? "lgmwino4::wino4_conv_kernel<0>" : "lgmwino4::wino4_conv_kernel<1>");
+  if (p.dbg) {
+    const int e = lgm_wino4_debug_exp;
+    if (cls == 1) LGM_W4LAUNCH(1, true, 0);
+    else if (e == 0) LGM_W4LAUNCH(0, true, 0);
+    else if (e == 1) LGM_W4LAUNCH(0, true, 1);
+    else if (e == 2) LGM_W4LAUNCH(0, true, 2);
+    else if (e == 3) LGM_W4LAUNCH(0, true, 3);
+    else if (e == 4) LGM_W4LAUNCH(0, true, 4);
+    else if (e == 7) LGM_W4LAUNCH(0, true, 7);
+    else if (e == 8) LGM_W4LAUNCH(0, true, 8);
+    else LGM_W4LAUNCH(0, true, 15);
+  } else if (cls == 0) LGM_W4LAUNCH(0, false, 0);
+  else LGM_W4LAUNCH(1, false, 0);
+#undef LGM_W4LAUNCH
+  if (partial) {
+    partial[0] = p.splits;
+    partial[1] = p.ws_stride;
+    LGM_LAUNCH_CHECK();
+    return LGM_OK;
+  }
+  if (p.splits > 1)
+    return lgm_splitk_reduce_launch(p.ws, p.ws_stride, p.splits, bias, res, res_pitch, out, out_pitch, M, p.N, s);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// ---- C-ABI ------------------------------------------------------------------------------------
+extern "C" int64_t lgm_conv3x3_wino4_supported(const LgmConvGeom* g, int yx) {
+  if (!g) return 0;
+  return lgm_wino4_supported(g, yx ? g->Nw : g->Cw, yx ? g->Cw : g->Nw) ? 1 : 0;
+}
+
+extern "C" int64_t lgm_conv3x3_wino4_workspace(const LgmConvGeom* g, int yx) {
+  if (!g) return -1;
+  const int gc = yx ? g->Nw : g->Cw, oc = yx ? g->Cw : g->Nw;
+  if (!lgm_wino4_supported(g, gc, oc)) return 0;
+  const int s = lgm_wino4_splits(g, gc, oc);
+  return s > 1 ? (int64_t)s * g->B * g->H * g->W * oc * (int64_t)sizeof(float) : 0;
+}
+
+// 1 when the F(4x4) kernel is expected to beat the F(2x2) kernel on this layer (measured on the MI355X, B = 128,
+// tools/wino4_bench.py): enough units to fill the chip without splitting the reduction more than twice
+extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
+  if (!g) return 0;
+  const int gc = yx ? g->Nw : g->Cw, oc = yx ? g->Cw : g->Nw;
+  if (!lgm_wino4_supported(g, gc, oc)) return 0;
+  static const int force = getenv("LGM_WINO4_FORCE") ? atoi(getenv("LGM_WINO4_FORCE")) : 0;
+  if (force) return 1;
+  static const long min_units = getenv("LGM_WINO4_MIN_UNITS") ? atol(getenv("LGM_WINO4_MIN_UNITS")) : 128;
+  const int cls = lgmwino4::unit_class(g->H, g->W);
+  const long base = cls == 1 ? (long)(g->B / 2) * (oc / 64) : (long)g->B * (g->H / 16) * (g->W / 32) * (oc / 64);
+  return base >= min_units ? 1 : 0;
+}
+
+extern "C" int lgm_wino4_weights(const float* src, float* dst_f, float* dst_b, const int64_t* table, int n_slots,
+                                 int64_t total_blocks, void* stream) {
+  LGM_REQUIRE(src && table && n_slots > 0 && total_blocks > 0 && (dst_f || dst_b), "wino4_weights: bad arguments");
+  hipLaunchKernelGGL(lgmwino4::wino4_weights_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     src, dst_f, dst_b, (const long*)table, n_slots);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+extern "C" int lgm_conv3x3_wino4(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,
+                                 const float* bias, const float* res, int64_t res_pitch, float* out, int64_t out_pitch,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  LGM_REQUIRE(g && a && u && out, "conv3x3_wino4: null pointer");
+  const int gc = yx ? g->Nw : g->Cw, oc = yx ? g->Cw : g->Nw;
+  LGM_REQUIRE(lgm_wino4_supported(g, gc, oc), "conv3x3_wino4: unsupported geometry (3x3/s1/p1, maps 16x16 or H %% 16 == 0 "
+              "and W %% 32 == 0, reduction channels %% 32, produced channels %% 64)");
+  LGM_REQUIRE(a_pitch % 4 == 0 && a_pitch >= gc && lgm_aligned16(a) && lgm_aligned16(u) && lgm_aligned16(out) &&
+              out_pitch % 4 == 0 && out_pitch >= oc && (!res || (lgm_aligned16(res) && res_pitch % 4 == 0 && res_pitch >= oc)) &&
+              (!bias || lgm_aligned16(bias)), "conv3x3_wino4: 16-byte aligned operands with pitch %% 4 == 0 expected");
+  const long pix = (long)g->B * g->H * g->W + g->W + 1;
+  LGM_REQUIRE(pix * a_pitch < (1L << 29) && pix * out_pitch < (1L << 29) && pix * (res ? res_pitch : 0) < (1L << 29),
+              "conv3x3_wino4: tensor too large for 32-bit offsets");
+  return lgm_wino4_launch(g, yx, a, a_pitch, u, bias, res, res_pitch, out, out_pitch, workspace, workspace_bytes,
+                          (hipStream_t)stream);
+}
+
+extern "C" int lgm_conv3x3_wino4_partial(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,
+                                         const float* bias, float* out, int64_t out_pitch, void* workspace,
+                                         int64_t workspace_bytes, int64_t* partial, void* stream) {
+  LGM_REQUIRE(g && a && u && out && partial, "conv3x3_wino4_partial: null pointer");
+  const int gc = yx ? g->Nw : g->Cw, oc = yx ? g->Cw : g->Nw;
+  LGM_REQUIRE(lgm_wino4_supported(g, gc, oc), "conv3x3_wino4_partial: unsupported geometry");
+  LGM_REQUIRE(a_pitch % 4 == 0 && a_pitch >= gc && lgm_aligned16(a) && lgm_aligned16(u) && lgm_aligned16(out) &&
+              out_pitch % 4 == 0 && out_pitch >= oc && (!bias || lgm_aligned16(bias)),
+              "conv3x3_wino4_partial: 16-byte aligned operands with pitch %% 4 == 0 expected");
+  const long pix = (long)g->B * g->H * g->W + g->W + 1;
+  LGM_REQUIRE(pix * a_pitch < (1L << 29) && pix * out_pitch < (1L << 29), "conv3x3_wino4_partial: tensor too large for 32-bit offsets");
+  return lgm_wino4_launch(g, yx, a, a_pitch, u, bias, nullptr, 0, out, out_pitch, workspace, workspace_bytes,
+                          (hipStream_t)stream, partial);
+}

@@ -96,6 +96,9 @@ class FlatParams:
         self._t_table = None
         self._t_skip = set()
         self._wino_off = {}
+        self._w4 = {}               # slot offset -> (Uf, Ub, Np, Cp) | False: F(4x4) operands, registered on first use
+        self._w4_table = None
+        self._w4_table_old = None
         # opt-in split-precision convolutions (LGM_CONV_MODE=bf16x3): three bf16 planes of the weights
         # (forward layout) and of their transposed copies, in MFMA fragment order
         self.wino = False           # Winograd-transformed 3x3 weights (see enable_wino)
@@ -169,6 +172,52 @@ class FlatParams:
         ops.lib().lgm_wino_weights(self.data.data_ptr(), self.data_uf.data_ptr(),
                                    self.data_ub.data_ptr() if backward_operand else None, self._wino_table.data_ptr(),
                                    self._wino_table.shape[0], self._wino_blocks, ops.stream())
+        self._refresh_wino4(backward_operand)
+
+    # -- F(4x4, 3x3) operands (csrc/winograd4.hip): only for the slots a large-map layer actually asked for ----------
+    def wino4_u(self, slot_offset: int, backward: bool):
+        """Address of the F(4x4) operand U = G g G^T (36 values per weight) of the 3x3 slot at ``slot_offset``, or None.
+        Slots register themselves on first use (the big-channel layers of the small maps never do: their operands
+        would be 4x the weights, per direction, rewritten every step).  Each slot owns its two tensors and they never
+        move, so addresses baked into captured graphs stay valid when another slot registers later; registration itself
+        is refused while a capture is running (the caller then takes the F(2x2) kernel)."""
+        ent = self._w4.get(slot_offset)
+        if ent is None:
+            if not self.wino or slot_offset not in self._wino_off or torch.cuda.is_current_stream_capturing():
+                return None
+            slot = next(s for s in self.slots if s.offset == slot_offset)
+            Np, T, Cp = slot.phys_shape
+            if T != 9 or Np % 64 or Cp % 64:
+                self._w4[slot_offset] = False
+                return None
+            ent = (torch.zeros(Np * Cp * 36, dtype=torch.float32, device=self.device),
+                   torch.zeros(Np * Cp * 36, dtype=torch.float32, device=self.device), Np, Cp)
+            self._w4[slot_offset] = ent
+            self._w4_table = None
+            self._refresh_wino4(True)                 # the new slot's operands exist before its first use
+        return (ent[1] if backward else ent[0]).data_ptr() if ent else None
+
+    def _refresh_wino4(self, backward_operand: bool = True):
+        from . import ops
+        live = [(off, e) for off, e in self._w4.items() if e]
+        if not live:
+            return
+        if self._w4_table is None:
+            # one table-driven launch for all registered slots: destination offsets are relative to the FIRST slot's
+            # tensors (the others sit wherever the allocator put them: signed offsets)
+            bf, bb = live[0][1][0].data_ptr(), live[0][1][1].data_ptr()
+            rows, blk = [], 0
+            for off, (uf, ub, Np, Cp) in live:
+                assert (uf.data_ptr() - bf) % 4 == 0 and (ub.data_ptr() - bb) % 4 == 0
+                rows.append([off, Np, Cp, (uf.data_ptr() - bf) // 4, (ub.data_ptr() - bb) // 4, blk])
+                blk += (Np // 32) * (Cp // 32)
+            if self._w4_table_old is not None:
+                ops._WS_RETIRED.append(self._w4_table_old)     # a captured refresh launch may still read the old table
+            self._w4_table = torch.tensor(rows, dtype=torch.int64, device=self.device).contiguous()
+            self._w4_table_old = self._w4_table
+            self._w4_blocks, self._w4_base = blk, (bf, bb)
+        ops.lib().lgm_wino4_weights(self.data.data_ptr(), self._w4_base[0], self._w4_base[1] if backward_operand else None,
+                                    self._w4_table.data_ptr(), self._w4_table.shape[0], self._w4_blocks, ops.stream())
 
     # -- split-precision planes ---------------------------------------------------------------
     def enable_b3(self):

@@ -220,6 +220,67 @@ def _wino_u(w_ptr: Optional[int], backward: bool):
     return None
 
 
+# Winograd F(4x4,3x3) on the large maps (csrc/winograd4.hip): taken before the F(2x2) kernel where the library's
+# measured table prefers it (lgm_conv3x3_wino4_preferred); LGM_NO_WINO4=1 switches it off.
+WINO4 = _os.environ.get("LGM_NO_WINO4", "0") != "1"
+_WINO4_OK = {}
+
+
+def _wino4_preferred(g: ConvGeom, yx: int) -> bool:
+    key = (g.B, g.H, g.W, g.Cw, g.Nw, g.KH, g.KW, g.stride, g.pad, yx)
+    v = _WINO4_OK.get(key)
+    if v is None:
+        v = bool(WINO4 and g.KH == 3 and g.KW == 3 and lib().lgm_conv3x3_wino4_preferred(ctypes.byref(g), yx))
+        _WINO4_OK[key] = v
+    return v
+
+
+def _wino4_u(w_ptr: Optional[int], backward: bool):
+    """-> address of the F(4x4) operand of the 3x3 weight slot at ``w_ptr`` (registered on first use), or None"""
+    if w_ptr is None:
+        return None
+    for ref in _WINO_FLATS:
+        fp = ref()
+        if fp is None:
+            continue
+        off = w_ptr - fp.data.data_ptr()
+        if 0 <= off < 4 * fp.total:
+            return fp.wino4_u(off // 4, backward) if off % 4 == 0 else None
+    return None
+
+
+def _wino4_call(yx: int, g: ConvGeom, a, u_ptr: int, bias_ptr, res, out, partial: bool = False):
+    """As _wino_call, through lgm_conv3x3_wino4[_partial]."""
+    if a.data_ptr() % 16 or out.data_ptr() % 16 or pitch(a) % 4 or pitch(out) % 4 or (bias_ptr or 0) % 16:
+        return False
+    if res is not None and (res.data_ptr() % 16 or pitch(res) % 4):
+        return False
+    fkey = (g.B, g.H, g.W, pitch(a), pitch(out), pitch(res) if res is not None else 0)
+    fits = _WINO_FITS.get(fkey)
+    if fits is None:
+        fits = bool(lib().lgm_conv3x3_wino_fits(ctypes.byref(g), fkey[3], fkey[4], fkey[5]))
+        _WINO_FITS[fkey] = fits
+    if not fits:
+        return False
+    key = (g.B, g.H, g.W, g.Cw, g.Nw, yx, "w4")
+    n = _WINO_WS.get(key)
+    if n is None:
+        n = lib().lgm_conv3x3_wino4_workspace(ctypes.byref(g), yx)
+        _WINO_WS[key] = n
+    ws = workspace(n, a.device) if n > 0 else None
+    if partial:
+        assert res is None
+        part = (ctypes.c_int64 * 2)()
+        lib().lgm_conv3x3_wino4_partial(yx, ctypes.byref(g), a.data_ptr(), pitch(a), u_ptr, bias_ptr, out.data_ptr(),
+                                        pitch(out), None if ws is None else ws.data_ptr(),
+                                        0 if ws is None else ws.numel() * 4, ctypes.addressof(part), stream())
+        return (ws.data_ptr(), int(part[1]), int(part[0])) if part[0] > 1 else True
+    lib().lgm_conv3x3_wino4(yx, ctypes.byref(g), a.data_ptr(), pitch(a), u_ptr, bias_ptr, _p(res),
+                            pitch(res) if res is not None else 0, out.data_ptr(), pitch(out),
+                            None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, stream())
+    return True
+
+
 def _wino_supported(g: ConvGeom, yx: int) -> bool:
     key = (g.B, g.H, g.W, g.Cw, g.Nw, g.KH, g.KW, g.stride, g.pad, yx)
     v = _WINO_OK.get(key)
@@ -325,6 +386,14 @@ def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y, partial
         if TIMER is not None:
             TIMER.end()
         return None
+    if WINO and _WINO_FLATS and not B3 and _wino4_preferred(g, 0):
+        u = _wino4_u(w_ptr, False)
+        if u is not None:
+            r = _wino4_call(0, g, x, u, bias_ptr, res, y, partial and PLANES and res is None)
+            if r:
+                if TIMER is not None:
+                    TIMER.end()
+                return None if r is True else r + (bias_ptr,)
     if WINO and _WINO_FLATS and not B3 and _wino_supported(g, 0):
         u = _wino_u(w_ptr, False)
         if u is not None:
@@ -391,6 +460,14 @@ def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr:
         if TIMER is not None:
             TIMER.end()
         return None
+    if WINO and _WINO_FLATS and not B3 and _wino4_preferred(g, 1):
+        u = _wino4_u(w_ptr, True)
+        if u is not None:
+            r = _wino4_call(1, g, y, u, bias_ptr, res, x, partial and PLANES and res is None)
+            if r:
+                if TIMER is not None:
+                    TIMER.end()
+                return None if r is True else r + (bias_ptr,)
     if WINO and _WINO_FLATS and not B3 and _wino_supported(g, 1):
         u = _wino_u(w_ptr, True)
         if u is not None:
@@ -456,6 +533,8 @@ def conv_bwd_pair(g: ConvGeom, gy, x, w_ptr: int, gw_ptr: int, beta: float, gbia
     or, with ``partial``, the planes tuple of conv_yx(partial=True)."""
     if not (WINO and _WINO_FLATS and not B3) or g.KH != 3 or g.KW != 3:
         return False
+    if _wino4_preferred(g, 1) and _wino4_u(w_ptr, True) is not None:
+        return False        # large maps: F(4x4) input gradient (conv_yx) + the stand-alone Winograd weight gradient
     u = _wino_u(w_ptr, True)
     if u is None:
         return False

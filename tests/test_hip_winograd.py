@@ -295,3 +295,118 @@ def test_backward_pair_launch_matches_separate_launches(dev, case, variant, pari
     y64 = F.conv2d(x64, w4, None, padding=1)
     (gw64,) = torch.autograd.grad(y64, w4, gy.cpu().permute(0, 3, 1, 2).double())
     parity("weight gradient vs float64 autograd", maxerr(gw - 0.5, gw64.permute(0, 2, 3, 1).reshape(co, 9, ci)), 5e-6)
+
+
+# ---- Winograd F(4x4, 3x3) on the large maps (csrc/winograd4.hip) ------------------------------------------------------
+def wino4_weights(w):
+    from lgm_hip import ops
+    Np, _, Cp = w.shape
+    uf = torch.empty(Np * Cp * 36, device=w.device)
+    ub = torch.empty(Np * Cp * 36, device=w.device)
+    tab = torch.tensor([[0, Np, Cp, 0, 0, 0]], dtype=torch.int64, device=w.device)
+    ops.lib().lgm_wino4_weights(w.data_ptr(), uf.data_ptr(), ub.data_ptr(), tab.data_ptr(), 1, (Np // 32) * (Cp // 32),
+                                ops.stream())
+    return uf, ub
+
+
+def wino4(yx, g, a, u, bias, res, out, partial=False):
+    from lgm_hip import ops
+    L = ops.lib()
+    n = L.lgm_conv3x3_wino4_workspace(ctypes.byref(g), yx)
+    ws = ops.workspace(n, a.device) if n > 0 else None
+    wsp, wsb = (None, 0) if ws is None else (ws.data_ptr(), ws.numel() * 4)
+    if partial:
+        part = (ctypes.c_int64 * 2)()
+        L.lgm_conv3x3_wino4_partial(yx, ctypes.byref(g), a.data_ptr(), ops.pitch(a), u.data_ptr(),
+                                    None if bias is None else bias.data_ptr(), out.data_ptr(), ops.pitch(out), wsp, wsb,
+                                    ctypes.addressof(part), ops.stream())
+        return ws, int(part[0]), int(part[1])
+    L.lgm_conv3x3_wino4(yx, ctypes.byref(g), a.data_ptr(), ops.pitch(a), u.data_ptr(), None if bias is None else bias.data_ptr(),
+                        None if res is None else res.data_ptr(), 0 if res is None else ops.pitch(res), out.data_ptr(),
+                        ops.pitch(out), wsp, wsb, ops.stream())
+    return n
+
+
+# (B, H, W, Cin, Cout): both unit classes (16 x 16 maps: two images per unit; >= 16 x 32: 4 x 8 tiles of one image), several
+# tile blocks per image, several channel blocks, with and without split-K, a non-square map
+CASES4 = [(2, 16, 16, 64, 64), (4, 16, 16, 192, 128), (3, 32, 32, 64, 64), (1, 32, 32, 128, 64), (1, 64, 64, 64, 64),
+          (2, 16, 32, 64, 128), (130, 16, 16, 64, 64)]
+F4_TOL = 1e-5     # F(4x4,3x3) in fp32: a few 1e-6 of the output scale against float64 (F(2x2): 2e-7); the parity bar is 1e-4
+
+
+@pytest.mark.parametrize("case", CASES4)
+def test_winograd4_forward_and_input_gradient(dev, case, parity):
+    """lgm_conv3x3_wino4 (reference op: Block.proj ddpm.py:157-173 and its input gradient) against a float64 convolution:
+    bias + residual, operands in channel slices of wider buffers, nothing written outside the output slice."""
+    from lgm_hip import ops
+    B, H, W, ci, co = case
+    gen = torch.Generator().manual_seed(sum(case))
+    xbuf = torch.randn(B, H, W, ci + 32, generator=gen)
+    ybuf = torch.randn(B, H, W, co + 64, generator=gen)
+    x, y = xbuf[..., 32:], ybuf[..., :co]
+    w = torch.randn(co, 9, ci, generator=gen) / (3 * ci ** 0.5)
+    bias = torch.randn(co, generator=gen)
+    res = torch.randn(B, H, W, co, generator=gen)
+    w4 = w.reshape(co, 3, 3, ci).permute(0, 3, 1, 2).double()
+    ref_xy = F.conv2d(x.permute(0, 3, 1, 2).double(), w4, bias.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+    ref_yx = F.conv_transpose2d(y.permute(0, 3, 1, 2).double(), w4, None, padding=1).permute(0, 2, 3, 1)
+    xd_buf, yd_buf = xbuf.to(dev), ybuf.to(dev)
+    xd, yd = xd_buf[..., 32:], yd_buf[..., :co]
+    wd, bd, rd = w.to(dev), bias.to(dev), res.to(dev)
+    uf, ub = wino4_weights(wd)
+    g = ops.make_geom(B, H, W, ci, co, 3, 3, 1, 1)
+    assert ops.lib().lgm_conv3x3_wino4_supported(ctypes.byref(g), 0) == 1
+    obuf = torch.full((B, H, W, co + 16), 7.0, device=dev)
+    out = obuf[..., 16:]
+    nws = wino4(0, g, xd, uf, bd, rd, out)
+    parity(f"F(4x4) forward (+bias +residual, pitched operands, split-K workspace {nws} B)", maxerr(out, ref_xy), F4_TOL)
+    assert float((obuf[..., :16] - 7.0).abs().max()) == 0
+    gx = torch.empty(B, H, W, ci, device=dev)
+    wino4(1, g, yd, ub, None, None, gx)
+    parity("F(4x4) input gradient", maxerr(gx, ref_yx), F4_TOL)
+    # accumulate form (res == out): the skip-connection gradients of the up path
+    gx2 = torch.randn(B, H, W, ci, generator=gen).to(dev)
+    ref2 = ref_yx + gx2.double().cpu()
+    wino4(1, g, yd, ub, None, gx2, gx2)
+    parity("F(4x4) input gradient accumulated in place", maxerr(gx2, ref2), F4_TOL)
+    # bit-reproducible (fixed summation orders everywhere)
+    o2 = torch.empty_like(out)
+    wino4(0, g, xd, uf, bd, rd, o2)
+    o3 = torch.empty_like(out)
+    wino4(0, g, xd, uf, bd, rd, o3)
+    assert torch.equal(o2, o3)
+
+
+def test_winograd4_partial_planes_and_weight_transform(dev, parity):
+    """The split-K planes lgm_conv3x3_wino4_partial leaves sum (plane 0, 1, ..., + bias: the reducer's order) to exactly
+    what the complete call writes; U = G g G^T matches its float64 definition."""
+    from lgm_hip import ops
+    B, H, W, ci, co = 4, 16, 16, 192, 128
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, ci, generator=gen).to(dev)
+    w = (torch.randn(co, 9, ci, generator=gen) / (3 * ci ** 0.5)).to(dev)
+    bias = torch.randn(co, generator=gen).to(dev)
+    uf, ub = wino4_weights(w)
+    g = ops.make_geom(B, H, W, ci, co, 3, 3, 1, 1)
+    full = torch.empty(B, H, W, co, device=dev)
+    wino4(0, g, x, uf, bias, None, full)
+    out = torch.full((B, H, W, co), 3.0, device=dev)
+    ws, planes, stride = wino4(0, g, x, uf, bias, None, out, partial=True)
+    assert planes > 1, "this geometry is expected to split its reduction"
+    acc = ws[:stride].clone()
+    for k in range(1, planes):
+        acc = acc + ws[k * stride:(k + 1) * stride]
+    acc = acc.view(B, H, W, co) + bias
+    assert torch.equal(acc, full) and float((out - 3.0).abs().max()) == 0      # `out` untouched in the partial form
+    # weight transform against the definition, float64
+    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                      [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+    g3 = w.double().cpu().reshape(co, 3, 3, ci)
+    U = torch.einsum("ia,nabc,jb->nijc", G, g3, G)                               # [n][6][6][c]
+    uf_l = uf.cpu().view(co // 64, ci // 8, 36, 2, 2, 32, 4)                     # [n/64][c/8][xi][(n%64)/32][(c%8)/4][n%32][c%4]
+    got = uf_l.permute(0, 3, 5, 2, 1, 4, 6).reshape(co, 36, ci)                  # [n][xi][c]
+    parity("F(4x4) forward operand vs G g G^T", maxerr(got, U.reshape(co, 36, ci)), 2e-7)
+    Ub = torch.einsum("ia,nabc,jb->cijn", G, g3.flip(1, 2), G)                   # mirrored taps, roles swapped: [c][6][6][n]
+    ub_l = ub.cpu().view(ci // 64, co // 8, 36, 2, 2, 32, 4)
+    gotb = ub_l.permute(0, 3, 5, 2, 1, 4, 6).reshape(ci, 36, co)
+    parity("F(4x4) input-gradient operand vs its definition", maxerr(gotb, Ub.reshape(ci, 36, co)), 2e-7)
