@@ -51,7 +51,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int KC = 8;              // reduction channels per phase
 constexpr int NXI = 36;
 constexpr int VBUF = NXI * 256;    // floats per V buffer: [xi][k-half][tile 32][4]
-constexpr int MBUF = NXI * 32 * 32;   // floats of the epilogue exchange: [xi][tile 32][8 quads (swizzled)][4]
+constexpr int MBUF = NXI * 32 * 32;   // floats of the epilogue exchange: two halves of [xi][tile 32][4 quads (swizzled)][4]
 
 template <int CLS>
 struct Geo;
@@ -62,6 +62,10 @@ struct Geo<0> {   // maps >= 16 x 32: 4 x 8 tiles of one image
 template <>
 struct Geo<1> {   // 16 x 16 maps: 4 x 4 tiles of two images; 4 RS = 16 (mod 32) spreads the two tile rows of a wave
   static constexpr int NI = 2, TTH = 4, TTW = 4, PH = 18, PW = 18, RS = 20, IMG = PH * RS, PLANE = 737;
+};
+template <>
+struct Geo<2> {   // 8 x 8 maps: 2 x 2 tiles of eight images; 4 RS = 8, IMG = 16 (mod 32): a wave's 2 x 2 x 2 (tx, ty, image)
+  static constexpr int NI = 8, TTH = 2, TTW = 2, PH = 10, PW = 10, RS = 10, IMG = 112, PLANE = 897;   // tiles on 8 banks apart
 };
 
 struct Args {
@@ -172,23 +176,27 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
     plds[j] = l;
   }
   u32x4 rp[NJ];
-  auto fetch = [&](int ph) {       // phase index relative to cc0; beyond the unit's range: zeros
+  auto fetch1 = [&](int j, int ph) -> u32x4 {   // phase index relative to cc0; beyond the unit's range: zeros
     const unsigned soff = (unsigned)((cc0 + ph) * (KC * 4));
-    const bool ok = ph < nph;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) rp[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? goff[j] : nrec_a, soff, 0);
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ph < nph ? goff[j] : nrec_a, soff, 0);
   };
-  auto commit = [&](float* rbuf) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      float* d = rbuf + plds[j];
-      const f32x4 f = __builtin_bit_cast(f32x4, rp[j]);     // cast the whole vector first (hipcc, DESIGN finding 14)
-      d[0] = f[0];
-      d[PLANE] = f[1];
-      d[2 * PLANE] = f[2];
-      d[3 * PLANE] = f[3];
-    }
+  auto commit_r = [&](float* rbuf, int j, const u32x4 r) {
+    float* d = rbuf + plds[j];
+    const f32x4 f = __builtin_bit_cast(f32x4, r);         // cast the whole vector first (hipcc, DESIGN finding 14)
+    d[0] = f[0];
+    d[PLANE] = f[1];
+    d[2 * PLANE] = f[2];
+    d[3 * PLANE] = f[3];
   };
+  // The first three patches are requested HERE, before the rest of the set-up (role addressing, descriptors, 144
+  // accumulator zeros): a workgroup's first loads miss every cache, and ~2 k cycles of set-up fit under them.
+  u32x4 rq0[NJ], rq1[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) rq0[j] = fetch1(j, 0);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) rq1[j] = fetch1(j, 1);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) rp[j] = fetch1(j, 2);
 
   // ---- transform role ----
   int t_tile, t_img, t_ty, t_tx;
@@ -199,11 +207,16 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
     t_ty = wid & 3;
     t_tx = (lane >> 2) & 7;
     t_tile = t_ty * 8 + t_tx;
-  } else {
+  } else if (CLS == 1) {
     t_img = (wid >> 1) & 1;
     t_ty = 2 * (wid & 1) + ((lane >> 4) & 1);
     t_tx = (lane >> 2) & 3;
     t_tile = t_img * 16 + t_ty * 4 + t_tx;
+  } else {
+    t_img = 2 * (wid & 3) + ((lane >> 4) & 1);
+    t_ty = (lane >> 3) & 1;
+    t_tx = (lane >> 2) & 1;
+    t_tile = t_img * 4 + t_ty * 2 + t_tx;
   }
   const int trd = tk * PLANE + t_img * IMG + 4 * t_ty * RS + 4 * t_tx;
   const int vwr = (tk >> 2) * 128 + t_tile * 4 + (tk & 3) + half * (18 * 256);
@@ -280,32 +293,22 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
         v[5 * 256] = __builtin_fmaf(4.f, t1, __builtin_fmaf(-5.f, t3, t5));
       }
     };
-    auto commit1 = [&](float* rbuf, int j) {
-      float* d = rbuf + plds[j];
-      const f32x4 f = __builtin_bit_cast(f32x4, rp[j]);     // cast the whole vector first (hipcc, DESIGN finding 14)
-      d[0] = f[0];
-      d[PLANE] = f[1];
-      d[2 * PLANE] = f[2];
-      d[3 * PLANE] = f[3];
-    };
 
     // ---- prologue ----
     stamp();
     f32x4 uq[3];
 #pragma unroll
     for (int e = 0; e < 3; ++e) uq[e] = load_u(0, e);
-    {   // both patches of the first two phases are requested before either is waited for
-      u32x4 r1[NJ];
-      fetch(1);
+    if (DBG) __builtin_amdgcn_sched_barrier(0);
+    stamp();                                         // (diagnostic) set-up and accumulator zeros done, loads in flight
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) r1[j] = rp[j];
-      fetch(0);
-      commit(Rb);
+    for (int j = 0; j < NJ; ++j) commit_r(Rb, j, rq0[j]);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) rp[j] = r1[j];
-      commit(Rb + RBUF);
-    }
+    for (int j = 0; j < NJ; ++j) commit_r(Rb + RBUF, j, rq1[j]);
+    if (DBG) __builtin_amdgcn_sched_barrier(0);
+    stamp();                                         // first two patches landed and committed
     __syncthreads();
+    stamp();
 #pragma unroll
     for (int cp = 0; cp < 3; ++cp) stage1(0, cp);
 #pragma unroll
@@ -313,11 +316,15 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
       stage2(Vb, i, 0);
       stage2(Vb, i, 1);
     }
+    if (DBG) __builtin_amdgcn_sched_barrier(0);
+    stamp();                                         // first transform
     __syncthreads();
     stamp();
 
     // ---- phase: nine steps of 4 MFMAs (one xi each), the side work dealt out over them; nothing crosses a step
-    // boundary (sched_barrier), so the U fragment loaded at the end of step e for step e + 3 IS three steps ahead ----
+    // boundary (sched_barrier), so the U fragment loaded at the end of step e for step e + 3 IS three steps ahead.
+    // Raw patches: raw(ph + 1) is transformed (steps 0-8), raw(ph + 2) - in registers since the previous phase - is
+    // committed (steps 6-8) and raw(ph + 3) requested in its place ----
     auto phase = [&](int ph, auto cur_c) {
       constexpr int cur = decltype(cur_c)::value;
       float* const rcur = Rb + cur * RBUF;
@@ -332,16 +339,18 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s], vf[s], acc[e], 0, 0, 0);
         if (!(EXP & 4)) uq[e % 3] = (e + 3 < 9) ? load_u(ph, e + 3) : load_u(ph + 1, e + 3 - 9);
-        if (e == 0 && !(EXP & 2)) fetch(ph + 2);
         if (!(EXP & 1)) {
           if (e < 3) stage1(cur ^ 1, e);
           else stage2(vnxt, (e - 3) >> 1, (e - 3) & 1);
         }
-        if (e >= 6 && !(EXP & 2)) commit1(rcur, e - 6);
+        if (e >= 9 - NJ && !(EXP & 2)) {               // raw(ph + 2), requested a whole phase ago, into the buffer
+          commit_r(rcur, e - (9 - NJ), rp[e - (9 - NJ)]);   // phase ph - 1 finished reading; then the request for raw(ph + 3)
+          rp[e - (9 - NJ)] = fetch1(e - (9 - NJ), ph + 3);
+        }
         vf = vfn;
         __builtin_amdgcn_sched_barrier(0);
       }
-      static_assert(NJ == 3, "the commit is dealt out over steps 6..8");
+      static_assert(NJ >= 1 && NJ <= 4, "the commit is dealt out over the last NJ steps");
       __syncthreads();
       stamp();
     };
@@ -350,78 +359,86 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
       if (ph + 1 < nph) phase(ph + 1, std::integral_constant<int, 1>{});
     }
 
-    // ---- epilogue addressing (computed here: no registers held across the phases) ----
-    const int eq = tid & 7, et = (tid >> 3) & 31;
+    // ---- epilogue.  The 36 xi of a (tile, channel) sit in four waves: the accumulators go through LDS.  Two ROUNDS of
+    // 16 output channels per half: each half (waves 0-3 / 4-7 = output channels 0-31 / 32-63) hands two channel quads per
+    // lane group to ITS OWN 72 KB buffer ([xi][tile][4 quads, XOR-swizzled][4]: conflict-free 16-byte writes and reads),
+    // then finishes them: thread = (tile, quad, output row pair), A^T . A in registers, 64-byte segments out with bias /
+    // residual fused.  All eight waves work in both rounds (two per SIMD: one's LDS / store latency under the other's
+    // arithmetic); after the first round's hand-over half of the accumulator registers are free for the transform. ----
+    const int th = tid & 255;
+    const int eq = th & 3, et = (th >> 2) & 31, rpair = __builtin_amdgcn_readfirstlane(th >> 7);
     int e_img, e_ty, e_tx;
     if (CLS == 0) {
       e_img = 0;
       e_ty = et >> 3;
       e_tx = et & 7;
-    } else {
+    } else if (CLS == 1) {
       e_img = et >> 4;
       e_ty = (et >> 2) & 3;
       e_tx = et & 3;
+    } else {
+      e_img = et >> 2;
+      e_ty = (et >> 1) & 1;
+      e_tx = et & 1;
     }
     const long opix = ((long)(b0 + e_img) * p.H + h0 + 4 * e_ty) * p.W + w0 + 4 * e_tx;
     const bool partial = p.splits > 1;
-    float* const obase = partial ? p.ws + (long)split * p.ws_stride + opix * p.N + n0 + eq * 4
-                                 : p.out + opix * p.out_pitch + n0 + eq * 4;
+    const int ncol = n0 + HALF * 32 + eq * 4;
+    float* const obase = partial ? p.ws + (long)split * p.ws_stride + opix * p.N + ncol : p.out + opix * p.out_pitch + ncol;
     const long opitch = partial ? (long)p.N : p.out_pitch;
     const bool has_res = !partial && p.res != nullptr;           // kernel argument: a scalar branch
-    const float* const rbase = p.res + opix * p.res_pitch + n0 + eq * 4;
-    const int mrd = (et * 8 + (eq ^ (et & 7))) * 4;
-
-    // ---- epilogue: two passes of 32 output channels through LDS; this half finishes output rows HALF, HALF + 2 ----
+    const float* const rbase = p.res + opix * p.res_pitch + ncol;
+    float* const Mh = Mb + HALF * (MBUF / 2);
+    const int mrd = (et * 4 + (eq ^ ((et >> 1) & 3))) * 4;
+    const int mwr = (lr * 4) * 4;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      // pass c: the waves that hold output channels 32 c .. 32 c + 31 (ch == HALF == c) hand their accumulators to LDS
-      // and - their registers now free - finish one (tile, channel quad) each: all four output rows, 36 reads.  The other
-      // half waits (pass 0: its accumulators are still live, 144 + the transform's ~120 registers would spill); per SIMD
-      // the instruction count is the same as with the work spread over both of its waves.
-      if (HALF == c) {
+    for (int rd = 0; rd < 2; ++rd) {
+      if (rd == 1) __syncthreads();                    // round 0's reads are done before its buffer is overwritten
 #pragma unroll
-        for (int e = 0; e < 9; ++e)
+      for (int e = 0; e < 9; ++e)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = {acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(Mb + (((xg * 9 + e) * 32 + lr) * 8 + ((2 * g + lh) ^ (lr & 7))) * 4) = v;
-          }
-      }
-      __syncthreads();
-      if (HALF == c) {
-        f32x4 X[4][6];                                 // A^T m: output row x xi column
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          auto m = [&](int i) -> f32x4 { return *reinterpret_cast<const f32x4*>(Mb + (i * 6 + j) * 1024 + mrd); };
-          const f32x4 m1 = m(1), m2 = m(2), m3 = m(3), m4 = m(4);
-          const f32x4 s1 = add4(m1, m2), d1 = sub4(m1, m2), s2 = add4(m3, m4), d2 = sub4(m3, m4);
-          X[0][j] = add4(add4(m(0), s1), s2);
-          X[1][j] = fma4(2.f, d2, d1);
-          X[2][j] = fma4(4.f, s2, s1);
-          X[3][j] = add4(fma4(8.f, d2, d1), m(5));
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * rd + gg;
+          const f32x4 v = {acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(Mh + (xg * 9 + e) * 512 + mwr + (((2 * gg + lh) ^ ((lr >> 1) & 3)) * 4)) = v;
         }
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (!partial && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c * 32 + eq * 4);
+      __syncthreads();
+      // stage 1 (over the xi rows i, per xi column j): this thread's two rows of A^T m
+      f32x4 X[2][6];
 #pragma unroll
-        for (int oi = 0; oi < 4; ++oi) {
-          const f32x4 s1 = add4(X[oi][1], X[oi][2]), d1 = sub4(X[oi][1], X[oi][2]);
-          const f32x4 s2 = add4(X[oi][3], X[oi][4]), d2 = sub4(X[oi][3], X[oi][4]);
-          f32x4 y[4];
-          y[0] = add4(add4(X[oi][0], s1), s2);
-          y[1] = fma4(2.f, d2, d1);
-          y[2] = fma4(4.f, s2, s1);
-          y[3] = add4(fma4(8.f, d2, d1), X[oi][5]);
-          if (has_res) {
+      for (int j = 0; j < 6; ++j) {
+        auto m = [&](int i) -> f32x4 { return *reinterpret_cast<const f32x4*>(Mh + (i * 6 + j) * 512 + mrd); };
+        const f32x4 m1 = m(1), m2 = m(2), m3 = m(3), m4 = m(4);
+        if (rpair == 0) {
+          const f32x4 s1 = add4(m1, m2), s2 = add4(m3, m4);
+          X[0][j] = add4(add4(m(0), s1), s2);          // row 0
+          X[1][j] = fma4(4.f, s2, s1);                 // row 2
+        } else {
+          const f32x4 d1 = sub4(m1, m2), d2 = sub4(m3, m4);
+          X[0][j] = fma4(2.f, d2, d1);                 // row 1
+          X[1][j] = add4(fma4(8.f, d2, d1), m(5));     // row 3
+        }
+      }
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (!partial && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol + rd * 16);
 #pragma unroll
-            for (int oj = 0; oj < 4; ++oj)
-              y[oj] = add4(y[oj], *reinterpret_cast<const f32x4*>(rbase + ((long)oi * p.W + oj) * p.res_pitch + c * 32));
-          }
+      for (int rr = 0; rr < 2; ++rr) {
+        const long orow = (long)(2 * rr + rpair) * p.W;
+        const f32x4 s1 = add4(X[rr][1], X[rr][2]), d1 = sub4(X[rr][1], X[rr][2]);
+        const f32x4 s2 = add4(X[rr][3], X[rr][4]), d2 = sub4(X[rr][3], X[rr][4]);
+        f32x4 y[4];
+        y[0] = add4(add4(X[rr][0], s1), s2);
+        y[1] = fma4(2.f, d2, d1);
+        y[2] = fma4(4.f, s2, s1);
+        y[3] = add4(fma4(8.f, d2, d1), X[rr][5]);
+        if (has_res) {
 #pragma unroll
           for (int oj = 0; oj < 4; ++oj)
-            *reinterpret_cast<f32x4*>(obase + ((long)oi * p.W + oj) * opitch + c * 32) = add4(y[oj], bv);
+            y[oj] = add4(y[oj], *reinterpret_cast<const f32x4*>(rbase + (orow + oj) * p.res_pitch + rd * 16));
         }
+#pragma unroll
+        for (int oj = 0; oj < 4; ++oj) *reinterpret_cast<f32x4*>(obase + (orow + oj) * opitch + rd * 16) = add4(y[oj], bv);
       }
-      if (c == 0) __syncthreads();
       stamp();
     }
     if (DBG && threadIdx.x == 0) {
@@ -524,7 +541,12 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
   }
 }
 
+static long unit_count(int cls, int B, int H, int W) {     // units per 64 produced channels, before split-K
+  return cls == 1 ? B / 2 : cls == 2 ? B / 8 : (long)B * (H / 16) * (W / 32);
+}
+
 static int unit_class(int H, int W) {
+  if (H == 8 && W == 8) return 2;
   if (H == 16 && W == 16) return 1;
   if (H >= 16 && W >= 32 && H % 16 == 0 && W % 32 == 0) return 0;
   return -1;
@@ -541,15 +563,14 @@ bool lgm_wino4_supported(const LgmConvGeom* g, int gather_channels, int out_chan
   const long pix = (long)g->B * g->H * g->W + g->W + 1;
   if (pix * gather_channels >= (1L << 29) || pix * out_channels >= (1L << 29)) return false;
   if ((long)gather_channels * out_channels * 36 >= (1L << 29)) return false;
-  return g->B % (cls == 1 ? 2 : 1) == 0;
+  return g->B % (cls == 1 ? 2 : cls == 2 ? 8 : 1) == 0;
 }
 
 int lgm_wino4_splits(const LgmConvGeom* g, int gather_channels, int out_channels) {
   using namespace lgmwino4;
   const int cls = unit_class(g->H, g->W);
   if (cls < 0) return 1;
-  const long base = cls == 1 ? (long)(g->B / 2) * (out_channels / 64)
-                             : (long)g->B * (g->H / 16) * (g->W / 32) * (out_channels / 64);
+  const long base = unit_count(cls, g->B, g->H, g->W) * (out_channels / 64);
   static const int forced = getenv("LGM_WINO4_SPLITS") ? atoi(getenv("LGM_WINO4_SPLITS")) : 0;
   const int phases = gather_channels / KC;
   int smax = phases / 2 < 16 ? phases / 2 : 16;
@@ -558,6 +579,7 @@ int lgm_wino4_splits(const LgmConvGeom* g, int gather_channels, int out_channels
   if (base >= 192) return 1;
   int s = (int)((256 + base - 1) / base);
   if (s > smax) s = smax;
+  while (s > 1 && phases / s < 6) --s;              // a split shorter than ~6 phases is mostly prologue and epilogue
   return s;
 }
 
@@ -573,9 +595,9 @@ int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch,
   p.C = yx ? g->Nw : g->Cw;
   p.N = yx ? g->Cw : g->Nw;
   const int cls = unit_class(g->H, g->W);
-  p.tb_h = cls == 1 ? 1 : g->H / 16;
-  p.tb_w = cls == 1 ? 1 : g->W / 32;
-  p.nbg = cls == 1 ? g->B / 2 : g->B;
+  p.tb_h = cls == 0 ? g->H / 16 : 1;
+  p.tb_w = cls == 0 ? g->W / 32 : 1;
+  p.nbg = cls == 1 ? g->B / 2 : cls == 2 ? g->B / 8 : g->B;
   p.tiles_n = p.N / 64;
   const long M = (long)g->B * g->H * g->W;
   p.splits = lgm_wino4_splits(g, p.C, p.N);
@@ -601,10 +623,12 @@ int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch,
     }                                                                                                           \
     hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(512), smem, s, p);                                   \
   } while (0)
-  lgm_note_kernel(cls == 0 ? "lgmwino4::wino4_conv_kernel<0>" : "lgmwino4::wino4_conv_kernel<1>");
+  lgm_note_kernel(cls == 0 ? "lgmwino4::wino4_conv_kernel<0, false, 0>" : cls == 1 ? "lgmwino4::wino4_conv_kernel<1, false, 0>"
+                                                                                    : "lgmwino4::wino4_conv_kernel<2, false, 0>");
   if (p.dbg) {
     const int e = lgm_wino4_debug_exp;
     if (cls == 1) LGM_W4LAUNCH(1, true, 0);
+    else if (cls == 2) LGM_W4LAUNCH(2, true, 0);
     else if (e == 0) LGM_W4LAUNCH(0, true, 0);
     else if (e == 1) LGM_W4LAUNCH(0, true, 1);
     else if (e == 2) LGM_W4LAUNCH(0, true, 2);
@@ -614,7 +638,8 @@ int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch,
     else if (e == 8) LGM_W4LAUNCH(0, true, 8);
     else LGM_W4LAUNCH(0, true, 15);
   } else if (cls == 0) LGM_W4LAUNCH(0, false, 0);
-  else LGM_W4LAUNCH(1, false, 0);
+  else if (cls == 1) LGM_W4LAUNCH(1, false, 0);
+  else LGM_W4LAUNCH(2, false, 0);
 #undef LGM_W4LAUNCH
   if (partial) {
     partial[0] = p.splits;
@@ -652,7 +677,15 @@ extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
   if (force) return 1;
   static const long min_units = getenv("LGM_WINO4_MIN_UNITS") ? atol(getenv("LGM_WINO4_MIN_UNITS")) : 128;
   const int cls = lgmwino4::unit_class(g->H, g->W);
-  const long base = cls == 1 ? (long)(g->B / 2) * (oc / 64) : (long)g->B * (g->H / 16) * (g->W / 32) * (oc / 64);
+  const long base = lgmwino4::unit_count(cls, g->B, g->H, g->W) * (oc / 64);
+  // 8 x 8 maps: few units (8 images each), so the reduction is split; worth it when a split still has >= 8 phases
+  static const bool no8 = getenv("LGM_WINO4_NO8") != nullptr;           // A/B switch
+  // (forward only: the input gradient of these layers shares ONE launch with the weight gradient - wino_bwd_pair_kernel -
+  // and taking it out of the pair costs what the faster kernel gains: 10.97 vs 10.95 ms per step, measured)
+  static const bool yx8 = getenv("LGM_WINO4_YX8") != nullptr;
+  if (cls == 2) return (!no8 && (yx == 0 || yx8) && base >= 32 && gc >= 256) ? 1 : 0;
+  static const int c1_minc = getenv("LGM_WINO4_C1_MINC") ? atoi(getenv("LGM_WINO4_C1_MINC")) : 0;
+  if (cls == 1 && gc < c1_minc) return 0;
   return base >= min_units ? 1 : 0;
 }
 

@@ -19,7 +19,8 @@ from wino_bench import timeit, wino, wino_weights  # noqa: E402
 
 SHAPES = [("64->64 @32", 64, 64, 32, 8), ("128->64 @32", 128, 64, 32, 4), ("64->64 @16", 64, 64, 16, 4),
           ("192->128 @16", 192, 128, 16, 2), ("128->128 @16", 128, 128, 16, 2), ("256->128 @16", 256, 128, 16, 1),
-          ("64->64 @64", 64, 64, 64, 0)]
+          ("64->64 @64", 64, 64, 64, 0), ("128->128 @8", 128, 128, 8, 4), ("384->256 @8", 384, 256, 8, 2),
+          ("256->256 @8", 256, 256, 8, 2), ("512->256 @8", 512, 256, 8, 1)]
 
 
 def wino4_weights(w):
@@ -51,7 +52,7 @@ def main():
         if flt and flt not in name:
             continue
         gen = torch.Generator().manual_seed(ci * 1000 + co + hw)
-        Bs = 4
+        Bs = 8
         x = torch.randn(Bs, hw, hw, ci, generator=gen)
         y = torch.randn(Bs, hw, hw, co, generator=gen)
         w = torch.randn(co, 9, ci, generator=gen) * (1.0 / (3 * ci ** 0.5))

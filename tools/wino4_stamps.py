@@ -46,7 +46,7 @@ def one(exp, g, x, uf, bias, y, dev):
     n = int(d[0, 0])
     st = d[:, 1:1 + n].double()
     dt = (st[:, 1:] - st[:, :-1])
-    names = ["setup", "prologue"] + [f"phase{i}" for i in range(n - 5)] + ["epi0", "epi1"]
+    names = ["setup", "zero+addr", "land+commit", "barrier", "transform", "barrier"] + [f"phase{i}" for i in range(n - 9)] + ["epi0", "epi1"]
     print(f"{d.shape[0]} workgroups, {n} stamps; cycles (median over workgroups):")
     for i, nm in enumerate(names):
         print(f"  {nm:10s} {dt[:, i].median():9.0f}   (min {dt[:, i].min():.0f} max {dt[:, i].max():.0f})")
