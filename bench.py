@@ -54,7 +54,17 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
-WINO_FACTOR = 2.25              # direct 3x3 multiplies per Winograd F(2x2,3x3) multiply
+WINO_FACTOR = 2.25              # direct 3x3 multiplies per Winograd F(2x2,3x3) multiply (36 / 16)
+WINO4_FACTOR = 4.0              # ... per Winograd F(4x4,3x3) multiply (144 / 36)
+
+
+def mfma_factor(kernel_name: str) -> float:
+    """algorithmic (direct-convolution) FLOPs per FLOP the MFMA pipe executes, by kernel family"""
+    if "wino4" in kernel_name:
+        return WINO4_FACTOR
+    if "wino_" in kernel_name:
+        return WINO_FACTOR
+    return 1.0
 HBM_PEAK = 8.0e12               # bytes / s (MI355X_MICROARCH.md)
 
 
@@ -395,14 +405,14 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
         return None
 
     def executed(name, flops):       # FLOPs the MFMA pipe executes for `flops` algorithmic ones
-        return flops / WINO_FACTOR if "wino_" in name else flops
+        return flops / mfma_factor(name)
     name, d = max(((k, v) for k, v in kern.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
     alg_tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
     exe_tflops = executed(name, d["flops"]) / (d["ms"] * 1e-3) / 1e12
     conv_ms = sum(v["ms"] for v in fam.values())
     conv_fl = sum(v["flops"] for v in fam.values())
     conv_exe = sum(executed(k, v["flops"]) for k, v in kern.items())
-    wino_alg = sum(v["flops"] for k, v in kern.items() if "wino_" in k)
+    wino_saved = sum(v["flops"] * (1.0 - 1.0 / mfma_factor(k)) for k, v in kern.items())   # FLOPs Winograd does not execute
     # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the
     # figure comes from the committed rocprofv3 --pmc summary of this same command (tools/pmc_kernels.py), if any
     traffic, traffic_src = None, None
@@ -423,7 +433,8 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": round(d.get("bytes", 0) / max(d["launches"], 1)) or None,
             "note": ("achieved / frac count the FLOPs the MFMA pipe EXECUTES: a Winograd F(2x2,3x3) kernel executes "
-                     "algorithmic / 2.25; algorithmic_tflops is the direct-convolution count over the same time"),
+                     "algorithmic / 2.25, an F(4x4,3x3) kernel (wino4) algorithmic / 4; algorithmic_tflops is the "
+                     "direct-convolution count over the same time"),
             "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                             "executed_tflops": round(executed(k, v["flops"]) / (v["ms"] * 1e-3) / 1e12, 2),
                             "frac": round(executed(k, v["flops"]) / (v["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
@@ -435,7 +446,7 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
             "conv_family_algorithmic_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
     # step level: algorithmic work (SURVEY.md §8(d) / the MAC counter) against both roofs, and the MFMA ceiling of the
     # algorithm actually run (Winograd on the layers that took it in the instrumented step)
-    exe_per_img = flop_per_img - (wino_alg / n_instr / per_gpu) * (1.0 - 1.0 / WINO_FACTOR)
+    exe_per_img = flop_per_img - wino_saved / n_instr / per_gpu
     roof["flop_per_img"] = round(flop_per_img)
     roof["executed_flop_per_img"] = round(exe_per_img)
     roof["step_algorithmic_frac_of_peak"] = round(value * flop_per_img / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 4)
@@ -445,8 +456,9 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
     roof["hbm_frac_of_8TBps"] = round(value / world * (bytes_per_img + bytes_per_step / per_gpu) / HBM_PEAK, 4)
     if detail:
         roof["work"] = detail
-    conv_mode = "bf16x3 (LGM_CONV_MODE)" if ops.B3 else ("fp32 MFMA, Winograd F(2x2,3x3) for the 3x3 layers"
-                                                         if ops.WINO else "fp32 MFMA, direct")
+    conv_mode = "bf16x3 (LGM_CONV_MODE)" if ops.B3 else (
+        ("fp32 MFMA, Winograd for the 3x3 layers: F(4x4,3x3) forward / input gradient on the large maps, F(2x2,3x3) elsewhere"
+         if ops.WINO4 else "fp32 MFMA, Winograd F(2x2,3x3) for the 3x3 layers") if ops.WINO else "fp32 MFMA, direct")
     line = {"metric": metric, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None,
@@ -498,8 +510,13 @@ def _sampling_leg(dev, kind, steps, batch, img):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fwd_flop = {32: 3.651e9, 64: 14.594e9}[img] * batch
-    wino_share = 0.879                                # share of the forward FLOPs in 3x3 layers that run as Winograd
-    exe = fwd_flop * (1.0 - wino_share * (1.0 - 1.0 / WINO_FACTOR))
+    # forward FLOPs by kernel family at 64 x 64 input (SURVEY section 8a layer table x 4): 3x3 layers on maps >= 16 x 16 run
+    # F(4x4,3x3) (0.75 of the forward FLOPs), the 8 x 8 maps F(2x2,3x3) (0.23), the rest (7x7, 1x1, attention) direct
+    share4, share2 = (0.75, 0.23) if img == 64 else (0.57, 0.41)
+    from lgm_hip import ops as _ops
+    if not _ops.WINO4:
+        share4, share2 = 0.0, share4 + share2
+    exe = fwd_flop * (1.0 - share4 * (1.0 - 1.0 / WINO4_FACTOR) - share2 * (1.0 - 1.0 / WINO_FACTOR))
     per = dt / steps
     name = "DDIM" if kind == "ddim" else "ancestral (p_sample_loop)"
     return {"metric": f"{name} sampling, {batch} images {img}x{img}, {steps} steps (UNet forward + update per step, one HIP "

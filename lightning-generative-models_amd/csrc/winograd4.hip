@@ -675,7 +675,11 @@ extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
   if (!lgm_wino4_supported(g, gc, oc)) return 0;
   static const int force = getenv("LGM_WINO4_FORCE") ? atoi(getenv("LGM_WINO4_FORCE")) : 0;
   if (force) return 1;
-  static const long min_units = getenv("LGM_WINO4_MIN_UNITS") ? atol(getenv("LGM_WINO4_MIN_UNITS")) : 128;
+  // maps >= 16 x 32 (one unit per CU-sized 16 x 32 pixel block): 128 units (B = 64 at 32 x 32) measured SLOWER than the
+  // F(2x2) pair on its joint plan (7.44 vs 7.37 ms per step), 256 units faster (10.9 vs 11.4); 16 x 16 maps (more phases
+  // per unit, split-K by two) pay from 128 units
+  static const long min_units0 = getenv("LGM_WINO4_MIN_UNITS") ? atol(getenv("LGM_WINO4_MIN_UNITS")) : 192;
+  static const long min_units1 = getenv("LGM_WINO4_MIN_UNITS1") ? atol(getenv("LGM_WINO4_MIN_UNITS1")) : 128;
   const int cls = lgmwino4::unit_class(g->H, g->W);
   const long base = lgmwino4::unit_count(cls, g->B, g->H, g->W) * (oc / 64);
   // 8 x 8 maps: few units (8 images each), so the reduction is split; worth it when a split still has >= 8 phases
@@ -686,7 +690,7 @@ extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
   if (cls == 2) return (!no8 && (yx == 0 || yx8) && base >= 32 && gc >= 256) ? 1 : 0;
   static const int c1_minc = getenv("LGM_WINO4_C1_MINC") ? atoi(getenv("LGM_WINO4_C1_MINC")) : 0;
   if (cls == 1 && gc < c1_minc) return 0;
-  return base >= min_units ? 1 : 0;
+  return base >= (cls == 1 ? min_units1 : min_units0) ? 1 : 0;
 }
 
 extern "C" int lgm_wino4_weights(const float* src, float* dst_f, float* dst_b, const int64_t* table, int n_slots,
