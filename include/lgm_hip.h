@@ -542,6 +542,17 @@ int lgm_conv3x3_wino_bwd(const LgmConvGeom* g, const float* gy, int64_t gy_pitch
                          const float* u_b, const float* res, int64_t res_pitch, float* gx, int64_t gx_pitch,
                          void* dgrad_ws, int64_t dgrad_ws_bytes, int64_t* partial, float* gw, float* gbias, float beta,
                          void* wgrad_ws, int64_t wgrad_ws_bytes, int64_t* desc, void* stream);
+/* Weight gradients of TWO 3x3 layers in one launch (deferred slab reduction: both descriptors as lgm_conv_wgrad_deferred
+ * fills them): the chip's workgroups are shared in proportion to the layers' work, each workgroup takes twice the pixels
+ * with one prologue and one slab - for the large-map layers whose weights are small and whose input gradient runs apart
+ * (lgm_conv3x3_wino4).  Workspace sizes: lgm_conv3x3_wino_wgrad2_workspaces. */
+int64_t lgm_conv3x3_wino_wgrad2_supported(const LgmConvGeom* ga, const LgmConvGeom* gb);
+int lgm_conv3x3_wino_wgrad2_workspaces(const LgmConvGeom* ga, const LgmConvGeom* gb, int64_t* out);   /* bytes, a / b */
+int lgm_conv3x3_wino_wgrad2(const LgmConvGeom* ga, const float* ya, int64_t ya_pitch, const float* xa, int64_t xa_pitch,
+                            float* gwa, float* gba, float beta_a, void* wsa, int64_t wsa_bytes, int64_t* desca,
+                            const LgmConvGeom* gb, const float* yb, int64_t yb_pitch, const float* xb, int64_t xb_pitch,
+                            float* gwb, float* gbb, float beta_b, void* wsb, int64_t wsb_bytes, int64_t* descb,
+                            void* stream);
 int lgm_conv3x3_wino_partial(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,
                              const float* bias, float* out, int64_t out_pitch, void* workspace,
                              int64_t workspace_bytes, int64_t* partial, void* stream);

@@ -1367,6 +1367,18 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WGArgs p) {
   wino_wgrad_body<G, DBG>(p, (int)blockIdx.x);
 }
 
+// Two layers' weight gradients in ONE launch (blocks [0, na): layer a, the rest: layer b).  On the large maps a layer's
+// weights are small (64 x 64 x 9) and its pixels many: standing alone the kernel splits the pixels 256 ways to fill the
+// chip, so every workgroup pays its prologue and a whole 147 KB slab for ~16 chunks of work.  Side by side, two layers
+// take 128 workgroups each with twice the chunks: the same chip-wide work with half the prologues, epilogues and slabs
+// (measured: 64 -> 64 at 32 x 32, B = 128: 65 us alone, 55 us per layer at twice the work per workgroup).  Same code and
+// summation order per slab as the single-layer kernel; only the split count differs, as it does between batches.
+template <int G>
+__global__ __launch_bounds__(256, 1) void wino_wgrad2_kernel(const WGArgs pa, const WGArgs pb, const int na) {
+  if ((int)blockIdx.x < na) wino_wgrad_body<G, false>(pa, (int)blockIdx.x);
+  else wino_wgrad_body<G, false>(pb, (int)blockIdx.x - na);
+}
+
 // Backward PAIR: the input gradient (blocks [0, nconv)) and the weight gradient (the rest) of ONE 3x3 layer in ONE
 // launch.  Both read the same output gradient and neither reads what the other writes.  At the per-GPU batches of a
 // strong-scaled run (16 ... 64 images) each of them fills a quarter to a half of the chip's 256 CUs and is bounded
@@ -1399,8 +1411,12 @@ bool lgm_wino_wgrad_supported(const LgmConvGeom* g) {
   return chunks >= 2;
 }
 
-// splits >= 2 always (the kernel only writes slabs); cps = chunks per split
+// splits >= 2 always (the kernel only writes slabs); cps = chunks per split; budget = workgroups of one round
+static void wino_wgrad_plan_budget(const LgmConvGeom* g, long budget, int* splits, int* cps, int* total_chunks);
 void lgm_wino_wgrad_plan(const LgmConvGeom* g, int* splits, int* cps, int* total_chunks) {
+  wino_wgrad_plan_budget(g, 256, splits, cps, total_chunks);
+}
+static void wino_wgrad_plan_budget(const LgmConvGeom* g, long budget, int* splits, int* cps, int* total_chunks) {
   using namespace lgmwino;
   int G, ipc;
   wgrad_class(g->H, g->W, &G, &ipc);
@@ -1409,11 +1425,11 @@ void lgm_wino_wgrad_plan(const LgmConvGeom* g, int* splits, int* cps, int* total
   // One workgroup per CU (4 waves = the CU's four SIMDs): 258 workgroups take twice as long as 256.  Pick the split
   // count that minimises  rounds of 256 workgroups x (chunks per workgroup + ~3 chunks of prologue / epilogue);
   // at least two chunks per workgroup and two slabs; ties go to fewer slabs.
-  long smax = chunks / 2 < 256 ? chunks / 2 : 256;
+  long smax = chunks / 2 < budget ? chunks / 2 : budget;
   if (smax < 2) smax = 2;
   long s = 2, best = -1;
   for (long c = 2; c <= smax; ++c) {
-    const long rounds = (blocks * c + 255) / 256;
+    const long rounds = (blocks * c + budget - 1) / budget;
     const long cost = rounds * ((chunks + c - 1) / c + 3);
     if (best < 0 || cost < best) {
       best = cost;
@@ -1469,6 +1485,118 @@ int lgm_wino_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, co
   else if (G == 4) LGM_WGL(4);
   else LGM_WGL(2);
 #undef LGM_WGL
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// ---- two layers' weight gradients in one launch (deferred slab reduction only) -------------------------------------
+static bool wgrad2_operands_ok(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch,
+                               const float* gw, const float* gbias) {
+  return y && x && gw && y_pitch % 4 == 0 && x_pitch % 4 == 0 && y_pitch >= g->Nw && x_pitch >= g->Cw && lgm_aligned16(y) &&
+         lgm_aligned16(x) && lgm_aligned16(gw) && (!gbias || lgm_aligned16(gbias)) &&
+         ((long)g->B * g->H * g->W + g->W + 1) * x_pitch < (1L << 29) && (long)g->B * g->H * g->W * y_pitch < (1L << 29);
+}
+
+// 1 when lgm_conv3x3_wino_wgrad2 takes this pair of layers: both run the Winograd weight-gradient kernel of the same map
+// class, and each still gets at least two slabs out of its share of the chip
+extern "C" int64_t lgm_conv3x3_wino_wgrad2_supported(const LgmConvGeom* ga, const LgmConvGeom* gb) {
+  using namespace lgmwino;
+  if (!ga || !gb || !lgm_wino_wgrad_supported(ga) || !lgm_wino_wgrad_supported(gb)) return 0;
+  int Ga, Gb, ia, ib;
+  wgrad_class(ga->H, ga->W, &Ga, &ia);
+  wgrad_class(gb->H, gb->W, &Gb, &ib);
+  if (Ga != Gb) return 0;
+  const long ba = (long)(ga->Nw / 64) * (ga->Cw / 64), bb = (long)(gb->Nw / 64) * (gb->Cw / 64);
+  return (ba * 2 + bb * 2 <= 256) ? 1 : 0;
+}
+
+static void wgrad2_budgets(const LgmConvGeom* ga, const LgmConvGeom* gb, long* budget_a, long* budget_b) {
+  // the chip's 256 workgroups are shared in proportion to the two layers' MFMA work
+  auto work = [](const LgmConvGeom* g) { return (double)g->B * g->H * g->W * g->Nw * g->Cw; };
+  const long ba = (long)(ga->Nw / 64) * (ga->Cw / 64), bb = (long)(gb->Nw / 64) * (gb->Cw / 64);
+  long share_a = (long)(256.0 * work(ga) / (work(ga) + work(gb)) + 0.5);
+  if (share_a < 2 * ba) share_a = 2 * ba;
+  if (256 - share_a < 2 * bb) share_a = 256 - 2 * bb;
+  *budget_a = share_a;
+  *budget_b = 256 - share_a;
+}
+
+// out[0] / out[1] = bytes of slab workspace layers a / b need in the grouped launch (their split counts are planned
+// against a share of the chip, so they differ from lgm_conv_wgrad_workspace's)
+extern "C" int lgm_conv3x3_wino_wgrad2_workspaces(const LgmConvGeom* ga, const LgmConvGeom* gb, int64_t* out) {
+  LGM_REQUIRE(ga && gb && out && lgm_conv3x3_wino_wgrad2_supported(ga, gb), "conv3x3_wino_wgrad2_workspaces: unsupported pair");
+  long bud[2];
+  wgrad2_budgets(ga, gb, &bud[0], &bud[1]);
+  const LgmConvGeom* gs[2] = {ga, gb};
+  for (int k = 0; k < 2; ++k) {
+    int splits, cps, total;
+    wino_wgrad_plan_budget(gs[k], bud[k], &splits, &cps, &total);
+    out[k] = (int64_t)splits * ((int64_t)gs[k]->Nw * 9 * gs[k]->Cw + gs[k]->Nw) * (int64_t)sizeof(float);
+  }
+  return LGM_OK;
+}
+
+extern "C" int lgm_conv3x3_wino_wgrad2(const LgmConvGeom* ga, const float* ya, int64_t ya_pitch, const float* xa,
+                                       int64_t xa_pitch, float* gwa, float* gba, float beta_a, void* wsa, int64_t wsa_bytes,
+                                       int64_t* desca, const LgmConvGeom* gb, const float* yb, int64_t yb_pitch,
+                                       const float* xb, int64_t xb_pitch, float* gwb, float* gbb, float beta_b, void* wsb,
+                                       int64_t wsb_bytes, int64_t* descb, void* stream) {
+  using namespace lgmwino;
+  LGM_REQUIRE(ga && gb && desca && descb && wsa && wsb, "conv3x3_wino_wgrad2: null pointer");
+  LGM_REQUIRE(lgm_conv3x3_wino_wgrad2_supported(ga, gb), "conv3x3_wino_wgrad2: unsupported pair of layers");
+  LGM_REQUIRE(wgrad2_operands_ok(ga, ya, ya_pitch, xa, xa_pitch, gwa, gba) &&
+              wgrad2_operands_ok(gb, yb, yb_pitch, xb, xb_pitch, gwb, gbb) && lgm_aligned16(wsa) && lgm_aligned16(wsb),
+              "conv3x3_wino_wgrad2: 16-byte aligned operands with pitch %% 4 == 0 inside 32-bit offsets expected");
+  int G, ipc;
+  wgrad_class(ga->H, ga->W, &G, &ipc);
+  long share_a, share_b;
+  wgrad2_budgets(ga, gb, &share_a, &share_b);
+  const LgmConvGeom* gs[2] = {ga, gb};
+  const float* ys[2] = {ya, yb};
+  const float* xs[2] = {xa, xb};
+  const long yps[2] = {ya_pitch, yb_pitch}, xps[2] = {xa_pitch, xb_pitch};
+  float* gws[2] = {gwa, gwb};
+  float* gbs[2] = {gba, gbb};
+  const float betas[2] = {beta_a, beta_b};
+  void* wss[2] = {wsa, wsb};
+  const int64_t wsbytes[2] = {wsa_bytes, wsb_bytes};
+  int64_t* descs[2] = {desca, descb};
+  const long budgets[2] = {share_a, share_b};
+  WGArgs pp[2];
+  unsigned nb[2];
+  for (int k = 0; k < 2; ++k) {
+    const LgmConvGeom* g = gs[k];
+    int splits, cps, total;
+    wino_wgrad_plan_budget(g, budgets[k], &splits, &cps, &total);
+    const long n_w = (long)g->Nw * 9 * g->Cw, slab = n_w + g->Nw;
+    LGM_REQUIRE(wsbytes[k] >= (int64_t)splits * slab * (int64_t)sizeof(float), "conv3x3_wino_wgrad2: workspace %d too small", k);
+    wino_wgrad_prepare(g, ys[k], yps[k], xs[k], xps[k], (float*)wss[k], gbs[k] ? 1 : 0, slab, splits, cps, total, pp[k]);
+    nb[k] = (unsigned)((g->Nw / 64) * (g->Cw / 64) * splits);
+    union { float f; int64_t i; } bbits;
+    bbits.i = 0;
+    bbits.f = betas[k];
+    int64_t* d = descs[k];
+    d[0] = (int64_t)(uintptr_t)wss[k]; d[1] = slab; d[2] = (int64_t)(uintptr_t)gws[k]; d[3] = n_w;
+    d[4] = (int64_t)(uintptr_t)gbs[k]; d[5] = gbs[k] ? g->Nw : 0; d[6] = splits; d[7] = bbits.i;
+  }
+  const size_t smem = (size_t)3 * WBUF * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define LGM_WG2(GG)                                                                                              \
+  do {                                                                                                           \
+    auto kern = wino_wgrad2_kernel<GG>;                                                                          \
+    static bool attr = false;                                                                                    \
+    if (!attr) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)smem);                                                                      \
+      attr = true;                                                                                               \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kern, dim3(nb[0] + nb[1]), dim3(256), smem, s, pp[0], pp[1], (int)nb[0]);                 \
+  } while (0)
+  lgm_note_kernel(G == 8 ? "lgmwino::wino_wgrad2_kernel<8>" : G == 4 ? "lgmwino::wino_wgrad2_kernel<4>" : "lgmwino::wino_wgrad2_kernel<2>");
+  if (G == 8) LGM_WG2(8);
+  else if (G == 4) LGM_WG2(4);
+  else LGM_WG2(2);
+#undef LGM_WG2
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

@@ -33,12 +33,32 @@ class GradCtx:
         # defer=True: conv weight-gradient slabs are reduced by ONE batched launch per flush() instead of
         # one launch per layer; the owner of the context MUST call flush() before the gradients are read
         self.deferred = [] if defer else None
+        self._pending = None
         if transposed:
             flat.refresh_transposed()      # one launch per backward pass
 
     def flush(self):
+        self.finish_pending()
         if self.deferred:
             ops.wgrad_reduce_batch(self.deferred, self.flat.device)
+
+    # -- large-map 3x3 weight gradients wait for a partner: two layers share ONE launch (ops.conv_wgrad2) ------------
+    def queue_wgrad(self, g, gy, x, gw_ptr: int, beta: float, gb_ptr):
+        """Deferred passes only.  The entry keeps ``gy`` and ``x`` alive until its launch; the pair is issued as soon as
+        the second layer arrives, a lone entry at the end of the bucket (finish_pending)."""
+        new = (g, gy, x, gw_ptr, beta, gb_ptr)
+        old, self._pending = self._pending, None
+        if old is not None:
+            if ops.wgrad2_supported(old[0], g):
+                ops.conv_wgrad2(old, new, self.deferred)
+                return
+            ops.conv_wgrad(old[0], old[1], old[2], old[3], old[4], old[5], defer=self.deferred)
+        self._pending = new
+
+    def finish_pending(self):
+        old, self._pending = self._pending, None
+        if old is not None:
+            ops.conv_wgrad(old[0], old[1], old[2], old[3], old[4], old[5], defer=self.deferred)
 
     def defer_for(self, p: nn.Parameter):
         """The deferred-reduction list for the FIRST gradient contribution of ``p`` in this pass, else None: the
@@ -156,7 +176,10 @@ class Conv2d(nn.Module):
                                  gx if accumulate else res, gx, post=ops.make_post(0, 0.0, mask, mask_slope),
                                  post_mask=mask)
             return gx
-        ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=dfr)
+        if dfr is not None and self.k == 3 and ops.wgrad_queueable(g, gy, x):
+            gc.queue_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb)      # issued with the next such layer's (one launch for two)
+        else:
+            ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=dfr)
         if not need_gx:
             return None
         if gx is None:

@@ -525,6 +525,72 @@ def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[
 _PAIR_OK = {}
 
 
+# Two large-map layers' weight gradients in one launch (lgm_conv3x3_wino_wgrad2): LGM_NO_WGRAD2=1 issues them singly.
+WGRAD2 = _os.environ.get("LGM_NO_WGRAD2", "0") != "1"
+_WG2_OK = {}
+_WG2_WS = {}
+
+
+def _gkey(g: ConvGeom):
+    return (g.B, g.H, g.W, g.Cw, g.Nw, g.KH, g.KW, g.stride, g.pad)
+
+
+def wgrad2_supported(ga: ConvGeom, gb: ConvGeom) -> bool:
+    key = (_gkey(ga), _gkey(gb))
+    v = _WG2_OK.get(key)
+    if v is None:
+        v = bool(lib().lgm_conv3x3_wino_wgrad2_supported(ctypes.byref(ga), ctypes.byref(gb)))
+        _WG2_OK[key] = v
+    return v
+
+
+def wgrad_queueable(g: ConvGeom, gy, x) -> bool:
+    """The layers whose weight gradient waits for a partner: 3x3 layers on the large maps whose input gradient runs
+    apart (F(4x4)), with operands the grouped launch accepts."""
+    if not (WGRAD2 and WINO and _WINO_FLATS and not B3 and _wino4_preferred(g, 1)):
+        return False
+    if gy.data_ptr() % 16 or x.data_ptr() % 16 or pitch(gy) % 4 or pitch(x) % 4:
+        return False
+    return wgrad2_supported(g, g)
+
+
+def conv_wgrad2(a, b, defer):
+    """a, b = (geometry, gy, x, gw address, beta, gbias address): both weight gradients in ONE launch; their slab
+    descriptors join ``defer`` (the bucket's batched reduction)."""
+    L = lib()
+    args, descs = [], []
+    flops = nbytes_alg = 0.0
+    wkey = (_gkey(a[0]), _gkey(b[0]))
+    need = _WG2_WS.get(wkey)
+    if need is None:
+        two = (ctypes.c_int64 * 2)()
+        L.lgm_conv3x3_wino_wgrad2_workspaces(ctypes.byref(a[0]), ctypes.byref(b[0]), ctypes.addressof(two))
+        # never smaller than the single-layer plan's need: the same slab buffer serves a layer whichever way it runs
+        need = tuple(max(int(two[k]), int(L.lgm_conv_wgrad_workspace(ctypes.byref(l[0])))) for k, l in enumerate((a, b)))
+        _WG2_WS[wkey] = need
+    for k, (g, gy, x, gw_ptr, beta, gb_ptr) in enumerate((a, b)):
+        nbytes = need[k]
+        key = (gw_ptr, nbytes)
+        ws = _WGRAD_WS.get(key)
+        if ws is None:
+            ws = torch.empty(max(nbytes // 4 + 4, 16), dtype=torch.float32, device=gy.device)
+            _WGRAD_WS[key] = ws
+        desc = (ctypes.c_int64 * 8)()
+        descs.append(desc)
+        args += [ctypes.byref(g), gy.data_ptr(), pitch(gy), x.data_ptr(), pitch(x), gw_ptr, gb_ptr, beta, ws.data_ptr(),
+                 ws.numel() * 4, ctypes.addressof(desc)]
+        flops += _conv_flops(g)
+        nbytes_alg += _conv_bytes(g)
+    if TIMER is not None:
+        TIMER.begin("wgrad", flops, nbytes_alg)
+    L.lgm_conv3x3_wino_wgrad2(*args, stream())
+    if TIMER is not None:
+        TIMER.end()
+    for desc in descs:
+        if desc[6] > 1:
+            defer.append(tuple(desc))
+
+
 def conv_bwd_pair(g: ConvGeom, gy, x, w_ptr: int, gw_ptr: int, beta: float, gbias_ptr: Optional[int], defer, res, gx,
                   partial: bool = False):
     """Input gradient AND weight gradient of a 3x3 layer in ONE launch (lgm_conv3x3_wino_bwd): at small per-GPU batches

@@ -515,6 +515,7 @@ class Unet(nn.Module):
         instead, which launches the reduction - and the bucket's all-reduce and Adam slice behind it - on a side stream
         next to the following backward phase: weight-sized, HBM-bound passes beside MFMA-bound convolutions."""
         col = getattr(self, "_flush_collect", None)
+        gc.finish_pending()              # a large-map weight gradient still waiting for a partner (GradCtx.queue_wgrad)
         if col is None:
             gc.flush()
         else:

@@ -410,3 +410,40 @@ def test_winograd4_partial_planes_and_weight_transform(dev, parity):
     ub_l = ub.cpu().view(ci // 64, co // 8, 36, 2, 2, 32, 4)
     gotb = ub_l.permute(0, 3, 5, 2, 1, 4, 6).reshape(ci, 36, co)
     parity("F(4x4) input-gradient operand vs its definition", maxerr(gotb, Ub.reshape(ci, 36, co)), 2e-7)
+
+
+@pytest.mark.parametrize("pair", [((3, 32, 64, 64), (3, 32, 128, 64)), ((4, 16, 192, 128), (4, 16, 128, 128)),
+                                  ((2, 64, 64, 64), (2, 64, 64, 64))])
+def test_two_layers_weight_gradients_in_one_launch(dev, pair, parity):
+    """lgm_conv3x3_wino_wgrad2: the weight / bias gradients of two large-map 3x3 layers from ONE launch (the chip's
+    workgroups shared by work), their slabs reduced by the bucket's batched fixed-order reducer - against float64
+    autograd (reference op: the weight gradient of Block.proj, ddpm.py:157-173), with beta = 0 and beta = 1, twice
+    (bit-reproducible)."""
+    from lgm_hip import ops
+    layers, refs = [], []
+    for i, (B, hw, ci, co) in enumerate(pair):
+        gen = torch.Generator().manual_seed(17 * i + sum(pair[i]))
+        x = torch.randn(B, hw, hw, ci, generator=gen)
+        y = torch.randn(B, hw, hw, co, generator=gen)
+        w0 = torch.zeros(co, ci, 3, 3, dtype=torch.double, requires_grad=True)
+        out = F.conv2d(x.permute(0, 3, 1, 2).double(), w0, None, padding=1)
+        gw_ref, = torch.autograd.grad(out, w0, y.permute(0, 3, 1, 2).double())
+        refs.append((gw_ref.permute(0, 2, 3, 1).reshape(co, 9, ci), y.double().sum((0, 1, 2))))
+        layers.append((ops.make_geom(B, hw, hw, ci, co, 3, 3, 1, 1), y.to(dev), x.to(dev)))
+    assert ops.wgrad2_supported(layers[0][0], layers[1][0])
+    results = []
+    for rep in range(2):
+        gws = [torch.ones((l[1].shape[-1], 9, l[2].shape[-1]), device=dev) for l in layers]
+        gbs = [torch.ones((l[1].shape[-1],), device=dev) for l in layers]           # the fused bias gradient shares beta
+        rows = []
+        a = (layers[0][0], layers[0][1], layers[0][2], gws[0].data_ptr(), 1.0, gbs[0].data_ptr())     # accumulate
+        b = (layers[1][0], layers[1][1], layers[1][2], gws[1].data_ptr(), 0.0, None)                  # overwrite, no bias
+        ops.conv_wgrad2(a, b, rows)
+        assert "wino_wgrad2_kernel" in ops.lib()._dll.lgm_last_kernel().decode()
+        assert len(rows) == 2
+        ops.wgrad_reduce_batch(rows, dev)
+        results.append((gws[0].clone(), gws[1].clone(), gbs[0].clone()))
+    parity("layer a, accumulated (beta = 1)", maxerr(results[0][0] - 1.0, refs[0][0]), 2e-6)
+    parity("layer a, fused bias gradient (beta = 1)", maxerr(results[0][2] - 1.0, refs[0][1]), 2e-6)
+    parity("layer b (beta = 0)", maxerr(results[0][1], refs[1][0]), 2e-6)
+    assert all(torch.equal(p, q) for p, q in zip(results[0], results[1]))
