@@ -547,6 +547,23 @@ int lgm_conv3x3_wino_bwd(const LgmConvGeom* g, const float* gy, int64_t gy_pitch
  * with one prologue and one slab - for the large-map layers whose weights are small and whose input gradient runs apart
  * (lgm_conv3x3_wino4).  Workspace sizes: lgm_conv3x3_wino_wgrad2_workspaces. */
 int64_t lgm_conv3x3_wino_wgrad2_supported(const LgmConvGeom* ga, const LgmConvGeom* gb);
+/* The same for 2 ... 4 layers.  LgmWgradItem = one layer's arguments of lgm_conv_wgrad_deferred. */
+typedef struct {
+  const LgmConvGeom* g;
+  const float* y;
+  int64_t y_pitch;
+  const float* x;
+  int64_t x_pitch;
+  float* gw;
+  float* gbias;
+  float beta;
+  void* ws;
+  int64_t ws_bytes;
+  int64_t* desc;
+} LgmWgradItem;
+int64_t lgm_conv3x3_wino_wgradn_supported(int n, const LgmConvGeom* const* geoms);
+int lgm_conv3x3_wino_wgradn_workspaces(int n, const LgmConvGeom* const* geoms, int64_t* out);
+int lgm_conv3x3_wino_wgradn(int n, const LgmWgradItem* items, void* stream);
 int lgm_conv3x3_wino_wgrad2_workspaces(const LgmConvGeom* ga, const LgmConvGeom* gb, int64_t* out);   /* bytes, a / b */
 int lgm_conv3x3_wino_wgrad2(const LgmConvGeom* ga, const float* ya, int64_t ya_pitch, const float* xa, int64_t xa_pitch,
                             float* gwa, float* gba, float beta_a, void* wsa, int64_t wsa_bytes, int64_t* desca,

@@ -1378,6 +1378,16 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2_kernel(const WGArgs pa, co
   if ((int)blockIdx.x < na) wino_wgrad_body<G, false>(pa, (int)blockIdx.x);
   else wino_wgrad_body<G, false>(pb, (int)blockIdx.x - na);
 }
+// ... and of up to four layers (e0 / e1 / e2 = first block of layers 1 / 2 / 3; an unused layer starts at the grid's end)
+template <int G>
+__global__ __launch_bounds__(256, 1) void wino_wgrad4_kernel(const WGArgs p0, const WGArgs p1, const WGArgs p2, const WGArgs p3,
+                                                             const int e0, const int e1, const int e2) {
+  const int b = (int)blockIdx.x;
+  if (b < e0) wino_wgrad_body<G, false>(p0, b);
+  else if (b < e1) wino_wgrad_body<G, false>(p1, b - e0);
+  else if (b < e2) wino_wgrad_body<G, false>(p2, b - e1);
+  else wino_wgrad_body<G, false>(p3, b - e2);
+}
 
 // Backward PAIR: the input gradient (blocks [0, nconv)) and the weight gradient (the rest) of ONE 3x3 layer in ONE
 // launch.  Both read the same output gradient and neither reads what the other writes.  At the per-GPU batches of a
@@ -1497,42 +1507,138 @@ static bool wgrad2_operands_ok(const LgmConvGeom* g, const float* y, long y_pitc
          ((long)g->B * g->H * g->W + g->W + 1) * x_pitch < (1L << 29) && (long)g->B * g->H * g->W * y_pitch < (1L << 29);
 }
 
-// 1 when lgm_conv3x3_wino_wgrad2 takes this pair of layers: both run the Winograd weight-gradient kernel of the same map
+// 1 when the grouped launch takes these n (2 ... 4) layers: all run the Winograd weight-gradient kernel of the same map
 // class, and each still gets at least two slabs out of its share of the chip
-extern "C" int64_t lgm_conv3x3_wino_wgrad2_supported(const LgmConvGeom* ga, const LgmConvGeom* gb) {
+static bool wgradn_supported(int n, const LgmConvGeom* const* gs) {
   using namespace lgmwino;
-  if (!ga || !gb || !lgm_wino_wgrad_supported(ga) || !lgm_wino_wgrad_supported(gb)) return 0;
-  int Ga, Gb, ia, ib;
-  wgrad_class(ga->H, ga->W, &Ga, &ia);
-  wgrad_class(gb->H, gb->W, &Gb, &ib);
-  if (Ga != Gb) return 0;
-  const long ba = (long)(ga->Nw / 64) * (ga->Cw / 64), bb = (long)(gb->Nw / 64) * (gb->Cw / 64);
-  return (ba * 2 + bb * 2 <= 256) ? 1 : 0;
-}
-
-static void wgrad2_budgets(const LgmConvGeom* ga, const LgmConvGeom* gb, long* budget_a, long* budget_b) {
-  // the chip's 256 workgroups are shared in proportion to the two layers' MFMA work
-  auto work = [](const LgmConvGeom* g) { return (double)g->B * g->H * g->W * g->Nw * g->Cw; };
-  const long ba = (long)(ga->Nw / 64) * (ga->Cw / 64), bb = (long)(gb->Nw / 64) * (gb->Cw / 64);
-  long share_a = (long)(256.0 * work(ga) / (work(ga) + work(gb)) + 0.5);
-  if (share_a < 2 * ba) share_a = 2 * ba;
-  if (256 - share_a < 2 * bb) share_a = 256 - 2 * bb;
-  *budget_a = share_a;
-  *budget_b = 256 - share_a;
-}
-
-// out[0] / out[1] = bytes of slab workspace layers a / b need in the grouped launch (their split counts are planned
-// against a share of the chip, so they differ from lgm_conv_wgrad_workspace's)
-extern "C" int lgm_conv3x3_wino_wgrad2_workspaces(const LgmConvGeom* ga, const LgmConvGeom* gb, int64_t* out) {
-  LGM_REQUIRE(ga && gb && out && lgm_conv3x3_wino_wgrad2_supported(ga, gb), "conv3x3_wino_wgrad2_workspaces: unsupported pair");
-  long bud[2];
-  wgrad2_budgets(ga, gb, &bud[0], &bud[1]);
-  const LgmConvGeom* gs[2] = {ga, gb};
-  for (int k = 0; k < 2; ++k) {
-    int splits, cps, total;
-    wino_wgrad_plan_budget(gs[k], bud[k], &splits, &cps, &total);
-    out[k] = (int64_t)splits * ((int64_t)gs[k]->Nw * 9 * gs[k]->Cw + gs[k]->Nw) * (int64_t)sizeof(float);
+  if (n < 2 || n > 4) return false;
+  int G0 = 0;
+  long need = 0;
+  for (int k = 0; k < n; ++k) {
+    if (!gs[k] || !lgm_wino_wgrad_supported(gs[k])) return false;
+    int G, ipc;
+    wgrad_class(gs[k]->H, gs[k]->W, &G, &ipc);
+    if (k == 0) G0 = G;
+    else if (G != G0) return false;
+    need += 2L * (gs[k]->Nw / 64) * (gs[k]->Cw / 64);
   }
+  return need <= 256;
+}
+
+// the chip's 256 workgroups are shared in proportion to the layers' MFMA work, at least two slabs' worth each
+static void wgradn_budgets(int n, const LgmConvGeom* const* gs, long* budget) {
+  double w[4], tot = 0;
+  long mn[4], left = 256;
+  for (int k = 0; k < n; ++k) {
+    w[k] = (double)gs[k]->B * gs[k]->H * gs[k]->W * gs[k]->Nw * gs[k]->Cw;
+    tot += w[k];
+    mn[k] = 2L * (gs[k]->Nw / 64) * (gs[k]->Cw / 64);
+  }
+  for (int k = 0; k < n; ++k) {
+    long b = (long)(256.0 * w[k] / tot);
+    if (b < mn[k]) b = mn[k];
+    budget[k] = b;
+    left -= b;
+  }
+  // rounding leftovers (or a deficit from the minimums) go to / come from the largest share
+  int big = 0;
+  for (int k = 1; k < n; ++k)
+    if (budget[k] - mn[k] > budget[big] - mn[big]) big = k;
+  budget[big] += left;
+  if (budget[big] < mn[big]) budget[big] = mn[big];
+}
+
+extern "C" int64_t lgm_conv3x3_wino_wgradn_supported(int n, const LgmConvGeom* const* geoms) {
+  return (geoms && wgradn_supported(n, geoms)) ? 1 : 0;
+}
+extern "C" int64_t lgm_conv3x3_wino_wgrad2_supported(const LgmConvGeom* ga, const LgmConvGeom* gb) {
+  const LgmConvGeom* gs[2] = {ga, gb};
+  return wgradn_supported(2, gs) ? 1 : 0;
+}
+
+// out[k] = bytes of slab workspace layer k needs in the grouped launch (its split count is planned against a share of
+// the chip, so it differs from lgm_conv_wgrad_workspace's)
+extern "C" int lgm_conv3x3_wino_wgradn_workspaces(int n, const LgmConvGeom* const* geoms, int64_t* out) {
+  LGM_REQUIRE(geoms && out && wgradn_supported(n, geoms), "conv3x3_wino_wgradn_workspaces: unsupported group of layers");
+  long bud[4];
+  wgradn_budgets(n, geoms, bud);
+  for (int k = 0; k < n; ++k) {
+    int splits, cps, total;
+    wino_wgrad_plan_budget(geoms[k], bud[k], &splits, &cps, &total);
+    out[k] = (int64_t)splits * ((int64_t)geoms[k]->Nw * 9 * geoms[k]->Cw + geoms[k]->Nw) * (int64_t)sizeof(float);
+  }
+  return LGM_OK;
+}
+extern "C" int lgm_conv3x3_wino_wgrad2_workspaces(const LgmConvGeom* ga, const LgmConvGeom* gb, int64_t* out) {
+  const LgmConvGeom* gs[2] = {ga, gb};
+  return lgm_conv3x3_wino_wgradn_workspaces(2, gs, out);
+}
+
+extern "C" int lgm_conv3x3_wino_wgradn(int n, const LgmWgradItem* it, void* stream) {
+  using namespace lgmwino;
+  LGM_REQUIRE(it && n >= 2 && n <= 4, "conv3x3_wino_wgradn: 2 ... 4 layers expected");
+  const LgmConvGeom* gs[4];
+  for (int k = 0; k < n; ++k) gs[k] = it[k].g;
+  LGM_REQUIRE(wgradn_supported(n, gs), "conv3x3_wino_wgradn: unsupported group of layers");
+  for (int k = 0; k < n; ++k)
+    LGM_REQUIRE(it[k].desc && it[k].ws && lgm_aligned16(it[k].ws) &&
+                wgrad2_operands_ok(it[k].g, it[k].y, it[k].y_pitch, it[k].x, it[k].x_pitch, it[k].gw, it[k].gbias),
+                "conv3x3_wino_wgradn: layer %d: 16-byte aligned operands with pitch %% 4 == 0 inside 32-bit offsets expected", k);
+  int G, ipc;
+  wgrad_class(gs[0]->H, gs[0]->W, &G, &ipc);
+  long bud[4];
+  wgradn_budgets(n, gs, bud);
+  WGArgs pp[4];
+  unsigned nb[4] = {0, 0, 0, 0};
+  for (int k = 0; k < n; ++k) {
+    const LgmConvGeom* g = gs[k];
+    int splits, cps, total;
+    wino_wgrad_plan_budget(g, bud[k], &splits, &cps, &total);
+    const long n_w = (long)g->Nw * 9 * g->Cw, slab = n_w + g->Nw;
+    LGM_REQUIRE(it[k].ws_bytes >= (int64_t)splits * slab * (int64_t)sizeof(float), "conv3x3_wino_wgradn: workspace %d too small", k);
+    wino_wgrad_prepare(g, it[k].y, it[k].y_pitch, it[k].x, it[k].x_pitch, (float*)it[k].ws, it[k].gbias ? 1 : 0, slab, splits,
+                       cps, total, pp[k]);
+    nb[k] = (unsigned)((g->Nw / 64) * (g->Cw / 64) * splits);
+    union { float f; int64_t i; } bbits;
+    bbits.i = 0;
+    bbits.f = it[k].beta;
+    int64_t* d = it[k].desc;
+    d[0] = (int64_t)(uintptr_t)it[k].ws; d[1] = slab; d[2] = (int64_t)(uintptr_t)it[k].gw; d[3] = n_w;
+    d[4] = (int64_t)(uintptr_t)it[k].gbias; d[5] = it[k].gbias ? g->Nw : 0; d[6] = splits; d[7] = bbits.i;
+  }
+  for (int k = n; k < 4; ++k) pp[k] = pp[n - 1];           // never reached: its block range is empty
+  const size_t smem = (size_t)3 * WBUF * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  const int e0 = (int)nb[0], e1 = e0 + (int)nb[1], e2 = e1 + (int)nb[2];
+  const unsigned grid = nb[0] + nb[1] + nb[2] + nb[3];
+#define LGM_WGN(GG)                                                                                              \
+  do {                                                                                                           \
+    static bool attr2 = false, attr4 = false;                                                                    \
+    if (n == 2) {                                                                                                \
+      auto kern = wino_wgrad2_kernel<GG>;                                                                        \
+      if (!attr2) {                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        attr2 = true;                                                                                            \
+      }                                                                                                          \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, pp[0], pp[1], e0);                                \
+    } else {                                                                                                     \
+      auto kern = wino_wgrad4_kernel<GG>;                                                                        \
+      if (!attr4) {                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        attr4 = true;                                                                                            \
+      }                                                                                                          \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, pp[0], pp[1], pp[2], pp[3], e0, e1, e2);          \
+    }                                                                                                            \
+  } while (0)
+  if (n == 2)
+    lgm_note_kernel(G == 8 ? "lgmwino::wino_wgrad2_kernel<8>" : G == 4 ? "lgmwino::wino_wgrad2_kernel<4>" : "lgmwino::wino_wgrad2_kernel<2>");
+  else
+    lgm_note_kernel(G == 8 ? "lgmwino::wino_wgrad4_kernel<8>" : G == 4 ? "lgmwino::wino_wgrad4_kernel<4>" : "lgmwino::wino_wgrad4_kernel<2>");
+  if (G == 8) LGM_WGN(8);
+  else if (G == 4) LGM_WGN(4);
+  else LGM_WGN(2);
+#undef LGM_WGN
+  LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
 
@@ -1541,64 +1647,9 @@ extern "C" int lgm_conv3x3_wino_wgrad2(const LgmConvGeom* ga, const float* ya, i
                                        int64_t* desca, const LgmConvGeom* gb, const float* yb, int64_t yb_pitch,
                                        const float* xb, int64_t xb_pitch, float* gwb, float* gbb, float beta_b, void* wsb,
                                        int64_t wsb_bytes, int64_t* descb, void* stream) {
-  using namespace lgmwino;
-  LGM_REQUIRE(ga && gb && desca && descb && wsa && wsb, "conv3x3_wino_wgrad2: null pointer");
-  LGM_REQUIRE(lgm_conv3x3_wino_wgrad2_supported(ga, gb), "conv3x3_wino_wgrad2: unsupported pair of layers");
-  LGM_REQUIRE(wgrad2_operands_ok(ga, ya, ya_pitch, xa, xa_pitch, gwa, gba) &&
-              wgrad2_operands_ok(gb, yb, yb_pitch, xb, xb_pitch, gwb, gbb) && lgm_aligned16(wsa) && lgm_aligned16(wsb),
-              "conv3x3_wino_wgrad2: 16-byte aligned operands with pitch %% 4 == 0 inside 32-bit offsets expected");
-  int G, ipc;
-  wgrad_class(ga->H, ga->W, &G, &ipc);
-  long share_a, share_b;
-  wgrad2_budgets(ga, gb, &share_a, &share_b);
-  const LgmConvGeom* gs[2] = {ga, gb};
-  const float* ys[2] = {ya, yb};
-  const float* xs[2] = {xa, xb};
-  const long yps[2] = {ya_pitch, yb_pitch}, xps[2] = {xa_pitch, xb_pitch};
-  float* gws[2] = {gwa, gwb};
-  float* gbs[2] = {gba, gbb};
-  const float betas[2] = {beta_a, beta_b};
-  void* wss[2] = {wsa, wsb};
-  const int64_t wsbytes[2] = {wsa_bytes, wsb_bytes};
-  int64_t* descs[2] = {desca, descb};
-  const long budgets[2] = {share_a, share_b};
-  WGArgs pp[2];
-  unsigned nb[2];
-  for (int k = 0; k < 2; ++k) {
-    const LgmConvGeom* g = gs[k];
-    int splits, cps, total;
-    wino_wgrad_plan_budget(g, budgets[k], &splits, &cps, &total);
-    const long n_w = (long)g->Nw * 9 * g->Cw, slab = n_w + g->Nw;
-    LGM_REQUIRE(wsbytes[k] >= (int64_t)splits * slab * (int64_t)sizeof(float), "conv3x3_wino_wgrad2: workspace %d too small", k);
-    wino_wgrad_prepare(g, ys[k], yps[k], xs[k], xps[k], (float*)wss[k], gbs[k] ? 1 : 0, slab, splits, cps, total, pp[k]);
-    nb[k] = (unsigned)((g->Nw / 64) * (g->Cw / 64) * splits);
-    union { float f; int64_t i; } bbits;
-    bbits.i = 0;
-    bbits.f = betas[k];
-    int64_t* d = descs[k];
-    d[0] = (int64_t)(uintptr_t)wss[k]; d[1] = slab; d[2] = (int64_t)(uintptr_t)gws[k]; d[3] = n_w;
-    d[4] = (int64_t)(uintptr_t)gbs[k]; d[5] = gbs[k] ? g->Nw : 0; d[6] = splits; d[7] = bbits.i;
-  }
-  const size_t smem = (size_t)3 * WBUF * sizeof(float);
-  hipStream_t s = (hipStream_t)stream;
-#define LGM_WG2(GG)                                                                                              \
-  do {                                                                                                           \
-    auto kern = wino_wgrad2_kernel<GG>;                                                                          \
-    static bool attr = false;                                                                                    \
-    if (!attr) {                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)smem);                                                                      \
-      attr = true;                                                                                               \
-    }                                                                                                            \
-    hipLaunchKernelGGL(kern, dim3(nb[0] + nb[1]), dim3(256), smem, s, pp[0], pp[1], (int)nb[0]);                 \
-  } while (0)
-  lgm_note_kernel(G == 8 ? "lgmwino::wino_wgrad2_kernel<8>" : G == 4 ? "lgmwino::wino_wgrad2_kernel<4>" : "lgmwino::wino_wgrad2_kernel<2>");
-  if (G == 8) LGM_WG2(8);
-  else if (G == 4) LGM_WG2(4);
-  else LGM_WG2(2);
-#undef LGM_WG2
-  LGM_LAUNCH_CHECK();
-  return LGM_OK;
+  LgmWgradItem it[2] = {{ga, ya, ya_pitch, xa, xa_pitch, gwa, gba, beta_a, wsa, wsa_bytes, desca},
+                        {gb, yb, yb_pitch, xb, xb_pitch, gwb, gbb, beta_b, wsb, wsb_bytes, descb}};
+  return lgm_conv3x3_wino_wgradn(2, it, stream);
 }
 
 // Joint plan of the backward pair.  Standing alone, each kernel splits its reduction until ITS grid fills the 256 CUs;

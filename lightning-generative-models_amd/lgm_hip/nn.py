@@ -33,7 +33,7 @@ class GradCtx:
         # defer=True: conv weight-gradient slabs are reduced by ONE batched launch per flush() instead of
         # one launch per layer; the owner of the context MUST call flush() before the gradients are read
         self.deferred = [] if defer else None
-        self._pending = None
+        self._pending = []
         if transposed:
             flat.refresh_transposed()      # one launch per backward pass
 
@@ -42,23 +42,24 @@ class GradCtx:
         if self.deferred:
             ops.wgrad_reduce_batch(self.deferred, self.flat.device)
 
-    # -- large-map 3x3 weight gradients wait for a partner: two layers share ONE launch (ops.conv_wgrad2) ------------
+    # -- large-map 3x3 weight gradients wait for partners: up to four layers share ONE launch (ops.conv_wgrad_group) ---
     def queue_wgrad(self, g, gy, x, gw_ptr: int, beta: float, gb_ptr):
-        """Deferred passes only.  The entry keeps ``gy`` and ``x`` alive until its launch; the pair is issued as soon as
-        the second layer arrives, a lone entry at the end of the bucket (finish_pending)."""
+        """Deferred passes only.  An entry keeps ``gy`` and ``x`` alive until its launch; the group is issued when it is
+        full, when a layer arrives that cannot join it, or at the end of the bucket (finish_pending)."""
         new = (g, gy, x, gw_ptr, beta, gb_ptr)
-        old, self._pending = self._pending, None
-        if old is not None:
-            if ops.wgrad2_supported(old[0], g):
-                ops.conv_wgrad2(old, new, self.deferred)
-                return
-            ops.conv_wgrad(old[0], old[1], old[2], old[3], old[4], old[5], defer=self.deferred)
-        self._pending = new
+        if self._pending and not ops.wgrad_group_supported([e[0] for e in self._pending] + [g]):
+            self.finish_pending()
+        self._pending.append(new)
+        if len(self._pending) == ops.WGRAD_GROUP:
+            self.finish_pending()
 
     def finish_pending(self):
-        old, self._pending = self._pending, None
-        if old is not None:
-            ops.conv_wgrad(old[0], old[1], old[2], old[3], old[4], old[5], defer=self.deferred)
+        pend, self._pending = self._pending, []
+        if len(pend) == 1:
+            e = pend[0]
+            ops.conv_wgrad(e[0], e[1], e[2], e[3], e[4], e[5], defer=self.deferred)
+        elif pend:
+            ops.conv_wgrad_group(pend, self.deferred)
 
     def defer_for(self, p: nn.Parameter):
         """The deferred-reduction list for the FIRST gradient contribution of ``p`` in this pass, else None: the

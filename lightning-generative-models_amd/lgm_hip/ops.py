@@ -525,70 +525,97 @@ def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[
 _PAIR_OK = {}
 
 
-# Two large-map layers' weight gradients in one launch (lgm_conv3x3_wino_wgrad2): LGM_NO_WGRAD2=1 issues them singly.
+# Up to four large-map layers' weight gradients in one launch (lgm_conv3x3_wino_wgradn): LGM_NO_WGRAD2=1 issues them
+# singly, LGM_WGRAD_GROUP=n (2 ... 4) bounds the group (default 2: groups of 3 and 4 measured the same step time,
+# 10.66 / 10.67 / 10.67 ms - the second halving of prologues and slabs is below the noise - and hold buffers longer).
 WGRAD2 = _os.environ.get("LGM_NO_WGRAD2", "0") != "1"
+WGRAD_GROUP = max(2, min(4, int(_os.environ.get("LGM_WGRAD_GROUP", "2"))))
 _WG2_OK = {}
 _WG2_WS = {}
+
+
+class WgradItem(ctypes.Structure):
+    """LgmWgradItem (include/lgm_hip.h)"""
+    _fields_ = [("g", ctypes.c_void_p), ("y", ctypes.c_void_p), ("y_pitch", ctypes.c_int64), ("x", ctypes.c_void_p),
+                ("x_pitch", ctypes.c_int64), ("gw", ctypes.c_void_p), ("gbias", ctypes.c_void_p), ("beta", ctypes.c_float),
+                ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_int64), ("desc", ctypes.c_void_p)]
 
 
 def _gkey(g: ConvGeom):
     return (g.B, g.H, g.W, g.Cw, g.Nw, g.KH, g.KW, g.stride, g.pad)
 
 
-def wgrad2_supported(ga: ConvGeom, gb: ConvGeom) -> bool:
-    key = (_gkey(ga), _gkey(gb))
+def _geom_array(geoms):
+    arr = (ctypes.c_void_p * len(geoms))()
+    for i, g in enumerate(geoms):
+        arr[i] = ctypes.addressof(g)
+    return arr
+
+
+def wgrad_group_supported(geoms) -> bool:
+    key = tuple(_gkey(g) for g in geoms)
     v = _WG2_OK.get(key)
     if v is None:
-        v = bool(lib().lgm_conv3x3_wino_wgrad2_supported(ctypes.byref(ga), ctypes.byref(gb)))
+        v = bool(lib().lgm_conv3x3_wino_wgradn_supported(len(geoms), ctypes.addressof(_geom_array(geoms))))
         _WG2_OK[key] = v
     return v
 
 
+def wgrad2_supported(ga: ConvGeom, gb: ConvGeom) -> bool:
+    return wgrad_group_supported([ga, gb])
+
+
 def wgrad_queueable(g: ConvGeom, gy, x) -> bool:
-    """The layers whose weight gradient waits for a partner: 3x3 layers on the large maps whose input gradient runs
+    """The layers whose weight gradient waits for partners: 3x3 layers on the large maps whose input gradient runs
     apart (F(4x4)), with operands the grouped launch accepts."""
     if not (WGRAD2 and WINO and _WINO_FLATS and not B3 and _wino4_preferred(g, 1)):
         return False
     if gy.data_ptr() % 16 or x.data_ptr() % 16 or pitch(gy) % 4 or pitch(x) % 4:
         return False
-    return wgrad2_supported(g, g)
+    return wgrad_group_supported([g, g])
 
 
-def conv_wgrad2(a, b, defer):
-    """a, b = (geometry, gy, x, gw address, beta, gbias address): both weight gradients in ONE launch; their slab
-    descriptors join ``defer`` (the bucket's batched reduction)."""
+def conv_wgrad_group(entries, defer):
+    """entries = 2 ... 4 of (geometry, gy, x, gw address, beta, gbias address): all weight gradients in ONE launch; their
+    slab descriptors join ``defer`` (the bucket's batched reduction)."""
     L = lib()
-    args, descs = [], []
-    flops = nbytes_alg = 0.0
-    wkey = (_gkey(a[0]), _gkey(b[0]))
+    n = len(entries)
+    geoms = [e[0] for e in entries]
+    wkey = tuple(_gkey(g) for g in geoms)
     need = _WG2_WS.get(wkey)
     if need is None:
-        two = (ctypes.c_int64 * 2)()
-        L.lgm_conv3x3_wino_wgrad2_workspaces(ctypes.byref(a[0]), ctypes.byref(b[0]), ctypes.addressof(two))
+        out = (ctypes.c_int64 * n)()
+        L.lgm_conv3x3_wino_wgradn_workspaces(n, ctypes.addressof(_geom_array(geoms)), ctypes.addressof(out))
         # never smaller than the single-layer plan's need: the same slab buffer serves a layer whichever way it runs
-        need = tuple(max(int(two[k]), int(L.lgm_conv_wgrad_workspace(ctypes.byref(l[0])))) for k, l in enumerate((a, b)))
+        need = tuple(max(int(out[k]), int(L.lgm_conv_wgrad_workspace(ctypes.byref(g)))) for k, g in enumerate(geoms))
         _WG2_WS[wkey] = need
-    for k, (g, gy, x, gw_ptr, beta, gb_ptr) in enumerate((a, b)):
-        nbytes = need[k]
-        key = (gw_ptr, nbytes)
+    items = (WgradItem * n)()
+    descs = []
+    flops = nbytes_alg = 0.0
+    for k, (g, gy, x, gw_ptr, beta, gb_ptr) in enumerate(entries):
+        key = (gw_ptr, need[k])
         ws = _WGRAD_WS.get(key)
         if ws is None:
-            ws = torch.empty(max(nbytes // 4 + 4, 16), dtype=torch.float32, device=gy.device)
+            ws = torch.empty(max(need[k] // 4 + 4, 16), dtype=torch.float32, device=gy.device)
             _WGRAD_WS[key] = ws
         desc = (ctypes.c_int64 * 8)()
         descs.append(desc)
-        args += [ctypes.byref(g), gy.data_ptr(), pitch(gy), x.data_ptr(), pitch(x), gw_ptr, gb_ptr, beta, ws.data_ptr(),
-                 ws.numel() * 4, ctypes.addressof(desc)]
+        items[k] = WgradItem(ctypes.addressof(g), gy.data_ptr(), pitch(gy), x.data_ptr(), pitch(x), gw_ptr, gb_ptr, beta,
+                             ws.data_ptr(), ws.numel() * 4, ctypes.addressof(desc))
         flops += _conv_flops(g)
         nbytes_alg += _conv_bytes(g)
     if TIMER is not None:
         TIMER.begin("wgrad", flops, nbytes_alg)
-    L.lgm_conv3x3_wino_wgrad2(*args, stream())
+    L.lgm_conv3x3_wino_wgradn(n, ctypes.addressof(items), stream())
     if TIMER is not None:
         TIMER.end()
     for desc in descs:
         if desc[6] > 1:
             defer.append(tuple(desc))
+
+
+def conv_wgrad2(a, b, defer):
+    conv_wgrad_group([a, b], defer)
 
 
 def conv_bwd_pair(g: ConvGeom, gy, x, w_ptr: int, gw_ptr: int, beta: float, gbias_ptr: Optional[int], defer, res, gx,

@@ -447,3 +447,16 @@ def test_two_layers_weight_gradients_in_one_launch(dev, pair, parity):
     parity("layer a, fused bias gradient (beta = 1)", maxerr(results[0][2] - 1.0, refs[0][1]), 2e-6)
     parity("layer b (beta = 0)", maxerr(results[0][1], refs[1][0]), 2e-6)
     assert all(torch.equal(p, q) for p, q in zip(results[0], results[1]))
+    # four layers in one launch (the pair twice over): each layer against its reference
+    ents, gws4 = [], []
+    for k in range(4):
+        gk, yk, xk = layers[k % 2]
+        gws4.append(torch.full((yk.shape[-1], 9, xk.shape[-1]), float("nan"), device=dev))
+        ents.append((gk, yk, xk, gws4[-1].data_ptr(), 0.0, None))
+    if ops.wgrad_group_supported([e[0] for e in ents]):
+        rows = []
+        ops.conv_wgrad_group(ents, rows)
+        assert "wino_wgrad4_kernel" in ops.lib()._dll.lgm_last_kernel().decode() and len(rows) == 4
+        ops.wgrad_reduce_batch(rows, dev)
+        for k in range(4):
+            parity(f"four layers in one launch, layer {k}", maxerr(gws4[k], refs[k % 2][0]), 2e-6)
