@@ -416,7 +416,7 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
     # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the
     # figure comes from the committed rocprofv3 --pmc summary of this same command (tools/pmc_kernels.py), if any
     traffic, traffic_src = None, None
-    for cand in ("r03_pmc_traffic.json",):
+    for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(pmc) and wl == "ddpm32" and gb == 128 and world == 1:
             with open(pmc) as fh:

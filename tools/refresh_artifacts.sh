@@ -4,7 +4,7 @@
 # the SAME commands (graph replay) at the headline and the per-rank batches, one step's per-launch listing (eager),
 # the secondary workloads' kernel summaries, three PMC passes (FETCH_SIZE | WRITE_SIZE | MFMA busy) and the LDS pass
 set -e
-R=${1:-r03}
+R=${1:-r04}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out
 python3 bench.py 2> $out/${R}_bench.err | tail -1 > $out/${R}_bench.json
