@@ -9,7 +9,18 @@
  *     the `stream` argument (a hipStream_t passed as void*);
  *   - return 0 = OK, <0 = invalid argument / unsupported shape, >0 = hipError_t;
  *     lgm_last_error() returns a thread-local description;
- *   - stateless and re-entrant (safe from the autograd thread).
+ *   - re-entrant per THREAD (safe from the autograd thread next to the main thread): an entry point keeps no state
+ *     between calls.  What the library does hold, exactly:
+ *       . thread-local: the last error string, the last kernel name (lgm_last_error / lgm_last_kernel), and - only
+ *         INSIDE lgm_conv_bwd_pair[_post] - the pair-recording context in which that call's own input-gradient and
+ *         weight-gradient dispatchers record instead of launching; it is opened and closed by the same call on the same
+ *         thread and never visible between calls;
+ *       . process-wide, written once: hipFuncSetAttribute one-shot flags per kernel (idempotent: a race sets the same
+ *         attribute twice) and `static const` switches read from the environment on first use;
+ *       . process-wide, diagnostics only: the cycle-stamp buffers of lgm_wino_set_debug_buffer /
+ *         lgm_wino4_set_debug_buffer (NULL on the product path; a tool sets and clears them around its own launches,
+ *         single-threaded).
+ *     Callers that launch from several threads at once need no lock.
  *
  * Activation layout: NHWC fp32, addressed as (pointer, pitch) where pitch is the distance
  * in floats between consecutive pixels (>= channels; lets a tensor be a channel-slice of a

@@ -415,3 +415,69 @@ def test_sync_dist_logging_is_shape_safe_gloo_world2(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert "RANK0 raised" in r.stdout and "RANK1 raised" in r.stdout, r.stdout
     assert "RANK0 a=0.5 b=10.0" in r.stdout and "RANK1 a=0.5 b=10.0" in r.stdout, r.stdout
+
+
+def test_device_errors_are_told_from_argument_errors():
+    """the trainer keeps progress (last.ckpt) after a HOST-side rejection (rc < 0: nothing was launched) and
+    must not touch the GPU after a launch / runtime failure (rc > 0, torch.AcceleratorError, RCCL)."""
+    from lgm_hip._lib import LgmArgumentError, LgmDeviceError, LgmError
+    from lgm_hip.lightning import is_device_error
+    assert issubclass(LgmArgumentError, LgmError) and issubclass(LgmDeviceError, LgmError)
+    assert not is_device_error(LgmArgumentError("lgm_conv_xy failed (rc=-1): bad pitch"))
+    assert is_device_error(LgmDeviceError("lgm_conv_xy failed (rc=719): hipErrorLaunchFailure"))
+    assert is_device_error(RuntimeError("HIP error: an illegal memory access was encountered"))
+    assert is_device_error(RuntimeError("NCCL error in: ... unhandled system error"))
+    assert not is_device_error(ValueError("img_size mismatch")) and not is_device_error(KeyboardInterrupt())
+    assert not is_device_error(RuntimeError("shape '[2, 3]' is invalid for input of size 5"))
+
+
+def test_prescale_follows_the_optimizers_not_a_sticky_flag():
+    """1/world is folded into the fused optimizers' kernels (grad_scale); the gradient exchange divides unless
+    the optimizers the module holds NOW do that - fresh optimizers on a module that once trained prescaled get averages."""
+    from lgm_hip.lightning import MiniLightningModule, _CountingOptimizer, _prescaled
+
+    class Opt:
+        def __init__(self, gs):
+            self.grad_scale = gs
+
+        def step(self):
+            pass
+
+    m = MiniLightningModule()
+    assert not _prescaled(m, 2)                                  # no optimizers: divide
+    m._optimizers = [_CountingOptimizer(Opt(0.5), m)]
+    m._grads_prescaled = False
+    assert _prescaled(m, 2) and not _prescaled(m, 4)             # decided by grad_scale == 1 / world
+    m._optimizers = [_CountingOptimizer(Opt(0.5), m), _CountingOptimizer(Opt(1.0), m)]
+    m._grads_prescaled = True                                    # the old sticky flag is ignored
+    assert not _prescaled(m, 2)
+    m._optimizers = [_CountingOptimizer(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1), m)]
+    assert not _prescaled(m, 2)                                  # an optimizer without grad_scale
+
+
+def test_workspaces_of_live_flat_buffers_survive_cleanup():
+    """ops.forget_dead_flats() drops the slab workspaces / reducer tables of flat buffers that are gone and
+    keeps those of live ones (a captured graph of a live model has their addresses baked in)."""
+    import gc
+    from lgm_hip import ops
+    from lgm_hip.flat import FlatParams
+    from lgm_hip.nn import Conv2d, param_kind
+
+    def flat():
+        conv = Conv2d(4, 8, 3, padding=1)
+        return conv, FlatParams([(n, p, param_kind(n, p)) for n, p in conv.named_parameters()], "cpu")
+    c1, f1 = flat()
+    c2, f2 = flat()
+    k1, k2 = (f1.grad.data_ptr(), 64), (f2.grad.data_ptr() + 16, 64)
+    ops._WGRAD_WS[k1] = torch.zeros(16)
+    ops._WGRAD_WS[k2] = torch.zeros(16)
+    t1 = ((123, 1, f1.grad.data_ptr(), 4, 0, 0, 2, 0),)
+    t2 = ((456, 1, f2.grad.data_ptr(), 4, 0, 0, 2, 0),)
+    ops._WGRAD_TABLES[t1] = (torch.zeros(1), 1)
+    ops._WGRAD_TABLES[t2] = (torch.zeros(1), 1)
+    del c2, f2
+    gc.collect()
+    ops.forget_dead_flats()
+    assert k1 in ops._WGRAD_WS and t1 in ops._WGRAD_TABLES          # the live model keeps its workspaces
+    assert k2 not in ops._WGRAD_WS and t2 not in ops._WGRAD_TABLES  # the dead one's are gone
+    del ops._WGRAD_WS[k1], ops._WGRAD_TABLES[t1]
