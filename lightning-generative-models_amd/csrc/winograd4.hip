@@ -383,11 +383,13 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
     }
     const long opix = ((long)(b0 + e_img) * p.H + h0 + 4 * e_ty) * p.W + w0 + 4 * e_tx;
     const bool partial = p.splits > 1;
-    const int ncol = n0 + HALF * 32 + eq * 4;
-    float* const obase = partial ? p.ws + (long)split * p.ws_stride + opix * p.N + ncol : p.out + opix * p.out_pitch + ncol;
+    // accumulator row i of half HALF = produced channel 32 (i >> 4) + 16 HALF + (i & 15) (the operand's row order, see
+    // wino4_weights_kernel): round rd of the two halves covers channels [32 rd, 32 rd + 32) = one 128-byte line per pixel
+    const int ncol0 = n0 + HALF * 16 + eq * 4;
+    float* const obase = partial ? p.ws + (long)split * p.ws_stride + opix * p.N + ncol0 : p.out + opix * p.out_pitch + ncol0;
     const long opitch = partial ? (long)p.N : p.out_pitch;
     const bool has_res = !partial && p.res != nullptr;           // kernel argument: a scalar branch
-    const float* const rbase = p.res + opix * p.res_pitch + ncol;
+    const float* const rbase = p.res + opix * p.res_pitch + ncol0;
     float* const Mh = Mb + HALF * (MBUF / 2);
     const int mrd = (et * 4 + (eq ^ ((et >> 1) & 3))) * 4;
     const int mwr = (lr * 4) * 4;
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
         }
       }
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (!partial && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol + rd * 16);
+      if (!partial && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + rd * 32);
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
         const long orow = (long)(2 * rr + rpair) * p.W;
@@ -434,10 +436,10 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
         if (has_res) {
 #pragma unroll
           for (int oj = 0; oj < 4; ++oj)
-            y[oj] = add4(y[oj], *reinterpret_cast<const f32x4*>(rbase + (orow + oj) * p.res_pitch + rd * 16));
+            y[oj] = add4(y[oj], *reinterpret_cast<const f32x4*>(rbase + (orow + oj) * p.res_pitch + rd * 32));
         }
 #pragma unroll
-        for (int oj = 0; oj < 4; ++oj) *reinterpret_cast<f32x4*>(obase + (orow + oj) * opitch + rd * 16) = add4(y[oj], bv);
+        for (int oj = 0; oj < 4; ++oj) *reinterpret_cast<f32x4*>(obase + (orow + oj) * opitch + rd * 32) = add4(y[oj], bv);
       }
       stamp();
     }
@@ -453,8 +455,8 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
 // ---------------------------------------------------------------------------------------------
 // U = G g G^T for 3x3 weight slots of a flat buffer (weights [Np][9][Cp]), computed in float64, stored in the fragment
 // order the convolution kernel reads.  table rows: [src offset, Np, Cp, dst_f offset, dst_b offset, first block]
-//   forward operand  Uf[n/64][c/8][xi][(n%64)/32][(c%8)/4][n%32][c%4],  g[a][b] = w[n][3a+b][c]
-//   input-gradient   Ub[c/64][n/8][xi][(c%64)/32][(n%8)/4][c%32][n%4],  g'[a][b] = w[n][3(2-a)+(2-b)][c]
+//   forward operand  Uf[n/64][c/8][xi][(n%32)/16][(c%8)/4][16 ((n%64)/32) + n%16][c%4],  g[a][b] = w[n][3a+b][c]
+//   input-gradient   Ub[c/64][n/8][xi][(c%32)/16][(n%8)/4][16 ((c%64)/32) + c%16][n%4],  g'[a][b] = w[n][3(2-a)+(2-b)][c]
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ggt36(const float (&g)[9], float (&u)[36]) {
   double t[6][3];
@@ -516,9 +518,11 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
 #pragma unroll
       for (int x = 0; x < 36; ++x) uu[x][s] = u[x];
     }
-    // [(nb >> 1)][ph = cb * 4 + (cq >> 1)][xi][nb & 1][cq & 1][n][4]
+    // [(nb >> 1)][ph = cb * 4 + (cq >> 1)][xi][half = n >> 4][cq & 1][row = 16 (nb & 1) + (n & 15)][4]: the produced channels
+    // of a 64-block are dealt to the two wave halves in groups of 16 (0-15 | 16-31 | 32-47 | 48-63 -> half 0 | 1 | 0 | 1), so
+    // that one epilogue round of both halves completes a full 128-byte line per pixel
     float* d = dst_f + row[3] + (((long)(nb >> 1) * (Cp / 8) + cb * 4 + (cq >> 1)) * NXI) * 512 +
-               (((nb & 1) * 2 + (cq & 1)) * 32 + n) * 4;
+               (((n >> 4) * 2 + (cq & 1)) * 32 + 16 * (nb & 1) + (n & 15)) * 4;
 #pragma unroll
     for (int x = 0; x < 36; ++x) *reinterpret_cast<f32x4*>(d + x * 512) = uu[x];
   }
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
       for (int x = 0; x < 36; ++x) uu[x][s] = u[x];
     }
     float* d = dst_b + row[4] + (((long)(cb >> 1) * (Np / 8) + nb * 4 + (nq >> 1)) * NXI) * 512 +
-               (((cb & 1) * 2 + (nq & 1)) * 32 + c) * 4;
+               (((c >> 4) * 2 + (nq & 1)) * 32 + 16 * (cb & 1) + (c & 15)) * 4;
 #pragma unroll
     for (int x = 0; x < 36; ++x) *reinterpret_cast<f32x4*>(d + x * 512) = uu[x];
   }

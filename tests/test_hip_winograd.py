@@ -403,12 +403,13 @@ def test_winograd4_partial_planes_and_weight_transform(dev, parity):
                       [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
     g3 = w.double().cpu().reshape(co, 3, 3, ci)
     U = torch.einsum("ia,nabc,jb->nijc", G, g3, G)                               # [n][6][6][c]
-    uf_l = uf.cpu().view(co // 64, ci // 8, 36, 2, 2, 32, 4)                     # [n/64][c/8][xi][(n%64)/32][(c%8)/4][n%32][c%4]
-    got = uf_l.permute(0, 3, 5, 2, 1, 4, 6).reshape(co, 36, ci)                  # [n][xi][c]
+    # [n/64][c/8][xi][half = (n%32)/16][(c%8)/4][row = 16 ((n%64)/32) + n%16][c%4]: split row into (n%64)/32 and n%16
+    uf_l = uf.cpu().view(co // 64, ci // 8, 36, 2, 2, 2, 16, 4)
+    got = uf_l.permute(0, 5, 3, 6, 2, 1, 4, 7).reshape(co, 36, ci)               # [n/64][(n%64)/32][half][n%16] -> n; [xi]; c
     parity("F(4x4) forward operand vs G g G^T", maxerr(got, U.reshape(co, 36, ci)), 2e-7)
     Ub = torch.einsum("ia,nabc,jb->cijn", G, g3.flip(1, 2), G)                   # mirrored taps, roles swapped: [c][6][6][n]
-    ub_l = ub.cpu().view(ci // 64, co // 8, 36, 2, 2, 32, 4)
-    gotb = ub_l.permute(0, 3, 5, 2, 1, 4, 6).reshape(ci, 36, co)
+    ub_l = ub.cpu().view(ci // 64, co // 8, 36, 2, 2, 2, 16, 4)
+    gotb = ub_l.permute(0, 5, 3, 6, 2, 1, 4, 7).reshape(ci, 36, co)
     parity("F(4x4) input-gradient operand vs its definition", maxerr(gotb, Ub.reshape(ci, 36, co)), 2e-7)
 
 
