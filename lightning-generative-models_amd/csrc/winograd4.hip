@@ -583,7 +583,8 @@ int lgm_wino4_splits(const LgmConvGeom* g, int gather_channels, int out_channels
   if (base >= 192) return 1;
   int s = (int)((256 + base - 1) / base);
   if (s > smax) s = smax;
-  while (s > 1 && phases / s < 6) --s;              // a split shorter than ~6 phases is mostly prologue and epilogue
+  static const int min_pps = getenv("LGM_WINO4_MIN_PPS") ? atoi(getenv("LGM_WINO4_MIN_PPS")) : 4;
+  while (s > 1 && phases / s < min_pps) --s;        // a split shorter than ~4 phases is mostly prologue and epilogue
   return s;
 }
 
@@ -679,10 +680,10 @@ extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
   if (!lgm_wino4_supported(g, gc, oc)) return 0;
   static const int force = getenv("LGM_WINO4_FORCE") ? atoi(getenv("LGM_WINO4_FORCE")) : 0;
   if (force) return 1;
-  // maps >= 16 x 32 (one unit per CU-sized 16 x 32 pixel block): 128 units (B = 64 at 32 x 32) measured SLOWER than the
-  // F(2x2) pair on its joint plan (7.44 vs 7.37 ms per step), 256 units faster (10.9 vs 11.4); 16 x 16 maps (more phases
-  // per unit, split-K by two) pay from 128 units
-  static const long min_units0 = getenv("LGM_WINO4_MIN_UNITS") ? atol(getenv("LGM_WINO4_MIN_UNITS")) : 192;
+  // maps >= 16 x 32: from 128 units (B = 64 at 32 x 32: the reduction is split in two, 4 phases per workgroup: 7.28 vs
+  // 7.35 ms per step against the F(2x2) pair on its joint plan; without the split 7.44); 256 units: 10.9 vs 11.4 ms;
+  // 16 x 16 maps (more phases per unit) likewise from 128 units
+  static const long min_units0 = getenv("LGM_WINO4_MIN_UNITS") ? atol(getenv("LGM_WINO4_MIN_UNITS")) : 128;
   static const long min_units1 = getenv("LGM_WINO4_MIN_UNITS1") ? atol(getenv("LGM_WINO4_MIN_UNITS1")) : 128;
   const int cls = lgmwino4::unit_class(g->H, g->W);
   const long base = lgmwino4::unit_count(cls, g->B, g->H, g->W) * (oc / 64);
