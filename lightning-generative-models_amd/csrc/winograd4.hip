@@ -453,32 +453,38 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// U = G g G^T for 3x3 weight slots of a flat buffer (weights [Np][9][Cp]), computed in float64, stored in the fragment
+// U = G g G^T for 3x3 weight slots of a flat buffer (weights [Np][9][Cp]), stored in the fragment
 // order the convolution kernel reads.  table rows: [src offset, Np, Cp, dst_f offset, dst_b offset, first block]
 //   forward operand  Uf[n/64][c/8][xi][(n%32)/16][(c%8)/4][16 ((n%64)/32) + n%16][c%4],  g[a][b] = w[n][3a+b][c]
 //   input-gradient   Ub[c/64][n/8][xi][(c%32)/16][(n%8)/4][16 ((c%64)/32) + c%16][n%4],  g'[a][b] = w[n][3(2-a)+(2-b)][c]
 // ---------------------------------------------------------------------------------------------
+// fp32 throughout (fp64 made this kernel compute-bound: 150 us per call on the 64 x 64 configuration, 2 % of its step):
+// three roundings per stage on constants that are not dyadic (1/6, 1/12, 1/24) - measured against the float64 definition
+// in tests/test_hip_winograd.py (<= 3e-7 of the largest element), an order below the data transforms' own rounding
 __device__ __forceinline__ void ggt36(const float (&g)[9], float (&u)[36]) {
-  double t[6][3];
+  constexpr float k6 = 1.f / 6.f, k12 = 1.f / 12.f, k24 = 1.f / 24.f;
+  float t[6][3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
-    const double g0 = g[b], g1 = g[3 + b], g2 = g[6 + b];
-    t[0][b] = g0 * 0.25;
-    t[1][b] = -(g0 + g1 + g2) * (1.0 / 6.0);
-    t[2][b] = -(g0 - g1 + g2) * (1.0 / 6.0);
-    t[3][b] = g0 * (1.0 / 24.0) + g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0);
-    t[4][b] = g0 * (1.0 / 24.0) - g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0);
+    const float g0 = g[b], g1 = g[3 + b], g2 = g[6 + b];
+    const float s02 = g0 + g2, e = __builtin_fmaf(g0, k24, g2 * k6);
+    t[0][b] = g0 * 0.25f;
+    t[1][b] = -(s02 + g1) * k6;
+    t[2][b] = -(s02 - g1) * k6;
+    t[3][b] = __builtin_fmaf(g1, k12, e);
+    t[4][b] = __builtin_fmaf(g1, -k12, e);
     t[5][b] = g2;
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const double g0 = t[i][0], g1 = t[i][1], g2 = t[i][2];
-    u[i * 6 + 0] = (float)(g0 * 0.25);
-    u[i * 6 + 1] = (float)(-(g0 + g1 + g2) * (1.0 / 6.0));
-    u[i * 6 + 2] = (float)(-(g0 - g1 + g2) * (1.0 / 6.0));
-    u[i * 6 + 3] = (float)(g0 * (1.0 / 24.0) + g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0));
-    u[i * 6 + 4] = (float)(g0 * (1.0 / 24.0) - g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0));
-    u[i * 6 + 5] = (float)g2;
+    const float g0 = t[i][0], g1 = t[i][1], g2 = t[i][2];
+    const float s02 = g0 + g2, e = __builtin_fmaf(g0, k24, g2 * k6);
+    u[i * 6 + 0] = g0 * 0.25f;
+    u[i * 6 + 1] = -(s02 + g1) * k6;
+    u[i * 6 + 2] = -(s02 - g1) * k6;
+    u[i * 6 + 3] = __builtin_fmaf(g1, k12, e);
+    u[i * 6 + 4] = __builtin_fmaf(g1, -k12, e);
+    u[i * 6 + 5] = g2;
   }
 }
 

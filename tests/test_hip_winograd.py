@@ -406,11 +406,11 @@ def test_winograd4_partial_planes_and_weight_transform(dev, parity):
     # [n/64][c/8][xi][half = (n%32)/16][(c%8)/4][row = 16 ((n%64)/32) + n%16][c%4]: split row into (n%64)/32 and n%16
     uf_l = uf.cpu().view(co // 64, ci // 8, 36, 2, 2, 2, 16, 4)
     got = uf_l.permute(0, 5, 3, 6, 2, 1, 4, 7).reshape(co, 36, ci)               # [n/64][(n%64)/32][half][n%16] -> n; [xi]; c
-    parity("F(4x4) forward operand vs G g G^T", maxerr(got, U.reshape(co, 36, ci)), 2e-7)
+    parity("F(4x4) forward operand vs G g G^T", maxerr(got, U.reshape(co, 36, ci)), 4e-7)
     Ub = torch.einsum("ia,nabc,jb->cijn", G, g3.flip(1, 2), G)                   # mirrored taps, roles swapped: [c][6][6][n]
     ub_l = ub.cpu().view(ci // 64, co // 8, 36, 2, 2, 2, 16, 4)
     gotb = ub_l.permute(0, 5, 3, 6, 2, 1, 4, 7).reshape(ci, 36, co)
-    parity("F(4x4) input-gradient operand vs its definition", maxerr(gotb, Ub.reshape(ci, 36, co)), 2e-7)
+    parity("F(4x4) input-gradient operand vs its definition", maxerr(gotb, Ub.reshape(ci, 36, co)), 4e-7)
 
 
 @pytest.mark.parametrize("pair", [((3, 32, 64, 64), (3, 32, 128, 64)), ((4, 16, 192, 128), (4, 16, 128, 128)),
