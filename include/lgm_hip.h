@@ -619,6 +619,15 @@ int lgm_conv3x3_wino4(int yx, const LgmConvGeom* g, const float* a, int64_t a_pi
                       const float* bias, const float* res, int64_t res_pitch, float* out, int64_t out_pitch,
                       void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Weight gradient of those layers in F(4x4,3x3) form (csrc/winograd4_wgrad.hip; maps with W % 16 == 0, H % 4 == 0,
+ * Nw % 64 == 0, Cw % 32 == 0): dU = sum over tiles of (A dY A^T) (.) (B^T x B), dw = G^T dU G, fused bias sums.  Slabs only:
+ * `workspace` receives desc[6] slabs for the batched fixed-order reducer; desc as lgm_conv_wgrad_deferred fills it. */
+int64_t lgm_conv3x3_wino4_wgrad_supported(const LgmConvGeom* g);
+int64_t lgm_conv3x3_wino4_wgrad_workspace(const LgmConvGeom* g);
+int lgm_conv3x3_wino4_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x, int64_t x_pitch,
+                            float* gw, float* gbias, float beta, void* workspace, int64_t workspace_bytes,
+                            int64_t* desc, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Optimiser kernels on flat storage.
  * torch.optim.Adam (coupled L2; decoupled=1 gives AdamW) — ddpm.py:1053-1059, vqvae.py:207-214,

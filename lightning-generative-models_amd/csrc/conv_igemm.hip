@@ -37,6 +37,11 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
 
 // Winograd F(2x2,3x3) weight gradient (winograd.hip): always through slabs + the fixed-order reducer
 bool lgm_wino_wgrad_supported(const LgmConvGeom* g);
+// F(4x4,3x3) weight gradient of the large-map layers (csrc/winograd4_wgrad.hip)
+bool lgm_wino4_wgrad_use(const LgmConvGeom* g);
+void lgm_wino4_wgrad_plan(const LgmConvGeom* g, long budget, int* splits, int* gps, int* total_groups);
+int lgm_wino4_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch, float* out,
+                           int bias, long slab, int splits, int gps, int total, hipStream_t s);
 void lgm_wino_wgrad_plan(const LgmConvGeom* g, int* splits, int* cps, int* total_chunks);
 int lgm_wino_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch, float* out,
                           int bias, long slab, int splits, int cps, int total_chunks, hipStream_t s);
@@ -1597,6 +1602,11 @@ extern "C" int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g) {
     lgm_wino_wgrad_plan(g, &sw, &cps, &total);
     if (sw > splits) splits = sw;
   }
+  if (use_3x3() && use_wino() && lgm_wino4_wgrad_use(g)) {
+    int sw, gps, total;
+    lgm_wino4_wgrad_plan(g, 256, &sw, &gps, &total);
+    if (sw > splits) splits = sw;
+  }
   if (g->KH == 1 && g->KW == 1 && g->Nw % 64 == 0 && g->Cw % 64 == 0) {
     int s1, per;
     lgm_wgrad1x1_plan(g, &s1, &per);
@@ -1629,8 +1639,11 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
   const bool fast1 = !fast3 && !no_w1x1 && lgm_wgrad1x1_supported(g, y_pitch, x_pitch);
   // Winograd: same operand limits as the direct 3x3 kernel (the kernel always writes slabs, the reducer applies beta)
   const bool fastw = fast3 && use_wino() && lgm_wino_wgrad_supported(g);
+  const bool fastw4 = fastw && lgm_wino4_wgrad_use(g);          // large maps: F(4x4,3x3)
   int tps3 = 0, total3 = 0, per1 = 0, cpsw = 0, totalw = 0;
-  if (fastw)
+  if (fastw4)
+    lgm_wino4_wgrad_plan(g, 256, &a.splits, &cpsw, &totalw);
+  else if (fastw)
     lgm_wino_wgrad_plan(g, &a.splits, &cpsw, &totalw);
   else if (fast3)
     lgm_wgrad3x3_plan(g, &a.splits, &tps3, &total3);
@@ -1652,7 +1665,10 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
   a.tiles_m = lgm_cdiv(a.Nw, 64);
   a.tiles_n = lgm_cdiv(a.Q, 64);
   hipStream_t s = (hipStream_t)stream;
-  if (fastw) {
+  if (fastw4) {
+    if (int rc = lgm_wino4_wgrad_launch(g, y, y_pitch, x, x_pitch, a.out, gbias ? 1 : 0, a.slab, a.splits, cpsw, totalw, s))
+      return rc;
+  } else if (fastw) {
     if (int rc = lgm_wino_wgrad_launch(g, y, y_pitch, x, x_pitch, a.out, gbias ? 1 : 0, a.slab, a.splits, cpsw, totalw, s))
       return rc;
   } else if (fast3) {

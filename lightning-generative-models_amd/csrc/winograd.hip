@@ -1507,6 +1507,26 @@ static bool wgrad2_operands_ok(const LgmConvGeom* g, const float* y, long y_pitc
          ((long)g->B * g->H * g->W + g->W + 1) * x_pitch < (1L << 29) && (long)g->B * g->H * g->W * y_pitch < (1L << 29);
 }
 
+// F(4x4,3x3) weight gradient (csrc/winograd4_wgrad.hip): pairs of layers that both take it share a launch of THAT kernel
+bool lgm_wino4_wgrad_use(const LgmConvGeom* g);
+void lgm_wino4_wgrad_plan(const LgmConvGeom* g, long budget, int* splits, int* gps, int* total_groups);
+int lgm_wino4_wgrad2_launch(const LgmConvGeom* const* gs, const float* const* ys, const long* yps, const float* const* xs,
+                            const long* xps, float* const* outs, const int* biases, const long* slabs, const int* splits,
+                            const int* gpss, const int* totals, hipStream_t s);
+static bool wgradn_use4(int n, const LgmConvGeom* const* gs) {
+  return n == 2 && lgm_wino4_wgrad_use(gs[0]) && lgm_wino4_wgrad_use(gs[1]);
+}
+static void wgrad4_budgets(const LgmConvGeom* const* gs, long* budget) {     // two layers, blocks of 64 x 32 channels
+  const double w0 = (double)gs[0]->B * gs[0]->H * gs[0]->W * gs[0]->Nw * gs[0]->Cw;
+  const double w1 = (double)gs[1]->B * gs[1]->H * gs[1]->W * gs[1]->Nw * gs[1]->Cw;
+  const long m0 = 2L * (gs[0]->Nw / 64) * (gs[0]->Cw / 32), m1 = 2L * (gs[1]->Nw / 64) * (gs[1]->Cw / 32);
+  long b0 = (long)(256.0 * w0 / (w0 + w1) + 0.5);
+  if (b0 < m0) b0 = m0;
+  if (256 - b0 < m1) b0 = 256 - m1;
+  budget[0] = b0;
+  budget[1] = 256 - b0;
+}
+
 // 1 when the grouped launch takes these n (2 ... 4) layers: all run the Winograd weight-gradient kernel of the same map
 // class, and each still gets at least two slabs out of its share of the chip
 static bool wgradn_supported(int n, const LgmConvGeom* const* gs) {
@@ -1560,6 +1580,16 @@ extern "C" int64_t lgm_conv3x3_wino_wgrad2_supported(const LgmConvGeom* ga, cons
 // the chip, so it differs from lgm_conv_wgrad_workspace's)
 extern "C" int lgm_conv3x3_wino_wgradn_workspaces(int n, const LgmConvGeom* const* geoms, int64_t* out) {
   LGM_REQUIRE(geoms && out && wgradn_supported(n, geoms), "conv3x3_wino_wgradn_workspaces: unsupported group of layers");
+  if (wgradn_use4(n, geoms)) {
+    long b4[2];
+    wgrad4_budgets(geoms, b4);
+    for (int k = 0; k < 2; ++k) {
+      int splits, gps, total;
+      lgm_wino4_wgrad_plan(geoms[k], b4[k], &splits, &gps, &total);
+      out[k] = (int64_t)splits * ((int64_t)geoms[k]->Nw * 9 * geoms[k]->Cw + geoms[k]->Nw) * (int64_t)sizeof(float);
+    }
+    return LGM_OK;
+  }
   long bud[4];
   wgradn_budgets(n, geoms, bud);
   for (int k = 0; k < n; ++k) {
@@ -1584,6 +1614,32 @@ extern "C" int lgm_conv3x3_wino_wgradn(int n, const LgmWgradItem* it, void* stre
     LGM_REQUIRE(it[k].desc && it[k].ws && lgm_aligned16(it[k].ws) &&
                 wgrad2_operands_ok(it[k].g, it[k].y, it[k].y_pitch, it[k].x, it[k].x_pitch, it[k].gw, it[k].gbias),
                 "conv3x3_wino_wgradn: layer %d: 16-byte aligned operands with pitch %% 4 == 0 inside 32-bit offsets expected", k);
+  if (wgradn_use4(n, gs)) {                       // both layers on the F(4x4) kernel: one launch of that kernel
+    long b4[2];
+    wgrad4_budgets(gs, b4);
+    const float* ys[2];
+    const float* xs[2];
+    long yps[2], xps[2], slabs[2];
+    float* outs[2];
+    int biases[2], splits[2], gpss[2], totals[2];
+    for (int k = 0; k < 2; ++k) {
+      const LgmConvGeom* g = gs[k];
+      lgm_wino4_wgrad_plan(g, b4[k], &splits[k], &gpss[k], &totals[k]);
+      const long n_w = (long)g->Nw * 9 * g->Cw;
+      slabs[k] = n_w + g->Nw;
+      LGM_REQUIRE(it[k].ws_bytes >= (int64_t)splits[k] * slabs[k] * (int64_t)sizeof(float),
+                  "conv3x3_wino_wgradn: workspace %d too small", k);
+      ys[k] = it[k].y; xs[k] = it[k].x; yps[k] = it[k].y_pitch; xps[k] = it[k].x_pitch;
+      outs[k] = (float*)it[k].ws; biases[k] = it[k].gbias ? 1 : 0;
+      union { float f; int64_t i; } bbits;
+      bbits.i = 0;
+      bbits.f = it[k].beta;
+      int64_t* d = it[k].desc;
+      d[0] = (int64_t)(uintptr_t)it[k].ws; d[1] = slabs[k]; d[2] = (int64_t)(uintptr_t)it[k].gw; d[3] = n_w;
+      d[4] = (int64_t)(uintptr_t)it[k].gbias; d[5] = it[k].gbias ? g->Nw : 0; d[6] = splits[k]; d[7] = bbits.i;
+    }
+    return lgm_wino4_wgrad2_launch(gs, ys, yps, xs, xps, outs, biases, slabs, splits, gpss, totals, (hipStream_t)stream);
+  }
   int G, ipc;
   wgrad_class(gs[0]->H, gs[0]->W, &G, &ipc);
   long bud[4];

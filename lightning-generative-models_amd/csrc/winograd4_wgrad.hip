@@ -1,0 +1,521 @@
+// Winograd F(4x4, 3x3) WEIGHT GRADIENT in fp32 on v_mfma_f32_32x32x2_f32 — the 3x3 / stride 1 / pad 1 layers of the DDPM
+// UNet on the large maps (W % 16 == 0, H % 4 == 0; reference: autograd's weight / bias gradient of Block.proj,
+// ddpm.py:157-173).  Transposes the forward algorithm of winograd4.hip:
+//
+//   dU[xi][n][c] = sum over tiles t of  Yt[xi][t][n] * Xt[xi][t][c],     Yt = A dY A^T (4x4 -> 6x6),  Xt = B^T x B (6x6),
+//   dw = G^T dU G  (6x6 -> 3x3),        bias gradient = sum of dY
+//
+// 36 products per 16 output pixels instead of 64 (the F(2x2) weight gradient of winograd.hip) or 144 (direct).
+//
+// Work decomposition.  WORKGROUP = 64 output channels x 32 input channels x a range of tile GROUPS (a group = four tiles
+// in a row = 4 x 16 output pixels; one group per PHASE); it writes one slab [Nw][9][Cw] region (+ bias sums) for the
+// batched fixed-order slab reducer, exactly as the other weight-gradient kernels do.  512 threads = 8 waves:
+//   * MFMA role (all waves): wave = (9 of the 36 xi) x (32 of the 64 output channels): per xi two 8-byte LDS reads
+//     (A = Yt: output channels x tiles, B = Xt: tiles x input channels) and two MFMAs into one 32x32 accumulator;
+//   * waves 0-3 also build Yt: thread = (tile, output channel): 16 dword loads (64 consecutive channels per wave:
+//     coalesced), A . A^T in registers (80 operations), 36 values to LDS;
+//   * waves 4-7 also build Xt: thread = (tile, input channel, half of the six rows): 30 dword loads with the zero padding
+//     as out-of-range buffer offsets, B^T . B (54 operations), 18 values to LDS.
+// Operands double-buffered (2 x 55 KB), one barrier per phase; the raw values of group p + 2 are requested as soon as the
+// registers of group p + 1 have been transformed.  Epilogue: accumulators through LDS in two rounds (the 36 xi of an
+// (n, c) sit in four waves), thread = (input channel, four output channels, tap rows) applies G^T . G and stores 128-byte
+// segments of the slab.  Fixed summation orders: run-to-run identical.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "lgm_common.h"
+
+namespace lgmwino4w {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NXI = 36;
+constexpr int YB = NXI * 256;      // floats of a Yt buffer: [xi][tile pair][n 64][2]
+constexpr int XB = NXI * 128;      // floats of an Xt buffer: [xi][tile pair][c 32][2]
+constexpr int OPB = YB + XB;       // one operand buffer
+constexpr int MH = NXI * 512;      // floats of the epilogue exchange per half: [xi][n group 4][c 32][4 n]
+
+struct WArgs {
+  const float* y;      // output gradient, NHWC
+  const float* x;      // layer input, NHWC
+  float* out;          // slabs: split k at out + k * slab
+  long y_pitch, x_pitch, slab;
+  int bias;            // 1: sums of y into slab[n_w + n]
+  int B, H, W, Nw, Cw;
+  int tiles_c;         // Cw / 32
+  int splits, gps, total_groups;
+  int grow;            // groups per tile row (W / 16)
+  int trows;           // tile rows per image (H / 4)
+};
+
+__device__ __forceinline__ f32x4 add4(const f32x4 a, const f32x4 b) { return a + b; }
+__device__ __forceinline__ f32x4 sub4(const f32x4 a, const f32x4 b) {
+  f32x2 lo, hi;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+      : "=v"(lo)
+      : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+      : "=v"(hi)
+      : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 fma4(const float c, const f32x4 a, const f32x4 b) {   // c * a + b
+  return __builtin_elementwise_fma(f32x4{c, c, c, c}, a, b);
+}
+__device__ __forceinline__ f32x2 fma2(const float c, const f32x2 a, const f32x2 b) {
+  return __builtin_elementwise_fma(f32x2{c, c}, a, b);
+}
+
+// The kernel body as a device function of (arguments, logical block id): runs as its own launch or as a block range of a
+// grouped launch (several layers' weight gradients in one grid).
+__device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx) {
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  int bid = bidx;
+  const int split = bid % p.splits;
+  bid /= p.splits;
+  const int tc = bid % p.tiles_c, tn = bid / p.tiles_c;
+  const int n0 = tn * 64, c0 = tc * 32;
+  const int g_begin = split * p.gps;
+  const int g_end = min(p.total_groups, g_begin + p.gps);
+  const int nph = g_end - g_begin;
+
+  // MFMA role
+  const int xg = wid & 3, nh = wid >> 2;
+  const int ard = xg * (9 * 256) + lh * 128 + (nh * 32 + lr) * 2;             // A fragments (Yt), floats
+  const int brd = YB + xg * (9 * 128) + lh * 64 + lr * 2;                     // B fragments (Xt)
+
+  const unsigned nrec_y = (unsigned)((long)p.B * p.H * p.W * p.y_pitch * 4);
+  // the X descriptor starts one row and one column BEFORE the tensor (offsets of halo pixels stay non-negative; the W + 1
+  // pixels in front of the allocation are never requested: every padding position gets an out-of-range offset)
+  const unsigned nrec_x = (unsigned)(((long)p.B * p.H * p.W + p.W + 1) * p.x_pitch * 4);
+  auto rsrc = [&](const float* ptr, unsigned nrec) {
+    const unsigned long long ab = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ab);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ab >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_y = rsrc(p.y, nrec_y);
+  const __amdgpu_buffer_rsrc_t rsrc_x = rsrc(p.x - (long)(p.W + 1) * p.x_pitch, nrec_x);
+
+  // group g -> (image, tile row, group of the row): byte offset of output pixel (4 ty, 16 gx) of image b
+  struct GPos {
+    unsigned ybase, xbase;   // bytes, without the lane parts
+    int ty, gx;
+  };
+  auto gpos = [&](int g) {
+    GPos q;
+    q.gx = g % p.grow;
+    const int r = g / p.grow;
+    q.ty = r % p.trows;
+    const int b = r / p.trows;
+    const long pix = ((long)b * p.H + 4 * q.ty) * p.W + 16 * q.gx;
+    q.ybase = (unsigned)(pix * p.y_pitch * 4);
+    q.xbase = (unsigned)(pix * p.x_pitch * 4);
+    return q;
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+
+  auto mfma_step = [&](const float* buf, int e, f32x2& af, f32x2& bf) {     // xi e with the fragments read a step ago
+    f32x2 an = af, bn = bf;
+    if (e < 8) {
+      an = *reinterpret_cast<const f32x2*>(buf + ard + (e + 1) * 256);
+      bn = *reinterpret_cast<const f32x2*>(buf + brd + (e + 1) * 128);
+    }
+    acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc[e], 0, 0, 0);
+    acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc[e], 0, 0, 0);
+    af = an;
+    bf = bn;
+  };
+
+  float bsum = 0.f;
+
+  // =================================== waves 0-3: Yt = A dY A^T ===================================
+  auto body_y = [&]() {
+    const int tl = wid;                                  // tile of the group
+    const unsigned ylane = (unsigned)(((long)(4 * tl) * p.y_pitch + n0 + lane) * 4);
+    const int ywr = (tl >> 1) * 128 + lane * 2 + (tl & 1);
+    float d[4][4];
+    auto load = [&](int ph) {
+      const GPos q = gpos(g_begin + (ph < nph ? ph : 0));
+      const unsigned ok = ph < nph ? 0u : nrec_y;        // past the range: zeros
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          d[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+              rsrc_y, ylane + ok, q.ybase + (unsigned)(((long)r * p.W + c) * p.y_pitch * 4), 0));
+    };
+    // A = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1]
+    float T[6][4];
+    auto vertical = [&](int c) {
+      const float d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c];
+      const float s02 = d0 + d2, s13 = d1 + d3;
+      const float e = __builtin_fmaf(4.f, d2, d0), f = __builtin_fmaf(4.f, d3, d1);
+      T[0][c] = d0;
+      T[1][c] = s02 + s13;
+      T[2][c] = s02 - s13;
+      T[3][c] = __builtin_fmaf(2.f, f, e);
+      T[4][c] = __builtin_fmaf(-2.f, f, e);
+      T[5][c] = d3;
+      bsum += s02 + s13;                                  // (written only when the layer has a bias)
+    };
+    auto horizontal = [&](float* ybuf, int i) {
+      float* v = ybuf + ywr + i * (6 * 256);
+      const float t0 = T[i][0], t1 = T[i][1], t2 = T[i][2], t3 = T[i][3];
+      const float s02 = t0 + t2, s13 = t1 + t3;
+      const float e = __builtin_fmaf(4.f, t2, t0), f = __builtin_fmaf(4.f, t3, t1);
+      v[0 * 256] = t0;
+      v[1 * 256] = s02 + s13;
+      v[2 * 256] = s02 - s13;
+      v[3 * 256] = __builtin_fmaf(2.f, f, e);
+      v[4 * 256] = __builtin_fmaf(-2.f, f, e);
+      v[5 * 256] = t3;
+    };
+    load(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vertical(c);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) horizontal(smem, i);
+    load(1);
+    __syncthreads();
+    auto phase = [&](int ph, auto cur_c) {
+      constexpr int cur = decltype(cur_c)::value;
+      const float* const ocur = smem + cur * OPB;
+      float* const onxt = smem + (cur ^ 1) * OPB;
+      f32x2 af = *reinterpret_cast<const f32x2*>(ocur + ard);
+      f32x2 bf = *reinterpret_cast<const f32x2*>(ocur + brd);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        mfma_step(ocur, e, af, bf);
+        if (e < 2) {
+          vertical(2 * e);
+          vertical(2 * e + 1);
+        } else if (e < 8) {
+          horizontal(onxt, e - 2);
+        } else {
+          load(ph + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    };
+    for (int ph = 0; ph < nph; ph += 2) {
+      phase(ph, std::integral_constant<int, 0>{});
+      if (ph + 1 < nph) phase(ph + 1, std::integral_constant<int, 1>{});
+    }
+  };
+
+  // =================================== waves 4-7: Xt = B^T x B ===================================
+  auto body_x = [&](auto half_c) {
+    constexpr int HALF = decltype(half_c)::value;        // rows 0-2 / 3-5 of B^T x
+    const int tl = 2 * ((wid >> 1) & 1) + lh;            // tile of the group
+    const int c = lr;
+    const unsigned xlane = (unsigned)(((long)(4 * tl) * p.x_pitch + c0 + c) * 4);
+    const int xwr = YB + (tl >> 1) * 64 + c * 2 + (tl & 1) + HALF * (18 * 128);
+    constexpr int R0 = HALF ? 1 : 0;                     // the five raw rows this half needs: R0 .. R0 + 4
+    float d[5][6];
+    auto load_rows = [&](int ph, int r_lo, int r_hi) {   // raw rows (index into d) r_lo .. r_hi - 1 of group ph
+      const GPos q = gpos(g_begin + (ph < nph ? ph : 0));
+      const bool live = ph < nph;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        if (r < r_lo || r >= r_hi) continue;
+        const int yy = 4 * q.ty - 1 + R0 + r;            // image row
+        const bool rok = live && yy >= 0 && yy < p.H;    // wave-uniform
+        // in the shifted descriptor pixel (4 ty - 1, 16 gx - 1) has the offset q.xbase of pixel (4 ty, 16 gx)
+        const unsigned soff = rok ? q.xbase + (unsigned)((long)(R0 + r) * p.W * p.x_pitch * 4) : nrec_x;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+          unsigned vo = xlane + (unsigned)((long)cc * p.x_pitch * 4);
+          if (cc == 0) vo = (q.gx == 0 && tl == 0) ? nrec_x : vo;                       // column -1
+          if (cc == 5) vo = (q.gx == p.grow - 1 && tl == 3) ? nrec_x : vo;              // column W
+          d[r][cc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, vo, soff, 0));
+        }
+      }
+    };
+    f32x2 T[3][3];
+    auto stage1 = [&](int cp) {
+      auto D = [&](int rr) { return f32x2{d[rr - R0][2 * cp], d[rr - R0][2 * cp + 1]}; };
+      if (HALF == 0) {
+        T[0][cp] = fma2(4.f, D(0), fma2(-5.f, D(2), D(4)));
+        const f32x2 a = fma2(-4.f, D(2), D(4)), b = fma2(-4.f, D(1), D(3));
+        T[1][cp] = a + b;
+        T[2][cp] = a - b;
+      } else {
+        const f32x2 cd = D(4) - D(2), f = D(3) - D(1);
+        T[0][cp] = fma2(2.f, f, cd);
+        T[1][cp] = fma2(-2.f, f, cd);
+        T[2][cp] = fma2(4.f, D(1), fma2(-5.f, D(3), D(5)));
+      }
+    };
+    auto stage2 = [&](float* obuf, int i, int part) {
+      float* v = obuf + xwr + i * (6 * 128);
+      const float t0 = T[i][0][0], t1 = T[i][0][1], t2 = T[i][1][0], t3 = T[i][1][1], t4 = T[i][2][0], t5 = T[i][2][1];
+      if (part == 0) {
+        const float a = __builtin_fmaf(-4.f, t2, t4), b = __builtin_fmaf(-4.f, t1, t3);
+        v[0 * 128] = __builtin_fmaf(4.f, t0, __builtin_fmaf(-5.f, t2, t4));
+        v[1 * 128] = a + b;
+        v[2 * 128] = a - b;
+      } else {
+        const float cd = t4 - t2, f = t3 - t1;
+        v[3 * 128] = __builtin_fmaf(2.f, f, cd);
+        v[4 * 128] = __builtin_fmaf(-2.f, f, cd);
+        v[5 * 128] = __builtin_fmaf(4.f, t1, __builtin_fmaf(-5.f, t3, t5));
+      }
+    };
+    load_rows(0, 0, 5);
+#pragma unroll
+    for (int cp = 0; cp < 3; ++cp) stage1(cp);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      stage2(smem, i, 0);
+      stage2(smem, i, 1);
+    }
+    load_rows(1, 0, 5);
+    __syncthreads();
+    auto phase = [&](int ph, auto cur_c) {
+      constexpr int cur = decltype(cur_c)::value;
+      const float* const ocur = smem + cur * OPB;
+      float* const onxt = smem + (cur ^ 1) * OPB;
+      f32x2 af = *reinterpret_cast<const f32x2*>(ocur + ard);
+      f32x2 bf = *reinterpret_cast<const f32x2*>(ocur + brd);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        mfma_step(ocur, e, af, bf);
+        if (e < 3) stage1(e);
+        else stage2(onxt, (e - 3) >> 1, (e - 3) & 1);
+        // the registers of group ph + 1 are free after stage 1: group ph + 2 is requested over steps 3 .. 7, a row each
+        if (e >= 3 && e < 8) load_rows(ph + 2, e - 3, e - 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    };
+    for (int ph = 0; ph < nph; ph += 2) {
+      phase(ph, std::integral_constant<int, 0>{});
+      if (ph + 1 < nph) phase(ph + 1, std::integral_constant<int, 1>{});
+    }
+  };
+
+  if (wid < 4) body_y();
+  else if (wid & 1) body_x(std::integral_constant<int, 1>{});
+  else body_x(std::integral_constant<int, 0>{});
+
+  // =================================== epilogue ===================================
+  // bias sums: [tile 4][n 64] through LDS, summed in tile order by the first wave of the input-channel block 0
+  // (the operand buffers are dead: the last phase ended with a barrier)
+  float* const Bs = smem + 2 * MH;                         // behind the two exchange buffers (147 KB + 1 KB)
+  if (p.bias && wid < 4) Bs[wid * 64 + lane] = bsum;
+  const long n_w = (long)p.Nw * 9 * p.Cw;
+  float* const slab = p.out + (long)split * p.slab;
+  // the 36 xi of an (n, c) sit in four waves: accumulators through LDS, two rounds of 16 output channels per half
+  float* const Mh = smem + nh * MH;
+  const int th = tid & 255;
+  const int ec = th & 31, eg = (th >> 5) & 3, erow = __builtin_amdgcn_readfirstlane(th >> 7);   // input channel, n group, tap rows
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    if (rd == 1) __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int g = 2 * rd + gg;
+        const f32x4 v = {acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(Mh + (((xg * 9 + e) * 4 + (2 * gg + lh)) * 32 + lr) * 4) = v;
+      }
+    __syncthreads();
+    if (rd == 0 && p.bias && tc == 0 && tid < 64)
+      slab[n_w + n0 + tid] = ((Bs[tid] + Bs[64 + tid]) + Bs[128 + tid]) + Bs[192 + tid];
+    // G^T = [1/4 -1/6 -1/6 1/24 1/24 0; 0 -1/6 1/6 1/12 -1/12 0; 0 -1/6 -1/6 1/6 1/6 1]: rows a of the 3x3 result.
+    // This thread: input channel ec, output channels 4 eg .. 4 eg + 3 of the round (n on the vector lanes), tap rows
+    // {0, 1} (erow 0) or {2} (erow 1).
+    constexpr float k6 = 1.f / 6.f, k12 = 1.f / 12.f, k24 = 1.f / 24.f;
+    auto m = [&](int i, int j) -> f32x4 { return *reinterpret_cast<const f32x4*>(Mh + (((i * 6 + j) * 4 + eg) * 32 + ec) * 4); };
+    auto row3 = [&](const f32x4 (&q)[6], f32x4 (&o)[3]) {      // the same combination along the other axis
+      const f32x4 s12 = add4(q[1], q[2]), d21 = sub4(q[2], q[1]), s34 = add4(q[3], q[4]), d34 = sub4(q[3], q[4]);
+      o[0] = fma4(k24, s34, fma4(-k6, s12, q[0] * 0.25f));
+      o[1] = fma4(k12, d34, d21 * k6);
+      o[2] = add4(fma4(k6, s34, s12 * (-k6)), q[5]);
+    };
+    const int nbase = n0 + nh * 32 + rd * 16 + eg * 4;          // first of this thread's four output channels
+    auto finish = [&](int a, const f32x4 (&X)[6]) {             // X[j]: row a of G^T m, per xi column j
+      f32x4 o[3];
+      row3(X, o);
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) slab[((long)(nbase + k) * 9 + a * 3 + b) * p.Cw + c0 + ec] = o[b][k];
+    };
+    if (erow == 0) {
+      f32x4 X0[6], X1[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const f32x4 m1 = m(1, j), m2 = m(2, j), m3 = m(3, j), m4 = m(4, j);
+        const f32x4 s12 = add4(m1, m2), s34 = add4(m3, m4);
+        X0[j] = fma4(k24, s34, fma4(-k6, s12, m(0, j) * 0.25f));
+        X1[j] = fma4(k12, sub4(m3, m4), sub4(m2, m1) * k6);
+      }
+      finish(0, X0);
+      finish(1, X1);
+    } else {
+      f32x4 X2[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const f32x4 s12 = add4(m(1, j), m(2, j)), s34 = add4(m(3, j), m(4, j));
+        X2[j] = add4(fma4(k6, s34, s12 * (-k6)), m(5, j));
+      }
+      finish(2, X2);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void wino4_wgrad_kernel(const WArgs p) { wino4_wgrad_body(p, (int)blockIdx.x); }
+
+__global__ __launch_bounds__(512, 2) void wino4_wgrad2_kernel(const WArgs pa, const WArgs pb, const int na) {
+  if ((int)blockIdx.x < na) wino4_wgrad_body(pa, (int)blockIdx.x);
+  else wino4_wgrad_body(pb, (int)blockIdx.x - na);
+}
+
+}  // namespace lgmwino4w
+
+// ---- host ------------------------------------------------------------------------------------------------------------
+bool lgm_wino4_wgrad_supported(const LgmConvGeom* g) {
+  if (!(g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1)) return false;
+  if (g->Nw % 64 != 0 || g->Cw % 32 != 0) return false;
+  if (g->W % 16 != 0 || g->H % 4 != 0) return false;
+  const long groups = (long)g->B * (g->H / 4) * (g->W / 16);
+  return groups >= 4;
+}
+
+// The layers that take this kernel: where the F(4x4) input gradient is preferred (lgm_conv3x3_wino4_preferred: the large
+// maps at batches that fill the chip), so that a layer's two gradients switch together; LGM_NO_WINO4_WGRAD=1: never.
+extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx);
+bool lgm_wino4_wgrad_use(const LgmConvGeom* g) {
+  static const bool off = getenv("LGM_NO_WINO4_WGRAD") != nullptr || getenv("LGM_NO_WINO4") != nullptr;
+  return !off && lgm_wino4_wgrad_supported(g) && lgm_conv3x3_wino4_preferred(g, 1) != 0;
+}
+
+// splits >= 2 always (the kernel only writes slabs); gps = tile groups per split; budget = workgroups of one round
+void lgm_wino4_wgrad_plan(const LgmConvGeom* g, long budget, int* splits, int* gps, int* total_groups) {
+  const long groups = (long)g->B * (g->H / 4) * (g->W / 16);
+  const long blocks = (long)(g->Nw / 64) * (g->Cw / 32);
+  long smax = groups / 2 < budget ? groups / 2 : budget;
+  if (smax < 2) smax = 2;
+  // rounds of `budget` workgroups x (phases per workgroup + ~6 phases of prologue / epilogue); ties go to fewer slabs
+  long s = 2, best = -1;
+  for (long c = 2; c <= smax; ++c) {
+    const long rounds = (blocks * c + budget - 1) / budget;
+    const long cost = rounds * ((groups + c - 1) / c + 6);
+    if (best < 0 || cost < best) {
+      best = cost;
+      s = c;
+    }
+  }
+  long per = (groups + s - 1) / s;
+  s = (groups + per - 1) / per;
+  *splits = (int)s;
+  *gps = (int)per;
+  *total_groups = (int)groups;
+}
+
+static void wino4_wgrad_prepare(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch, float* out,
+                                int bias, long slab, int splits, int gps, int total, lgmwino4w::WArgs& p) {
+  p = lgmwino4w::WArgs{};
+  p.y = y; p.x = x; p.out = out; p.bias = bias; p.slab = slab; p.y_pitch = y_pitch; p.x_pitch = x_pitch;
+  p.B = g->B; p.H = g->H; p.W = g->W; p.Nw = g->Nw; p.Cw = g->Cw;
+  p.tiles_c = g->Cw / 32;
+  p.splits = splits; p.gps = gps; p.total_groups = total;
+  p.grow = g->W / 16;
+  p.trows = g->H / 4;
+}
+
+static constexpr size_t kW4Smem = (size_t)(2 * lgmwino4w::MH + 256) * sizeof(float);
+
+int lgm_wino4_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, const float* x, long x_pitch, float* out,
+                           int bias, long slab, int splits, int gps, int total, hipStream_t s) {
+  using namespace lgmwino4w;
+  WArgs p;
+  wino4_wgrad_prepare(g, y, y_pitch, x, x_pitch, out, bias, slab, splits, gps, total, p);
+  const unsigned nblocks = (unsigned)((g->Nw / 64) * (g->Cw / 32) * splits);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kW4Smem);
+    attr = true;
+  }
+  lgm_note_kernel("lgmwino4w::wino4_wgrad_kernel");
+  hipLaunchKernelGGL(wino4_wgrad_kernel, dim3(nblocks), dim3(512), kW4Smem, s, p);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// two layers in one launch: block ranges of one grid (as lgm_conv3x3_wino_wgradn does for the F(2x2) kernel)
+int lgm_wino4_wgrad2_launch(const LgmConvGeom* const* gs, const float* const* ys, const long* yps, const float* const* xs,
+                            const long* xps, float* const* outs, const int* biases, const long* slabs, const int* splits,
+                            const int* gpss, const int* totals, hipStream_t s) {
+  using namespace lgmwino4w;
+  WArgs pp[2];
+  unsigned nb[2];
+  for (int k = 0; k < 2; ++k) {
+    wino4_wgrad_prepare(gs[k], ys[k], yps[k], xs[k], xps[k], outs[k], biases[k], slabs[k], splits[k], gpss[k], totals[k], pp[k]);
+    nb[k] = (unsigned)((gs[k]->Nw / 64) * (gs[k]->Cw / 32) * splits[k]);
+  }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kW4Smem);
+    attr = true;
+  }
+  lgm_note_kernel("lgmwino4w::wino4_wgrad2_kernel");
+  hipLaunchKernelGGL(wino4_wgrad2_kernel, dim3(nb[0] + nb[1]), dim3(512), kW4Smem, s, pp[0], pp[1], (int)nb[0]);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// ---- C-ABI (stand-alone form; the product reaches the kernel through lgm_conv_wgrad[_deferred] / lgm_conv3x3_wino_wgradn) ----
+extern "C" int64_t lgm_conv3x3_wino4_wgrad_supported(const LgmConvGeom* g) {
+  return (g && lgm_wino4_wgrad_supported(g)) ? 1 : 0;
+}
+
+extern "C" int64_t lgm_conv3x3_wino4_wgrad_workspace(const LgmConvGeom* g) {
+  if (!g || !lgm_wino4_wgrad_supported(g)) return 0;
+  int splits, gps, total;
+  lgm_wino4_wgrad_plan(g, 256, &splits, &gps, &total);
+  return (int64_t)splits * ((int64_t)g->Nw * 9 * g->Cw + g->Nw) * (int64_t)sizeof(float);
+}
+
+// slabs only: `workspace` receives `desc[6]` slabs [Nw][9][Cw] (+ Nw bias sums each); desc as lgm_conv_wgrad_deferred
+extern "C" int lgm_conv3x3_wino4_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x, int64_t x_pitch,
+                                       float* gw, float* gbias, float beta, void* workspace, int64_t workspace_bytes,
+                                       int64_t* desc, void* stream) {
+  LGM_REQUIRE(g && y && x && gw && workspace && desc, "conv3x3_wino4_wgrad: null pointer");
+  LGM_REQUIRE(lgm_wino4_wgrad_supported(g), "conv3x3_wino4_wgrad: unsupported geometry");
+  LGM_REQUIRE(y_pitch % 4 == 0 && x_pitch % 4 == 0 && y_pitch >= g->Nw && x_pitch >= g->Cw && lgm_aligned16(y) && lgm_aligned16(x) &&
+              lgm_aligned16(gw) && lgm_aligned16(workspace) && (!gbias || lgm_aligned16(gbias)) &&
+              ((long)g->B * g->H * g->W + g->W + 1) * x_pitch < (1L << 29) && (long)g->B * g->H * g->W * y_pitch < (1L << 29),
+              "conv3x3_wino4_wgrad: 16-byte aligned operands with pitch %% 4 == 0 inside 32-bit offsets expected");
+  int splits, gps, total;
+  lgm_wino4_wgrad_plan(g, 256, &splits, &gps, &total);
+  const long n_w = (long)g->Nw * 9 * g->Cw, slab = n_w + g->Nw;
+  LGM_REQUIRE(workspace_bytes >= (int64_t)splits * slab * (int64_t)sizeof(float), "conv3x3_wino4_wgrad: workspace too small");
+  if (int rc = lgm_wino4_wgrad_launch(g, y, y_pitch, x, x_pitch, (float*)workspace, gbias ? 1 : 0, slab, splits, gps, total,
+                                      (hipStream_t)stream))
+    return rc;
+  union { float f; int64_t i; } bb;
+  bb.i = 0;
+  bb.f = beta;
+  desc[0] = (int64_t)(uintptr_t)workspace; desc[1] = slab; desc[2] = (int64_t)(uintptr_t)gw; desc[3] = n_w;
+  desc[4] = (int64_t)(uintptr_t)gbias; desc[5] = gbias ? g->Nw : 0; desc[6] = splits; desc[7] = bb.i;
+  return LGM_OK;
+}

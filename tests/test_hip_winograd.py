@@ -461,3 +461,79 @@ def test_two_layers_weight_gradients_in_one_launch(dev, pair, parity):
         ops.wgrad_reduce_batch(rows, dev)
         for k in range(4):
             parity(f"four layers in one launch, layer {k}", maxerr(gws4[k], refs[k % 2][0]), 2e-6)
+
+
+# ---- Winograd F(4x4, 3x3) weight gradient (csrc/winograd4_wgrad.hip) -----------------------------------------------------
+CASES4W = [(3, 32, 32, 64, 64), (2, 32, 32, 128, 64), (5, 16, 16, 192, 128), (1, 64, 64, 64, 64), (2, 16, 32, 64, 128),
+           (128, 16, 16, 64, 64)]
+
+
+@pytest.mark.parametrize("case", CASES4W)
+def test_winograd4_weight_gradient(dev, case, parity):
+    """lgm_conv3x3_wino4_wgrad (reference op: autograd's weight / bias gradient of Block.proj, ddpm.py:157-173) against
+    float64 autograd: dU = sum over tiles (A dY A^T) (.) (B^T x B), dw = G^T dU G, fused bias sums; operands in channel
+    slices of wider buffers, slabs through the batched fixed-order reducer with beta = 0 and beta = 1, bit-reproducible."""
+    from lgm_hip import ops
+    B, H, W, ci, co = case
+    gen = torch.Generator().manual_seed(sum(case) + 7)
+    xbuf = torch.randn(B, H, W, ci + 32, generator=gen)
+    ybuf = torch.randn(B, H, W, co + 64, generator=gen)
+    x, y = xbuf[..., 32:], ybuf[..., :co]
+    w0 = torch.zeros(co, ci, 3, 3, dtype=torch.double, requires_grad=True)
+    out = F.conv2d(x.permute(0, 3, 1, 2).double(), w0, None, padding=1)
+    gw_ref, = torch.autograd.grad(out, w0, y.permute(0, 3, 1, 2).double())
+    gw_ref = gw_ref.permute(0, 2, 3, 1).reshape(co, 9, ci)
+    gb_ref = y.double().sum((0, 1, 2))
+    xd, yd = xbuf.to(dev)[..., 32:], ybuf.to(dev)[..., :co]
+    g = ops.make_geom(B, H, W, ci, co, 3, 3, 1, 1)
+    L = ops.lib()
+    assert L.lgm_conv3x3_wino4_wgrad_supported(ctypes.byref(g)) == 1
+    n = L.lgm_conv3x3_wino4_wgrad_workspace(ctypes.byref(g))
+    ws = torch.empty(n // 4 + 16, device=dev)
+
+    def run(gw, gb, beta):
+        desc = (ctypes.c_int64 * 8)()
+        L.lgm_conv3x3_wino4_wgrad(ctypes.byref(g), yd.data_ptr(), ops.pitch(yd), xd.data_ptr(), ops.pitch(xd), gw.data_ptr(),
+                                  None if gb is None else gb.data_ptr(), beta, ws.data_ptr(), ws.numel() * 4,
+                                  ctypes.addressof(desc), ops.stream())
+        assert "wino4_wgrad_kernel" in L._dll.lgm_last_kernel().decode() and desc[6] >= 2
+        ops.wgrad_reduce_batch([tuple(desc)], dev)
+    gw = torch.full((co, 9, ci), float("nan"), device=dev)
+    gb = torch.full((co,), float("nan"), device=dev)
+    run(gw, gb, 0.0)
+    parity("F(4x4) weight gradient", maxerr(gw, gw_ref), 1e-5)
+    parity("F(4x4) fused bias gradient", maxerr(gb, gb_ref), 2e-6)
+    gw2 = torch.ones((co, 9, ci), device=dev)
+    run(gw2, None, 1.0)
+    parity("F(4x4) weight gradient accumulated (beta = 1)", maxerr(gw2 - 1.0, gw_ref), 1e-5)
+    gw3 = torch.empty_like(gw)
+    run(gw3, gb, 0.0)
+    assert torch.equal(gw, gw3)
+
+
+def test_winograd4_weight_gradients_of_two_layers_in_one_launch(dev, parity):
+    """The grouped launch takes the F(4x4) kernel when both layers do (large maps at a chip-filling batch): against float64."""
+    from lgm_hip import ops
+    layers, refs = [], []
+    for i, (B, hw, ci, co) in enumerate([(128, 32, 64, 64), (128, 32, 128, 64)]):
+        gen = torch.Generator().manual_seed(31 + i)
+        x = torch.randn(B, hw, hw, ci, generator=gen)
+        y = torch.randn(B, hw, hw, co, generator=gen)
+        w0 = torch.zeros(co, ci, 3, 3, dtype=torch.double, requires_grad=True)
+        # the gradient is a sum over images: reference = sum of per-slice gradients (16 slices of 8 images, float64)
+        acc = torch.zeros(co, 9, ci, dtype=torch.double)
+        for k in range(0, B, 8):
+            out = F.conv2d(x[k:k + 8].permute(0, 3, 1, 2).double(), w0, None, padding=1)
+            gk, = torch.autograd.grad(out, w0, y[k:k + 8].permute(0, 3, 1, 2).double())
+            acc += gk.permute(0, 2, 3, 1).reshape(co, 9, ci)
+        refs.append(acc)
+        layers.append((ops.make_geom(B, hw, hw, ci, co, 3, 3, 1, 1), y.to(dev), x.to(dev)))
+    gws = [torch.full((l[1].shape[-1], 9, l[2].shape[-1]), float("nan"), device=dev) for l in layers]
+    rows = []
+    ops.conv_wgrad_group([(l[0], l[1], l[2], gw.data_ptr(), 0.0, None) for l, gw in zip(layers, gws)], rows)
+    k = ops.lib()._dll.lgm_last_kernel().decode()
+    assert "wino4_wgrad2_kernel" in k, k
+    ops.wgrad_reduce_batch(rows, dev)
+    for i in range(2):
+        # 131,072 pixels per sum in fp32: the error grows with the batch (5.7e-6 measured at B = 128, 2e-6 at B <= 5)
+        parity(f"grouped F(4x4) weight gradient, layer {i}", maxerr(gws[i], refs[i]), 2e-5)
