@@ -104,22 +104,29 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
   const __amdgpu_buffer_rsrc_t rsrc_y = rsrc(p.y, nrec_y);
   const __amdgpu_buffer_rsrc_t rsrc_x = rsrc(p.x - (long)(p.W + 1) * p.x_pitch, nrec_x);
 
-  // group g -> (image, tile row, group of the row): byte offset of output pixel (4 ty, 16 gx) of image b
+  // group g -> (image, tile row, group of the row).  Decoded ONCE (three integer divisions cost ~60 instructions, and a phase
+  // has only 18 MFMAs per wave to hide them under); every later group is the previous one advanced like an odometer.
   struct GPos {
-    unsigned ybase, xbase;   // bytes, without the lane parts
-    int ty, gx;
+    int gx, ty, b;
   };
-  auto gpos = [&](int g) {
+  auto gdecode = [&](int g) {
     GPos q;
     q.gx = g % p.grow;
     const int r = g / p.grow;
     q.ty = r % p.trows;
-    const int b = r / p.trows;
-    const long pix = ((long)b * p.H + 4 * q.ty) * p.W + 16 * q.gx;
-    q.ybase = (unsigned)(pix * p.y_pitch * 4);
-    q.xbase = (unsigned)(pix * p.x_pitch * 4);
+    q.b = r / p.trows;
     return q;
   };
+  auto gnext = [&](GPos& q) {
+    if (++q.gx == p.grow) {
+      q.gx = 0;
+      if (++q.ty == p.trows) {
+        q.ty = 0;
+        ++q.b;
+      }
+    }
+  };
+  auto gpix = [&](const GPos& q) -> long { return ((long)q.b * p.H + 4 * q.ty) * p.W + 16 * q.gx; };   // output pixel (4 ty, 16 gx)
 
   f32x16 acc[9];
 #pragma unroll
@@ -147,29 +154,37 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
     const unsigned ylane = (unsigned)(((long)(4 * tl) * p.y_pitch + n0 + lane) * 4);
     const int ywr = (tl >> 1) * 128 + lane * 2 + (tl & 1);
     float d[4][4];
+    GPos gq = gdecode(g_begin);                          // the group the next load() fetches
     auto load = [&](int ph) {
-      const GPos q = gpos(g_begin + (ph < nph ? ph : 0));
       const unsigned ok = ph < nph ? 0u : nrec_y;        // past the range: zeros
+      const unsigned ybase = (unsigned)(gpix(gq) * p.y_pitch * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           d[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-              rsrc_y, ylane + ok, q.ybase + (unsigned)(((long)r * p.W + c) * p.y_pitch * 4), 0));
+              rsrc_y, ylane + ok, ybase + (unsigned)(((long)r * p.W + c) * p.y_pitch * 4), 0));
+      if (ph + 1 < nph) gnext(gq);                       // (stays on the last group past the range: in-range addresses)
     };
     // A = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1]
     float T[6][4];
-    auto vertical = [&](int c) {
-      const float d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c];
-      const float s02 = d0 + d2, s13 = d1 + d3;
-      const float e = __builtin_fmaf(4.f, d2, d0), f = __builtin_fmaf(4.f, d3, d1);
-      T[0][c] = d0;
-      T[1][c] = s02 + s13;
-      T[2][c] = s02 - s13;
-      T[3][c] = __builtin_fmaf(2.f, f, e);
-      T[4][c] = __builtin_fmaf(-2.f, f, e);
-      T[5][c] = d3;
-      bsum += s02 + s13;                                  // (written only when the layer has a bias)
+    auto vertical2 = [&](int cp) {                        // columns 2 cp, 2 cp + 1 at once (packed fp32)
+      const f32x2 d0 = {d[0][2 * cp], d[0][2 * cp + 1]}, d1 = {d[1][2 * cp], d[1][2 * cp + 1]};
+      const f32x2 d2 = {d[2][2 * cp], d[2][2 * cp + 1]}, d3 = {d[3][2 * cp], d[3][2 * cp + 1]};
+      const f32x2 s02 = d0 + d2, s13 = d1 + d3;
+      const f32x2 e = fma2(4.f, d2, d0), f = fma2(4.f, d3, d1);
+      const f32x2 t1 = s02 + s13, t2 = s02 - s13, t3 = fma2(2.f, f, e), t4 = fma2(-2.f, f, e);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int c = 2 * cp + k;
+        T[0][c] = d0[k];
+        T[1][c] = t1[k];
+        T[2][c] = t2[k];
+        T[3][c] = t3[k];
+        T[4][c] = t4[k];
+        T[5][c] = d3[k];
+      }
+      bsum += t1[0] + t1[1];                              // (written only when the layer has a bias)
     };
     auto horizontal = [&](float* ybuf, int i) {
       float* v = ybuf + ywr + i * (6 * 256);
@@ -184,8 +199,8 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
       v[5 * 256] = t3;
     };
     load(0);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) vertical(c);
+    vertical2(0);
+    vertical2(1);
 #pragma unroll
     for (int i = 0; i < 6; ++i) horizontal(smem, i);
     load(1);
@@ -200,8 +215,7 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
       for (int e = 0; e < 9; ++e) {
         mfma_step(ocur, e, af, bf);
         if (e < 2) {
-          vertical(2 * e);
-          vertical(2 * e + 1);
+          vertical2(e);
         } else if (e < 8) {
           horizontal(onxt, e - 2);
         } else {
@@ -226,16 +240,18 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
     const int xwr = YB + (tl >> 1) * 64 + c * 2 + (tl & 1) + HALF * (18 * 128);
     constexpr int R0 = HALF ? 1 : 0;                     // the five raw rows this half needs: R0 .. R0 + 4
     float d[5][6];
+    GPos gq = gdecode(g_begin);                          // the group the next load_rows() calls fetch
     auto load_rows = [&](int ph, int r_lo, int r_hi) {   // raw rows (index into d) r_lo .. r_hi - 1 of group ph
-      const GPos q = gpos(g_begin + (ph < nph ? ph : 0));
+      const GPos q = gq;
+      const unsigned xbase = (unsigned)(gpix(q) * p.x_pitch * 4);
       const bool live = ph < nph;
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
         if (r < r_lo || r >= r_hi) continue;
         const int yy = 4 * q.ty - 1 + R0 + r;            // image row
         const bool rok = live && yy >= 0 && yy < p.H;    // wave-uniform
-        // in the shifted descriptor pixel (4 ty - 1, 16 gx - 1) has the offset q.xbase of pixel (4 ty, 16 gx)
-        const unsigned soff = rok ? q.xbase + (unsigned)((long)(R0 + r) * p.W * p.x_pitch * 4) : nrec_x;
+        // in the shifted descriptor pixel (4 ty - 1, 16 gx - 1) has the offset of pixel (4 ty, 16 gx)
+        const unsigned soff = rok ? xbase + (unsigned)((long)(R0 + r) * p.W * p.x_pitch * 4) : nrec_x;
 #pragma unroll
         for (int cc = 0; cc < 6; ++cc) {
           unsigned vo = xlane + (unsigned)((long)cc * p.x_pitch * 4);
@@ -244,6 +260,7 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
           d[r][cc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, vo, soff, 0));
         }
       }
+      if (r_hi == 5 && ph + 1 < nph) gnext(gq);          // the group's last row: on to the next group
     };
     f32x2 T[3][3];
     auto stage1 = [&](int cp) {
