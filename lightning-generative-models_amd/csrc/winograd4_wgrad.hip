@@ -26,6 +26,12 @@
 
 #include "lgm_common.h"
 
+// W4W_EXP (attribution builds only, -DW4W_EXP=n into a separate library, LGM_LIB=<path>): bit 0 drops the Yt transform,
+// bit 1 the Xt transform, bit 2 the raw loads, bit 3 the operand reads of the MFMA steps -- wrong results, timing valid.
+#ifndef W4W_EXP
+#define W4W_EXP 0
+#endif
+
 namespace lgmwino4w {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -136,7 +142,7 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
 
   auto mfma_step = [&](const float* buf, int e, f32x2& af, f32x2& bf) {     // xi e with the fragments read a step ago
     f32x2 an = af, bn = bf;
-    if (e < 8) {
+    if (e < 8 && !(W4W_EXP & 8)) {
       an = *reinterpret_cast<const f32x2*>(buf + ard + (e + 1) * 256);
       bn = *reinterpret_cast<const f32x2*>(buf + brd + (e + 1) * 128);
     }
@@ -153,9 +159,11 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
     const int tl = wid;                                  // tile of the group
     const unsigned ylane = (unsigned)(((long)(4 * tl) * p.y_pitch + n0 + lane) * 4);
     const int ywr = (tl >> 1) * 128 + lane * 2 + (tl & 1);
-    float d[4][4];
+    // two register sets: group ph + 2 is requested at the START of phase ph into the set phase ph - 1 emptied - a whole
+    // phase ahead of its use (requested at step 2 of the same set, six steps ahead, the next phase still opened with a wait)
+    float dA[4][4], dB[4][4];
     GPos gq = gdecode(g_begin);                          // the group the next load() fetches
-    auto load = [&](int ph) {
+    auto load = [&](float (&d)[4][4], int ph) {
       const unsigned ok = ph < nph ? 0u : nrec_y;        // past the range: zeros
       const unsigned ybase = (unsigned)(gpix(gq) * p.y_pitch * 4);
 #pragma unroll
@@ -168,7 +176,7 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
     };
     // A = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1]
     float T[6][4];
-    auto vertical2 = [&](int cp) {                        // columns 2 cp, 2 cp + 1 at once (packed fp32)
+    auto vertical2 = [&](const float (&d)[4][4], int cp) {   // columns 2 cp, 2 cp + 1 at once (packed fp32)
       const f32x2 d0 = {d[0][2 * cp], d[0][2 * cp + 1]}, d1 = {d[1][2 * cp], d[1][2 * cp + 1]};
       const f32x2 d2 = {d[2][2 * cp], d[2][2 * cp + 1]}, d3 = {d[3][2 * cp], d[3][2 * cp + 1]};
       const f32x2 s02 = d0 + d2, s13 = d1 + d3;
@@ -198,15 +206,15 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
       v[4 * 256] = __builtin_fmaf(-2.f, f, e);
       v[5 * 256] = t3;
     };
-    load(0);
-    vertical2(0);
-    vertical2(1);
+    load(dA, 0);                                         // group 0 -> set A, transformed here
+    load(dB, 1);                                         // group 1 -> set B, transformed during phase 0
+    vertical2(dA, 0);
+    vertical2(dA, 1);
 #pragma unroll
     for (int i = 0; i < 6; ++i) horizontal(smem, i);
-    load(1);
     __syncthreads();
     auto phase = [&](int ph, auto cur_c) {
-      constexpr int cur = decltype(cur_c)::value;
+      constexpr int cur = decltype(cur_c)::value;        // phase parity: group ph + 1 sits in set B (cur 0) / A (cur 1)
       const float* const ocur = smem + cur * OPB;
       float* const onxt = smem + (cur ^ 1) * OPB;
       f32x2 af = *reinterpret_cast<const f32x2*>(ocur + ard);
@@ -214,12 +222,17 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
         mfma_step(ocur, e, af, bf);
+        if (e == 0 && !(W4W_EXP & 4)) {                  // group ph + 2 into the set whose group was transformed last phase
+          if (cur == 0) load(dA, ph + 2);
+          else load(dB, ph + 2);
+        }
         if (e < 2) {
-          vertical2(e);
+          if (!(W4W_EXP & 1)) {
+            if (cur == 0) vertical2(dB, e);
+            else vertical2(dA, e);
+          }
         } else if (e < 8) {
-          horizontal(onxt, e - 2);
-        } else {
-          load(ph + 2);
+          if (!(W4W_EXP & 1)) horizontal(onxt, e - 2);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -311,10 +324,14 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
         mfma_step(ocur, e, af, bf);
-        if (e < 3) stage1(e);
-        else stage2(onxt, (e - 3) >> 1, (e - 3) & 1);
-        // the registers of group ph + 1 are free after stage 1: group ph + 2 is requested over steps 3 .. 7, a row each
-        if (e >= 3 && e < 8) load_rows(ph + 2, e - 3, e - 2);
+        if (!(W4W_EXP & 2)) {
+          if (e < 3) stage1(e);
+          else stage2(onxt, (e - 3) >> 1, (e - 3) & 1);
+        }
+        // the registers of group ph + 1 are free after stage 1: group ph + 2 is requested right behind it (steps 3 and 4),
+        // five steps ahead of its use
+        if (e == 3 && !(W4W_EXP & 4)) load_rows(ph + 2, 0, 3);
+        if (e == 4 && !(W4W_EXP & 4)) load_rows(ph + 2, 3, 5);
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
