@@ -695,10 +695,12 @@ extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
   const long base = lgmwino4::unit_count(cls, g->B, g->H, g->W) * (oc / 64);
   // 8 x 8 maps: few units (8 images each), so the reduction is split; worth it when a split still has >= 8 phases
   static const bool no8 = getenv("LGM_WINO4_NO8") != nullptr;           // A/B switch
-  // (forward only: the input gradient of these layers shares ONE launch with the weight gradient - wino_bwd_pair_kernel -
-  // and taking it out of the pair costs what the faster kernel gains: 10.97 vs 10.95 ms per step, measured)
-  static const bool yx8 = getenv("LGM_WINO4_YX8") != nullptr;
-  if (cls == 2) return (!no8 && (yx == 0 || yx8) && base >= 32 && gc >= 256) ? 1 : 0;
+  // Forward and backward: the heavy 8 x 8 layers leave the F(2x2) pair (input gradient + weight gradient in one launch) for
+  // the F(4x4) input gradient + the F(4x4) weight gradient on 2 x 2-tile groups (winograd4_wgrad.hip), two layers per
+  // launch: 10.28 -> 10.16 ms per step.  (With the F(2x2) weight gradient left standing alone the same move cost what it
+  // gained: 10.97 vs 10.95, later 10.66 vs 10.66.)  LGM_WINO4_NOYX8=1: forward only.
+  static const bool noyx8 = getenv("LGM_WINO4_NOYX8") != nullptr;
+  if (cls == 2) return (!no8 && (yx == 0 || !noyx8) && base >= 32 && gc >= 256) ? 1 : 0;
   static const int c1_minc = getenv("LGM_WINO4_C1_MINC") ? atoi(getenv("LGM_WINO4_C1_MINC")) : 0;
   if (cls == 1 && gc < c1_minc) return 0;
   return base >= (cls == 1 ? min_units1 : min_units0) ? 1 : 0;

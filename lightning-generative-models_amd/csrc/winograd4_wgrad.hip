@@ -51,8 +51,9 @@ struct WArgs {
   int B, H, W, Nw, Cw;
   int tiles_c;         // Cw / 32
   int splits, gps, total_groups;
-  int grow;            // groups per tile row (W / 16)
-  int trows;           // tile rows per image (H / 4)
+  int grow;            // groups per group row (W / 16, or W / 8 for square groups)
+  int trows;           // group rows per image (H / 4, or H / 8)
+  int sq;              // group shape: 0 = four tiles in a row (4 x 16 output pixels), 1 = 2 x 2 tiles (8 x 8: the 8 x 8 maps)
 };
 
 __device__ __forceinline__ f32x4 add4(const f32x4 a, const f32x4 b) { return a + b; }
@@ -132,7 +133,10 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
       }
     }
   };
-  auto gpix = [&](const GPos& q) -> long { return ((long)q.b * p.H + 4 * q.ty) * p.W + 16 * q.gx; };   // output pixel (4 ty, 16 gx)
+  const int gh = p.sq ? 8 : 4, gw = p.sq ? 8 : 16;                          // output pixels of a group
+  auto gpix = [&](const GPos& q) -> long { return ((long)q.b * p.H + gh * q.ty) * p.W + gw * q.gx; };   // the group's first pixel
+  auto tile_row = [&](int tl) { return p.sq ? (tl >> 1) : 0; };             // tile position inside the group, in tiles
+  auto tile_col = [&](int tl) { return p.sq ? (tl & 1) : tl; };
 
   f32x16 acc[9];
 #pragma unroll
@@ -157,7 +161,7 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
   // =================================== waves 0-3: Yt = A dY A^T ===================================
   auto body_y = [&]() {
     const int tl = wid;                                  // tile of the group
-    const unsigned ylane = (unsigned)(((long)(4 * tl) * p.y_pitch + n0 + lane) * 4);
+    const unsigned ylane = (unsigned)((((long)(4 * tile_row(tl)) * p.W + 4 * tile_col(tl)) * p.y_pitch + n0 + lane) * 4);
     const int ywr = (tl >> 1) * 128 + lane * 2 + (tl & 1);
     // two register sets: group ph + 2 is requested at the START of phase ph into the set phase ph - 1 emptied - a whole
     // phase ahead of its use (requested at step 2 of the same set, six steps ahead, the next phase still opened with a wait)
@@ -249,7 +253,9 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
     constexpr int HALF = decltype(half_c)::value;        // rows 0-2 / 3-5 of B^T x
     const int tl = 2 * ((wid >> 1) & 1) + lh;            // tile of the group
     const int c = lr;
-    const unsigned xlane = (unsigned)(((long)(4 * tl) * p.x_pitch + c0 + c) * 4);
+    const int trow = tile_row(tl), tcol = tile_col(tl);  // (trow is wave-uniform: tl >> 1 comes from the wave id)
+    const int tlast = p.sq ? 1 : 3;
+    const unsigned xlane = (unsigned)((((long)(4 * trow) * p.W + 4 * tcol) * p.x_pitch + c0 + c) * 4);
     const int xwr = YB + (tl >> 1) * 64 + c * 2 + (tl & 1) + HALF * (18 * 128);
     constexpr int R0 = HALF ? 1 : 0;                     // the five raw rows this half needs: R0 .. R0 + 4
     float d[5][6];
@@ -261,15 +267,15 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
         if (r < r_lo || r >= r_hi) continue;
-        const int yy = 4 * q.ty - 1 + R0 + r;            // image row
+        const int yy = gh * q.ty + 4 * trow - 1 + R0 + r;   // image row
         const bool rok = live && yy >= 0 && yy < p.H;    // wave-uniform
         // in the shifted descriptor pixel (4 ty - 1, 16 gx - 1) has the offset of pixel (4 ty, 16 gx)
         const unsigned soff = rok ? xbase + (unsigned)((long)(R0 + r) * p.W * p.x_pitch * 4) : nrec_x;
 #pragma unroll
         for (int cc = 0; cc < 6; ++cc) {
           unsigned vo = xlane + (unsigned)((long)cc * p.x_pitch * 4);
-          if (cc == 0) vo = (q.gx == 0 && tl == 0) ? nrec_x : vo;                       // column -1
-          if (cc == 5) vo = (q.gx == p.grow - 1 && tl == 3) ? nrec_x : vo;              // column W
+          if (cc == 0) vo = (q.gx == 0 && tcol == 0) ? nrec_x : vo;                     // column -1
+          if (cc == 5) vo = (q.gx == p.grow - 1 && tcol == tlast) ? nrec_x : vo;        // column W
           d[r][cc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, vo, soff, 0));
         }
       }
@@ -427,8 +433,9 @@ __global__ __launch_bounds__(512, 2) void wino4_wgrad2_kernel(const WArgs pa, co
 bool lgm_wino4_wgrad_supported(const LgmConvGeom* g) {
   if (!(g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1)) return false;
   if (g->Nw % 64 != 0 || g->Cw % 32 != 0) return false;
-  if (g->W % 16 != 0 || g->H % 4 != 0) return false;
-  const long groups = (long)g->B * (g->H / 4) * (g->W / 16);
+  const bool row_groups = g->W % 16 == 0 && g->H % 4 == 0, square_groups = g->W % 8 == 0 && g->H % 8 == 0;
+  if (!row_groups && !square_groups) return false;
+  const long groups = (long)g->B * g->H * g->W / 64;
   return groups >= 4;
 }
 
@@ -442,7 +449,7 @@ bool lgm_wino4_wgrad_use(const LgmConvGeom* g) {
 
 // splits >= 2 always (the kernel only writes slabs); gps = tile groups per split; budget = workgroups of one round
 void lgm_wino4_wgrad_plan(const LgmConvGeom* g, long budget, int* splits, int* gps, int* total_groups) {
-  const long groups = (long)g->B * (g->H / 4) * (g->W / 16);
+  const long groups = (long)g->B * g->H * g->W / 64;
   const long blocks = (long)(g->Nw / 64) * (g->Cw / 32);
   long smax = groups / 2 < budget ? groups / 2 : budget;
   if (smax < 2) smax = 2;
@@ -470,8 +477,9 @@ static void wino4_wgrad_prepare(const LgmConvGeom* g, const float* y, long y_pit
   p.B = g->B; p.H = g->H; p.W = g->W; p.Nw = g->Nw; p.Cw = g->Cw;
   p.tiles_c = g->Cw / 32;
   p.splits = splits; p.gps = gps; p.total_groups = total;
-  p.grow = g->W / 16;
-  p.trows = g->H / 4;
+  p.sq = (g->W % 16 != 0) ? 1 : 0;
+  p.grow = p.sq ? g->W / 8 : g->W / 16;
+  p.trows = p.sq ? g->H / 8 : g->H / 4;
 }
 
 static constexpr size_t kW4Smem = (size_t)(2 * lgmwino4w::MH + 256) * sizeof(float);

@@ -465,7 +465,7 @@ def test_two_layers_weight_gradients_in_one_launch(dev, pair, parity):
 
 # ---- Winograd F(4x4, 3x3) weight gradient (csrc/winograd4_wgrad.hip) -----------------------------------------------------
 CASES4W = [(3, 32, 32, 64, 64), (2, 32, 32, 128, 64), (5, 16, 16, 192, 128), (1, 64, 64, 64, 64), (2, 16, 32, 64, 128),
-           (128, 16, 16, 64, 64)]
+           (128, 16, 16, 64, 64), (8, 8, 8, 128, 128), (24, 8, 8, 384, 256), (4, 8, 24, 64, 64)]
 
 
 @pytest.mark.parametrize("case", CASES4W)
