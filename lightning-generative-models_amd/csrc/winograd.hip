@@ -1514,7 +1514,11 @@ int lgm_wino4_wgrad2_launch(const LgmConvGeom* const* gs, const float* const* ys
                             const long* xps, float* const* outs, const int* biases, const long* slabs, const int* splits,
                             const int* gpss, const int* totals, hipStream_t s);
 static bool wgradn_use4(int n, const LgmConvGeom* const* gs) {
-  return n == 2 && lgm_wino4_wgrad_use(gs[0]) && lgm_wino4_wgrad_use(gs[1]);
+  if (!(n == 2 && lgm_wino4_wgrad_use(gs[0]) && lgm_wino4_wgrad_use(gs[1]))) return false;
+  // each layer needs at least two slabs' worth of its 64 x 32-channel blocks out of the 256 workgroups (the 512-channel
+  // layers of the 64 x 64 configuration do not fit side by side: they take the F(2x2) grouped launch or go alone)
+  const long m0 = 2L * (gs[0]->Nw / 64) * (gs[0]->Cw / 32), m1 = 2L * (gs[1]->Nw / 64) * (gs[1]->Cw / 32);
+  return m0 + m1 <= 256;
 }
 static void wgrad4_budgets(const LgmConvGeom* const* gs, long* budget) {     // two layers, blocks of 64 x 32 channels
   const double w0 = (double)gs[0]->B * gs[0]->H * gs[0]->W * gs[0]->Nw * gs[0]->Cw;

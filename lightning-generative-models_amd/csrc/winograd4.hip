@@ -700,7 +700,8 @@ extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
   // launch: 10.28 -> 10.16 ms per step.  (With the F(2x2) weight gradient left standing alone the same move cost what it
   // gained: 10.97 vs 10.95, later 10.66 vs 10.66.)  LGM_WINO4_NOYX8=1: forward only.
   static const bool noyx8 = getenv("LGM_WINO4_NOYX8") != nullptr;
-  if (cls == 2) return (!no8 && (yx == 0 || !noyx8) && base >= 32 && gc >= 256) ? 1 : 0;
+  static const int c2_minc = getenv("LGM_WINO4_C2_MINC") ? atoi(getenv("LGM_WINO4_C2_MINC")) : 256;
+  if (cls == 2) return (!no8 && (yx == 0 || !noyx8) && base >= 32 && gc >= c2_minc) ? 1 : 0;
   static const int c1_minc = getenv("LGM_WINO4_C1_MINC") ? atoi(getenv("LGM_WINO4_C1_MINC")) : 0;
   if (cls == 1 && gc < c1_minc) return 0;
   return base >= (cls == 1 ? min_units1 : min_units0) ? 1 : 0;
