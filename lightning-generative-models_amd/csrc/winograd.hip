@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(wt + r * 36 + c4) = *reinterpret_cast<const f32x4*>(w + (long)r * Cp + c4);
   }
   __syncthreads();
-  if (dst_f) {      // thread = (n, c quad): 16 stores of 16 bytes, 512 contiguous bytes per (xi, k-half) and wave half
+  if (dst_f && row[3] >= 0) {      // thread = (n, c quad): 16 stores of 16 bytes, 512 contiguous bytes per (xi, k-half) and wave half
     const int n = tid & 31, cq = tid >> 5;        // cq 0..7 -> chunk cq >> 1, k-half cq & 1
     f32x4 g[9], u[16];
 #pragma unroll
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 #pragma unroll
     for (int x = 0; x < 16; ++x) *reinterpret_cast<f32x4*>(d + x * 256) = u[x];
   }
-  if (dst_b) {      // thread = (c, n quad)
+  if (dst_b && row[4] >= 0) {      // thread = (c, n quad)
     const int c = tid & 31, nq = tid >> 5;
     f32x4 g[9], u[16];
 #pragma unroll

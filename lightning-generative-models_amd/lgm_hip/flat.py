@@ -144,21 +144,25 @@ class FlatParams:
         from . import ops
         if self.wino:
             return
-        rows, off, blk = [], 0, 0
+        off = 0
         self._wino_off = {}
+        self._wino_dims = {}
         for s in self.slots:
             if s.kind != "weight":
                 continue
             Np, T, Cp = s.phys_shape
             if T == 9 and Np % 32 == 0 and Cp % 32 == 0:
-                rows.append([s.offset, Np, Cp, off, off, blk])
                 self._wino_off[s.offset] = off
+                self._wino_dims[s.offset] = (Np, Cp)
                 off += Np * Cp * 16
-                blk += (Np // 32) * (Cp // 32)
-        if not rows:
+        if not self._wino_off:
             return
-        self._wino_table = torch.tensor(rows, dtype=torch.int64, device=self.device).contiguous()
-        self._wino_blocks = blk
+        # the copies of ALL slots are allocated once (addresses baked into captured graphs never move); which of them
+        # the refresh launch rewrites is decided by use (wino_u): a layer that runs on the F(4x4) kernel in both
+        # directions never asks, and its 2 x 16/9 of the weights are not rewritten every step
+        self._wino_used = {}
+        self._wino_table = None
+        self._wino_table_old = None
         self.data_uf = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.data_ub = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.wino = True
@@ -169,10 +173,47 @@ class FlatParams:
         from . import ops
         if not self.wino:
             return
+        self._refresh_wino2(backward_operand)
+        self._refresh_wino4(backward_operand)
+
+    def wino_u(self, slot_offset: int, backward: bool):
+        """Address of the F(2x2) operand (forward or input-gradient copy) of the 3x3 slot at ``slot_offset``, or None.
+        The first request of a (slot, direction) adds it to the refresh launch's table and transforms the current
+        weights at once; like ``wino4_u`` that is refused while a capture is running."""
+        uo = self._wino_off.get(slot_offset) if self.wino else None
+        if uo is None:
+            return None
+        used = self._wino_used.get(slot_offset)
+        if used is None or not used[1 if backward else 0]:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            if used is None:
+                used = self._wino_used[slot_offset] = [False, False]
+            used[1 if backward else 0] = True
+            self._wino_table = None
+            self._refresh_wino2(True)
+        return (self.data_ub if backward else self.data_uf).data_ptr() + 4 * uo
+
+    def _refresh_wino2(self, backward_operand: bool = True):
+        from . import ops
+        if not self._wino_used:
+            return
+        if self._wino_table is None:
+            rows, blk = [], 0
+            for off in sorted(self._wino_used):
+                f, b = self._wino_used[off]
+                Np, Cp = self._wino_dims[off]
+                uo = self._wino_off[off]
+                rows.append([off, Np, Cp, uo if f else -1, uo if b else -1, blk])      # -1: that copy is not in use
+                blk += (Np // 32) * (Cp // 32)
+            if self._wino_table_old is not None:
+                ops._WS_RETIRED.append(self._wino_table_old)   # a captured refresh launch may still read the old table
+            self._wino_table = torch.tensor(rows, dtype=torch.int64, device=self.device).contiguous()
+            self._wino_table_old = self._wino_table
+            self._wino_blocks = blk
         ops.lib().lgm_wino_weights(self.data.data_ptr(), self.data_uf.data_ptr(),
                                    self.data_ub.data_ptr() if backward_operand else None, self._wino_table.data_ptr(),
                                    self._wino_table.shape[0], self._wino_blocks, ops.stream())
-        self._refresh_wino4(backward_operand)
 
     # -- F(4x4, 3x3) operands (csrc/winograd4.hip): only for the slots a large-map layer actually asked for ----------
     def wino4_u(self, slot_offset: int, backward: bool):

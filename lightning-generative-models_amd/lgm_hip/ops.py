@@ -213,10 +213,7 @@ def _wino_u(w_ptr: Optional[int], backward: bool):
             continue
         off = w_ptr - fp.data.data_ptr()
         if 0 <= off < 4 * fp.total:
-            uo = fp._wino_off.get(off // 4) if off % 4 == 0 else None
-            if uo is None:
-                return None
-            return (fp.data_ub if backward else fp.data_uf).data_ptr() + 4 * uo
+            return fp.wino_u(off // 4, backward) if off % 4 == 0 else None
     return None
 
 
