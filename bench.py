@@ -385,7 +385,7 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
     if rank == 0:
         print(f"[bench] {wl}: timed region: {steps} steps in {elapsed:.3f}s ({value:.1f} img/s)", file=sys.stderr, flush=True)
     launch = info["fast"].mode if info["fast"] is not None else "eager"
-    if not roofline:
+    if not roofline or args.no_roofline:
         return {"ms_per_step": round(ms, 3), "value": round(value, 2), "launch": launch, "steps": steps, "warmup": warmup}
 
     # ---- roofline leg: one extra instrumented step (a whole 5 D : 1 G cycle for the WGAN), per-launch HIP events on
@@ -574,6 +574,9 @@ def main():
     ap.add_argument("--vq-ema", action="store_true", help="vqvae workload: EMA codebook (= --workload vqvae_ema)")
     ap.add_argument("--only", action="store_true", help="only the named workload: no secondary configs, no per-rank proxy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="profiling runs (rocprofv3 --kernel-trace / --pmc around this command): only warm-up + the timed "
+                         "steps, no instrumented step and none of the stream filler it queues behind")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="timed CPU work per cpu_baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python (no HIP-graph replay)")
     ap.add_argument("--batch", type=int, default=None, help="global batch (default: the workload's config value)")

@@ -189,9 +189,15 @@ class FlatParams:
                 return None
             if used is None:
                 used = self._wino_used[slot_offset] = [False, False]
+            from . import ops
             used[1 if backward else 0] = True
             self._wino_table = None
-            self._refresh_wino2(True)
+            # the new copy exists before its first use: a one-row launch now, the whole table from the next refresh on
+            Np, Cp = self._wino_dims[slot_offset]
+            row = torch.tensor([[slot_offset, Np, Cp, -1 if backward else uo, uo if backward else -1, 0]],
+                               dtype=torch.int64, device=self.device)
+            ops.lib().lgm_wino_weights(self.data.data_ptr(), self.data_uf.data_ptr(), self.data_ub.data_ptr(),
+                                       row.data_ptr(), 1, (Np // 32) * (Cp // 32), ops.stream())
         return (self.data_ub if backward else self.data_uf).data_ptr() + 4 * uo
 
     def _refresh_wino2(self, backward_operand: bool = True):
@@ -235,7 +241,12 @@ class FlatParams:
                    torch.zeros(Np * Cp * 36, dtype=torch.float32, device=self.device), Np, Cp)
             self._w4[slot_offset] = ent
             self._w4_table = None
-            self._refresh_wino4(True)                 # the new slot's operands exist before its first use
+            from . import ops
+            # the new slot's operands exist before its first use: a one-row launch now, the whole table from the next
+            # refresh on
+            row = torch.tensor([[slot_offset, Np, Cp, 0, 0, 0]], dtype=torch.int64, device=self.device)
+            ops.lib().lgm_wino4_weights(self.data.data_ptr(), ent[0].data_ptr(), ent[1].data_ptr(), row.data_ptr(), 1,
+                                        (Np // 32) * (Cp // 32), ops.stream())
         return (ent[1] if backward else ent[0]).data_ptr() if ent else None
 
     def _refresh_wino4(self, backward_operand: bool = True):

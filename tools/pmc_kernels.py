@@ -1,5 +1,5 @@
 """Per-kernel counter summary from separate rocprofv3 --pmc passes over the same command
-(`python3 bench.py --only --steps 3 --warmup 1 --no-graph --no-cpu-baseline`):
+(`python3 bench.py --only --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline`):
 
     python tools/pmc_kernels.py <fetch-dir> <write-dir> <mfma-dir> > profiles/rNN_pmc_traffic.json
 
@@ -34,7 +34,7 @@ def main():
     mt, mn = load(sys.argv[3]) if len(sys.argv) > 3 else ({}, {})
     out = {"method": "rocprofv3 --pmc in separate passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES "
                      "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) over `python3 bench.py --only --steps 3 --warmup 1 --no-graph "
-                     "--no-cpu-baseline`; KB -> bytes; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md); means per launch",
+                     "--no-cpu-baseline --no-roofline`; KB -> bytes; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md); means per launch",
            "kernels": {}}
     steps = max((fn[k]["FETCH_SIZE"] for k in fn if "adam_kernel" in k), default=1)
     tf = tw = 0.0

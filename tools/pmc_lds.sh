@@ -2,7 +2,7 @@
 # usage (GPU box): bash tools/pmc_lds.sh   -> LDS bank-conflict share per kernel of one DDPM step (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
 export TMPDIR=/tmp
 rm -rf /tmp/pmc_lds
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES -d /tmp/pmc_lds --output-format csv -- python3 bench.py --only --steps 2 --warmup 1 --no-graph --no-cpu-baseline > gpurun_out/pmc_lds.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES -d /tmp/pmc_lds --output-format csv -- python3 bench.py --only --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > gpurun_out/pmc_lds.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 tot=collections.defaultdict(lambda: collections.defaultdict(float))
