@@ -542,8 +542,11 @@ def test_winograd4_weight_gradients_of_two_layers_in_one_launch(dev, parity):
 def test_grouped_weight_gradients_of_wide_layers_do_not_share_the_f4x4_launch(dev, parity):
     """Two 512 -> 512 layers at 8 x 8 (the 64 x 64 configuration's deepest large-map layers): each needs 256 workgroups'
     worth of 64 x 32-channel blocks for two slabs, so the pair cannot share the F(4x4) launch (a zero budget once divided
-    by zero on the host); the grouped entry point falls back to the F(2x2) grouped launch - results against float64."""
+    by zero on the host).  The grouped entry point refuses the pair (GradCtx.queue_wgrad asks first) and each layer goes
+    alone on the F(4x4) kernel - measured faster than the two together on the F(2x2) grouped launch; results against
+    float64."""
     from lgm_hip import ops
+    from lgm_hip._lib import LgmError
     B, hw, ci, co = 32, 8, 512, 512
     layers, refs = [], []
     for i in range(2):
@@ -556,15 +559,15 @@ def test_grouped_weight_gradients_of_wide_layers_do_not_share_the_f4x4_launch(de
         refs.append(gw_ref.permute(0, 2, 3, 1).reshape(co, 9, ci))
         layers.append((ops.make_geom(B, hw, hw, ci, co, 3, 3, 1, 1), y.to(dev), x.to(dev)))
     assert ops.lib().lgm_conv3x3_wino4_preferred(ctypes.byref(layers[0][0]), 1) == 1      # each alone takes the F(4x4) kernels
+    assert not ops.wgrad_group_supported([l[0] for l in layers])
     gws = [torch.full((co, 9, ci), float("nan"), device=dev) for _ in layers]
-    rows = []
-    ops.conv_wgrad_group([(l[0], l[1], l[2], gw.data_ptr(), 0.0, None) for l, gw in zip(layers, gws)], rows)
-    assert "wino_wgrad2_kernel" in ops.lib()._dll.lgm_last_kernel().decode()
-    ops.wgrad_reduce_batch(rows, dev)
+    with pytest.raises(LgmError):                      # asked anyway: an error code, no launch
+        ops.conv_wgrad_group([(l[0], l[1], l[2], gw.data_ptr(), 0.0, None) for l, gw in zip(layers, gws)], [])
+    # what GradCtx does with them: one launch each through lgm_conv_wgrad - the F(4x4) kernel on 2 x 2-tile groups
+    gc_rows = []
+    for l, gw in zip(layers, gws):
+        ops.conv_wgrad(l[0], l[1], l[2], gw.data_ptr(), 0.0, None, defer=gc_rows)
+        assert "wino4_wgrad_kernel" in ops.lib()._dll.lgm_last_kernel().decode()
+    ops.wgrad_reduce_batch(gc_rows, dev)
     for i in range(2):
-        parity(f"wide layer {i} through the F(2x2) grouped launch", maxerr(gws[i], refs[i]), 2e-6)
-    # and alone, through lgm_conv_wgrad: the F(4x4) kernel on 2 x 2-tile groups
-    gw1 = torch.full((co, 9, ci), float("nan"), device=dev)
-    ops.conv_wgrad(layers[0][0], layers[0][1], layers[0][2], gw1.data_ptr(), 0.0, None)
-    assert "wino4_wgrad_kernel" in ops.lib()._dll.lgm_last_kernel().decode()
-    parity("wide layer alone, F(4x4)", maxerr(gw1, refs[0]), 1e-5)
+        parity(f"wide layer {i} alone, F(4x4)", maxerr(gws[i], refs[i]), 1e-5)
