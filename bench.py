@@ -477,6 +477,10 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 5), "launch": launch,
                        "conv_mode": conv_mode},
             "roofline": roof}
+    if world > 1:
+        line["config"]["grad_exchange"] = ("bucketed all-reduce overlapped with the backward (RCCL)"
+                                           if os.environ.get("LGM_DDP_OVERLAP", "1") != "0"
+                                           else "one all-reduce after the backward (LGM_DDP_OVERLAP=0)")
     if world == 1 and cpu and not args.no_cpu_baseline:
         secs = args.cpu_seconds
         if wl == "ddpm32":

@@ -222,24 +222,49 @@ class FlatGradSync:
     The hand-written backward fills the flat buffer in a known order; ``ready(lo, hi)`` is called
     as soon as the slice [lo, hi) is final and launches an asynchronous all-reduce on it (RCCL
     runs it on its own stream, ordered after the kernels already enqueued), ``finish()`` waits
-    for all buckets.  The 1/world average is folded into the optimiser (``grad_scale``)."""
+    for all buckets.  The 1/world average is folded into the optimiser (``grad_scale``).
 
-    def __init__(self, flat, group=None):
+    ``LGM_DDP_OVERLAP=0`` (A/B switch for the multi-GPU run): ``ready`` only notes the slice and ``finish`` exchanges what
+    was noted - the whole buffer in ONE all-reduce when everything was - after the backward pass.  A collective kernel
+    that sits on even one CU beside the backward makes every chip-filling persistent launch wait for a second round
+    (+27 ... 35 % on those launches, tools/cu_hog_step.py), so overlap hides the exchange at a price; which
+    side wins depends on the link time and can only be measured on more than one GPU."""
+
+    def __init__(self, flat, group=None, overlap: Optional[bool] = None):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.overlap = (os.environ.get("LGM_DDP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
         self.handles = []
+        self.pending = []
         self.covered = 0
 
     def ready(self, lo: int, hi: int):
-        """-> the asynchronous work handle (None on one rank); ``finish()`` waits for whatever is still pending"""
+        """-> the asynchronous work handle (None on one rank, and when the exchange is deferred to ``finish``);
+        ``finish()`` waits for whatever is still pending"""
         if self.world == 1 or hi <= lo:
+            return None
+        self.covered += hi - lo
+        if not self.overlap:
+            self.pending.append((lo, hi))
             return None
         h = dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True)
         self.handles.append(h)
-        self.covered += hi - lo
         return h
 
     def finish(self):
+        if self.pending:
+            if self.covered == self.flat.total:
+                spans = [(0, self.flat.total)]
+            else:                                    # merge adjacent slices: as few collectives as the coverage allows
+                spans = []
+                for lo, hi in sorted(self.pending):
+                    if spans and spans[-1][1] == lo:
+                        spans[-1] = (spans[-1][0], hi)
+                    else:
+                        spans.append((lo, hi))
+            self.pending = []
+            for lo, hi in spans:
+                self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True))
         for h in self.handles:
             h.wait()
         self.handles = []

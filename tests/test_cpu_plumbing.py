@@ -177,6 +177,17 @@ sync.ready(0, third)
 sync.finish()
 expect = torch.arange(fp.total, dtype=torch.float32) * sum(range(1, world + 1))
 ok = ok and bool(torch.allclose(fp.grad * sync.grad_scale, expect / world))
+# LGM_DDP_OVERLAP=0: the same slices noted during the "backward", ONE all-reduce of the whole buffer in finish()
+fp.grad.copy_(torch.arange(fp.total, dtype=torch.float32) * (rank + 1))
+late = FlatGradSync(fp, overlap=False)
+calls = []
+real = dist.all_reduce
+dist.all_reduce = lambda t, **kw: (calls.append(t.numel()), real(t, **kw))[1]
+assert late.ready(2 * third, fp.total) is None and late.ready(third, 2 * third) is None and late.ready(0, third) is None
+assert not calls
+late.finish()
+dist.all_reduce = real
+ok = ok and calls == [fp.total] and bool(torch.allclose(fp.grad * late.grad_scale, expect / world))
 print(f"RANK{rank} err={err:.3e} flat_ok={ok}", flush=True)
 dist.destroy_process_group()
 '''
