@@ -128,7 +128,8 @@ class GraphedDDPMStep:
         net = self.net
         self.t = torch.zeros(x.shape[0], dtype=torch.long, device=x.device) if inject else None
         self.noise = torch.zeros_like(x) if inject else None
-        self.pipeline = _STEP_PIPELINE
+        # (the pipelined variant applies a bucket's Adam slice right behind ITS all-reduce: only with the overlapped exchange)
+        self.pipeline = _STEP_PIPELINE and (sync is None or getattr(sync, "overlap", True))
         split = sync is not None or self.pipeline
 
         def part1a():

@@ -353,7 +353,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("mode", ["graph", "eager"])
+@pytest.mark.parametrize("mode", ["graph", "eager", "graph-late"])
 def test_two_rank_ddpm_step_equals_one_rank_on_concatenated_batch(dev, tmp_path, mode, parity):
     """2 ranks (gloo collectives, both on the box's one GPU), per-rank batch 4, three
     optimizer steps through DDPMFastStep — bucketed all-reduce overlapped with the hand-written backward, 1/N
@@ -362,7 +362,10 @@ def test_two_rank_ddpm_step_equals_one_rank_on_concatenated_batch(dev, tmp_path,
     script = tmp_path / "ddp_worker.py"
     script.write_text(_DDP_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    port = "29551" if mode == "graph" else "29553"
+    port = {"graph": "29551", "eager": "29553", "graph-late": "29555"}[mode]
+    if mode == "graph-late":        # LGM_DDP_OVERLAP=0: ONE all-reduce of the whole gradient buffer after the backward
+        env["LGM_DDP_OVERLAP"] = "0"
+        mode = "graph"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script), PKG, mode],
                        capture_output=True, text=True, timeout=600, env=env)
