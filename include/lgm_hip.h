@@ -176,11 +176,23 @@ int lgm_gn_fwd(const float* x, int64_t x_pitch, int B, int HW, int C, int G, flo
  * conv_bias), the finished x is WRITTEN to `x` (the backward pass reads it) and normalised in the same pass: one
  * launch and one round trip of x less per convolution.  Only shapes with lgm_gn_planes_supported(...) == 1. */
 int64_t lgm_gn_planes_supported(int B, int HW, int C, int G);
+/* 1 when lgm_gn_fwd runs its one-pass kernel for this shape (the slices fit a block's registers), 0: two passes over x */
+int64_t lgm_gn_fwd_fused_supported(int B, int HW, int C, int G);
 int lgm_gn_fwd_planes(const float* planes, int64_t plane_stride, int splits, const float* conv_bias, float* x,
                       int64_t x_pitch, int B, int HW, int C, int G, float eps, const float* gamma,
                       const float* beta, const float* ss, int64_t ss_pitch, int act, const float* res,
                       int64_t res_pitch, float* y, int64_t y_pitch, float* mean, float* rstd, float* coefA,
                       float* coefB, void* stream);
+/* The same, with the STATISTICS already gathered by the convolution that produced x (lgm_conv3x3_wino4_stats; Block.proj
+ * -> Block.norm, ddpm.py:157-173, on maps whose (image, channel block) slices do not fit a one-pass GroupNorm block - the
+ * 64 x 64 maps of configs/diffusion/ddpm_64.json): `stats` holds, per image, `parts_per_image` rows of (sum, sum of
+ * squares) per channel of the convolution's outputs BEFORE its bias (`conv_bias`, may be NULL), layout
+ * [b * parts + q][2][C].  A small kernel combines them in float64 in a fixed order into mean / rstd / coefA / coefB, then
+ * the apply pass reads x once.  C / G must divide 64. */
+int lgm_gn_fwd_stats(const float* stats, int parts_per_image, const float* conv_bias, const float* x, int64_t x_pitch,
+                     int B, int HW, int C, int G, float eps, const float* gamma, const float* beta, const float* ss,
+                     int64_t ss_pitch, int act, const float* res, int64_t res_pitch, float* y, int64_t y_pitch,
+                     float* mean, float* rstd, float* coefA, float* coefB, void* stream);
 /* Backward.  gx (optionally accumulated), ggamma/gbeta (= affine_beta*old + new), gss [B, >=2C]
  * (optional; = gss_beta*old + new).  workspace: 5*B*C floats. */
 int lgm_gn_bwd(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
@@ -611,6 +623,12 @@ int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx);
 int lgm_conv3x3_wino4_partial(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,
                               const float* bias, float* out, int64_t out_pitch, void* workspace,
                               int64_t workspace_bytes, int64_t* partial, void* stream);
+/* Forward with the consumer GroupNorm's raw statistics from the epilogue: floats the `stats` buffer needs (0: this
+ * geometry does not take it - maps that are multiples of 16 x 32, an unsplit reduction) and the rows per image;
+ * lgm_gn_fwd_stats consumes them.  No residual operand. */
+int64_t lgm_conv3x3_wino4_stats_floats(const LgmConvGeom* g, int* parts_per_image);
+int lgm_conv3x3_wino4_stats(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* u, const float* bias,
+                            float* y, int64_t y_pitch, float* stats, int64_t stats_floats, void* stream);
 int lgm_wino4_weights(const float* src, float* dst_f, float* dst_b, const int64_t* table, int n_slots,
                       int64_t total_blocks, void* stream);
 /* diagnostic only: buf != NULL makes lgm_conv3x3_wino4 run its cycle-stamped build (32 int64 per workgroup) */

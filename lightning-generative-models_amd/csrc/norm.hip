@@ -807,6 +807,14 @@ static GnPlan gn_plan(int B, int HW, int C, int G, bool bwd) {
   return p;
 }
 
+// 1 when the forward runs the one-pass (register-resident) kernel for this shape, 0 when it needs two passes over x
+extern "C" int64_t lgm_gn_fwd_fused_supported(int B, int HW, int C, int G) {
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || C % 4 || G > 64) return 0;
+  const int cb = gn_cb(C, G);
+  if (!(cb % 4 == 0 && C % cb == 0 && cb / 4 <= 256 && cb <= 256)) return 0;
+  return gn_plan(B, HW, C, G, false).nv > 0 ? 1 : 0;
+}
+
 extern "C" int64_t lgm_gn_planes_supported(int B, int HW, int C, int G) {
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || C % 4 || G > 64) return 0;
   const int cb = gn_cb(C, G);
@@ -856,6 +864,89 @@ static int gn_fwd_impl(const float* x, int64_t x_pitch, int B, int HW, int C, in
   const long npix = (long)B * HW;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(lgm_cdiv(npix * (C / 4), 256)), dim3(256), 0, s, x, (long)x_pitch, coefA,
                      coefB, res, (long)res_pitch, y, (long)y_pitch, npix, HW, C, act);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// GroupNorm forward whose statistics come from the producing convolution's epilogue (lgm_conv3x3_wino4_stats): per image
+// `parts` rows of (sum, sum of squares) per channel of the PRE-BIAS outputs, layout [b * parts + q][2][C].  One block per
+// (image, group) adds them in float64 in a fixed order, shifts by the convolution bias, and leaves mean / rstd / the
+// per-(image, channel) coefficients exactly as gn_stats_kernel does; gn_apply_kernel follows.  x is read ONCE.
+__global__ __launch_bounds__(64) void gn_coef_from_stats_kernel(const float* __restrict__ stats, int parts, int C, int G,
+                                                                long HW, const float* __restrict__ cbias, float eps,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ ss,
+                                                                long ss_pitch, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, float* __restrict__ A,
+                                                                float* __restrict__ Bc) {
+  __shared__ double sh1[64], sh2[64];
+  __shared__ float smean, srstd;
+  const int Cg = C / G;                    // host: Cg divides 64
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int t = threadIdx.x, c = t % Cg, j = t / Cg, J = 64 / Cg;
+  const float* base = stats + ((long)b * parts) * 2 * C + g * Cg + c;
+  double a1 = 0.0, a2 = 0.0;
+  for (int q = j; q < parts; q += J) {
+    a1 += (double)base[(long)q * 2 * C];
+    a2 += (double)base[(long)q * 2 * C + C];
+  }
+  sh1[t] = a1;
+  sh2[t] = a2;
+  __syncthreads();
+  if (t == 0) {
+    const double n = (double)HW;
+    double sx = 0.0, sxx = 0.0;
+    for (int cc = 0; cc < Cg; ++cc) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int jj = 0; jj < J; ++jj) {
+        t1 += sh1[jj * Cg + cc];
+        t2 += sh2[jj * Cg + cc];
+      }
+      const double bb = cbias ? (double)cbias[g * Cg + cc] : 0.0;
+      sx += t1 + n * bb;
+      sxx += t2 + 2.0 * bb * t1 + n * bb * bb;
+    }
+    const double cnt = n * (double)Cg;
+    const double m = sx / cnt;
+    double var = sxx / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    smean = (float)m;
+    srstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean[b * G + g] = smean;
+    rstd[b * G + g] = srstd;
+  }
+  __syncthreads();
+  if (t < Cg) {
+    const int ch = g * Cg + t;
+    float a = srstd * gamma[ch];
+    float bb = beta[ch] - smean * a;
+    if (ss) {
+      const float sc = ss[(long)b * ss_pitch + ch] + 1.f;
+      const float shf = ss[(long)b * ss_pitch + C + ch];
+      a *= sc;
+      bb = bb * sc + shf;
+    }
+    A[(long)b * C + ch] = a;
+    Bc[(long)b * C + ch] = bb;
+  }
+}
+
+extern "C" int lgm_gn_fwd_stats(const float* stats, int parts_per_image, const float* conv_bias, const float* x,
+                                int64_t x_pitch, int B, int HW, int C, int G, float eps, const float* gamma,
+                                const float* beta, const float* ss, int64_t ss_pitch, int act, const float* res,
+                                int64_t res_pitch, float* y, int64_t y_pitch, float* mean, float* rstd, float* coefA,
+                                float* coefB, void* stream) {
+  if (int rc = gn_check(B, HW, C, G)) return rc;
+  LGM_REQUIRE(stats && parts_per_image > 0 && x && gamma && beta && y && mean && rstd && coefA && coefB,
+              "gn_fwd_stats: null pointer");
+  LGM_REQUIRE(x_pitch % 4 == 0 && y_pitch % 4 == 0 && (!res || res_pitch % 4 == 0) && C % 4 == 0 && 64 % (C / G) == 0,
+              "gn_fwd_stats: pitch %% 4 != 0 or a group width that does not divide 64");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_coef_from_stats_kernel, dim3(B * G), dim3(64), 0, s, stats, parts_per_image, C, G, (long)HW, conv_bias,
+                     eps, gamma, beta, ss, (long)ss_pitch, mean, rstd, coefA, coefB);
+  const long npix = (long)B * HW;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(lgm_cdiv(npix * (C / 4), 256)), dim3(256), 0, s, x, (long)x_pitch, coefA, coefB,
+                     res, (long)res_pitch, y, (long)y_pitch, npix, HW, C, act);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

@@ -83,6 +83,7 @@ struct Args {
   float* ws;
   long ws_stride;
   long long* dbg;      // diagnostic build only (wino4_conv_kernel<CLS, true>): per-workgroup cycle stamps
+  float* stats;        // STATS build only: [spatial unit][4 parts][2: sum y, sum y^2][N] of the PRE-BIAS outputs
 };
 
 __device__ __forceinline__ f32x4 add4(const f32x4 a, const f32x4 b) { return a + b; }
@@ -106,7 +107,10 @@ __device__ __forceinline__ f32x2 fma2(const float c, const f32x2 a, const f32x2 
 
 // EXP (diagnostic builds only): bit 0 drops the transform, bit 1 the patch fetch / commit, bit 2 the U loads, bit 3 the V
 // reads of the phase loop -- wrong results, used to attribute the phase time.
-template <int CLS, bool DBG = false, int EXP = 0>
+// STATS (class 0, unsplit, no residual; the consumer is a GroupNorm whose slices do not fit a one-pass block): every wave
+// also leaves, per produced channel, the sum and the sum of squares of its 128 output pixels BEFORE the bias is added
+// (zero-mean-ish values: no cancellation in the squares) - lgm_gn_fwd_stats combines them in float64.
+template <int CLS, bool DBG = false, int EXP = 0, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
   using GE = Geo<CLS>;
   int nstamp = 0;
@@ -423,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
       }
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (!partial && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + rd * 32);
+      f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
         const long orow = (long)(2 * rr + rpair) * p.W;
@@ -433,6 +438,13 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
         y[1] = fma4(2.f, d2, d1);
         y[2] = fma4(4.f, s2, s1);
         y[3] = add4(fma4(8.f, d2, d1), X[rr][5]);
+        if (STATS) {
+#pragma unroll
+          for (int oj = 0; oj < 4; ++oj) {
+            st1 = add4(st1, y[oj]);
+            st2 = __builtin_elementwise_fma(y[oj], y[oj], st2);
+          }
+        }
         if (has_res) {
 #pragma unroll
           for (int oj = 0; oj < 4; ++oj)
@@ -440,6 +452,24 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
         }
 #pragma unroll
         for (int oj = 0; oj < 4; ++oj) *reinterpret_cast<f32x4*>(obase + (orow + oj) * opitch + rd * 32) = add4(y[oj], bv);
+      }
+      if (STATS) {
+        // the 16 lanes of this wave that share the channel quad eq (lane = eq + 4 (tile & 15)): a fixed butterfly
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            st1[k] += __shfl_xor(st1[k], m, 64);
+            st2[k] += __shfl_xor(st2[k], m, 64);
+          }
+        }
+        if ((lane >> 2) == 0) {
+          const int ublk = (bg * p.tb_h + thi) * p.tb_w + twi;
+          const int part = (tid >> 6) & 3;                                   // wave within the half: 16 tiles x one row pair
+          float* sp = p.stats + ((long)(ublk * 4 + part) * 2) * p.N + ncol0 + rd * 32;
+          *reinterpret_cast<f32x4*>(sp) = st1;
+          *reinterpret_cast<f32x4*>(sp + p.N) = st2;
+        }
       }
       stamp();
     }
@@ -597,9 +627,10 @@ int lgm_wino4_splits(const LgmConvGeom* g, int gather_channels, int out_channels
 // partial (optional, int64 x 2): as lgm_wino_launch - the caller's consumer sums the split-K planes itself
 int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, const float* u, const float* bias,
                      const float* res, long res_pitch, float* out, long out_pitch, void* workspace, long workspace_bytes,
-                     hipStream_t s, int64_t* partial = nullptr) {
+                     hipStream_t s, int64_t* partial = nullptr, float* stats = nullptr) {
   using namespace lgmwino4;
   Args p{};
+  p.stats = stats;
   p.a = a; p.u = u; p.bias = bias; p.res = res; p.out = out;
   p.a_pitch = a_pitch; p.res_pitch = res_pitch; p.out_pitch = out_pitch;
   p.B = g->B; p.H = g->H; p.W = g->W;
@@ -648,6 +679,19 @@ int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch,
     else if (e == 7) LGM_W4LAUNCH(0, true, 7);
     else if (e == 8) LGM_W4LAUNCH(0, true, 8);
     else LGM_W4LAUNCH(0, true, 15);
+  } else if (stats) {
+    if (cls != 0 || p.splits != 1 || res || partial) {
+      lgm_set_error("wino4 (stats): class-0 maps, an unsplit reduction and no residual expected");
+      return LGM_ERR_UNSUPPORTED;
+    }
+    auto kern = wino4_conv_kernel<0, false, 0, true>;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr = true;
+    }
+    lgm_note_kernel("lgmwino4::wino4_conv_kernel<0, false, 0, true>");
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(512), smem, s, p);
   } else if (cls == 0) LGM_W4LAUNCH(0, false, 0);
   else if (cls == 1) LGM_W4LAUNCH(1, false, 0);
   else LGM_W4LAUNCH(2, false, 0);
@@ -668,6 +712,20 @@ int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch,
 extern "C" int64_t lgm_conv3x3_wino4_supported(const LgmConvGeom* g, int yx) {
   if (!g) return 0;
   return lgm_wino4_supported(g, yx ? g->Nw : g->Cw, yx ? g->Cw : g->Nw) ? 1 : 0;
+}
+
+// Forward convolution that also leaves the GroupNorm statistics' raw material (lgm_conv3x3_wino4_stats): floats of the
+// `stats` buffer it needs, or 0 when this geometry does not take it (class-0 maps, unsplit reduction, preferred at all);
+// *parts_per_image = the partial (sum, sum of squares) rows every image contributes per channel.
+extern "C" int64_t lgm_conv3x3_wino4_stats_floats(const LgmConvGeom* g, int* parts_per_image) {
+  if (parts_per_image) *parts_per_image = 0;
+  if (!g || !lgm_wino4_supported(g, g->Cw, g->Nw) || lgmwino4::unit_class(g->H, g->W) != 0) return 0;
+  if (lgm_wino4_splits(g, g->Cw, g->Nw) != 1) return 0;
+  static const bool off = getenv("LGM_NO_GN_EPI_STATS") != nullptr;      // A/B switch
+  if (off) return 0;
+  const int per = (g->H / 16) * (g->W / 32) * 4;
+  if (parts_per_image) *parts_per_image = per;
+  return (int64_t)g->B * per * 2 * g->Nw;
 }
 
 extern "C" int64_t lgm_conv3x3_wino4_workspace(const LgmConvGeom* g, int yx) {
@@ -731,6 +789,22 @@ extern "C" int lgm_conv3x3_wino4(int yx, const LgmConvGeom* g, const float* a, i
               "conv3x3_wino4: tensor too large for 32-bit offsets");
   return lgm_wino4_launch(g, yx, a, a_pitch, u, bias, res, res_pitch, out, out_pitch, workspace, workspace_bytes,
                           (hipStream_t)stream);
+}
+
+extern "C" int lgm_conv3x3_wino4_stats(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* u,
+                                       const float* bias, float* y, int64_t y_pitch, float* stats, int64_t stats_floats,
+                                       void* stream) {
+  LGM_REQUIRE(g && x && u && y && stats, "conv3x3_wino4_stats: null pointer");
+  int per = 0;
+  const int64_t need = lgm_conv3x3_wino4_stats_floats(g, &per);
+  LGM_REQUIRE(need > 0 && stats_floats >= need && lgm_aligned16(stats) && g->Nw % 4 == 0,
+              "conv3x3_wino4_stats: geometry not taken or statistics buffer too small (ask lgm_conv3x3_wino4_stats_floats)");
+  LGM_REQUIRE(x_pitch % 4 == 0 && x_pitch >= g->Cw && lgm_aligned16(x) && lgm_aligned16(u) && lgm_aligned16(y) &&
+              y_pitch % 4 == 0 && y_pitch >= g->Nw && (!bias || lgm_aligned16(bias)),
+              "conv3x3_wino4_stats: 16-byte aligned operands with pitch %% 4 == 0 expected");
+  const long pix = (long)g->B * g->H * g->W + g->W + 1;
+  LGM_REQUIRE(pix * x_pitch < (1L << 29) && pix * y_pitch < (1L << 29), "conv3x3_wino4_stats: tensor too large for 32-bit offsets");
+  return lgm_wino4_launch(g, 0, x, x_pitch, u, bias, nullptr, 0, y, y_pitch, nullptr, 0, (hipStream_t)stream, nullptr, stats);
 }
 
 extern "C" int lgm_conv3x3_wino4_partial(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,

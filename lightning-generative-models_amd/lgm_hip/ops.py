@@ -278,6 +278,50 @@ def _wino4_call(yx: int, g: ConvGeom, a, u_ptr: int, bias_ptr, res, out, partial
     return True
 
 
+# GroupNorm statistics from the convolution's epilogue (lgm_conv3x3_wino4_stats + lgm_gn_fwd_stats): only where the
+# GroupNorm forward would otherwise need two passes over x (the 64 x 64 maps); LGM_NO_GN_EPI_STATS=1 switches it off.
+_EPI_STATS = {}
+
+
+def conv_xy_stats(g: ConvGeom, x, w_ptr: Optional[int], bias_ptr, y, groups: int):
+    """Forward 3x3 convolution whose consumer is GroupNorm(groups): -> ("stats", rows, rows per image, bias address) for
+    gn_fwd(planes=...), or None when this layer does not take the path (the caller runs conv_xy)."""
+    if not (WINO and WINO4 and _WINO_FLATS and not B3) or g.KH != 3 or g.KW != 3 or w_ptr is None:
+        return None
+    key = (g.B, g.H, g.W, g.Cw, g.Nw, groups)
+    ent = _EPI_STATS.get(key)
+    if ent is None:
+        n, per = 0, ctypes.c_int(0)
+        C = g.Nw
+        if (_wino4_preferred(g, 0) and C % groups == 0 and 64 % (C // groups) == 0
+                and not lib().lgm_gn_fwd_fused_supported(g.B, g.H * g.W, C, groups)):
+            n = int(lib().lgm_conv3x3_wino4_stats_floats(ctypes.byref(g), ctypes.addressof(per)))
+        ent = (n, int(per.value))
+        _EPI_STATS[key] = ent
+    if ent[0] <= 0:
+        return None
+    if x.data_ptr() % 16 or y.data_ptr() % 16 or pitch(x) % 4 or pitch(y) % 4 or (bias_ptr or 0) % 16:
+        return None
+    fkey = (g.B, g.H, g.W, pitch(x), pitch(y), 0)
+    fits = _WINO_FITS.get(fkey)
+    if fits is None:
+        fits = bool(lib().lgm_conv3x3_wino_fits(ctypes.byref(g), fkey[3], fkey[4], fkey[5]))
+        _WINO_FITS[fkey] = fits
+    if not fits:
+        return None
+    u = _wino4_u(w_ptr, False)
+    if u is None:
+        return None
+    st = torch.empty(ent[0], dtype=torch.float32, device=x.device)
+    if TIMER is not None:
+        TIMER.begin("igemm_xy", _conv_flops(g), _conv_bytes(g))
+    lib().lgm_conv3x3_wino4_stats(ctypes.byref(g), x.data_ptr(), pitch(x), u, bias_ptr, y.data_ptr(), pitch(y),
+                                  st.data_ptr(), ent[0], stream())
+    if TIMER is not None:
+        TIMER.end()
+    return ("stats", st, ent[1], bias_ptr)
+
+
 def _wino_supported(g: ConvGeom, yx: int) -> bool:
     key = (g.B, g.H, g.W, g.Cw, g.Nw, g.KH, g.KW, g.stride, g.pad, yx)
     v = _WINO_OK.get(key)
@@ -838,12 +882,19 @@ def _gn_scratch(nfloats: int, device) -> torch.Tensor:
 
 def gn_fwd(x, G, eps, gamma_ptr, beta_ptr, ss, act: bool, res, y, planes=None) -> GNSaved:
     """``planes`` = (address, stride, count, conv bias address) from conv_xy(partial=True): x is summed from them,
-    WRITTEN to ``x`` and normalised in the same pass."""
+    WRITTEN to ``x`` and normalised in the same pass; or ("stats", tensor, rows per image, conv bias address) from
+    conv_xy_stats: the statistics come from the convolution's epilogue and x is read once."""
     B, H, W, C = x.shape
     sv = GNSaved()
     stats = new((2, B, G), x)
     coef = new((2, B, C), x)
     sv.mean, sv.rstd, sv.A, sv.Bc = stats[0], stats[1], coef[0], coef[1]
+    if planes is not None and planes[0] == "stats":
+        lib().lgm_gn_fwd_stats(planes[1].data_ptr(), planes[2], planes[3], x.data_ptr(), pitch(x), B, H * W, C, G, eps,
+                               gamma_ptr, beta_ptr, _p(ss), pitch(ss) if ss is not None else 0, 1 if act else 0,
+                               _p(res), pitch(res) if res is not None else 0, y.data_ptr(), pitch(y),
+                               sv.mean.data_ptr(), sv.rstd.data_ptr(), sv.A.data_ptr(), sv.Bc.data_ptr(), stream())
+        return sv
     if planes is not None:
         lib().lgm_gn_fwd_planes(planes[0], planes[1], planes[2], planes[3], x.data_ptr(), pitch(x), B, H * W, C, G, eps,
                                 gamma_ptr, beta_ptr, _p(ss), pitch(ss) if ss is not None else 0, 1 if act else 0,

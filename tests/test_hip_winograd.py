@@ -511,6 +511,59 @@ def test_winograd4_weight_gradient(dev, case, parity):
     assert torch.equal(gw, gw3)
 
 
+@pytest.mark.parametrize("case", [(24, 64, 64, 64, 64), (12, 64, 64, 64, 128), (48, 32, 64, 64, 64)])
+def test_winograd4_forward_leaves_the_groupnorm_statistics(dev, case, parity):
+    """Block.forward (ddpm.py:164-173) on maps whose GroupNorm needs two passes over x (64 x 64): lgm_conv3x3_wino4_stats
+    writes the convolution output AND, per wave, (sum, sum of squares) of its pre-bias outputs; lgm_gn_fwd_stats combines
+    them in float64 and normalises reading x once.  Against the two-step path of the same library (convolution, then
+    lgm_gn_fwd) and against float64: outputs, mean / rstd, FiLM + SiLU + residual."""
+    from lgm_hip import ops
+    B, H, W, ci, co = case
+    G = 8
+    L = ops.lib()
+    gen = torch.Generator().manual_seed(sum(case) + 3)
+    x = torch.randn(B, H, W, ci, generator=gen).to(dev)
+    w = (torch.randn(co, 9, ci, generator=gen) / (3 * ci ** 0.5)).to(dev)
+    bias = (torch.randn(co, generator=gen) * 2.0).to(dev)          # a bias far from zero: the shift in the statistics matters
+    gamma, beta = (torch.randn(co, generator=gen).to(dev) for _ in range(2))
+    ss = torch.randn(B, 2 * co, generator=gen).to(dev) * 0.3
+    res = torch.randn(B, H, W, co, generator=gen).to(dev)
+    uf, _ = wino4_weights(w)
+    g = ops.make_geom(B, H, W, ci, co, 3, 3, 1, 1)
+    per = ctypes.c_int(0)
+    n = L.lgm_conv3x3_wino4_stats_floats(ctypes.byref(g), ctypes.addressof(per))
+    assert n == B * per.value * 2 * co and per.value == (H // 16) * (W // 32) * 4
+    u_ref = torch.empty(B, H, W, co, device=dev)
+    wino4(0, g, x, uf, bias, None, u_ref)
+    y_ref = torch.empty_like(u_ref)
+    sv_ref = ops.gn_fwd(u_ref, G, 1e-5, gamma.data_ptr(), beta.data_ptr(), ss, True, res, y_ref)
+    u_st = torch.full((B, H, W, co), 3.0, device=dev)
+    st = torch.full((n + 16,), float("nan"), device=dev)
+    L.lgm_conv3x3_wino4_stats(ctypes.byref(g), x.data_ptr(), ops.pitch(x), uf.data_ptr(), bias.data_ptr(), u_st.data_ptr(),
+                              ops.pitch(u_st), st.data_ptr(), n, ops.stream())
+    assert "wino4_conv_kernel<0, false, 0, true>" in L._dll.lgm_last_kernel().decode()
+    assert torch.equal(u_st, u_ref)                                # the same convolution, bit for bit
+    assert not bool(torch.isnan(st[:n]).any()) and bool(torch.isnan(st[n:]).all())     # every row written, nothing beyond
+    y_st = torch.empty_like(u_ref)
+    sv = ops.gn_fwd(u_st, G, 1e-5, gamma.data_ptr(), beta.data_ptr(), ss, True, res, y_st,
+                    planes=("stats", st, per.value, bias.data_ptr()))
+    u64 = F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), w.cpu().reshape(co, 3, 3, ci).permute(0, 3, 1, 2).double(),
+                   bias.cpu().double(), padding=1)
+    v = u64.reshape(B, G, -1)
+    m64, r64 = v.mean(-1), 1.0 / torch.sqrt(v.var(-1, unbiased=False) + 1e-5)
+    parity("mean from the epilogue statistics vs float64", maxerr(sv.mean, m64), 2e-5)
+    parity("rstd from the epilogue statistics vs float64", maxerr(sv.rstd, r64), 2e-5)
+    parity("mean / rstd: epilogue statistics vs the two-pass kernel",
+           max(maxerr(sv.mean, sv_ref.mean.double().cpu()), maxerr(sv.rstd, sv_ref.rstd.double().cpu())), 2e-5)
+    parity("GroupNorm output (FiLM, SiLU, residual): epilogue statistics vs the two-pass kernel",
+           maxerr(y_st, y_ref.double().cpu()), 2e-5)
+    # run to run identical (fixed butterfly, fixed float64 order)
+    st2 = torch.empty_like(st)
+    L.lgm_conv3x3_wino4_stats(ctypes.byref(g), x.data_ptr(), ops.pitch(x), uf.data_ptr(), bias.data_ptr(), u_st.data_ptr(),
+                              ops.pitch(u_st), st2.data_ptr(), n, ops.stream())
+    assert torch.equal(st[:n], st2[:n])
+
+
 def test_winograd4_weight_gradients_of_two_layers_in_one_launch(dev, parity):
     """The grouped launch takes the F(4x4) kernel when both layers do (large maps at a chip-filling batch): against float64."""
     from lgm_hip import ops
