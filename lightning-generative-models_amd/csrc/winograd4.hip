@@ -762,6 +762,10 @@ extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
   if (cls == 2) return (!no8 && (yx == 0 || !noyx8) && base >= 32 && gc >= c2_minc) ? 1 : 0;
   static const int c1_minc = getenv("LGM_WINO4_C1_MINC") ? atoi(getenv("LGM_WINO4_C1_MINC")) : 0;
   if (cls == 1 && gc < c1_minc) return 0;
+  // 16 x 16 maps with a reduction of >= 128 channels (>= 16 phases: two splits of >= 8) already from 64 units - the
+  // per-rank batch of two GPUs: 6.98 -> 6.94 ms per step at B = 64, nothing changes at B = 128 (LGM_WINO4_MIN_UNITS1W)
+  static const long min_units1w = getenv("LGM_WINO4_MIN_UNITS1W") ? atol(getenv("LGM_WINO4_MIN_UNITS1W")) : 64;
+  if (cls == 1 && gc >= 128 && base >= min_units1w) return 1;
   return base >= (cls == 1 ? min_units1 : min_units0) ? 1 : 0;
 }
 
