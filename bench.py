@@ -424,14 +424,20 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
     wino_saved = sum(v["flops"] * (1.0 - 1.0 / mfma_factor(k)) for k, v in kern.items())   # FLOPs Winograd does not execute
     # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the
     # figure comes from the committed rocprofv3 --pmc summary of this same command (tools/pmc_kernels.py), if any
-    traffic, traffic_src = None, None
-    for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    # (newest round first; a file whose rows do not hold this kernel's exact name is skipped, never half-used).  The same
+    # file's step totals give the counter-side HBM fraction of the whole step.
+    traffic, traffic_src, step_counter_bytes = None, None, None
+    for cand in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", cand)
-        if os.path.exists(pmc) and wl == "ddpm32" and gb == 128 and world == 1:
+        if traffic is None and os.path.exists(pmc) and wl == "ddpm32" and gb == 128 and world == 1:
             with open(pmc) as fh:
-                t = json.load(fh).get("kernels", {}).get(name)
+                doc = json.load(fh)
+            t = doc.get("kernels", {}).get(name)
             if t:
                 traffic, traffic_src = t["traffic_bytes_per_launch"], f"profiles/{cand}"
+                st = doc.get("step_total") or {}
+                if "fetch_bytes" in st and "write_bytes" in st:
+                    step_counter_bytes = st["fetch_bytes"] + st["write_bytes"]
     flop_per_img, bytes_per_img, bytes_per_step, detail = info["work"]()
     roof = {"bound": "mfma", "kernel": name, "achieved": round(exe_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(exe_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -441,6 +447,10 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
             "launches_per_step": round(d["launches"] / n_instr, 2), "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": round(d.get("bytes", 0) / max(d["launches"], 1)) or None,
+            "traffic_over_algorithmic": (round(traffic / (d["bytes"] / d["launches"]), 3)
+                                         if traffic and d.get("bytes") else None),
+            "kernel_hbm_counter_frac_of_8TBps": (round(traffic / (d["ms"] * 1e-3 / d["launches"]) / HBM_PEAK, 4)
+                                                 if traffic else None),
             "note": ("achieved / frac count the FLOPs the MFMA pipe EXECUTES: a Winograd F(2x2,3x3) kernel executes "
                      "algorithmic / 2.25, an F(4x4,3x3) kernel (wino4) algorithmic / 4; algorithmic_tflops is the "
                      "direct-convolution count over the same time"),
@@ -463,6 +473,12 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
     roof["ceiling_img_per_s"] = round(FP32_MFMA_PEAK_TFLOPS * 1e12 * world / exe_per_img, 1)
     roof["ceiling_img_per_s_direct_conv"] = round(FP32_MFMA_PEAK_TFLOPS * 1e12 * world / flop_per_img, 1)
     roof["hbm_frac_of_8TBps"] = round(value / world * (bytes_per_img + bytes_per_step / per_gpu) / HBM_PEAK, 4)
+    # the same fraction from the counters (FETCH_SIZE + WRITE_SIZE of one step, committed PMC passes) over THIS run's step time
+    roof["hbm_counter_bytes_per_step"] = step_counter_bytes
+    roof["hbm_counter_frac_of_8TBps"] = (round(step_counter_bytes / (ms * 1e-3) / HBM_PEAK, 4)
+                                         if step_counter_bytes else None)
+    roof["hbm_counter_over_algorithmic"] = (round(step_counter_bytes / (per_gpu * bytes_per_img + bytes_per_step), 3)
+                                            if step_counter_bytes else None)
     if detail:
         roof["work"] = detail
     conv_mode = "bf16x3 (LGM_CONV_MODE)" if ops.B3 else (

@@ -39,7 +39,9 @@
 extern "C" {
 #endif
 
-#define LGM_ABI_VERSION 2   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial */
+#define LGM_ABI_VERSION 3   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial;
+                             * 3: lgm_conv3x3_wino4*, lgm_gn_fwd_stats, lgm_conv3x3_wino_wgradn* + LgmWgradItem, a negative
+                             *    dst offset in lgm_wino_weights table rows means "skip that copy", lgm_kernel_name* */
 #define LGM_OK 0
 #define LGM_ERR_INVALID (-1)
 #define LGM_ERR_UNSUPPORTED (-2)
@@ -49,6 +51,11 @@ const char* lgm_last_error(void);
 /* diagnostic: name (as rocprofv3 prints it, without the argument list) of the primary kernel launched by the calling
  * thread's last convolution-family call (lgm_conv_xy / _yx / _wgrad / lgm_conv3x3_wino) */
 const char* lgm_last_kernel(void);
+/* diagnostic: every name lgm_last_kernel() can ever return (one entry per site in the library that notes a name, in link
+ * order; duplicates possible).  Each is a prefix of the demangled name of a kernel in liblgm_hip.so - checked on the CPU by
+ * tests/test_cabi.py, so that bench.py's per-kernel attribution and the rocprofv3 rows under profiles/ cannot drift apart. */
+int lgm_kernel_name_count(void);
+const char* lgm_kernel_name(int i);
 
 /* ---------------------------------------------------------------------------------------
  * Convolution family (implicit GEMM on v_mfma_f32_32x32x2_f32, exact fp32).

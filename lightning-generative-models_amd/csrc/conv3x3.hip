@@ -1189,7 +1189,7 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
     }                                                                                                  \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                    \
   } while (0)
-  lgm_note_kernel(mode == MODE_XY ? "lgm3x3::conv3x3_kernel<0>" : mode == MODE_YX ? "lgm3x3::conv3x3_kernel<1>" : "lgm3x3::conv3x3_kernel<2>");
+  lgm_note_kernel(mode == MODE_XY ? LGM_KNAME("lgm3x3::conv3x3_kernel<0>") : mode == MODE_YX ? LGM_KNAME("lgm3x3::conv3x3_kernel<1>") : LGM_KNAME("lgm3x3::conv3x3_kernel<2>"));
   if (mode == MODE_XY) LGM_C3_LAUNCH(MODE_XY);
   else if (mode == MODE_YX) LGM_C3_LAUNCH(MODE_YX);
   else LGM_C3_LAUNCH(MODE_YXT);
@@ -1355,7 +1355,7 @@ int lgm_wgrad3x3_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
       attr = smem;                                                                                     \
     }                                                                                                  \
-    lgm_note_kernel("lgm3x3::wgrad3x3_kernel<" #TWV ", " #GSV ">");                                    \
+    lgm_note_kernel(LGM_KNAME("lgm3x3::wgrad3x3_kernel<" #TWV ", " #GSV ">"));                                    \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                    \
   } while (0)
 #define LGM_W3_LAUNCH(TWV)                                                                             \

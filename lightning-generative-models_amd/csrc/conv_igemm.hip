@@ -615,6 +615,26 @@ struct PairCtx {
 };
 static thread_local PairCtx t_pair = {};
 
+struct IgemmName { char c[64]; };
+constexpr IgemmName igemm_name(int mode, int bm, int bn, int tm, int tn, bool uni) {
+  IgemmName r = {};
+  int n = 0;
+  const char* head = "igemm_kernel<";
+  for (int i = 0; head[i]; ++i) r.c[n++] = head[i];
+  const int v[5] = {mode, bm, bn, tm, tn};
+  for (int k = 0; k < 5; ++k) {
+    char d[8] = {};
+    int nd = 0, x = v[k];
+    do { d[nd++] = (char)('0' + x % 10); x /= 10; } while (x);
+    while (nd) r.c[n++] = d[--nd];
+    r.c[n++] = ',';
+    r.c[n++] = ' ';
+  }
+  const char* tail = uni ? "true>" : "false>";
+  for (int i = 0; tail[i]; ++i) r.c[n++] = tail[i];
+  return r;
+}
+
 template <int MODE, int BM, int BN, int TM, int TN, bool UNI>
 int launch_igemm_t(IgemmArgs& a, hipStream_t s) {
   a.tiles_m = lgm_cdiv(a.M, BM);
@@ -628,9 +648,10 @@ int launch_igemm_t(IgemmArgs& a, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  static char name[64] = "";
-  if (!name[0]) snprintf(name, sizeof(name), "igemm_kernel<%d, %d, %d, %d, %d, %s>", MODE, BM, BN, TM, TN, UNI ? "true" : "false");
-  lgm_note_kernel(name);
+  // the instantiation's name as the profiler prints it, built at compile time so that it can sit in the name registry
+  static constexpr IgemmName name = igemm_name(MODE, BM, BN, TM, TN, UNI);
+  static const char* const name_reg __attribute__((section("lgm_knames"), used)) = name.c;
+  lgm_note_kernel(name_reg);
   if (MODE == MODE_YX && BM == 64 && BN == 64 && UNI && t_pair.active && !t_pair.rec_i && !a.stats) {
     t_pair.ig = a;                                   // launched by lgm_conv_bwd_pair, together with the weight gradient
     t_pair.ig_smem = smem;
@@ -852,11 +873,11 @@ static int conv_xy_impl(const LgmConvGeom* g, const float* x, int64_t x_pitch, c
                               (hipStream_t)stream);
   if (use_3x3() && use_gstream() && wide_ok(y, y_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 &&
       g->stride == 1 && g->pad == 0 && lgm_gemm_stream_supported((long)g->B * g->H * g->W, g->Nw, g->Cw, x_pitch, y_pitch, res ? res_pitch : 0))
-    return lgm_note_kernel("gemm_stream_kernel"), lgm_gemm_stream_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch,
+    return lgm_note_kernel(LGM_KNAME("gemm_stream_kernel")), lgm_gemm_stream_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch,
                                                                         (long)g->B * g->H * g->W, g->Nw, g->Cw, (hipStream_t)stream);
   if (use_3x3() && wide_ok(y, y_pitch, res, res_pitch, bias) && g->KH == 1 && g->KW == 1 && g->stride == 1 &&
       g->pad == 0 && lgm_gemm_rows_supported((long)g->B * g->H * g->W, g->Nw, g->Cw))
-    return lgm_note_kernel("gemm_rows_kernel"), lgm_gemm_rows_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch,
+    return lgm_note_kernel(LGM_KNAME("gemm_rows_kernel")), lgm_gemm_rows_launch(x, x_pitch, w, bias, res, res_pitch, y, y_pitch,
                                                                     (long)g->B * g->H * g->W, g->Nw, g->Cw, (hipStream_t)stream);
   IgemmArgs a{};
   a.a = x; a.w = w; a.bias = bias; a.res = res; a.out = y;
@@ -1672,12 +1693,12 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
     if (int rc = lgm_wino_wgrad_launch(g, y, y_pitch, x, x_pitch, a.out, gbias ? 1 : 0, a.slab, a.splits, cpsw, totalw, s))
       return rc;
   } else if (fast3) {
-    lgm_note_kernel("lgm3x3::wgrad3x3_kernel");
+    lgm_note_kernel(LGM_KNAME("lgm3x3::wgrad3x3_kernel"));
     if (int rc = lgm_wgrad3x3_launch(g, y, y_pitch, x, x_pitch, a.out, a.bias_out, beta, a.slab, a.splits, tps3,
                                      total3, s))
       return rc;
   } else if (fast1) {
-    lgm_note_kernel("wgrad1x1_kernel");
+    lgm_note_kernel(LGM_KNAME("wgrad1x1_kernel"));
     if (int rc = lgm_wgrad1x1_launch(g, y, y_pitch, x, x_pitch, a.out, a.bias_out, beta, a.slab, a.splits, per1, s))
       return rc;
   } else {
@@ -1692,8 +1713,8 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
     // and these layers need the parallelism more than the operand reuse.
     static const bool want_big = getenv("LGM_WGRAD_BIG") != nullptr;
     const bool big = fast && want_big && a.Nw % 128 == 0 && (long)(a.Nw / 128) * a.tiles_n * a.splits >= 512;
-    lgm_note_kernel(big ? "wgrad_kernel<128, 64, 2, 1, true>"
-                        : fast ? "wgrad_kernel<64, 64, 1, 1, true>" : "wgrad_kernel<64, 64, 1, 1, false>");
+    lgm_note_kernel(big ? LGM_KNAME("wgrad_kernel<128, 64, 2, 1, true>")
+                        : fast ? LGM_KNAME("wgrad_kernel<64, 64, 1, 1, true>") : LGM_KNAME("wgrad_kernel<64, 64, 1, 1, false>"));
     static_assert(sizeof(WgradArgs) <= sizeof(t_pair.wg), "PairCtx::wg too small");
     a.swz = swz_on();
     if (!big && fast && t_pair.active && !t_pair.rec_w) {       // launched by lgm_conv_bwd_pair, with the input gradient
@@ -1856,12 +1877,12 @@ static int conv_bwd_pair_impl(const LgmConvGeom* g, const float* gy, int64_t gy_
                           (int)c.ig_smem);
       attr = c.ig_smem;
     }
-    lgm_note_kernel("gemm_bwd_pair_kernel");
+    lgm_note_kernel(LGM_KNAME("gemm_bwd_pair_kernel"));
     hipLaunchKernelGGL(gemm_bwd_pair_kernel, dim3(c.ig_blocks + c.wg_blocks), dim3(256), c.ig_smem, s, c.ig, wa,
                        (int)c.ig_blocks);
   } else {
     if (c.rec_w) {
-      lgm_note_kernel("wgrad_kernel<64, 64, 1, 1, true>");
+      lgm_note_kernel(LGM_KNAME("wgrad_kernel<64, 64, 1, 1, true>"));
       hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1, true>), dim3(c.wg_blocks), dim3(256), 0, s, wa);
     }
     if (c.rec_i) {
@@ -1988,7 +2009,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const long long
 
 extern "C" int lgm_wgrad_reduce_batch(const int64_t* table, int n_entries, int64_t total_blocks, void* stream) {
   LGM_REQUIRE(table && n_entries > 0 && total_blocks > 0, "wgrad_reduce_batch: bad arguments");
-  lgm_note_kernel("wgrad_reduce_batch_kernel");
+  lgm_note_kernel(LGM_KNAME("wgrad_reduce_batch_kernel"));
   hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const long long*>(table), n_entries);
   LGM_LAUNCH_CHECK();

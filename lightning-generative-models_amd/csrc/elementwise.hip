@@ -18,6 +18,13 @@ extern "C" const char* lgm_last_error(void) { return g_err; }
 static thread_local const char* g_kernel = "";
 void lgm_note_kernel(const char* name) { g_kernel = name; }
 extern "C" const char* lgm_last_kernel(void) { return g_kernel; }
+// the name registry: one pointer per LGM_KNAME site of the whole library (section bounds from the linker)
+extern "C" const char* const __start_lgm_knames[];
+extern "C" const char* const __stop_lgm_knames[];
+extern "C" int lgm_kernel_name_count(void) { return (int)(__stop_lgm_knames - __start_lgm_knames); }
+extern "C" const char* lgm_kernel_name(int i) {
+  return (i >= 0 && i < lgm_kernel_name_count()) ? __start_lgm_knames[i] : nullptr;
+}
 extern "C" int lgm_abi_version(void) { return LGM_ABI_VERSION; }
 
 namespace {

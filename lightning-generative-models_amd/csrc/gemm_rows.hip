@@ -167,7 +167,7 @@ int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const flo
       hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr = smem;
     }
-    lgm_note_kernel("gemm_rows_kernel<2>");
+    lgm_note_kernel(LGM_KNAME("gemm_rows_kernel<2>"));
     hipLaunchKernelGGL(gemm_rows_kernel<2>, dim3(nblocks), dim3(256), smem, s, p);
   } else {
     static size_t attr = 0;
@@ -175,7 +175,7 @@ int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const flo
       hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr = smem;
     }
-    lgm_note_kernel("gemm_rows_kernel<1>");
+    lgm_note_kernel(LGM_KNAME("gemm_rows_kernel<1>"));
     hipLaunchKernelGGL(gemm_rows_kernel<1>, dim3(nblocks), dim3(256), smem, s, p);
   }
   LGM_LAUNCH_CHECK();

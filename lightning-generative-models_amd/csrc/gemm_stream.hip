@@ -253,7 +253,7 @@ int lgm_gemm_stream_launch(const float* x, long x_pitch, const float* w, const f
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    lgm_note_kernel("gemm_stream_kernel<" #KQV ", " #TNV ", " #RESV ">");                                              \
+    lgm_note_kernel(LGM_KNAME("gemm_stream_kernel<" #KQV ", " #TNV ", " #RESV ">"));                                              \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                                    \
   } while (0)
 #define LGM_GS_LAUNCH(KQV, TNV)                    \

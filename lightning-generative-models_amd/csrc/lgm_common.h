@@ -14,6 +14,15 @@ void lgm_set_error(const char* fmt, ...);
 // name (as rocprofv3 prints it, without the argument list) of the primary kernel the calling thread's last
 // convolution-family entry point launched: lets bench.py attribute its HIP-event timings to profiler rows
 void lgm_note_kernel(const char* name);
+// Every name handed to lgm_note_kernel goes through LGM_KNAME: the literal's address is also placed in the ELF section
+// "lgm_knames" at link time (no code runs), so lgm_kernel_name(i) can list every name the library may ever note and
+// tests/test_cabi.py checks each against the kernel symbols of liblgm_hip.so - a template argument added to a kernel
+// can no longer silently detach bench.py's per-kernel attribution from the profiler's rows.
+#define LGM_KNAME(lit)                                                                                          \
+  ([]() -> const char* {                                                                                        \
+    static const char* const lgm_kn_ __attribute__((section("lgm_knames"), used)) = lit;                        \
+    return lgm_kn_;                                                                                             \
+  }())
 
 #define LGM_REQUIRE(cond, ...)              \
   do {                                      \

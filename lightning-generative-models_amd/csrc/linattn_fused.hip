@@ -354,7 +354,7 @@ int lgm_linattn_bwd_fused_launch(const float* qkv, long pitch, const float* gout
   a.slabs = slabs; a.n = n; a.scale = scale;
   const int blocks = plan_blocks(B, n, &a.tiles, &a.items, &a.per);
   *blocks_out = blocks;
-  lgm_note_kernel("linattn_bwd_fused_kernel");
+  lgm_note_kernel(LGM_KNAME("linattn_bwd_fused_kernel"));
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_bwd_fused_kernel),
@@ -572,8 +572,8 @@ int lgm_linattn_out_fused_launch(const float* qkv, long pitch, const float* ctx,
   const int nb = a.items < slots ? a.items : slots;
   a.per = lgm_cdiv(a.items, nb);
   const int blocks = lgm_cdiv(a.items, a.per);
-  lgm_note_kernel(Cout == 64 ? "linattn_out_fused_kernel<2>" : Cout == 128 ? "linattn_out_fused_kernel<4>"
-                                                                             : "linattn_out_fused_kernel<8>");
+  lgm_note_kernel(Cout == 64 ? LGM_KNAME("linattn_out_fused_kernel<2>") : Cout == 128 ? LGM_KNAME("linattn_out_fused_kernel<4>")
+                                                                             : LGM_KNAME("linattn_out_fused_kernel<8>"));
   if (Cout == 64) return launch_out<2>(a, blocks, s);
   if (Cout == 128) return launch_out<4>(a, blocks, s);
   return launch_out<8>(a, blocks, s);
@@ -732,7 +732,7 @@ extern "C" int lgm_rms_qkv_fused(const float* x, int64_t x_pitch, const float* g
   const int nb = a.items < slots ? a.items : slots;
   a.per = lgm_cdiv(a.items, nb);
   const int blocks = lgm_cdiv(a.items, a.per);
-  lgm_note_kernel(C == 64 ? "rms_qkv_fused_kernel<2>" : C == 128 ? "rms_qkv_fused_kernel<4>" : "rms_qkv_fused_kernel<8>");
+  lgm_note_kernel(C == 64 ? LGM_KNAME("rms_qkv_fused_kernel<2>") : C == 128 ? LGM_KNAME("rms_qkv_fused_kernel<4>") : LGM_KNAME("rms_qkv_fused_kernel<8>"));
   hipStream_t s = (hipStream_t)stream;
   if (C == 64) return launch_qkv<2>(a, blocks, s);
   if (C == 128) return launch_qkv<4>(a, blocks, s);

@@ -131,7 +131,7 @@ extern "C" int lgm_resstack_fwd(const float* x, int64_t x_pitch, int B, int H, i
                     lgm_aligned16(z[l]), "resstack_fwd: layer %d: null / unaligned pointer", l);
     a.w3[l] = w3[l]; a.w1[l] = w1[l]; a.y[l] = y[l]; a.z[l] = z[l];
   }
-  lgm_note_kernel("resstack_fwd_kernel");
+  lgm_note_kernel(LGM_KNAME("resstack_fwd_kernel"));
   hipLaunchKernelGGL(resstack_fwd_kernel, dim3((unsigned)lgm_cdiv(a.rows, 32)), dim3(256), 0, (hipStream_t)stream, a);
   LGM_LAUNCH_CHECK();
   return LGM_OK;

@@ -273,7 +273,7 @@ int lgm_wgrad1x1_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    lgm_note_kernel("wgrad1x1_kernel<" #TNV ", " #TKV ">");                                                            \
+    lgm_note_kernel(LGM_KNAME("wgrad1x1_kernel<" #TNV ", " #TKV ">"));                                                            \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                                    \
   } while (0)
   if (NB == 128 && KB == 128) LGM_W1_LAUNCH(2, 2);

@@ -878,8 +878,8 @@ int lgm_wino_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, 
     }                                                                                                           \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                             \
   } while (0)
-  lgm_note_kernel(TTW == 8 ? "lgmwino::wino_conv_kernel<8, false, 0>" : TTW == 4 ? "lgmwino::wino_conv_kernel<4, false, 0>"
-                                                                                : "lgmwino::wino_conv_kernel<2, false, 0>");
+  lgm_note_kernel(TTW == 8 ? LGM_KNAME("lgmwino::wino_conv_kernel<8, false, 0>") : TTW == 4 ? LGM_KNAME("lgmwino::wino_conv_kernel<4, false, 0>")
+                                                                                : LGM_KNAME("lgmwino::wino_conv_kernel<2, false, 0>"));
   if (!p.dbg) {
     if (TTW == 8) LGM_WLAUNCH(8, false, 0);
     else if (TTW == 4) LGM_WLAUNCH(4, false, 0);
@@ -1484,8 +1484,8 @@ int lgm_wino_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, co
     }                                                                                                            \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, p);                                              \
   } while (0)
-  lgm_note_kernel(G == 8 ? "lgmwino::wino_wgrad_kernel<8, false>" : G == 4 ? "lgmwino::wino_wgrad_kernel<4, false>"
-                                                                          : "lgmwino::wino_wgrad_kernel<2, false>");
+  lgm_note_kernel(G == 8 ? LGM_KNAME("lgmwino::wino_wgrad_kernel<8, false>") : G == 4 ? LGM_KNAME("lgmwino::wino_wgrad_kernel<4, false>")
+                                                                          : LGM_KNAME("lgmwino::wino_wgrad_kernel<2, false>"));
   p.dbg = (long long*)lgm_wino_debug_buffer;
   if (p.dbg && G == 8) {
     auto kern = wino_wgrad_kernel<8, true>;
@@ -1700,9 +1700,9 @@ extern "C" int lgm_conv3x3_wino_wgradn(int n, const LgmWgradItem* it, void* stre
     }                                                                                                            \
   } while (0)
   if (n == 2)
-    lgm_note_kernel(G == 8 ? "lgmwino::wino_wgrad2_kernel<8>" : G == 4 ? "lgmwino::wino_wgrad2_kernel<4>" : "lgmwino::wino_wgrad2_kernel<2>");
+    lgm_note_kernel(G == 8 ? LGM_KNAME("lgmwino::wino_wgrad2_kernel<8>") : G == 4 ? LGM_KNAME("lgmwino::wino_wgrad2_kernel<4>") : LGM_KNAME("lgmwino::wino_wgrad2_kernel<2>"));
   else
-    lgm_note_kernel(G == 8 ? "lgmwino::wino_wgrad4_kernel<8>" : G == 4 ? "lgmwino::wino_wgrad4_kernel<4>" : "lgmwino::wino_wgrad4_kernel<2>");
+    lgm_note_kernel(G == 8 ? LGM_KNAME("lgmwino::wino_wgrad4_kernel<8>") : G == 4 ? LGM_KNAME("lgmwino::wino_wgrad4_kernel<4>") : LGM_KNAME("lgmwino::wino_wgrad4_kernel<2>"));
   if (G == 8) LGM_WGN(8);
   else if (G == 4) LGM_WGN(4);
   else LGM_WGN(2);
@@ -1857,8 +1857,8 @@ int lgm_wino_pair_launch(const LgmConvGeom* g, const float* gy, long gy_pitch, c
     }                                                                                                            \
     hipLaunchKernelGGL(kern, dim3(nconv + nw), dim3(256), smem, s, pc, pw, (int)nconv);                          \
   } while (0)
-  lgm_note_kernel(G == 8 ? "lgmwino::wino_bwd_pair_kernel<8>" : G == 4 ? "lgmwino::wino_bwd_pair_kernel<4>"
-                                                                        : "lgmwino::wino_bwd_pair_kernel<2>");
+  lgm_note_kernel(G == 8 ? LGM_KNAME("lgmwino::wino_bwd_pair_kernel<8>") : G == 4 ? LGM_KNAME("lgmwino::wino_bwd_pair_kernel<4>")
+                                                                        : LGM_KNAME("lgmwino::wino_bwd_pair_kernel<2>"));
   if (G == 8) LGM_PAIR(8);
   else if (G == 4) LGM_PAIR(4);
   else LGM_PAIR(2);

@@ -665,8 +665,8 @@ int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch,
     }                                                                                                           \
     hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(512), smem, s, p);                                   \
   } while (0)
-  lgm_note_kernel(cls == 0 ? "lgmwino4::wino4_conv_kernel<0, false, 0>" : cls == 1 ? "lgmwino4::wino4_conv_kernel<1, false, 0>"
-                                                                                    : "lgmwino4::wino4_conv_kernel<2, false, 0>");
+  lgm_note_kernel(cls == 0 ? LGM_KNAME("lgmwino4::wino4_conv_kernel<0, false, 0, false>") : cls == 1 ? LGM_KNAME("lgmwino4::wino4_conv_kernel<1, false, 0, false>")
+                                                                                    : LGM_KNAME("lgmwino4::wino4_conv_kernel<2, false, 0, false>"));
   if (p.dbg) {
     const int e = lgm_wino4_debug_exp;
     if (cls == 1) LGM_W4LAUNCH(1, true, 0);
@@ -690,7 +690,7 @@ int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch,
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr = true;
     }
-    lgm_note_kernel("lgmwino4::wino4_conv_kernel<0, false, 0, true>");
+    lgm_note_kernel(LGM_KNAME("lgmwino4::wino4_conv_kernel<0, false, 0, true>"));
     hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(512), smem, s, p);
   } else if (cls == 0) LGM_W4LAUNCH(0, false, 0);
   else if (cls == 1) LGM_W4LAUNCH(1, false, 0);

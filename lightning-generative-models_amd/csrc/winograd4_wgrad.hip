@@ -496,7 +496,7 @@ int lgm_wino4_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, c
                               (int)kW4Smem);
     attr = true;
   }
-  lgm_note_kernel("lgmwino4w::wino4_wgrad_kernel");
+  lgm_note_kernel(LGM_KNAME("lgmwino4w::wino4_wgrad_kernel"));
   hipLaunchKernelGGL(wino4_wgrad_kernel, dim3(nblocks), dim3(512), kW4Smem, s, p);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
@@ -519,7 +519,7 @@ int lgm_wino4_wgrad2_launch(const LgmConvGeom* const* gs, const float* const* ys
                               (int)kW4Smem);
     attr = true;
   }
-  lgm_note_kernel("lgmwino4w::wino4_wgrad2_kernel");
+  lgm_note_kernel(LGM_KNAME("lgmwino4w::wino4_wgrad2_kernel"));
   hipLaunchKernelGGL(wino4_wgrad2_kernel, dim3(nb[0] + nb[1]), dim3(512), kW4Smem, s, pp[0], pp[1], (int)nb[0]);
   LGM_LAUNCH_CHECK();
   return LGM_OK;

@@ -15,6 +15,7 @@ import signal
 import socket
 import subprocess
 import sys
+import threading
 from typing import List, Optional, Sequence
 
 _VISIBLE_VARS = ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
@@ -96,20 +97,52 @@ def spawn_ranks(script: str, argv: Sequence[str], nproc: int, *, extra_env: Opti
         timeout = float(os.environ["LGM_LAUNCH_TIMEOUT"])
     print(f"[launch] starting {nproc} ranks: {' '.join(cmd[1:])}", file=sys.stderr, flush=True)
     proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    # The ranks live in their own session: a SIGTERM / SIGHUP / SIGINT that ends THIS process (``timeout -k``, a
+    # scheduler, a closed terminal) would otherwise leave them running and holding the GPUs.  While the child runs the
+    # signals are turned into an exception, so the ``finally``-like paths below end exactly the group started here.
+    caught: List[int] = []
+
+    def _on_signal(signum, _frame):
+        caught.append(signum)
+        raise _Interrupted(signum)
+
+    old = {}
+    if threading.current_thread() is threading.main_thread():
+        for sig in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+            try:
+                old[sig] = signal.signal(sig, _on_signal)
+            except (ValueError, OSError):
+                pass
     try:
         return int(proc.wait(timeout=timeout))
     except subprocess.TimeoutExpired:
         print(f"[launch] {nproc}-rank run exceeded {timeout:.0f} s: ending its process group", file=sys.stderr, flush=True)
         _end_group(proc)
         return 124
+    except _Interrupted as e:
+        print(f"[launch] signal {e.signum}: ending the {nproc}-rank process group", file=sys.stderr, flush=True)
+        for sig in old:                      # a second signal while the group is being ended must not re-enter
+            signal.signal(sig, signal.SIG_IGN)
+        _end_group(proc, first=e.signum if e.signum != signal.SIGHUP else signal.SIGTERM)
+        return 128 + int(e.signum)
     except BaseException:
         _end_group(proc)
         raise
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
 
 
-def _end_group(proc: subprocess.Popen) -> None:
-    """SIGTERM, then SIGKILL, to exactly the process group this module started."""
-    for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+class _Interrupted(Exception):
+    def __init__(self, signum: int):
+        super().__init__(f"signal {signum}")
+        self.signum = signum
+
+
+def _end_group(proc: subprocess.Popen, first: int = signal.SIGTERM) -> None:
+    """``first`` (SIGTERM unless a caught signal is being forwarded), then SIGKILL, to exactly the process group this
+    module started."""
+    for sig, wait in ((first, 10.0), (signal.SIGKILL, 5.0)):
         try:
             os.killpg(proc.pid, sig)
         except (ProcessLookupError, PermissionError):

@@ -597,7 +597,9 @@ def wgrad_group_supported(geoms) -> bool:
     key = tuple(_gkey(g) for g in geoms)
     v = _WG2_OK.get(key)
     if v is None:
-        v = bool(lib().lgm_conv3x3_wino_wgradn_supported(len(geoms), ctypes.addressof(_geom_array(geoms))))
+        arr = _geom_array(geoms)        # bound to a local: the C side reads it during the call
+        v = bool(lib().lgm_conv3x3_wino_wgradn_supported(len(geoms), ctypes.addressof(arr)))
+        del arr
         _WG2_OK[key] = v
     return v
 
@@ -626,7 +628,9 @@ def conv_wgrad_group(entries, defer):
     need = _WG2_WS.get(wkey)
     if need is None:
         out = (ctypes.c_int64 * n)()
-        L.lgm_conv3x3_wino_wgradn_workspaces(n, ctypes.addressof(_geom_array(geoms)), ctypes.addressof(out))
+        arr = _geom_array(geoms)        # bound to a local: the C side reads it during the call
+        L.lgm_conv3x3_wino_wgradn_workspaces(n, ctypes.addressof(arr), ctypes.addressof(out))
+        del arr
         # never smaller than the single-layer plan's need: the same slab buffer serves a layer whichever way it runs
         need = tuple(max(int(out[k]), int(L.lgm_conv_wgrad_workspace(ctypes.byref(g)))) for k, g in enumerate(geoms))
         _WG2_WS[wkey] = need

@@ -42,6 +42,16 @@ seed_everything(seed=10, workers=True)
 EXPERIMENT_TIME = datetime.now().strftime("%Y-%m-%d_%H:%M")
 
 
+def check_precision(value):
+    """``--precision`` is handed to ``pl.Trainer(precision=...)`` by the reference (train.py:40,132); its default ``None``
+    is Lightning's "32-true".  This engine computes in fp32 only (exact fp32 MFMA, parity at 1e-4): the fp32 spellings are
+    accepted, anything else is an error instead of a silent fp32 run."""
+    if value is None or str(value) in ("32", "32-true"):
+        return None if value is None else str(value)
+    raise SystemExit(f"--precision {value!r}: this engine trains in fp32 only (accepted: omitted, 32, 32-true); "
+                     "mixed / half / double precision of the reference's Trainer is not implemented")
+
+
 def setup_arguments(argv=None, print_args=True, save_args=True):
     p = argparse.ArgumentParser("Train script")
     p.add_argument("--config_path", type=str, required=True, help="Path to configs")
@@ -61,6 +71,7 @@ def setup_arguments(argv=None, print_args=True, save_args=True):
     p.add_argument("--devices", type=str, default="auto",
                    help="ranks to run as (Lightning's Trainer(devices=...)): auto = every visible GPU, like the reference")
     args = p.parse_args(argv)
+    args.precision = check_precision(args.precision)
     args.config = load_config(args.config_path)
     args.experiment_dir = os.path.join(EXPERIMENT_DIR, args.config["model"]["name"], args.experiment_name)
     os.makedirs(args.experiment_dir, exist_ok=True)

@@ -26,7 +26,7 @@ def test_header_parses_and_library_exports_all_symbols():
 
 def test_abi_version_and_error_string():
     L = _lib.lib()
-    assert L.lgm_abi_version() == _lib.ABI_VERSION == 2        # the loader refuses a library built for another ABI
+    assert L.lgm_abi_version() == _lib.ABI_VERSION == 3        # the loader refuses a library built for another ABI
     # invalid-argument path works without a GPU: null geometry is rejected before any launch
     with pytest.raises(_lib.LgmError) as e:
         L.lgm_conv_xy(None, None, 0, None, None, None, 0, None, 0, None, 0, None)
@@ -45,3 +45,43 @@ def test_geometry_validation_rejects_inconsistent_shapes():
     with pytest.raises(_lib.LgmError):
         L.lgm_conv_xy(ctypes.byref(g), 16, 4, 16, None, None, 0, 16, 4, None, 0, None)
     assert L.lgm_conv_wgrad_workspace(ctypes.byref(g)) == -1
+
+
+def _kernel_symbols():
+    """Demangled names of the kernels of liblgm_hip.so, normalised as tools/pmc_kernels.py normalises rocprofv3's rows
+    (no return type, no anonymous-namespace qualifier, no argument list).  The host side of a HIP library holds one
+    handle object per kernel under the kernel's own mangled name (and a `__device_stub__` function)."""
+    import re
+    import subprocess
+    out = subprocess.run(["nm", "-C", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    names = set()
+    for ln in out.splitlines():
+        m = re.match(r"^[0-9a-f]+ \w (.*)$", ln)
+        if not m or "__device_stub__" not in m.group(1):
+            continue
+        k = m.group(1).replace("__device_stub__", "").replace("(anonymous namespace)::", "")
+        k = re.sub(r"^void ", "", k)
+        names.add(re.sub(r"\(.*$", "", k).strip())
+    return names
+
+
+def test_every_noted_kernel_name_is_a_kernel_of_the_library():
+    """`lgm_last_kernel()` is how bench.py attributes HIP-event spans to rocprofv3 rows and looks the
+    dominant kernel up in profiles/*_pmc_traffic.json.  A kernel that gained a template argument left a stale name behind
+    for a whole round.  Every name the library can note (the LGM_KNAME registry) must be a prefix of a real kernel name,
+    and a name that carries template arguments must match one exactly."""
+    L = _lib.lib()
+    n = L._dll.lgm_kernel_name_count()
+    assert n >= 40
+    L._dll.lgm_kernel_name.restype = ctypes.c_char_p
+    noted = sorted({L._dll.lgm_kernel_name(i).decode() for i in range(n)})
+    kernels = _kernel_symbols()
+    assert len(kernels) > 100
+    for name in noted:
+        if name.endswith(">"):
+            assert name in kernels, f"noted kernel name {name!r} is not a kernel of liblgm_hip.so"
+        else:
+            assert any(k == name or k.startswith(name + "<") for k in kernels), \
+                f"noted kernel name {name!r} is not a prefix of any kernel of liblgm_hip.so"
+    assert "lgmwino4::wino4_conv_kernel<0, false, 0, false>" in noted
+    assert L._dll.lgm_kernel_name(n) is None and L._dll.lgm_kernel_name(-1) is None

@@ -414,6 +414,64 @@ def test_launcher_counts_devices_without_touching_them_and_reports_a_dead_rank(t
     assert launch.spawn_ranks(str(slow), [], 2, timeout=8) == 124 and time.time() - t0 < 60
 
 
+def test_precision_flag_is_checked_not_ignored():
+    """reference train.py:40,132 passes --precision to pl.Trainer; here only the fp32 spellings exist and anything else
+    must say so."""
+    import train
+    assert train.check_precision(None) is None
+    assert train.check_precision("32") == "32" and train.check_precision("32-true") == "32-true"
+    for bad in ("16-mixed", "bf16-mixed", "16", "64", "bf16-true"):
+        with pytest.raises(SystemExit) as e:
+            train.check_precision(bad)
+        assert "fp32 only" in str(e.value)
+    r = subprocess.run([sys.executable, os.path.join(PKG, "train.py"), "--config_path",
+                        os.path.join(PKG, "configs", "vae", "vae.json"), "--precision", "16-mixed", "--accelerator", "cpu"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "fp32 only" in (r.stderr + r.stdout)
+
+
+def test_a_signal_to_the_launching_parent_ends_its_ranks(tmp_path):
+    """the ranks run in their own session; SIGTERM to the parent (``timeout -k``, a scheduler) must end them
+    too.  The parent here is a real child process of the test so that the signal goes to exactly one PID."""
+    import signal
+    import subprocess
+    import time
+    slow = tmp_path / "slow_rank.py"
+    slow.write_text("import os, time\nopen(os.environ['PIDDIR'] + '/' + str(os.getpid()), 'w').close()\ntime.sleep(600)\n")
+    piddir = tmp_path / "pids"
+    piddir.mkdir()
+    parent = tmp_path / "parent.py"
+    parent.write_text(
+        "import sys\nsys.path.insert(0, %r)\nfrom lgm_hip import launch\n"
+        "sys.exit(launch.spawn_ranks(%r, [], 2, extra_env={'PIDDIR': %r}))\n" % (PKG, str(slow), str(piddir)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    proc = subprocess.Popen([sys.executable, str(parent)], env=env)
+    try:
+        t0 = time.time()
+        while len(os.listdir(piddir)) < 2 and time.time() - t0 < 90:
+            time.sleep(0.2)
+        pids = [int(x) for x in os.listdir(piddir)]
+        assert len(pids) == 2, "the two ranks never started"
+        proc.send_signal(signal.SIGTERM)
+        rc = proc.wait(timeout=40)
+        assert rc == 128 + signal.SIGTERM
+        t0 = time.time()
+        alive = pids
+        while alive and time.time() - t0 < 20:
+            alive = [p for p in alive if os.path.exists(f"/proc/{p}") and
+                     open(f"/proc/{p}/stat").read().split(")")[-1].split()[0] != "Z"]
+            time.sleep(0.2)
+        assert not alive, f"ranks {alive} outlived their launcher"
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+        for x in os.listdir(piddir):
+            try:
+                os.kill(int(x), signal.SIGKILL)
+            except (ProcessLookupError, ValueError):
+                pass
+
+
 def test_sync_dist_logging_is_shape_safe_gloo_world2(tmp_path):
     """a scalar logged with sync_dist=True under a rank-dependent condition must not leave the ranks in
     mismatched collectives: every rank raises the same error; names registered but not logged on a rank average over

@@ -454,13 +454,28 @@ def test_two_layers_weight_gradients_in_one_launch(dev, pair, parity):
         gk, yk, xk = layers[k % 2]
         gws4.append(torch.full((yk.shape[-1], 9, xk.shape[-1]), float("nan"), device=dev))
         ents.append((gk, yk, xk, gws4[-1].data_ptr(), 0.0, None))
-    if ops.wgrad_group_supported([e[0] for e in ents]):
-        rows = []
-        ops.conv_wgrad_group(ents, rows)
-        assert "wino_wgrad4_kernel" in ops.lib()._dll.lgm_last_kernel().decode() and len(rows) == 4
-        ops.wgrad_reduce_batch(rows, dev)
-        for k in range(4):
-            parity(f"four layers in one launch, layer {k}", maxerr(gws4[k], refs[k % 2][0]), 2e-6)
+    # the geometries need <= 256 workgroups: the grouped launch MUST take them (an `if` here hid a
+    # dangling-pointer bug in ops.wgrad_group_supported for two rounds)
+    assert ops.wgrad_group_supported([e[0] for e in ents])
+    rows = []
+    ops.conv_wgrad_group(ents, rows)
+    assert "wino_wgrad4_kernel" in ops.lib()._dll.lgm_last_kernel().decode() and len(rows) == 4
+    ops.wgrad_reduce_batch(rows, dev)
+    for k in range(4):
+        parity(f"four layers in one launch, layer {k}", maxerr(gws4[k], refs[k % 2][0]), 2e-6)
+    # three layers: the budget split for an odd group
+    ents3, gws3 = [], []
+    for k in range(3):
+        gk, yk, xk = layers[(k + 1) % 2]
+        gws3.append(torch.full((yk.shape[-1], 9, xk.shape[-1]), float("nan"), device=dev))
+        ents3.append((gk, yk, xk, gws3[-1].data_ptr(), 0.0, None))
+    assert ops.wgrad_group_supported([e[0] for e in ents3])
+    rows = []
+    ops.conv_wgrad_group(ents3, rows)
+    assert "wino_wgrad4_kernel" in ops.lib()._dll.lgm_last_kernel().decode() and len(rows) == 3
+    ops.wgrad_reduce_batch(rows, dev)
+    for k in range(3):
+        parity(f"three layers in one launch, layer {k}", maxerr(gws3[k], refs[(k + 1) % 2][0]), 2e-6)
 
 
 # ---- Winograd F(4x4, 3x3) weight gradient (csrc/winograd4_wgrad.hip) -----------------------------------------------------
