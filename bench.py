@@ -382,6 +382,24 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
     final_loss = float(loss.item()) if loss is not None else float("nan")
     ms = elapsed / steps * 1e3
     value = gb * steps / elapsed
+    # N > 1: a few more steps (outside the timed region) with HIP events around the waits for the gradient exchange - how
+    # much of the communication the backward did NOT hide - and the collectives one step issues, for the line's `config`
+    comm = None
+    sync = getattr(info.get("fast"), "sync", None)
+    if world > 1 and sync is not None and not isinstance(sync, dict):
+        sync.measure = True
+        for i in range(min(5, steps)):
+            step(warmup + steps + i)
+        ev_ms, host_ms, n_meas = sync.exposed_ms()
+        sync.measure = False
+        cm = torch.tensor([ev_ms or 0.0, host_ms or 0.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(cm, op=dist.ReduceOp.MAX)
+        comm = {"comm_exposed_ms": round(float(cm[0]), 4), "comm_host_wait_ms": round(float(cm[1]), 4),
+                "comm_measured_steps": n_meas,
+                "bucket_bytes": [4 * int(n) for n in sync.last_buckets], "collectives_per_step": len(sync.last_buckets),
+                "exchange": ("bucketed all-reduce overlapped with the backward" if sync.overlap
+                             else "one all-reduce after the backward (LGM_DDP_OVERLAP=0)"),
+                "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size()}
     if rank == 0:
         print(f"[bench] {wl}: timed region: {steps} steps in {elapsed:.3f}s ({value:.1f} img/s)", file=sys.stderr, flush=True)
     launch = info["fast"].mode if info["fast"] is not None else "eager"
@@ -497,6 +515,11 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
         line["config"]["grad_exchange"] = ("bucketed all-reduce overlapped with the backward (RCCL)"
                                            if os.environ.get("LGM_DDP_OVERLAP", "1") != "0"
                                            else "one all-reduce after the backward (LGM_DDP_OVERLAP=0)")
+        if comm:
+            line["config"].update({k: comm[k] for k in ("bucket_bytes", "collectives_per_step", "backend", "rccl_ranks")})
+            line["comm_exposed_ms"] = comm["comm_exposed_ms"]
+            line["comm_host_wait_ms"] = comm["comm_host_wait_ms"]
+            line["comm_exposed_frac_of_step"] = round(comm["comm_exposed_ms"] / ms, 4) if ms else None
     if world == 1 and cpu and not args.no_cpu_baseline:
         secs = args.cpu_seconds
         if wl == "ddpm32":

@@ -237,6 +237,25 @@ class FlatGradSync:
         self.handles = []
         self.pending = []
         self.covered = 0
+        # self-description for the bench line: the collectives of the last finished step in element
+        # counts, and - while ``measure`` is on - per step the time the launch stream (HIP events around the waits) and
+        # the host (gloo's waits block it) spent waiting for the exchange = the communication that was NOT hidden
+        self.measure = False
+        self.last_buckets = []
+        self._buckets = []
+        self._spans = []
+
+    def exposed_ms(self):
+        """-> (mean stream-side wait per step in ms, mean host-side wait per step in ms, steps) over the steps finished
+        while ``measure`` was on; synchronises the device.  Resets the record."""
+        if not self._spans:
+            return None, None, 0
+        torch.cuda.synchronize()
+        ev = [a.elapsed_time(b) for a, b, _ in self._spans if a is not None]
+        host = [h * 1e3 for _, _, h in self._spans]
+        n = len(self._spans)
+        self._spans = []
+        return (sum(ev) / len(ev) if ev else None), sum(host) / n, n
 
     def ready(self, lo: int, hi: int):
         """-> the asynchronous work handle (None on one rank, and when the exchange is deferred to ``finish``);
@@ -249,6 +268,7 @@ class FlatGradSync:
             return None
         h = dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True)
         self.handles.append(h)
+        self._buckets.append(hi - lo)
         return h
 
     def finish(self):
@@ -265,9 +285,26 @@ class FlatGradSync:
             self.pending = []
             for lo, hi in spans:
                 self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True))
-        for h in self.handles:
-            h.wait()
+                self._buckets.append(hi - lo)
+        if self.measure and self.handles:
+            on_gpu = self.flat.grad.is_cuda
+            e0 = torch.cuda.Event(enable_timing=True) if on_gpu else None
+            e1 = torch.cuda.Event(enable_timing=True) if on_gpu else None
+            if on_gpu:
+                e0.record()
+            t0 = time.perf_counter()
+            for h in self.handles:
+                h.wait()
+            dt = time.perf_counter() - t0
+            if on_gpu:
+                e1.record()
+            self._spans.append((e0, e1, dt))
+        else:
+            for h in self.handles:
+                h.wait()
         self.handles = []
+        if self._buckets:
+            self.last_buckets, self._buckets = self._buckets, []
         if self.world > 1:
             assert self.covered == self.flat.total, \
                 f"gradient buckets covered {self.covered} of {self.flat.total} elements"

@@ -35,6 +35,11 @@ def parity(request):
         print(f"[parity] {request.node.name}: {what}: {err:.3e} (tol {tol:.1e})")
         assert err < tol, rec
         return err
+
+    def record(what, **values):
+        """Put measured values on record without a bound of their own (the asserting comparison is made elsewhere)."""
+        _PARITY_LOG.append({"test": request.node.name, "what": what, **{k: float(v) for k, v in values.items()}})
+    check.record = record
     return check
 
 

@@ -579,6 +579,43 @@ def test_winograd4_forward_leaves_the_groupnorm_statistics(dev, case, parity):
     assert torch.equal(st[:n], st2[:n])
 
 
+def test_epilogue_statistics_survive_a_large_common_offset(dev, parity):
+    """the statistics rows are fp32 sums of y and y^2, and E[y^2] - mean^2 cancels when |mean| >> std inside a
+    group.  Activations with mean 30 and std 0.1 give pre-bias outputs whose per-channel mean is hundreds of standard
+    deviations: lgm_gn_fwd_stats must detect that from the rows and measure the slice itself (float64, two passes).  mean /
+    rstd against float64 statistics of the SAME convolution output, GroupNorm output against the two-pass kernel."""
+    from lgm_hip import ops
+    B, H, W, ci, co, G = 6, 64, 64, 64, 64, 8
+    L = ops.lib()
+    gen = torch.Generator().manual_seed(77)
+    x = (30.0 + 0.1 * torch.randn(B, H, W, ci, generator=gen)).to(dev)
+    w = (torch.randn(co, 9, ci, generator=gen) / (3 * ci ** 0.5)).to(dev)
+    bias = torch.randn(co, generator=gen).to(dev)
+    gamma, beta = (torch.randn(co, generator=gen).to(dev) for _ in range(2))
+    uf, _ = wino4_weights(w)
+    g = ops.make_geom(B, H, W, ci, co, 3, 3, 1, 1)
+    per = ctypes.c_int(0)
+    n = L.lgm_conv3x3_wino4_stats_floats(ctypes.byref(g), ctypes.addressof(per))
+    u = torch.empty(B, H, W, co, device=dev)
+    st = torch.empty(n, device=dev)
+    L.lgm_conv3x3_wino4_stats(ctypes.byref(g), x.data_ptr(), ops.pitch(x), uf.data_ptr(), bias.data_ptr(), u.data_ptr(),
+                              ops.pitch(u), st.data_ptr(), n, ops.stream())
+    # interior pixels only see the offset; keep a slice whose groups really are "large mean, small spread"
+    v = u.double().cpu().reshape(B, H * W, G, co // G).permute(0, 2, 1, 3).reshape(B, G, -1)
+    m64, var64 = v.mean(-1), v.var(-1, unbiased=False)
+    r64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    y_st, y_ref = torch.empty_like(u), torch.empty_like(u)
+    sv = ops.gn_fwd(u, G, 1e-5, gamma.data_ptr(), beta.data_ptr(), None, True, None, y_st,
+                    planes=("stats", st, per.value, bias.data_ptr()))
+    sv_ref = ops.gn_fwd(u, G, 1e-5, gamma.data_ptr(), beta.data_ptr(), None, True, None, y_ref)
+    parity("large offset: mean from the statistics path vs float64 (|d mean| * rstd)",
+           float(((sv.mean.double().cpu().reshape(B, G) - m64).abs() * r64).max()), 2e-5)
+    parity("large offset: rstd from the statistics path vs float64 (relative)",
+           float(((sv.rstd.double().cpu().reshape(B, G) - r64).abs() / r64).max()), 2e-5)
+    parity("large offset: GroupNorm output, statistics path vs the two-pass kernel",
+           float((y_st - y_ref).abs().max() / y_ref.abs().max()), 5e-5)
+
+
 def test_winograd4_weight_gradients_of_two_layers_in_one_launch(dev, parity):
     """The grouped launch takes the F(4x4) kernel when both layers do (large maps at a chip-filling batch): against float64."""
     from lgm_hip import ops
