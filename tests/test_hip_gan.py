@@ -212,7 +212,9 @@ def test_wgan_gp_at_the_benchmark_batch_against_the_oracle(dev, parity):
             assert e_ref < tol or d_hip < max(tol, 3 * d_ref), (n, e_ref, d_ref, d_hip)
             worst = max(worst, min(e_ref, d_hip))
         return worst
-    parity("worst critic gradient norm through the gradient penalty, B = 128", grads(m.D, dn32, dn64, "critic", RTOL),
+    # critic gradients run through the double backward of train-mode BatchNorm: GP_GRAD_TOL as in the fixture test (at
+    # B = 128 the fp32 oracle's own TENSORS are 3e-4 ... 1e-3 from float64, the HIP ones 5e-4 ... 2e-3: tools/wgan_b128_diag.py)
+    parity("worst critic gradient norm through the gradient penalty, B = 128", grads(m.D, dn32, dn64, "critic", GP_GRAD_TOL),
            GP_GRAD_TOL)
     g_opt.zero_grad()
     gl = m._calculate_g_loss(m.G(z.to(dev)))["g_loss"]

@@ -584,8 +584,8 @@ def test_bench_starts_its_own_ranks(tmp_path):
     # the backward did not hide, and the rank count the collectives really ran on
     cfg = rec["config"]
     assert cfg["rccl_ranks"] == 2 and cfg["backend"] == "gloo" and "all-reduce" in cfg["grad_exchange"]
-    assert cfg["collectives_per_step"] == len(cfg["bucket_bytes"]) == 5 and sum(cfg["bucket_bytes"]) == 4 * 35_719_555 + 4 * sum(
-        0 for _ in ()) or sum(cfg["bucket_bytes"]) >= 4 * 35_719_555        # padded channel lanes make the flat buffer larger
+    assert cfg["collectives_per_step"] == len(cfg["bucket_bytes"]) == 5
+    assert sum(cfg["bucket_bytes"]) >= 4 * 35_719_555                      # padded channel lanes make the flat buffer larger
     assert rec["comm_exposed_ms"] >= 0 and rec["comm_host_wait_ms"] >= 0 and 0 <= rec["comm_exposed_frac_of_step"] < 1.5
     # under a launcher that disagrees with --gpus the run is refused; it never prints a line with another rank count
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")

@@ -585,7 +585,7 @@ def test_epilogue_statistics_survive_a_large_common_offset(dev, parity):
     deviations: lgm_gn_fwd_stats must detect that from the rows and measure the slice itself (float64, two passes).  mean /
     rstd against float64 statistics of the SAME convolution output, GroupNorm output against the two-pass kernel."""
     from lgm_hip import ops
-    B, H, W, ci, co, G = 6, 64, 64, 64, 64, 8
+    B, H, W, ci, co, G = 24, 64, 64, 64, 64, 8          # 192 units: the reduction is not split, the statistics path is taken
     L = ops.lib()
     gen = torch.Generator().manual_seed(77)
     x = (30.0 + 0.1 * torch.randn(B, H, W, ci, generator=gen)).to(dev)
@@ -596,6 +596,7 @@ def test_epilogue_statistics_survive_a_large_common_offset(dev, parity):
     g = ops.make_geom(B, H, W, ci, co, 3, 3, 1, 1)
     per = ctypes.c_int(0)
     n = L.lgm_conv3x3_wino4_stats_floats(ctypes.byref(g), ctypes.addressof(per))
+    assert n > 0
     u = torch.empty(B, H, W, co, device=dev)
     st = torch.empty(n, device=dev)
     L.lgm_conv3x3_wino4_stats(ctypes.byref(g), x.data_ptr(), ops.pitch(x), uf.data_ptr(), bias.data_ptr(), u.data_ptr(),
