@@ -644,6 +644,21 @@ int lgm_conv3x3_wino4(int yx, const LgmConvGeom* g, const float* a, int64_t a_pi
                       const float* bias, const float* res, int64_t res_pitch, float* out, int64_t out_pitch,
                       void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same convolution (same operands, same U from lgm_wino4_weights, same contract) from LIGHT workgroups
+ * (csrc/winograd4l.hip; reference ops as above, ddpm.py:157-173): 16-tile units, 256 threads, one wave per SIMD, 74 KB of LDS,
+ * so that two fit a CU and one fits beside a foreign resident workgroup (a collective's kernel).  Maps 8 x 8 (B % 4 == 0),
+ * 16 x 16, or H % 8 == 0 and W % 32 == 0.  Direct entry points for tests and tools; lgm_conv3x3_wino4* choose between the
+ * two workgroup sizes themselves (LGM_WINO4_LIGHT). */
+/* diagnostic / tests: 1 = light workgroups wherever they take the geometry, 0 = 32-tile workgroups only, -1 = what the
+ * environment says (LGM_WINO4_LIGHT; default: light when WORLD_SIZE > 1).  Process-wide; callers that cache plans (split counts, workspace sizes)
+ * must not flip it between a size query and the launch it sizes. */
+int lgm_wino4_set_light(int mode);
+int64_t lgm_conv3x3_wino4l_supported(const LgmConvGeom* g, int yx);
+int64_t lgm_conv3x3_wino4l_workspace(const LgmConvGeom* g, int yx);   /* split-K partial outputs (bytes) */
+int lgm_conv3x3_wino4l(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,
+                       const float* bias, const float* res, int64_t res_pitch, float* out, int64_t out_pitch,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Weight gradient of those layers in F(4x4,3x3) form (csrc/winograd4_wgrad.hip; maps with W % 16 == 0, H % 4 == 0,
  * Nw % 64 == 0, Cw % 32 == 0): dU = sum over tiles of (A dY A^T) (.) (B^T x B), dw = G^T dU G, fused bias sums.  Slabs only:
  * `workspace` receives desc[6] slabs for the batched fixed-order reducer; desc as lgm_conv_wgrad_deferred fills it. */

@@ -594,7 +594,37 @@ static int unit_class(int H, int W) {
 
 }  // namespace lgmwino4
 
+// ---- light workgroups (winograd4l.hip): same operands, 16-tile units, 256 threads ----
+bool lgm_wino4l_supported(const LgmConvGeom* g, int gather_channels, int out_channels);
+long lgm_wino4l_units(const LgmConvGeom* g, int out_channels);
+int lgm_wino4l_stats_parts(const LgmConvGeom* g);
+int lgm_wino4l_splits(const LgmConvGeom* g, int gather_channels, int out_channels);
+int lgm_wino4l_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, const float* u, const float* bias,
+                      const float* res, long res_pitch, float* out, long out_pitch, void* workspace, long workspace_bytes,
+                      hipStream_t s, int64_t* partial, float* stats);
+// LGM_WINO4_LIGHT: 1 = the light workgroups wherever they take the geometry, 0 = the 32-tile workgroups only.  Default: light
+// when this process is one of several ranks (WORLD_SIZE > 1: a resident collective shares the chip - with one foreign
+// workgroup resident the step costs +38 % on the 32-tile kernels and +30 % with the light ones, tools/cu_hog_step.py - and the
+// per-rank batches are the ones they win at: 6.89 vs 6.96 ms at B = 64), the 32-tile workgroups on one GPU (B = 128: 10.13 vs
+// 10.22 ms per step; isolated and cache-warm the light kernel is 4-20 % faster at every batch, tools/wino4l_bench.py, but
+// inside the step every launch starts cold and two waves per SIMD hide more of that).
+static int lgm_wino4_light_override = -1;         // diagnostic / tests: lgm_wino4_set_light
+extern "C" int lgm_wino4_set_light(int mode) {
+  lgm_wino4_light_override = mode;
+  return LGM_OK;
+}
+static bool wino4_use_light(const LgmConvGeom* g, int gather_channels, int out_channels) {
+  static const int env_mode = getenv("LGM_WINO4_LIGHT") ? atoi(getenv("LGM_WINO4_LIGHT"))
+                              : (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 ? 1 : 0);
+  const int mode = lgm_wino4_light_override >= 0 ? lgm_wino4_light_override : env_mode;
+  return mode != 0 && lgm_wino4l_supported(g, gather_channels, out_channels);
+}
+
+static bool wino4_big_supported(const LgmConvGeom* g, int gather_channels, int out_channels);
 bool lgm_wino4_supported(const LgmConvGeom* g, int gather_channels, int out_channels) {
+  return wino4_use_light(g, gather_channels, out_channels) || wino4_big_supported(g, gather_channels, out_channels);
+}
+static bool wino4_big_supported(const LgmConvGeom* g, int gather_channels, int out_channels) {
   using namespace lgmwino4;
   if (!(g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1)) return false;
   if (gather_channels % 8 != 0 || out_channels % 64 != 0 || gather_channels % 32 != 0) return false;
@@ -608,6 +638,7 @@ bool lgm_wino4_supported(const LgmConvGeom* g, int gather_channels, int out_chan
 
 int lgm_wino4_splits(const LgmConvGeom* g, int gather_channels, int out_channels) {
   using namespace lgmwino4;
+  if (wino4_use_light(g, gather_channels, out_channels)) return lgm_wino4l_splits(g, gather_channels, out_channels);
   const int cls = unit_class(g->H, g->W);
   if (cls < 0) return 1;
   const long base = unit_count(cls, g->B, g->H, g->W) * (out_channels / 64);
@@ -629,6 +660,9 @@ int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch,
                      const float* res, long res_pitch, float* out, long out_pitch, void* workspace, long workspace_bytes,
                      hipStream_t s, int64_t* partial = nullptr, float* stats = nullptr) {
   using namespace lgmwino4;
+  if (wino4_use_light(g, yx ? g->Nw : g->Cw, yx ? g->Cw : g->Nw))
+    return lgm_wino4l_launch(g, yx, a, a_pitch, u, bias, res, res_pitch, out, out_pitch, workspace, workspace_bytes, s, partial,
+                             stats);
   Args p{};
   p.stats = stats;
   p.a = a; p.u = u; p.bias = bias; p.res = res; p.out = out;
@@ -719,11 +753,13 @@ extern "C" int64_t lgm_conv3x3_wino4_supported(const LgmConvGeom* g, int yx) {
 // *parts_per_image = the partial (sum, sum of squares) rows every image contributes per channel.
 extern "C" int64_t lgm_conv3x3_wino4_stats_floats(const LgmConvGeom* g, int* parts_per_image) {
   if (parts_per_image) *parts_per_image = 0;
-  if (!g || !lgm_wino4_supported(g, g->Cw, g->Nw) || lgmwino4::unit_class(g->H, g->W) != 0) return 0;
+  if (!g || !lgm_wino4_supported(g, g->Cw, g->Nw)) return 0;
+  const bool light = wino4_use_light(g, g->Cw, g->Nw);
+  if (light ? lgm_wino4l_stats_parts(g) == 0 : lgmwino4::unit_class(g->H, g->W) != 0) return 0;
   if (lgm_wino4_splits(g, g->Cw, g->Nw) != 1) return 0;
   static const bool off = getenv("LGM_NO_GN_EPI_STATS") != nullptr;      // A/B switch
   if (off) return 0;
-  const int per = (g->H / 16) * (g->W / 32) * 4;
+  const int per = light ? lgm_wino4l_stats_parts(g) : (g->H / 16) * (g->W / 32) * 4;
   if (parts_per_image) *parts_per_image = per;
   return (int64_t)g->B * per * 2 * g->Nw;
 }
@@ -749,8 +785,15 @@ extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
   // 16 x 16 maps (more phases per unit) likewise from 128 units
   static const long min_units0 = getenv("LGM_WINO4_MIN_UNITS") ? atol(getenv("LGM_WINO4_MIN_UNITS")) : 128;
   static const long min_units1 = getenv("LGM_WINO4_MIN_UNITS1") ? atol(getenv("LGM_WINO4_MIN_UNITS1")) : 128;
-  const int cls = lgmwino4::unit_class(g->H, g->W);
-  const long base = lgmwino4::unit_count(cls, g->B, g->H, g->W) * (oc / 64);
+  const bool light = wino4_use_light(g, gc, oc);
+  const int cls = g->H == 8 && g->W == 8 ? 2 : g->H == 16 && g->W == 16 ? 1 : 0;
+  // counted in 32-tile units whichever workgroup size runs: the thresholds keep their meaning
+  const long base = light ? lgm_wino4l_units(g, oc) / 2 : lgmwino4::unit_count(cls, g->B, g->H, g->W) * (oc / 64);
+  // forward with the light workgroups: LGM_WINO4_FWD_ALL=1 takes every layer they support (tuning knob)
+  static const int fwd_all = getenv("LGM_WINO4_FWD_ALL") ? atoi(getenv("LGM_WINO4_FWD_ALL")) : 0;
+  if (light && yx == 0 && fwd_all) return 1;
+  static const int bwd_all = getenv("LGM_WINO4_BWD_ALL") ? atoi(getenv("LGM_WINO4_BWD_ALL")) : 0;
+  if (light && yx == 1 && bwd_all) return 1;
   // 8 x 8 maps: few units (8 images each), so the reduction is split; worth it when a split still has >= 8 phases
   static const bool no8 = getenv("LGM_WINO4_NO8") != nullptr;           // A/B switch
   // Forward and backward: the heavy 8 x 8 layers leave the F(2x2) pair (input gradient + weight gradient in one launch) for

@@ -302,16 +302,26 @@ def wino4_weights(w):
     from lgm_hip import ops
     Np, _, Cp = w.shape
     uf = torch.empty(Np * Cp * 36, device=w.device)
-    ub = torch.empty(Np * Cp * 36, device=w.device)
+    # the input-gradient operand is laid out in blocks of 64 INPUT channels: a 32-channel layer has none (forward only)
+    ub = torch.empty(Np * Cp * 36, device=w.device) if Cp % 64 == 0 else None
     tab = torch.tensor([[0, Np, Cp, 0, 0, 0]], dtype=torch.int64, device=w.device)
-    ops.lib().lgm_wino4_weights(w.data_ptr(), uf.data_ptr(), ub.data_ptr(), tab.data_ptr(), 1, (Np // 32) * (Cp // 32),
-                                ops.stream())
+    ops.lib().lgm_wino4_weights(w.data_ptr(), uf.data_ptr(), None if ub is None else ub.data_ptr(), tab.data_ptr(), 1,
+                                (Np // 32) * (Cp // 32), ops.stream())
     return uf, ub
 
 
-def wino4(yx, g, a, u, bias, res, out, partial=False):
+def wino4(yx, g, a, u, bias, res, out, partial=False, light=False):
     from lgm_hip import ops
     L = ops.lib()
+    if light:                                    # csrc/winograd4l.hip through its direct entry point
+        n = L.lgm_conv3x3_wino4l_workspace(ctypes.byref(g), yx)
+        ws = ops.workspace(n, a.device) if n > 0 else None
+        wsp, wsb = (None, 0) if ws is None else (ws.data_ptr(), ws.numel() * 4)
+        L.lgm_conv3x3_wino4l(yx, ctypes.byref(g), a.data_ptr(), ops.pitch(a), u.data_ptr(),
+                             None if bias is None else bias.data_ptr(), None if res is None else res.data_ptr(),
+                             0 if res is None else ops.pitch(res), out.data_ptr(), ops.pitch(out), wsp, wsb, ops.stream())
+        assert "wino4l_conv_kernel" in L._dll.lgm_last_kernel().decode()
+        return n
     n = L.lgm_conv3x3_wino4_workspace(ctypes.byref(g), yx)
     ws = ops.workspace(n, a.device) if n > 0 else None
     wsp, wsb = (None, 0) if ws is None else (ws.data_ptr(), ws.numel() * 4)
@@ -334,8 +344,18 @@ CASES4 = [(2, 16, 16, 64, 64), (4, 16, 16, 192, 128), (3, 32, 32, 64, 64), (1, 3
 F4_TOL = 2e-5     # F(4x4,3x3) in fp32: 2e-6 ... 8e-6 of the output scale against float64 (F(2x2): 2e-7); the parity bar is 1e-4
 
 
+@pytest.fixture(params=[0, 1], ids=["wg32tile", "wglight"])
+def w4mode(request):
+    """lgm_conv3x3_wino4* with the 32-tile workgroups only (winograd4.hip) / with the light workgroups wherever they take
+    the geometry (winograd4l.hip, the default): both kernels stay under test whatever the default is."""
+    from lgm_hip import ops
+    ops.lib().lgm_wino4_set_light(request.param)
+    yield request.param
+    ops.lib().lgm_wino4_set_light(-1)
+
+
 @pytest.mark.parametrize("case", CASES4)
-def test_winograd4_forward_and_input_gradient(dev, case, parity):
+def test_winograd4_forward_and_input_gradient(dev, case, parity, w4mode):
     """lgm_conv3x3_wino4 (reference op: Block.proj ddpm.py:157-173 and its input gradient) against a float64 convolution:
     bias + residual, operands in channel slices of wider buffers, nothing written outside the output slice."""
     from lgm_hip import ops
@@ -377,7 +397,68 @@ def test_winograd4_forward_and_input_gradient(dev, case, parity):
     assert torch.equal(o2, o3)
 
 
-def test_winograd4_partial_planes_and_weight_transform(dev, parity):
+# light workgroups (csrc/winograd4l.hip): the cases above that its unit classes take, plus maps only it takes (H = 8 with W a
+# multiple of 32; 8 x 8 maps in groups of four images), split and unsplit reductions
+CASES4L = [c for c in CASES4 if not (c[1] == 8 and c[0] % 4)] + [(2, 8, 32, 64, 64), (4, 8, 8, 128, 128), (5, 24, 64, 32, 64),
+                                                                (64, 32, 32, 64, 64), (12, 8, 8, 512, 256)]
+
+
+@pytest.mark.parametrize("case", CASES4L)
+def test_winograd4_light_workgroups(dev, case, parity):
+    """lgm_conv3x3_wino4l (reference op: Block.proj ddpm.py:157-173 and its input gradient): 16-tile units on 16x16x4 MFMAs,
+    the same U operands as the 32-tile kernel.  Against a float64 convolution (bias + residual, pitched operands, nothing
+    written outside the output slice, accumulate-in-place form), against the 32-tile kernel where that takes the geometry,
+    and twice (bit-reproducible)."""
+    from lgm_hip import ops
+    B, H, W, ci, co = case
+    gen = torch.Generator().manual_seed(sum(case) + 11)
+    xbuf = torch.randn(B, H, W, ci + 32, generator=gen)
+    ybuf = torch.randn(B, H, W, co + 64, generator=gen)
+    x, y = xbuf[..., 32:], ybuf[..., :co]
+    w = torch.randn(co, 9, ci, generator=gen) / (3 * ci ** 0.5)
+    bias = torch.randn(co, generator=gen)
+    res = torch.randn(B, H, W, co, generator=gen)
+    w4 = w.reshape(co, 3, 3, ci).permute(0, 3, 1, 2).double()
+    ref_xy = F.conv2d(x.permute(0, 3, 1, 2).double(), w4, bias.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+    ref_yx = F.conv_transpose2d(y.permute(0, 3, 1, 2).double(), w4, None, padding=1).permute(0, 2, 3, 1)
+    xd_buf, yd_buf = xbuf.to(dev), ybuf.to(dev)
+    xd, yd = xd_buf[..., 32:], yd_buf[..., :co]
+    wd, bd, rd = w.to(dev), bias.to(dev), res.to(dev)
+    uf, ub = wino4_weights(wd)
+    g = ops.make_geom(B, H, W, ci, co, 3, 3, 1, 1)
+    assert ops.lib().lgm_conv3x3_wino4l_supported(ctypes.byref(g), 0) == 1
+    obuf = torch.full((B, H, W, co + 16), 7.0, device=dev)
+    out = obuf[..., 16:]
+    nws = wino4(0, g, xd, uf, bd, rd, out, light=True)
+    parity(f"light F(4x4) forward (+bias +residual, pitched operands, split-K workspace {nws} B)", maxerr(out, ref_xy), F4_TOL)
+    assert float((obuf[..., :16] - 7.0).abs().max()) == 0
+    if ops.lib().lgm_conv3x3_wino4l_supported(ctypes.byref(g), 1) == 1:      # 32 input channels: forward only
+        gx = torch.empty(B, H, W, ci, device=dev)
+        wino4(1, g, yd, ub, None, None, gx, light=True)
+        parity("light F(4x4) input gradient", maxerr(gx, ref_yx), F4_TOL)
+        gx2 = torch.randn(B, H, W, ci, generator=gen).to(dev)
+        ref2 = ref_yx + gx2.double().cpu()
+        wino4(1, g, yd, ub, None, gx2, gx2, light=True)
+        parity("light F(4x4) input gradient accumulated in place", maxerr(gx2, ref2), F4_TOL)
+    else:
+        assert ci % 64
+    L = ops.lib()
+    L.lgm_wino4_set_light(0)
+    try:
+        if L.lgm_conv3x3_wino4_supported(ctypes.byref(g), 0) == 1:
+            big = torch.empty_like(out)
+            wino4(0, g, xd, uf, bd, rd, big)
+            assert "lgmwino4::wino4_conv_kernel" in L._dll.lgm_last_kernel().decode()
+            parity("light vs 32-tile workgroups (same products, other summation order over the reduction)",
+                   maxerr(out, big.double().cpu()), 1e-5)
+    finally:
+        L.lgm_wino4_set_light(-1)
+    o2 = torch.empty_like(out)
+    wino4(0, g, xd, uf, bd, rd, o2, light=True)
+    assert torch.equal(o2, out.contiguous())
+
+
+def test_winograd4_partial_planes_and_weight_transform(dev, parity, w4mode):
     """The split-K planes lgm_conv3x3_wino4_partial leaves sum (plane 0, 1, ..., + bias: the reducer's order) to exactly
     what the complete call writes; U = G g G^T matches its float64 definition."""
     from lgm_hip import ops
@@ -527,7 +608,7 @@ def test_winograd4_weight_gradient(dev, case, parity):
 
 
 @pytest.mark.parametrize("case", [(24, 64, 64, 64, 64), (12, 64, 64, 64, 128), (48, 32, 64, 64, 64)])
-def test_winograd4_forward_leaves_the_groupnorm_statistics(dev, case, parity):
+def test_winograd4_forward_leaves_the_groupnorm_statistics(dev, case, parity, w4mode):
     """Block.forward (ddpm.py:164-173) on maps whose GroupNorm needs two passes over x (64 x 64): lgm_conv3x3_wino4_stats
     writes the convolution output AND, per wave, (sum, sum of squares) of its pre-bias outputs; lgm_gn_fwd_stats combines
     them in float64 and normalises reading x once.  Against the two-step path of the same library (convolution, then
@@ -547,7 +628,7 @@ def test_winograd4_forward_leaves_the_groupnorm_statistics(dev, case, parity):
     g = ops.make_geom(B, H, W, ci, co, 3, 3, 1, 1)
     per = ctypes.c_int(0)
     n = L.lgm_conv3x3_wino4_stats_floats(ctypes.byref(g), ctypes.addressof(per))
-    assert n == B * per.value * 2 * co and per.value == (H // 16) * (W // 32) * 4
+    assert n == B * per.value * 2 * co and per.value == ((H // 8) if w4mode else (H // 16)) * (W // 32) * 4
     u_ref = torch.empty(B, H, W, co, device=dev)
     wino4(0, g, x, uf, bias, None, u_ref)
     y_ref = torch.empty_like(u_ref)
@@ -556,7 +637,7 @@ def test_winograd4_forward_leaves_the_groupnorm_statistics(dev, case, parity):
     st = torch.full((n + 16,), float("nan"), device=dev)
     L.lgm_conv3x3_wino4_stats(ctypes.byref(g), x.data_ptr(), ops.pitch(x), uf.data_ptr(), bias.data_ptr(), u_st.data_ptr(),
                               ops.pitch(u_st), st.data_ptr(), n, ops.stream())
-    assert "wino4_conv_kernel<0, false, 0, true>" in L._dll.lgm_last_kernel().decode()
+    assert ("wino4l_conv_kernel<0, true>" if w4mode else "wino4_conv_kernel<0, false, 0, true>") in L._dll.lgm_last_kernel().decode()
     assert torch.equal(u_st, u_ref)                                # the same convolution, bit for bit
     assert not bool(torch.isnan(st[:n]).any()) and bool(torch.isnan(st[n:]).all())     # every row written, nothing beyond
     y_st = torch.empty_like(u_ref)
