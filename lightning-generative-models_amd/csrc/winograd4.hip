@@ -44,6 +44,10 @@ extern "C" int lgm_wino4_set_debug_buffer(void* buf, int exp) {
   return LGM_OK;
 }
 
+#ifndef LGM_WINO4_PFU
+#define LGM_WINO4_PFU 1            // operand prefetch at kernel start (-DLGM_WINO4_PFU=0: A/B builds)
+#endif
+
 namespace lgmwino4 {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -80,6 +84,7 @@ struct Args {
   int N;               // produced channels
   int tb_h, tb_w, tiles_n, nbg;
   int splits, pps, units;
+  int tn_slowest;      // unit order, see the kernel
   float* ws;
   long ws_stride;
   long long* dbg;      // diagnostic build only (wino4_conv_kernel<CLS, true>): per-workgroup cycle stamps
@@ -113,6 +118,7 @@ __device__ __forceinline__ f32x2 fma2(const float c, const f32x2 a, const f32x2 
 template <int CLS, bool DBG = false, int EXP = 0, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
   using GE = Geo<CLS>;
+  constexpr bool PFU = LGM_WINO4_PFU != 0;
   int nstamp = 0;
   auto stamp = [&]() {
     if (DBG) {
@@ -135,15 +141,38 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
   const int lr = lane & 31, lh = lane >> 5;
 
   // ---- unit ----
-  int L = blockIdx.x;
-  const int tn = L % p.tiles_n;
-  L /= p.tiles_n;
-  const int split = L % p.splits;
-  L /= p.splits;
-  const int twi = L % p.tb_w;
-  L /= p.tb_w;
-  const int thi = L % p.tb_h;
-  const int bg = L / p.tb_h;
+  // Hardware deals consecutive workgroup ids to the eight XCDs round-robin, each with its own 4 MB 16-way L2.  With
+  // unit = blockIdx the 32 (64) workgroups an XCD runs together are units x, x + 8, ...: the same tile block of images
+  // four apart, i.e. patches whose addresses differ by multiples of 1 MB and fall on the SAME L2 sets - they evict each
+  // other between the four phases that share a 128-byte line (FETCH_SIZE 85 MB per launch for 33.5 MB of input at
+  // 64 -> 64 @ 32 x 32, B = 128; the F(2x2) kernel, which always walked XCD-contiguous unit ranges: 38 MB).  An XCD takes a
+  // CONTIGUOUS unit range instead: neighbouring tile blocks and images, addresses spread over all sets, halo rows and
+  // the channel blocks of one tile block shared in one L2.
+  int L = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  // Two unit orders (host: wino4_unit_order): channel block fastest - the channel blocks and splits of one tile block sit in
+  // one L2 and share its patch (large maps: the input is the big operand) - or channel block SLOWEST - an XCD works on
+  // one or two (channel block, split) slices of U and streams the images past them (8 x 8 maps with hundreds of channels:
+  // U is the big operand, 9 ... 19 MB, and every XCD would otherwise stream all of it)
+  int tn, split, twi, thi, bg;
+  if (p.tn_slowest) {
+    twi = L % p.tb_w;
+    L /= p.tb_w;
+    thi = L % p.tb_h;
+    L /= p.tb_h;
+    bg = L % p.nbg;
+    L /= p.nbg;
+    split = L % p.splits;
+    tn = L / p.splits;
+  } else {
+    tn = L % p.tiles_n;
+    L /= p.tiles_n;
+    split = L % p.splits;
+    L /= p.splits;
+    twi = L % p.tb_w;
+    L /= p.tb_w;
+    thi = L % p.tb_h;
+    bg = L / p.tb_h;
+  }
   const int n0 = tn * 64;
   const int h0 = thi * (4 * GE::TTH), w0 = twi * (4 * GE::TTW), b0 = bg * NI;
   const int ncc = p.C / KC;
@@ -239,6 +268,25 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
   }
   const unsigned ulane = (unsigned)((ch * 64 + lane) * 16);
   const unsigned ubase = (unsigned)((tn * ncc + cc0) * NXI + xg * 9) * 2048u;
+  // Warm this XCD's L2 with the unit's whole operand range.  Inside a training step every launch finds the caches cold
+  // (tools/cold_launch.py: +5 ... 15 us per launch against back-to-back timing): the phase loop asks for U three xi ahead,
+  // which hides an L2 hit, not a miss to memory - and every phase's 74 KB are new.  Workgroups with blockIdx = x (mod 8)
+  // share an XCD; each touches its share of the range, one 128-byte line per thread (up to 2 MB: what stays in a 4 MB L2
+  // beside the patches).  The value is consumed (nowhere) after the prologue's first barrier, by when it has long landed.
+  unsigned pf = 0;
+  if (PFU) {
+    // (an XCD's contiguous unit range holds gridDim / 8 / (tiles_n * splits) workgroups with this (channel block, split):
+    // they share the range between them)
+    const unsigned ubytes = min((unsigned)nph * (NXI * 2048u), 2u << 20);
+    const unsigned nx = gridDim.x >> 3;
+    const unsigned spatial = (unsigned)(p.nbg * p.tb_h * p.tb_w);          // workgroups per (channel block, split) slice
+    const unsigned grp = p.tn_slowest ? 1u : (unsigned)(p.tiles_n * p.splits);
+    const unsigned share = p.tn_slowest ? ((unsigned)blockIdx.x >> 3) % spatial : ((unsigned)blockIdx.x >> 3) / grp;
+    const unsigned nshare = p.tn_slowest ? min(nx, spatial) : nx / grp;
+    const unsigned off = (share * 512u + (unsigned)tid) * 128u;
+    if ((gridDim.x & 7) == 0 && off < ubytes && nshare * 512u * 128u >= ubytes)
+      pf = __builtin_amdgcn_raw_buffer_load_b32(rsrc_u, off, (unsigned)((tn * ncc + cc0) * NXI) * 2048u, 0);
+  }
   auto load_u = [&](int ph, int e) -> f32x4 {        // phases past the unit's range are never consumed
     const unsigned soff = ubase + (unsigned)(ph * NXI + e) * 2048u;
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, ulane, soff, 0);
@@ -312,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
     if (DBG) __builtin_amdgcn_sched_barrier(0);
     stamp();                                         // first two patches landed and committed
     __syncthreads();
+    if (PFU) asm volatile("" ::"v"(pf));             // the operand prefetch, issued before those patches, is complete
     stamp();
 #pragma unroll
     for (int cp = 0; cp < 3; ++cp) stage1(0, cp);
@@ -686,6 +735,13 @@ int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch,
   p.pps = lgm_cdiv(p.C / KC, p.splits);
   p.splits = lgm_cdiv(p.C / KC, p.pps);
   p.units = (int)((long)p.nbg * p.tb_h * p.tb_w * p.tiles_n * p.splits);
+  {
+    // bytes the chip's eight L2s fetch under either order: patches once (x 1.2 halo) and all of U per XCD, or patches once per
+    // channel block and U once
+    static const int forced = getenv("LGM_WINO4_TN_SLOWEST") ? atoi(getenv("LGM_WINO4_TN_SLOWEST")) : -1;
+    const double in_b = 1.2 * (double)M * p.C * 4.0, u_b = 36.0 * p.C * p.N * 4.0;
+    p.tn_slowest = forced >= 0 ? forced : ((in_b + 8.0 * u_b > in_b * p.tiles_n + u_b) ? 1 : 0);
+  }
   const size_t smem = (size_t)MBUF * sizeof(float);
   p.dbg = (long long*)lgm_wino4_debug_buffer;
 #define LGM_W4LAUNCH(CC, DD, EE)                                                                                \
