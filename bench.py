@@ -725,12 +725,20 @@ def main():
         sec["ddpm64_sampling_1000"] = leg("ddpm64_sampling_1000", lambda: run_sampling_ancestral(dev))
         line["secondary"] = sec
         proxy = {}
-        for b in (64, 32, 16):
-            r = leg(f"proxy_b{b}", lambda b=b: run_workload("ddpm32", args, dev, 1, 0, 20, 5, batch=b, roofline=False,
-                                                             cpu=False))
-            proxy[f"b{b}"] = r.get("ms_per_step") if isinstance(r, dict) else None
+        # the proxies run what a RANK of an N > 1 job runs: the library picks the light F(4x4) workgroups when WORLD_SIZE > 1
+        # (csrc/winograd4.hip: wino4_use_light), so the proxy legs switch them on the same way (and back off afterwards)
+        from lgm_hip import ops as _ops
+        _ops.lib().lgm_wino4_set_light(1)
+        try:
+            for b in (64, 32, 16):
+                r = leg(f"proxy_b{b}", lambda b=b: run_workload("ddpm32", args, dev, 1, 0, 20, 5, batch=b, roofline=False,
+                                                                 cpu=False))
+                proxy[f"b{b}"] = r.get("ms_per_step") if isinstance(r, dict) else None
+        finally:
+            _ops.lib().lgm_wino4_set_light(-1)
         proxy["note"] = ("ms per step of the headline workload on ONE GPU at the per-rank batch of 2 / 4 / 8 GPUs "
-                         "(global batch 128): compute between the gradient exchanges under strong scaling")
+                         "(global batch 128): compute between the gradient exchanges under strong scaling; kernel "
+                         "selection as under WORLD_SIZE > 1 (light F(4x4) workgroups)")
         line["per_rank_proxy"] = proxy
         if faulted is not None:
             line["device_error_in"] = faulted
