@@ -839,8 +839,12 @@ extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
   // maps >= 16 x 32: from 128 units (B = 64 at 32 x 32: the reduction is split in two, 4 phases per workgroup: 7.28 vs
   // 7.35 ms per step against the F(2x2) pair on its joint plan; without the split 7.44); 256 units: 10.9 vs 11.4 ms;
   // 16 x 16 maps (more phases per unit) likewise from 128 units
-  static const long min_units0 = getenv("LGM_WINO4_MIN_UNITS") ? atol(getenv("LGM_WINO4_MIN_UNITS")) : 128;
-  static const long min_units1 = getenv("LGM_WINO4_MIN_UNITS1") ? atol(getenv("LGM_WINO4_MIN_UNITS1")) : 128;
+  // with the light workgroups (16-tile units: twice the workgroups, one wave per SIMD each) already from 32 such units -
+  // the per-rank batches 32 and 16 at 32 x 32: 5.35 -> 5.27 and 4.54 -> 4.52 ms per step, nothing changes at 64 and 128
+  static const long min_units0_env = getenv("LGM_WINO4_MIN_UNITS") ? atol(getenv("LGM_WINO4_MIN_UNITS")) : -1;
+  static const long min_units1_env = getenv("LGM_WINO4_MIN_UNITS1") ? atol(getenv("LGM_WINO4_MIN_UNITS1")) : -1;
+  const long min_units0 = min_units0_env >= 0 ? min_units0_env : (wino4_use_light(g, gc, oc) ? 32 : 128);
+  const long min_units1 = min_units1_env >= 0 ? min_units1_env : (wino4_use_light(g, gc, oc) ? 32 : 128);
   const bool light = wino4_use_light(g, gc, oc);
   const int cls = g->H == 8 && g->W == 8 ? 2 : g->H == 16 && g->W == 16 ? 1 : 0;
   // counted in 32-tile units whichever workgroup size runs: the thresholds keep their meaning
@@ -863,7 +867,8 @@ extern "C" int64_t lgm_conv3x3_wino4_preferred(const LgmConvGeom* g, int yx) {
   if (cls == 1 && gc < c1_minc) return 0;
   // 16 x 16 maps with a reduction of >= 128 channels (>= 16 phases: two splits of >= 8) already from 64 units - the
   // per-rank batch of two GPUs: 6.98 -> 6.94 ms per step at B = 64, nothing changes at B = 128 (LGM_WINO4_MIN_UNITS1W)
-  static const long min_units1w = getenv("LGM_WINO4_MIN_UNITS1W") ? atol(getenv("LGM_WINO4_MIN_UNITS1W")) : 64;
+  static const long min_units1w_env = getenv("LGM_WINO4_MIN_UNITS1W") ? atol(getenv("LGM_WINO4_MIN_UNITS1W")) : -1;
+  const long min_units1w = min_units1w_env >= 0 ? min_units1w_env : (light ? 32 : 64);
   if (cls == 1 && gc >= 128 && base >= min_units1w) return 1;
   return base >= (cls == 1 ? min_units1 : min_units0) ? 1 : 0;
 }
