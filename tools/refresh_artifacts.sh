@@ -4,16 +4,17 @@
 # the SAME commands (graph replay) at the headline and the per-rank batches, one step's per-launch listing (eager),
 # the secondary workloads' kernel summaries, three PMC passes (FETCH_SIZE | WRITE_SIZE | MFMA busy) and the LDS pass
 set -e
-R=${1:-r04}
+R=${1:-r05}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out
 python3 bench.py 2> $out/${R}_bench.err | tail -1 > $out/${R}_bench.json
 echo "bench line done"
 GRAPH=1 bash tools/prof_workload.sh ddpm32 ${R}_bench_b128 > /dev/null
-for b in 64 32 16; do GRAPH=1 bash tools/prof_workload.sh ddpm32 ${R}_bench_b$b --batch $b > /dev/null; done
+# the per-rank batches run the kernel selection of an N > 1 job (light F(4x4) workgroups), as bench.py's per_rank_proxy does
+for b in 64 32 16; do LGM_WINO4_LIGHT=1 GRAPH=1 bash tools/prof_workload.sh ddpm32 ${R}_bench_b$b --batch $b > /dev/null; done
 for w in ddpm64 wgan_gp64 vqvae vqvae_ema; do GRAPH=1 bash tools/prof_workload.sh $w ${R}_bench_$w > /dev/null; done
 bash tools/prof_launches.sh ddpm32 ${R}_b128 > /dev/null
-bash tools/prof_launches.sh ddpm32 ${R}_b16 --batch 16 > /dev/null
+LGM_WINO4_LIGHT=1 bash tools/prof_launches.sh ddpm32 ${R}_b16 --batch 16 > /dev/null
 bash tools/prof_launches.sh vqvae ${R}_vqvae > /dev/null
 echo "kernel traces done"
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
