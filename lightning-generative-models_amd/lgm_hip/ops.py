@@ -567,8 +567,9 @@ _PAIR_OK = {}
 
 
 # Up to four large-map layers' weight gradients in one launch (lgm_conv3x3_wino_wgradn): LGM_NO_WGRAD2=1 issues them
-# singly, LGM_WGRAD_GROUP=n (2 ... 4) bounds the group (default 2: groups of 3 and 4 measured the same step time,
-# 10.66 / 10.67 / 10.67 ms - the second halving of prologues and slabs is below the noise - and hold buffers longer).
+# singly, LGM_WGRAD_GROUP=n (2 ... 4) bounds the group (default 2: measured in round 5 with the larger groups really
+# forming - round 4's "same step time" came through a dangling geometry array that refused every group above two -
+# 10.08 / 10.08 / 10.11 ms per step at B = 128 for n = 2 / 3 / 4, and larger groups hold buffers longer).
 WGRAD2 = _os.environ.get("LGM_NO_WGRAD2", "0") != "1"
 WGRAD_GROUP = max(2, min(4, int(_os.environ.get("LGM_WGRAD_GROUP", "2"))))
 _WG2_OK = {}
