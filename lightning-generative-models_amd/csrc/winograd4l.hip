@@ -72,6 +72,7 @@ struct Args {
   int tb_h, tb_w, tiles_n, nbg;
   int splits, pps, units;
   int tn_slowest;      // unit order, see the kernel
+  int xcd_ranges;      // 1: an XCD takes a contiguous unit range (default); 0: unit = blockIdx (LGM_WINO4_NO_XCD_RANGES=1, A/B)
   float* ws;
   long ws_stride;
   float* stats;        // STATS build only: [spatial unit][4 parts][2: sum y, sum y^2][N] of the PRE-BIAS outputs
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void wino4l_conv_kernel(const Args p) {
   // 64 -> 64 @ 32 x 32, B = 128; the F(2x2) kernel, which always walked XCD-contiguous unit ranges: 38 MB).  An XCD takes a
   // CONTIGUOUS unit range instead: neighbouring tile blocks and images, addresses spread over all sets, halo rows and
   // the channel blocks of one tile block shared in one L2.
-  int L = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  int L = (p.xcd_ranges && (gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
   // Two unit orders (host: wino4_unit_order): channel block fastest - the channel blocks and splits of one tile block sit in
   // one L2 and share its patch (large maps: the input is the big operand) - or channel block SLOWEST - an XCD works on
   // one or two (channel block, split) slices of U and streams the images past them (8 x 8 maps with hundreds of channels:
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void wino4l_conv_kernel(const Args p) {
     const unsigned share = p.tn_slowest ? ((unsigned)blockIdx.x >> 3) % spatial : ((unsigned)blockIdx.x >> 3) / grp;
     const unsigned nshare = p.tn_slowest ? min(nx, spatial) : nx / grp;
     const unsigned off = (share * 256u + (unsigned)tid) * 128u;
-    if ((gridDim.x & 7) == 0 && off < ubytes && nshare * 256u * 128u >= ubytes)
+    if (p.xcd_ranges && (gridDim.x & 7) == 0 && off < ubytes && nshare * 256u * 128u >= ubytes)
       pf = __builtin_amdgcn_raw_buffer_load_b32(rsrc_u, off, (unsigned)((tn * ncc + cc0) * NXI) * 2048u, 0);
   }
   struct UF {
@@ -569,6 +570,8 @@ int lgm_wino4l_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch
   {
     // bytes the chip's eight L2s fetch under either order: patches once (x 1.2 halo) and all of U per XCD, or patches once per
     // channel block and U once
+    static const bool no_ranges = getenv("LGM_WINO4_NO_XCD_RANGES") != nullptr;
+    p.xcd_ranges = no_ranges ? 0 : 1;
     static const int forced = getenv("LGM_WINO4_TN_SLOWEST") ? atoi(getenv("LGM_WINO4_TN_SLOWEST")) : -1;
     const double in_b = 1.2 * (double)M * p.C * 4.0, u_b = 36.0 * p.C * p.N * 4.0;
     p.tn_slowest = forced >= 0 ? forced : ((in_b + 8.0 * u_b > in_b * p.tiles_n + u_b) ? 1 : 0);

@@ -52,6 +52,13 @@ def one(exp, g, x, uf, bias, y, dev):
         print(f"  {nm:10s} {dt[:, i].median():9.0f}   (min {dt[:, i].min():.0f} max {dt[:, i].max():.0f})")
     tot = st[:, -1] - st[:, 0]
     print(f"  total      {tot.median():9.0f}")
+    # launch ramp and tail: entry stamps (s_memtime: shader clock, compared across workgroups - meaningful if the XCDs'
+    # counters run together) and exit stamps (s_memrealtime, 100 MHz, one clock for the chip)
+    ent = st[:, 0] - st[:, 0].min()
+    ext = (d[:, 31].double() - d[:, 31].double().min()) * 10.0          # ns
+    q = torch.tensor([0.1, 0.5, 0.9, 1.0], dtype=torch.float64)
+    print("  entry stamp - earliest entry (cycles), 10 / 50 / 90 / 100 %:", [int(v) for v in torch.quantile(ent, q)])
+    print("  exit time - earliest exit (ns), 10 / 50 / 90 / 100 %:", [int(v) for v in torch.quantile(ext, q)])
 
 
 if __name__ == "__main__":
