@@ -798,8 +798,10 @@ static GnPlan gn_plan(int B, int HW, int C, int G, bool bwd) {
   // tuning knob.  8-channel (one group, 32-byte row) blocks were 2 % slower at B = 32 while their siblings sat in
   // different L2s; with gn_sibling_map they are 0.3 % faster at B = 16 / 32 and neutral at B = 64
   static const int min_cb = getenv("LGM_GN_MINCB") ? atoi(getenv("LGM_GN_MINCB")) : 8;
+  // blocks a launch should reach before the narrowing stops (tuning knob; 256 = one block per CU)
+  static const long want = getenv("LGM_GN_BLOCKS") ? atol(getenv("LGM_GN_BLOCKS")) : 256;
   if (!wide_only)
-    while ((long)B * (C / cb) < 256 && cb > Cg && cb / 2 >= min_cb && (cb / 2) % Cg == 0 && (cb / 2) % 4 == 0) cb /= 2;
+    while ((long)B * (C / cb) < want && cb > Cg && cb / 2 >= min_cb && (cb / 2) % Cg == 0 && (cb / 2) % 4 == 0) cb /= 2;
   GnPlan p = gn_plan_cb(HW, cb, bwd);
   // (Large maps - 64 x 64 at 64 channels: 4096 pixels x 32 channels do not fit a block's registers - stay on the two-pass
   // kernels.  Narrowing the block to ONE group so that its slice fits was tried: one pass over x instead of two, but

@@ -84,12 +84,35 @@ def test_graph_replay_is_bit_identical_to_eager_steps(dev, pipeline, monkeypatch
     assert not torch.equal(t0, step.t)
 
 
-def test_ddpm_at_the_baseline_batch_matches_the_cpu_oracle(dev, parity):
-    """B=128, dim 64, 32x32 (BASELINE config 2 as benched): HIP loss and every parameter gradient against
-    oracle.diffusion_forward + autograd on the CPU (a few seconds)."""
+def _plan_caches():
+    from lgm_hip import ops
+    return [getattr(ops, n) for n in ("_WINO4_OK", "_WINO_WS", "_EPI_STATS", "_PAIR_OK", "_WG2_OK", "_WG2_WS", "_WINO_OK")
+            if hasattr(ops, n)]
+
+
+@pytest.mark.parametrize("B,light", [(128, 0), (64, 1), (16, 1)], ids=["b128", "rank_of_2_b64_light", "rank_of_8_b16_light"])
+def test_ddpm_at_the_baseline_batch_matches_the_cpu_oracle(dev, parity, B, light):
+    """dim 64, 32x32 (BASELINE config 2 as benched): HIP loss and every parameter gradient against
+    oracle.diffusion_forward + autograd on the CPU (a few seconds) - at B = 128 with the kernel selection of one GPU, and at
+    the per-rank batches of 2 and 8 GPUs with the selection a RANK gets (light F(4x4) workgroups, csrc/winograd4l.hip: the
+    library switches them on when WORLD_SIZE > 1, here through lgm_wino4_set_light)."""
+    from lgm_hip import ops
+    for c in _plan_caches():
+        c.clear()                 # plans are cached per geometry: none may survive a change of the kernel selection
+    ops.lib().lgm_wino4_set_light(1 if light else -1)
+    try:
+        _ddpm_vs_oracle(dev, parity, B, light)
+    finally:
+        ops.lib().lgm_wino4_set_light(-1)
+        for c in _plan_caches():
+            c.clear()
+
+
+def _ddpm_vs_oracle(dev, parity, B, light):
     from models.generative.diffusion.ddpm import GaussianDiffusion, Unet
     from oracle import diffusion as OD
-    dim, S, B = 64, 32, 128
+    from lgm_hip import ops
+    dim, S = 64, 32
     P = OD.unet_init(dim=dim, channels=3, seed=128)
     g = torch.Generator().manual_seed(1280)
     img = torch.rand(B, 3, S, S, generator=g)
@@ -106,6 +129,10 @@ def test_ddpm_at_the_baseline_batch_matches_the_cpu_oracle(dev, parity):
     loss = gd.p_losses(img.to(dev), t.to(dev), noise.to(dev), _normalize=True)
     parity("loss", abs(loss.item() - loss_ref.item()) / loss_ref.item(), RTOL)
     loss.backward()
+    if light:                     # the light kernel really ran (its name is the last F(4x4) launch the library noted somewhere
+        g32 = ops.make_geom(B, S, S, dim, dim, 3, 3, 1, 1)      # in this pass; asked directly: the first level's 3x3 layers take it)
+        assert ops.lib().lgm_conv3x3_wino4_preferred(__import__("ctypes").byref(g32), 0) == 1
+        assert ops.lib().lgm_conv3x3_wino4l_supported(__import__("ctypes").byref(g32), 0) == 1
     errs = {n: rel(p.grad, Pr[n].grad) for n, p in net.named_parameters()}
     wn = max(errs, key=errs.get)
     parity(f"worst of ALL {len(errs)} parameter gradients ({wn})", errs[wn], RTOL)
