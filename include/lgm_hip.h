@@ -39,9 +39,10 @@
 extern "C" {
 #endif
 
-#define LGM_ABI_VERSION 3   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial;
+#define LGM_ABI_VERSION 4   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial;
                              * 3: lgm_conv3x3_wino4*, lgm_gn_fwd_stats, lgm_conv3x3_wino_wgradn* + LgmWgradItem, a negative
-                             *    dst offset in lgm_wino_weights table rows means "skip that copy", lgm_kernel_name* */
+                             *    dst offset in lgm_wino_weights table rows means "skip that copy", lgm_kernel_name*;
+                             * 4: LgmPostOp carries the BatchNorm-backward sums (bn_*), lgm_bn_reduce3_coef_tiles */
 #define LGM_OK 0
 #define LGM_ERR_INVALID (-1)
 #define LGM_ERR_UNSUPPORTED (-2)
@@ -107,6 +108,21 @@ typedef struct {
   const float* mask;
   int64_t mask_pitch;
   float mask_slope;
+  /* ABI 4.  BatchNorm's backward sums from THIS epilogue (reference: autograd's backward of nn.BatchNorm2d behind a
+   * convolution's input gradient, dcgan.py:150-161, wgan.py:117-156): when the finished output `out` is the gradient gn
+   * that arrives at a train-mode BatchNorm whose input was `bn_a` (same [rows][channels] shape as `out`, statistics
+   * bn_mean / bn_rstd), every full row tile also leaves (sum gn, sum gn * xhat, 0) per channel in
+   * bn_partial[tile][3][N] - the layout lgm_bn_reduce3's first stage writes - and *bn_tiles receives the number of
+   * tiles; lgm_bn_reduce3_coef_tiles finishes from there and the separate read pass over (gn, a) disappears.
+   * *bn_tiles == 0: this launch could not (split-K, ragged tiles, a path without the hook): run lgm_bn_reduce3_coef.
+   * bn_a NULL: off. */
+  const float* bn_a;
+  int64_t bn_a_pitch;
+  const float* bn_mean;
+  const float* bn_rstd;
+  float* bn_partial;
+  int64_t bn_partial_floats;     /* capacity of bn_partial */
+  int32_t* bn_tiles;             /* out (host memory) */
 } LgmPostOp;
 int lgm_conv_xy_post(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w, const float* bias,
                      const float* res, int64_t res_pitch, float* y, int64_t y_pitch, void* workspace,
@@ -454,6 +470,10 @@ int lgm_bn_reduce3_coef(int modes, const float* v1, int64_t v1_pitch, const floa
                         const float* gamma, const float* saved_m, int64_t rows, int C, float* coef8,
                         float* ggamma0, float* gbeta0, float beta_acc0, float* m_out, float* ggamma1,
                         float beta_acc1, float* sums3, void* workspace, void* stream);
+/* the same second stage over partial sums a convolution's epilogue left (LgmPostOp.bn_partial, `tiles` row tiles) */
+int lgm_bn_reduce3_coef_tiles(int modes, const float* partial, int tiles, const float* gamma, const float* rstd,
+                              const float* saved_m, int64_t rows, int C, float* coef8, float* ggamma0, float* gbeta0,
+                              float beta_acc0, float* m_out, float* ggamma1, float beta_acc1, float* sums3, void* stream);
 /* out_k = A1k*v1 + A2k*v2 + A3k*xhat + A4k for the two coefficient sets of coef8 = [2][4][C] (set 0 without its
  * v2 term), one pass over v1, v2, a */
 int lgm_bn_affine3x2(const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch, const float* a,

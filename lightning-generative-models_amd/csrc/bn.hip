@@ -444,6 +444,22 @@ extern "C" int lgm_bn_reduce3_coef(int modes, const float* v1, int64_t v1_pitch,
                      (hipStream_t)stream);
 }
 
+// the second stage alone, over (sum v1, sum v1 * xhat, 0) rows a convolution's epilogue left per row tile (LgmPostOp.bn_*)
+extern "C" int lgm_bn_reduce3_coef_tiles(int modes, const float* partial, int tiles, const float* gamma, const float* rstd,
+                                         const float* saved_m, int64_t rows, int C, float* coef8, float* ggamma0,
+                                         float* gbeta0, float beta_acc0, float* m_out, float* ggamma1, float beta_acc1,
+                                         float* sums3, void* stream) {
+  LGM_REQUIRE(partial && tiles > 0 && rstd && gamma && coef8 && rows > 0 && C > 0 && (modes & 3) && (!(modes & 2) || saved_m),
+              "bn_reduce3_coef_tiles: bad arguments");
+  BnEpi e{};
+  e.epi = 2; e.modes = modes; e.M = (long)rows; e.gamma = gamma; e.rstd_in = rstd; e.saved_m = saved_m;
+  e.coef = coef8; e.ggamma0 = ggamma0; e.gbeta0 = gbeta0; e.beta_acc0 = beta_acc0; e.m_out = m_out;
+  e.ggamma1 = ggamma1; e.beta_acc1 = beta_acc1; e.sums_out = sums3;
+  hipLaunchKernelGGL(bn_stage2_epi_kernel, dim3(lgm_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, tiles, C, e);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
 extern "C" int lgm_bn_affine3x2(const float* v1, int64_t v1_pitch, const float* v2, int64_t v2_pitch, const float* a,
                                 int64_t a_pitch, const float* mean, const float* rstd, const float* coef8, float* out0,
                                 int64_t out0_pitch, float* out1, int64_t out1_pitch, int64_t rows, int C, void* stream) {

@@ -128,6 +128,14 @@ struct IgemmArgs {
   const float* mask;
   long mask_pitch;
   float mask_slope;
+  // BatchNorm backward sums of the finished output gn (LgmPostOp.bn_*): per full row tile (sum gn, sum gn * xhat, 0) per
+  // column into bn_part[row tile][3][N], xhat = (bn_a - bn_mean) * bn_rstd at the output's own (row, column).  Host
+  // guarantees: wide epilogue, full tiles everywhere, splits == 1.
+  const float* bn_a;
+  long bn_a_pitch;
+  const float* bn_mean;
+  const float* bn_rstd;
+  float* bn_part;
 };
 
 __device__ __forceinline__ float lgm_post_act(float v, int act, float slope) {
@@ -522,18 +530,26 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, const int bidx) {
     // element serialises on s_waitcnt vmcnt(0) and is issue-bound)
     __syncthreads();
     float* Ts = smem + wid * LGM_TS_FLOATS;
+    float* const Bst = smem + 4 * LGM_TS_FLOATS;       // BatchNorm sums: [2 sums][wm][wn][TN][32 columns] behind the four wave tiles
+    const bool bnred = p.bn_part != nullptr;           // kernel argument: wave-uniform
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nc = n0 + wn * 32 * TN + j * 32 + (lane & 7) * 4;
       const f32x4 bv4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 bs1 = {0.f, 0.f, 0.f, 0.f}, bs2 = {0.f, 0.f, 0.f, 0.f}, bmu = bs1, brs = bs1;
+      if (bnred) {
+        bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + nc);
+        brs = *reinterpret_cast<const f32x4*>(p.bn_rstd + nc);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         long orow[4];
-        f32x4 rv4[4];
+        f32x4 rv4[4], ba4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           orow[q] = out_row(m0 + wm * 32 * TM + i * 32 + (lane >> 3) + 8 * q);
           rv4[q] = p.res ? *reinterpret_cast<const f32x4*>(p.res + orow[q] * p.res_pitch + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (bnred) ba4[q] = *reinterpret_cast<const f32x4*>(p.bn_a + orow[q] * p.bn_a_pitch + nc);
         }
         lgm_wave_lds_sync();
         lgm_tile_to_lds(acc[i][j], Ts, lane);
@@ -551,6 +567,38 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, const int bidx) {
             }
           }
           *reinterpret_cast<f32x4*>(p.out + orow[q] * p.out_pitch + nc) = v4;
+          if (bnred) {                                  // fixed order: rows (lane >> 3) + 8 q of tile i, q then i ascending
+            bs1 += v4;
+            bs2 += v4 * ((ba4[q] - bmu) * brs);
+          }
+        }
+      }
+      if (bnred) {
+        // the 8 row lanes of a column quad (lane & 7 fixed): a fixed butterfly; then this wave's 32 TM rows of column
+        // quad (lane & 7) sit in lanes 0-7
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bs1[e] += __shfl_xor(bs1[e], m, 64);
+            bs2[e] += __shfl_xor(bs2[e], m, 64);
+          }
+        if (lane < 8) {
+          *reinterpret_cast<f32x4*>(Bst + (((0 * 2 + wm) * 2 + wn) * TN + j) * 32 + lane * 4) = bs1;
+          *reinterpret_cast<f32x4*>(Bst + (((1 * 2 + wm) * 2 + wn) * TN + j) * 32 + lane * 4) = bs2;
+        }
+      }
+    }
+    if (bnred) {
+      __syncthreads();
+      if (wm == 0 && lane < 32) {       // the two row halves of the tile, in order
+        float* o = p.bn_part + ((long)(pc * p.tiles_m + tm) * 3) * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * 32 * TN + j * 32 + lane;
+          o[n] = Bst[(((0 * 2 + 0) * 2 + wn) * TN + j) * 32 + lane] + Bst[(((0 * 2 + 1) * 2 + wn) * TN + j) * 32 + lane];
+          o[p.N + n] = Bst[(((1 * 2 + 0) * 2 + wn) * TN + j) * 32 + lane] + Bst[(((1 * 2 + 1) * 2 + wn) * TN + j) * 32 + lane];
+          o[2 * p.N + n] = 0.f;
         }
       }
     }
@@ -762,11 +810,24 @@ int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool 
   a.KWs = a.KW;
   a.act = 0; a.slope = 0.f; a.mask = nullptr; a.mask_pitch = 0; a.mask_slope = 0.f;
   const LgmPostOp* post = t_post.post;
+  a.bn_a = nullptr; a.bn_a_pitch = 0; a.bn_mean = a.bn_rstd = nullptr; a.bn_part = nullptr;
   if (post) {          // every launch of this dispatcher applies it: in the epilogue, or in the split-K reducer
     a.act = post->act; a.slope = post->slope; a.mask = post->mask; a.mask_pitch = post->mask_pitch;
     a.mask_slope = post->mask_slope;
     t_post.done = true;
   }
+  // BatchNorm backward sums from the epilogue: full tiles of the kernel this dispatcher is about to pick, no split-K
+  auto want_bn = [&](int bm, int bn) {
+    if (!(post && post->bn_a && post->bn_tiles)) return;
+    const long tiles = (long)(a.M / bm) * a.phases;
+    if (a.wide && a.M % bm == 0 && a.N % bn == 0 && post->bn_partial && post->bn_mean && post->bn_rstd &&
+        post->bn_a_pitch % 4 == 0 && lgm_aligned16(post->bn_a) && lgm_aligned16(post->bn_mean) &&
+        lgm_aligned16(post->bn_rstd) && post->bn_partial_floats >= tiles * 3 * a.N) {
+      a.bn_a = post->bn_a; a.bn_a_pitch = post->bn_a_pitch; a.bn_mean = post->bn_mean; a.bn_rstd = post->bn_rstd;
+      a.bn_part = post->bn_partial;
+      *post->bn_tiles = (int)tiles;
+    }
+  };
   if (MODE == MODE_YX && a.stride > 1 && a.KH % a.stride == 0 && a.KW % a.stride == 0 && a.H % a.stride == 0 &&
       a.W % a.stride == 0) {
     a.phases = a.stride * a.stride;
@@ -789,10 +850,12 @@ int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool 
   };
   if (a.N > 64 && t128 * lgm_cdiv(a.N, 128) >= 384) {
     want_stats(128, 128);
+    want_bn(128, 128);
     return launch_igemm<MODE, 128, 128, 2, 2>(a, s);
   }
   if (t128 * lgm_cdiv(a.N, 64) >= 384) {
     want_stats(128, 64);
+    want_bn(128, 64);
     return launch_igemm<MODE, 128, 64, 2, 1>(a, s);
   }
   int kchunk;
@@ -823,6 +886,7 @@ int dispatch_igemm(IgemmArgs& a, void* workspace, int64_t workspace_bytes, bool 
                                     a.N, s);
   }
   want_stats(64, 64);
+  want_bn(64, 64);
   return launch_igemm<MODE, 64, 64, 1, 1>(a, s);
 }
 
@@ -906,6 +970,7 @@ static int post_check(const LgmPostOp* post, const char* who) {
 // taken had no epilogue hook
 template <typename F>
 static int with_post(const LgmPostOp* post, float* out, int64_t out_pitch, long M, int N, void* stream, F call) {
+  if (post && post->bn_tiles) *post->bn_tiles = 0;      // set by the dispatcher when the epilogue takes the sums
   t_post.post = post;
   t_post.done = false;
   const int rc = call();
@@ -1853,6 +1918,7 @@ static int conv_bwd_pair_impl(const LgmConvGeom* g, const float* gy, int64_t gy_
   bool post_done = true;
   if (rc == LGM_OK) {
     // the post-op belongs to the input gradient only: parked for the duration of ITS dispatch (see with_post)
+    if (post && post->bn_tiles) *post->bn_tiles = 0;
     t_post.post = post;
     t_post.done = false;
     rc = conv_yx_impl(g, gy, gy_pitch, w, w_t, nullptr, res, res_pitch, gx, gx_pitch, dgrad_ws, dgrad_ws_bytes, nullptr,

@@ -95,8 +95,15 @@ class BatchNorm2d(nn.Module):
         return h, BNSaved(a, mean, rstd)
 
     # ---- T(v), optionally with the parameter gradients of the forward node -------------------
-    def apply_T(self, sv: BNSaved, v, gc: GradCtx = None, want_m: bool = False, out=None, accumulate=False):
-        """returns (T(v), mvec) where mvec = [mean v, mean v*xhat] (when want_m)."""
+    def sums_request(self, sv: BNSaved):
+        """-> ops.BnSums for the convolution that is about to produce the gradient arriving at this BatchNorm (pass it as
+        ``bn_sums=`` to that layer's bwd / dgrad, then as ``sums=`` to apply_T)."""
+        return ops.BnSums(sv.a, sv.mean, sv.rstd)
+
+    def apply_T(self, sv: BNSaved, v, gc: GradCtx = None, want_m: bool = False, out=None, accumulate=False, sums=None):
+        """returns (T(v), mvec) where mvec = [mean v, mean v*xhat] (when want_m).
+        ``sums`` (ops.BnSums with tiles > 0): the convolution that wrote ``v`` left the per-tile sums (sum v, sum v * xhat)
+        behind - the reduction pass over (v, a) is skipped, the second stage runs on them."""
         a = sv.a
         C = a.shape[-1]
         rows = ops.rows(a)
@@ -110,11 +117,17 @@ class BatchNorm2d(nn.Module):
             gg, gb = gc.flat.gptr(self.weight), gc.flat.gptr(self.bias)
             beta = gc.beta(self.weight)
             gc.beta(self.bias)
-        # sums (v, v*xhat) and the coefficients of T in two launches (the per-channel math runs in stage 2)
-        L.lgm_bn_reduce3_coef(1, v.data_ptr(), ops.pitch(v), None, 0, a.data_ptr(), ops.pitch(a), sv.mean.data_ptr(),
-                              sv.rstd.data_ptr(), fp.ptr(self.weight), None, rows, C, coef.data_ptr(), gg, gb, beta,
-                              None if mvec is None else mvec.data_ptr(), None, 0.0, None, _ws(a).data_ptr(),
-                              ops.stream())
+        if sums is not None and sums.tiles > 0:
+            assert sums.a is sv.a
+            L.lgm_bn_reduce3_coef_tiles(1, sums.partial.data_ptr(), sums.tiles, fp.ptr(self.weight), sv.rstd.data_ptr(),
+                                        None, rows, C, coef.data_ptr(), gg, gb, beta,
+                                        None if mvec is None else mvec.data_ptr(), None, 0.0, None, ops.stream())
+        else:
+            # sums (v, v*xhat) and the coefficients of T in two launches (the per-channel math runs in stage 2)
+            L.lgm_bn_reduce3_coef(1, v.data_ptr(), ops.pitch(v), None, 0, a.data_ptr(), ops.pitch(a), sv.mean.data_ptr(),
+                                  sv.rstd.data_ptr(), fp.ptr(self.weight), None, rows, C, coef.data_ptr(), gg, gb, beta,
+                                  None if mvec is None else mvec.data_ptr(), None, 0.0, None, _ws(a).data_ptr(),
+                                  ops.stream())
         if out is None:
             out = ops.new(a.shape, a)
             accumulate = False

@@ -142,12 +142,14 @@ class Conv2d(nn.Module):
         return (y, (None, 0)) if stats else y
 
     def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None, planes_for_groups=0,
-            mask=None, mask_slope=0.0):
+            mask=None, mask_slope=0.0, bn_sums=None):
         """gW, gb into flat grads; returns gx = dgrad(gy) (+ res) (+ existing gx when accumulate).
         ``mask`` (a saved ReLU / LeakyReLU output): gx is multiplied by that activation's derivative in the input
         gradient's epilogue - the backward of an activation that sat in front of this layer's input.
         ``planes_for_groups`` = G > 0: the only reader of gx is the backward of a GroupNorm(G) - returns (gx, planes) as
-        ``fwd_planes`` does (planes given: gx itself is NOT written)."""
+        ``fwd_planes`` does (planes given: gx itself is NOT written).
+        ``bn_sums`` (ops.BnSums): gx is the gradient arriving at a train-mode BatchNorm - ask the input gradient's epilogue
+        for that BatchNorm's backward sums (bn_sums.tiles > 0 afterwards when it delivered)."""
         B, H, W, _ = x.shape
         g = self.geom(B, H, W)
         fp = gc.flat
@@ -160,7 +162,7 @@ class Conv2d(nn.Module):
                 gb = fp.gptr(self.bias)              # bias gradient fused into the wgrad kernel
             else:
                 ops.colsum(gy, fp.gptr(self.bias), bb)
-        if need_gx and self.k == 3 and mask is None:
+        if need_gx and self.k == 3 and mask is None and bn_sums is None:
             # 3x3 layers: input gradient and weight gradient side by side in ONE launch (ops.conv_bwd_pair)
             if gx is None:
                 gx = ops.new(x.shape, x)
@@ -171,7 +173,7 @@ class Conv2d(nn.Module):
             r = ops.conv_bwd_pair(g, gy, x, fp.ptr(self.weight), fp.gptr(self.weight), bw, gb, dfr, pres, gx, partial=ok_pl)
             if r is not False:
                 return (gx, r) if planes_for_groups else gx
-        if need_gx and (self.k != 3 or mask is not None) and not planes_for_groups and not ops.B3:
+        if need_gx and (self.k != 3 or mask is not None or bn_sums is not None) and not planes_for_groups and not ops.B3:
             # the other layers (1x1, 4x4 / stride 2, 7x7; a 3x3 layer the pair above did not take keeps its Winograd /
             # direct input gradient below): both gradients through lgm_conv_bwd_pair - one launch when the kernels can
             # share a grid
@@ -180,7 +182,7 @@ class Conv2d(nn.Module):
                 accumulate = False
             assert not (accumulate and res is not None)
             ops.conv_bwd_generic(g, gy, x, fp.ptr(self.weight), fp.tptr(self.weight), fp.gptr(self.weight), bw, gb, dfr,
-                                 gx if accumulate else res, gx, post=ops.make_post(0, 0.0, mask, mask_slope),
+                                 gx if accumulate else res, gx, post=ops.make_post(0, 0.0, mask, mask_slope, bn=bn_sums),
                                  post_mask=mask)
             return gx
         if dfr is not None and self.k == 3 and ops.wgrad_queueable(g, gy, x):
@@ -199,7 +201,7 @@ class Conv2d(nn.Module):
             ok = self.k == 3 and res is None and ops.gn_planes_ok(B, H * W, x.shape[-1], planes_for_groups)
             return gx, ops.conv_yx(g, gy, fp.ptr(self.weight), None, res, gx, fp.tptr(self.weight), partial=ok)
         ops.conv_yx(g, gy, fp.ptr(self.weight), None, res, gx, fp.tptr(self.weight),
-                    post=ops.make_post(0, 0.0, mask, mask_slope), post_mask=mask)
+                    post=ops.make_post(0, 0.0, mask, mask_slope, bn=bn_sums), post_mask=mask)
         return gx
 
 
@@ -213,9 +215,9 @@ def _conv_linear(self, x, out=None):
     return y
 
 
-def _conv_dgrad(self, gy, in_shape, gx=None, accumulate=False, mask=None, mask_slope=0.0):
+def _conv_dgrad(self, gy, in_shape, gx=None, accumulate=False, mask=None, mask_slope=0.0, bn_sums=None):
     """W^T * gy (input gradient only, no parameter gradients).  ``mask``: as Conv2d.bwd - the derivative of the
-    activation that produced this layer's input, applied in the epilogue."""
+    activation that produced this layer's input, applied in the epilogue.  ``bn_sums``: as Conv2d.bwd."""
     B, H, W, _ = in_shape
     g = self.geom(B, H, W)
     fp = _flat(self.weight)
@@ -223,7 +225,7 @@ def _conv_dgrad(self, gy, in_shape, gx=None, accumulate=False, mask=None, mask_s
         gx = ops.new(tuple(in_shape), gy)
         accumulate = False
     ops.conv_yx(g, gy, fp.ptr(self.weight), None, gx if accumulate else None, gx,
-                post=ops.make_post(0, 0.0, mask, mask_slope), post_mask=mask)
+                post=ops.make_post(0, 0.0, mask, mask_slope, bn=bn_sums), post_mask=mask)
     return gx
 
 
@@ -279,7 +281,8 @@ class ConvTranspose2d(nn.Module):
                     post=ops.make_post(act, slope))
         return (y, (None, 0)) if stats else y
 
-    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None, mask=None, mask_slope=0.0):
+    def bwd(self, gc: GradCtx, x, gy, gx=None, accumulate=False, need_gx=True, res=None, mask=None, mask_slope=0.0,
+            bn_sums=None):
         B, H, W, _ = x.shape
         g = self.geom(B, H, W)
         fp = gc.flat
@@ -296,7 +299,8 @@ class ConvTranspose2d(nn.Module):
         if accumulate:
             assert res is None
             res = gx
-        ops.conv_xy(g, gy, fp.ptr(self.weight), None, res, gx, post=ops.make_post(0, 0.0, mask, mask_slope), post_mask=mask)
+        ops.conv_xy(g, gy, fp.ptr(self.weight), None, res, gx, post=ops.make_post(0, 0.0, mask, mask_slope, bn=bn_sums),
+                    post_mask=mask)
         return gx
 
 

@@ -383,17 +383,54 @@ POSTOPS = _os.environ.get("LGM_NO_POSTOP", "0") != "1"    # A/B switch: activati
 
 
 class PostOp(ctypes.Structure):
-    """LgmPostOp (include/lgm_hip.h): out = act(conv + bias + res) * (mask > 0 ? 1 : mask_slope)"""
+    """LgmPostOp (include/lgm_hip.h): out = act(conv + bias + res) * (mask > 0 ? 1 : mask_slope); optionally the
+    BatchNorm-backward sums of ``out`` from the same epilogue (bn_*)"""
     _fields_ = [("act", ctypes.c_int32), ("slope", ctypes.c_float), ("mask", ctypes.c_void_p),
-                ("mask_pitch", ctypes.c_int64), ("mask_slope", ctypes.c_float)]
+                ("mask_pitch", ctypes.c_int64), ("mask_slope", ctypes.c_float),
+                ("bn_a", ctypes.c_void_p), ("bn_a_pitch", ctypes.c_int64), ("bn_mean", ctypes.c_void_p),
+                ("bn_rstd", ctypes.c_void_p), ("bn_partial", ctypes.c_void_p), ("bn_partial_floats", ctypes.c_int64),
+                ("bn_tiles", ctypes.c_void_p)]
 
 
-def make_post(act: int = 0, slope: float = 0.0, mask: Optional[torch.Tensor] = None, mask_slope: float = 0.0):
+# BatchNorm's backward reductions from the producing convolution's epilogue (LgmPostOp.bn_*): LGM_NO_BN_EPI=1 switches the
+# request off (every BatchNorm backward then runs its own reduction pass, as before round 5)
+BN_EPI = _os.environ.get("LGM_NO_BN_EPI", "0") != "1"
+
+
+class BnSums:
+    """A request for (sum gn, sum gn * xhat) per channel of the gradient ``gn`` a convolution is about to write, where
+    xhat belongs to the train-mode BatchNorm that will consume gn (its saved input ``a`` and statistics).  After the
+    convolution call ``tiles`` > 0 says the epilogue left ``partial[tile][3][C]``; 0: not on this path / geometry - the
+    BatchNorm runs its own reduction (lgm_bn_reduce3_coef)."""
+    __slots__ = ("a", "mean", "rstd", "partial", "_tiles")
+
+    def __init__(self, a, mean, rstd):
+        self.a, self.mean, self.rstd = a, mean, rstd
+        r, C = rows(a), a.shape[-1]
+        # at most one row tile per 64 rows (the smallest tile of the implicit-GEMM kernels)
+        self.partial = torch.empty((r + 63) // 64 * 3 * C, dtype=torch.float32, device=a.device)
+        self._tiles = ctypes.c_int32(0)
+
+    @property
+    def tiles(self) -> int:
+        return int(self._tiles.value)
+
+
+def make_post(act: int = 0, slope: float = 0.0, mask: Optional[torch.Tensor] = None, mask_slope: float = 0.0,
+              bn: Optional[BnSums] = None):
     """None when there is nothing to do"""
-    if act == 0 and mask is None:
+    if bn is not None and not BN_EPI:
+        bn = None
+    if act == 0 and mask is None and bn is None:
         return None
     assert act in (0, ACT_RELU, ACT_LRELU)
-    return PostOp(act, slope, None if mask is None else mask.data_ptr(), 0 if mask is None else pitch(mask), mask_slope)
+    po = PostOp(act, slope, None if mask is None else mask.data_ptr(), 0 if mask is None else pitch(mask), mask_slope)
+    if bn is not None:
+        po.bn_a, po.bn_a_pitch = bn.a.data_ptr(), pitch(bn.a)
+        po.bn_mean, po.bn_rstd = bn.mean.data_ptr(), bn.rstd.data_ptr()
+        po.bn_partial, po.bn_partial_floats = bn.partial.data_ptr(), bn.partial.numel()
+        po.bn_tiles = ctypes.addressof(bn._tiles)
+    return po
 
 
 def _apply_post_separately(post: PostOp, out, mask):

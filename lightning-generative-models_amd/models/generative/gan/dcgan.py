@@ -110,6 +110,7 @@ class Generator(_Net):
         gc = GradCtx(self._flat)
         n = len(self.model)
         g = gout
+        sums = None      # BatchNorm backward sums of `g`, left by the epilogue of the convolution that produced it
         for i in range(n - 1, -1, -1):
             blk = self.model[i]
             h_in, sv, hn = tape[i]
@@ -117,10 +118,11 @@ class Generator(_Net):
                 ga = ops.new(g.shape, g)
                 ops.act_bwd(sv, None, g, ga, False, ops.ACT_TANH)        # sv = pre-activation here
             else:
-                ga, _ = blk[1].apply_T(sv, g, gc)                        # g arrives with relu'(hn) applied (below)
+                ga, _ = blk[1].apply_T(sv, g, gc, sums=sums)             # g arrives with relu'(hn) applied (below)
             # the ReLU in front of this layer's input (h_in = the previous block's output): its backward mask rides in
-            # the input gradient's epilogue
-            g = blk[0].bwd(gc, h_in, ga, need_gx=(i > 0), mask=(h_in if i > 0 else None))
+            # the input gradient's epilogue - and so do the reduction sums of the BatchNorm that produced h_in
+            sums = self.model[i - 1][1].sums_request(tape[i - 1][1]) if i > 0 else None
+            g = blk[0].bwd(gc, h_in, ga, need_gx=(i > 0), mask=(h_in if i > 0 else None), bn_sums=sums)
         self._flat.bind_grad_views()
 
     def forward(self, z: torch.Tensor) -> torch.Tensor:
@@ -199,18 +201,21 @@ class Discriminator(_Net):
         """Backward from score gradients gs [B,1,1,4].  gc None => input gradient only."""
         g = gs
         n = len(self.model)
+        sums = None         # BatchNorm backward sums of `g` from the epilogue of the convolution that produced it
         for i in range(n - 1, -1, -1):
             blk = self.model[i]
             ci, co, k, s, p, bn, final = self.spec[i]
             h_in, a, sv, hn = tape[i]
             gn = g          # below the head g arrives with lrelu'(hn) applied: the mask rides in the producer's epilogue
-            ga = blk[1].apply_T(sv, gn, gc)[0] if bn else gn
+            ga = blk[1].apply_T(sv, gn, gc, sums=sums)[0] if bn else gn
             last = i == 0
             mk = None if last else h_in                  # h_in = the previous block's LeakyReLU output
+            sums = self.model[i - 1][1].sums_request(tape[i - 1][2]) if (i > 0 and self.spec[i - 1][5]) else None
             if gc is not None:
-                g = blk[0].bwd(gc, h_in, ga, need_gx=(not last) or need_gx, mask=mk, mask_slope=SLOPE)
+                g = blk[0].bwd(gc, h_in, ga, need_gx=(not last) or need_gx, mask=mk, mask_slope=SLOPE, bn_sums=sums)
             else:
-                g = blk[0].dgrad(ga, h_in.shape, mask=mk, mask_slope=SLOPE) if ((not last) or need_gx) else None
+                g = (blk[0].dgrad(ga, h_in.shape, mask=mk, mask_slope=SLOPE, bn_sums=sums)
+                     if ((not last) or need_gx) else None)
         return g
 
     # ---- engine: gradient penalty with its second-order backward (wgan.py:117-156) ---------------
@@ -226,6 +231,7 @@ class Discriminator(_Net):
         L.lgm_fill_col(g.data_ptr(), 4, B, 4, 0, 1.0, None, ops.stream())
         n = len(self.model)
         first = [None] * n
+        sums = None
         for i in range(n - 1, -1, -1):
             blk = self.model[i]
             ci, co, k, s, p, bn, final = self.spec[i]
@@ -233,11 +239,12 @@ class Discriminator(_Net):
             gn = g          # already multiplied by lrelu'(hn) in the epilogue of the layer above
             mvec = None
             if bn:
-                ga, mvec = blk[1].apply_T(sv, gn, None, want_m=True)
+                ga, mvec = blk[1].apply_T(sv, gn, None, want_m=True, sums=sums)
             else:
                 ga = gn
             first[i] = (gn, ga, mvec)
-            g = blk[0].dgrad(ga, h_in.shape, mask=(h_in if i > 0 else None), mask_slope=SLOPE)
+            sums = self.model[i - 1][1].sums_request(tape[i - 1][2]) if (i > 0 and self.spec[i - 1][5]) else None
+            g = blk[0].dgrad(ga, h_in.shape, mask=(h_in if i > 0 else None), mask_slope=SLOPE, bn_sums=sums)
         Bx, H, W, Cp = x4.shape
         pen = ops.new((1,), x4)
         ws = ops.workspace(L.lgm_gp_penalty_workspace(Bx * H * W), x4.device)

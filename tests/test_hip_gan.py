@@ -164,6 +164,67 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(dev, case, parity):
     parity("running_mean, tiles vs stand-alone (|d| * rstd)",
            float(((bn_a.running_mean.double() - bn_b.running_mean.double()).abs() * r64).max()), 2e-6)
 
+@pytest.mark.parametrize("case", [(0, 128, 32, 64, 128), (0, 128, 16, 128, 256), (0, 16, 8, 256, 512), (1, 128, 4, 1024, 512),
+                                  (1, 64, 16, 256, 128), (0, 3, 8, 64, 64)])
+def test_batchnorm_backward_sums_from_the_input_gradient_epilogue(dev, case, parity):
+    """autograd's backward of Conv2d / ConvTranspose2d -> BatchNorm2d (train) -> LeakyReLU as the DCGAN critic / generator
+    chain them (dcgan.py:86-90, 150-161): the input gradient of the NEXT layer is the gradient gn arriving at the BatchNorm;
+    its epilogue (LgmPostOp.bn_*) leaves (sum gn, sum gn * xhat) per row tile and lgm_bn_reduce3_coef_tiles finishes
+    T(gn), the gamma / beta gradients and the saved means without the reduction pass over (gn, a).  Against the stand-alone
+    reduction of the same gn (same library) and against float64; the last case is a geometry the epilogue cannot serve
+    (ragged tiles) and must report 0 tiles."""
+    from lgm_hip import ops
+    from lgm_hip.bn import BatchNorm2d
+    from lgm_hip.flat import FlatParams
+    from lgm_hip.nn import Conv2d, ConvTranspose2d, GradCtx, param_kind
+    transposed, B, hw, ci, co = case
+    torch.manual_seed(sum(case) + 5)
+    # layer i (ci -> co) + its BatchNorm, then layer i + 1 whose input gradient produces gn for that BatchNorm
+    if transposed:
+        l0, l1 = ConvTranspose2d(ci, co, 4, 2, 1, bias=False), ConvTranspose2d(co, 64, 4, 2, 1, bias=False)
+    else:
+        l0, l1 = Conv2d(ci, co, 4, 2, 1, bias=False), Conv2d(co, 64, 4, 2, 1, bias=False)
+    bn = BatchNorm2d(co)
+    net = torch.nn.ModuleList([l0, bn, l1]).to(dev)
+    fp = FlatParams([(n, p, param_kind(n, p)) for n, p in net.named_parameters()], dev)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(co, device=dev))
+        bn.bias.copy_(0.2 * torch.randn(co, device=dev))
+    x = torch.randn(B, hw, hw, ci, device=dev)
+    a = l0.fwd(x)
+    h, sv = bn.fwd(a, ops.ACT_LRELU, 0.2, True)
+    y = l1.fwd(h)
+    gy = torch.randn_like(y)
+    res = {}
+    for use in (False, True):
+        fp.grad.zero_()
+        fp.fresh = True
+        gc = GradCtx(fp)
+        sums = bn.sums_request(sv) if use else None
+        gn = l1.bwd(gc, h, gy, mask=h, mask_slope=0.2, bn_sums=sums)
+        if use:
+            if case == (0, 3, 8, 64, 64):
+                assert sums.tiles == 0
+            else:
+                assert sums.tiles > 0, "this geometry is expected to take the epilogue path"
+        ga, mvec = bn.apply_T(sv, gn, gc, want_m=True, sums=sums)
+        res[use] = (gn.clone(), ga.clone(), mvec.clone(), fp.grad[fp.slot(bn.weight).offset:][:co].clone(),
+                    fp.grad[fp.slot(bn.bias).offset:][:co].clone())
+    assert torch.equal(res[False][0], res[True][0])                 # the same gn, bit for bit
+    gn64 = res[True][0].double().reshape(-1, co).cpu()
+    a64 = a.double().reshape(-1, co).cpu()
+    xh = (a64 - a64.mean(0)) / torch.sqrt(a64.var(0, unbiased=False) + bn.eps)
+    s1, s2 = gn64.sum(0), (gn64 * xh).sum(0)
+    sc = max(float(s1.abs().max()), float(s2.abs().max()))
+    parity("gbeta = sum gn: epilogue sums vs float64", float((res[True][4].double().cpu() - s1).abs().max()) / sc, 2e-5)
+    parity("ggamma = sum gn xhat: epilogue sums vs float64", float((res[True][3].double().cpu() - s2).abs().max()) / sc, 2e-5)
+    parity("ggamma / gbeta: epilogue sums vs the stand-alone reduction",
+           max(rel(res[True][3], res[False][3]), rel(res[True][4], res[False][4])), 2e-5)
+    parity("T(gn): epilogue sums vs the stand-alone reduction", rel(res[True][1], res[False][1]), 2e-5)
+    parity("saved means (mean gn, mean gn xhat): epilogue sums vs the stand-alone reduction", rel(res[True][2], res[False][2]),
+           2e-5)
+
+
 def test_wgan_gp_at_the_benchmark_batch_against_the_oracle(dev, parity):
     """BASELINE config 3 at ITS batch (64 x 64, B = 128; reference wgan.py:84-156, dcgan.py:35-164): at B = 128 other code
     paths run than at the fixtures' B = 4 (BatchNorm statistics from full convolution tiles, other split plans, the
