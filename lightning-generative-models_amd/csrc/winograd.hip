@@ -1510,25 +1510,41 @@ static bool wgrad2_operands_ok(const LgmConvGeom* g, const float* y, long y_pitc
 // F(4x4,3x3) weight gradient (csrc/winograd4_wgrad.hip): pairs of layers that both take it share a launch of THAT kernel
 bool lgm_wino4_wgrad_use(const LgmConvGeom* g);
 void lgm_wino4_wgrad_plan(const LgmConvGeom* g, long budget, int* splits, int* gps, int* total_groups);
-int lgm_wino4_wgrad2_launch(const LgmConvGeom* const* gs, const float* const* ys, const long* yps, const float* const* xs,
-                            const long* xps, float* const* outs, const int* biases, const long* slabs, const int* splits,
-                            const int* gpss, const int* totals, hipStream_t s);
+int lgm_wino4_wgradn_launch(int n, const LgmConvGeom* const* gs, const float* const* ys, const long* yps,
+                            const float* const* xs, const long* xps, float* const* outs, const int* biases, const long* slabs,
+                            const int* splits, const int* gpss, const int* totals, hipStream_t s);
+// F(4x4) weight gradients of 2 ... 4 layers in one launch (LGM_W4W_GROUP bounds n, default 4): every layer takes the F(4x4)
+// kernel and still gets at least two slabs' worth of its 64 x 32-channel blocks out of the 256 workgroups (the 512-channel
+// layers of the 64 x 64 configuration do not fit side by side: they take the F(2x2) grouped launch or go alone)
 static bool wgradn_use4(int n, const LgmConvGeom* const* gs) {
-  if (!(n == 2 && lgm_wino4_wgrad_use(gs[0]) && lgm_wino4_wgrad_use(gs[1]))) return false;
-  // each layer needs at least two slabs' worth of its 64 x 32-channel blocks out of the 256 workgroups (the 512-channel
-  // layers of the 64 x 64 configuration do not fit side by side: they take the F(2x2) grouped launch or go alone)
-  const long m0 = 2L * (gs[0]->Nw / 64) * (gs[0]->Cw / 32), m1 = 2L * (gs[1]->Nw / 64) * (gs[1]->Cw / 32);
-  return m0 + m1 <= 256;
+  static const int nmax = getenv("LGM_W4W_GROUP") ? atoi(getenv("LGM_W4W_GROUP")) : 4;
+  if (n < 2 || n > 4 || n > nmax) return false;
+  long need = 0;
+  for (int k = 0; k < n; ++k) {
+    if (!lgm_wino4_wgrad_use(gs[k])) return false;
+    need += 2L * (gs[k]->Nw / 64) * (gs[k]->Cw / 32);
+  }
+  return need <= 256;
 }
-static void wgrad4_budgets(const LgmConvGeom* const* gs, long* budget) {     // two layers, blocks of 64 x 32 channels
-  const double w0 = (double)gs[0]->B * gs[0]->H * gs[0]->W * gs[0]->Nw * gs[0]->Cw;
-  const double w1 = (double)gs[1]->B * gs[1]->H * gs[1]->W * gs[1]->Nw * gs[1]->Cw;
-  const long m0 = 2L * (gs[0]->Nw / 64) * (gs[0]->Cw / 32), m1 = 2L * (gs[1]->Nw / 64) * (gs[1]->Cw / 32);
-  long b0 = (long)(256.0 * w0 / (w0 + w1) + 0.5);
-  if (b0 < m0) b0 = m0;
-  if (256 - b0 < m1) b0 = 256 - m1;
-  budget[0] = b0;
-  budget[1] = 256 - b0;
+static void wgrad4_budgets(int n, const LgmConvGeom* const* gs, long* budget) {     // blocks of 64 x 32 channels, shares by work
+  double w[4], tot = 0;
+  long mn[4], left = 256;
+  for (int k = 0; k < n; ++k) {
+    w[k] = (double)gs[k]->B * gs[k]->H * gs[k]->W * gs[k]->Nw * gs[k]->Cw;
+    tot += w[k];
+    mn[k] = 2L * (gs[k]->Nw / 64) * (gs[k]->Cw / 32);
+  }
+  for (int k = 0; k < n; ++k) {
+    long b = (long)(256.0 * w[k] / tot + (n == 2 && k == 0 ? 0.5 : 0.0));
+    if (b < mn[k]) b = mn[k];
+    budget[k] = b;
+    left -= b;
+  }
+  int big = 0;
+  for (int k = 1; k < n; ++k)
+    if (budget[k] - mn[k] > budget[big] - mn[big]) big = k;
+  budget[big] += left;
+  if (budget[big] < mn[big]) budget[big] = mn[big];
 }
 
 // 1 when the grouped launch takes these n (2 ... 4) layers: all run the Winograd weight-gradient kernel of the same map
@@ -1594,9 +1610,9 @@ extern "C" int64_t lgm_conv3x3_wino_wgrad2_supported(const LgmConvGeom* ga, cons
 extern "C" int lgm_conv3x3_wino_wgradn_workspaces(int n, const LgmConvGeom* const* geoms, int64_t* out) {
   LGM_REQUIRE(geoms && out && wgradn_supported(n, geoms), "conv3x3_wino_wgradn_workspaces: unsupported group of layers");
   if (wgradn_use4(n, geoms)) {
-    long b4[2];
-    wgrad4_budgets(geoms, b4);
-    for (int k = 0; k < 2; ++k) {
+    long b4[4];
+    wgrad4_budgets(n, geoms, b4);
+    for (int k = 0; k < n; ++k) {
       int splits, gps, total;
       lgm_wino4_wgrad_plan(geoms[k], b4[k], &splits, &gps, &total);
       out[k] = (int64_t)splits * ((int64_t)geoms[k]->Nw * 9 * geoms[k]->Cw + geoms[k]->Nw) * (int64_t)sizeof(float);
@@ -1627,15 +1643,15 @@ extern "C" int lgm_conv3x3_wino_wgradn(int n, const LgmWgradItem* it, void* stre
     LGM_REQUIRE(it[k].desc && it[k].ws && lgm_aligned16(it[k].ws) &&
                 wgrad2_operands_ok(it[k].g, it[k].y, it[k].y_pitch, it[k].x, it[k].x_pitch, it[k].gw, it[k].gbias),
                 "conv3x3_wino_wgradn: layer %d: 16-byte aligned operands with pitch %% 4 == 0 inside 32-bit offsets expected", k);
-  if (wgradn_use4(n, gs)) {                       // both layers on the F(4x4) kernel: one launch of that kernel
-    long b4[2];
-    wgrad4_budgets(gs, b4);
-    const float* ys[2];
-    const float* xs[2];
-    long yps[2], xps[2], slabs[2];
-    float* outs[2];
-    int biases[2], splits[2], gpss[2], totals[2];
-    for (int k = 0; k < 2; ++k) {
+  if (wgradn_use4(n, gs)) {                       // all layers on the F(4x4) kernel: one launch of that kernel
+    long b4[4];
+    wgrad4_budgets(n, gs, b4);
+    const float* ys[4];
+    const float* xs[4];
+    long yps[4], xps[4], slabs[4];
+    float* outs[4];
+    int biases[4], splits[4], gpss[4], totals[4];
+    for (int k = 0; k < n; ++k) {
       const LgmConvGeom* g = gs[k];
       lgm_wino4_wgrad_plan(g, b4[k], &splits[k], &gpss[k], &totals[k]);
       const long n_w = (long)g->Nw * 9 * g->Cw;
@@ -1651,7 +1667,7 @@ extern "C" int lgm_conv3x3_wino_wgradn(int n, const LgmWgradItem* it, void* stre
       d[0] = (int64_t)(uintptr_t)it[k].ws; d[1] = slabs[k]; d[2] = (int64_t)(uintptr_t)it[k].gw; d[3] = n_w;
       d[4] = (int64_t)(uintptr_t)it[k].gbias; d[5] = it[k].gbias ? g->Nw : 0; d[6] = splits[k]; d[7] = bbits.i;
     }
-    return lgm_wino4_wgrad2_launch(gs, ys, yps, xs, xps, outs, biases, slabs, splits, gpss, totals, (hipStream_t)stream);
+    return lgm_wino4_wgradn_launch(n, gs, ys, yps, xs, xps, outs, biases, slabs, splits, gpss, totals, (hipStream_t)stream);
   }
   int G, ipc;
   wgrad_class(gs[0]->H, gs[0]->W, &G, &ipc);

@@ -427,6 +427,16 @@ __global__ __launch_bounds__(512, 2) void wino4_wgrad2_kernel(const WArgs pa, co
   else wino4_wgrad_body(pb, (int)blockIdx.x - na);
 }
 
+// up to four layers in one launch: block ranges [0, e0), [e0, e1), [e1, e2), [e2, grid) (unused ranges are empty)
+__global__ __launch_bounds__(512, 2) void wino4_wgrad4_kernel(const WArgs p0, const WArgs p1, const WArgs p2, const WArgs p3,
+                                                               const int e0, const int e1, const int e2) {
+  const int b = (int)blockIdx.x;
+  if (b < e0) wino4_wgrad_body(p0, b);
+  else if (b < e1) wino4_wgrad_body(p1, b - e0);
+  else if (b < e2) wino4_wgrad_body(p2, b - e1);
+  else wino4_wgrad_body(p3, b - e2);
+}
+
 }  // namespace lgmwino4w
 
 // ---- host ------------------------------------------------------------------------------------------------------------
@@ -502,25 +512,39 @@ int lgm_wino4_wgrad_launch(const LgmConvGeom* g, const float* y, long y_pitch, c
   return LGM_OK;
 }
 
-// two layers in one launch: block ranges of one grid (as lgm_conv3x3_wino_wgradn does for the F(2x2) kernel)
-int lgm_wino4_wgrad2_launch(const LgmConvGeom* const* gs, const float* const* ys, const long* yps, const float* const* xs,
-                            const long* xps, float* const* outs, const int* biases, const long* slabs, const int* splits,
-                            const int* gpss, const int* totals, hipStream_t s) {
+// two ... four layers in one launch: block ranges of one grid (as lgm_conv3x3_wino_wgradn does for the F(2x2) kernel)
+int lgm_wino4_wgradn_launch(int n, const LgmConvGeom* const* gs, const float* const* ys, const long* yps,
+                            const float* const* xs, const long* xps, float* const* outs, const int* biases, const long* slabs,
+                            const int* splits, const int* gpss, const int* totals, hipStream_t s) {
   using namespace lgmwino4w;
-  WArgs pp[2];
-  unsigned nb[2];
-  for (int k = 0; k < 2; ++k) {
+  WArgs pp[4];
+  unsigned nb[4] = {0, 0, 0, 0};
+  for (int k = 0; k < n; ++k) {
     wino4_wgrad_prepare(gs[k], ys[k], yps[k], xs[k], xps[k], outs[k], biases[k], slabs[k], splits[k], gpss[k], totals[k], pp[k]);
     nb[k] = (unsigned)((gs[k]->Nw / 64) * (gs[k]->Cw / 32) * splits[k]);
   }
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kW4Smem);
-    attr = true;
+  for (int k = n; k < 4; ++k) pp[k] = pp[n - 1];            // never reached: its block range is empty
+  if (n == 2) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kW4Smem);
+      attr = true;
+    }
+    lgm_note_kernel(LGM_KNAME("lgmwino4w::wino4_wgrad2_kernel"));
+    hipLaunchKernelGGL(wino4_wgrad2_kernel, dim3(nb[0] + nb[1]), dim3(512), kW4Smem, s, pp[0], pp[1], (int)nb[0]);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_wgrad4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kW4Smem);
+      attr = true;
+    }
+    const int e0 = (int)nb[0], e1 = e0 + (int)nb[1], e2 = e1 + (int)nb[2];
+    lgm_note_kernel(LGM_KNAME("lgmwino4w::wino4_wgrad4_kernel"));
+    hipLaunchKernelGGL(wino4_wgrad4_kernel, dim3(nb[0] + nb[1] + nb[2] + nb[3]), dim3(512), kW4Smem, s, pp[0], pp[1], pp[2],
+                       pp[3], e0, e1, e2);
   }
-  lgm_note_kernel(LGM_KNAME("lgmwino4w::wino4_wgrad2_kernel"));
-  hipLaunchKernelGGL(wino4_wgrad2_kernel, dim3(nb[0] + nb[1]), dim3(512), kW4Smem, s, pp[0], pp[1], (int)nb[0]);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

@@ -604,11 +604,12 @@ _PAIR_OK = {}
 
 
 # Up to four large-map layers' weight gradients in one launch (lgm_conv3x3_wino_wgradn): LGM_NO_WGRAD2=1 issues them
-# singly, LGM_WGRAD_GROUP=n (2 ... 4) bounds the group (default 2: measured in round 5 with the larger groups really
-# forming - round 4's "same step time" came through a dangling geometry array that refused every group above two -
-# 10.08 / 10.08 / 10.11 ms per step at B = 128 for n = 2 / 3 / 4, and larger groups hold buffers longer).
+# singly, LGM_WGRAD_GROUP=n (2 ... 4) bounds the group.  Default 4 since the F(4x4) weight-gradient kernel takes up to four
+# layers per launch (wino4_wgrad4_kernel): 10.03 / 10.02 / 10.01 ms per step at B = 128 and 6.98 / 6.95 / 6.93 at B = 64 for
+# n = 2 / 3 / 4 (round 4's "groups of 3 and 4 measured the same" came through a dangling geometry array that refused every
+# group above two; with only the F(2x2) kernel grouping, n = 4 was 10.11 vs 10.08).
 WGRAD2 = _os.environ.get("LGM_NO_WGRAD2", "0") != "1"
-WGRAD_GROUP = max(2, min(4, int(_os.environ.get("LGM_WGRAD_GROUP", "2"))))
+WGRAD_GROUP = max(2, min(4, int(_os.environ.get("LGM_WGRAD_GROUP", "4"))))
 _WG2_OK = {}
 _WG2_WS = {}
 

@@ -724,6 +724,26 @@ def test_winograd4_weight_gradients_of_two_layers_in_one_launch(dev, parity):
     for i in range(2):
         # 131,072 pixels per sum in fp32: the error grows with the batch (5.7e-6 measured at B = 128, 2e-6 at B <= 5)
         parity(f"grouped F(4x4) weight gradient, layer {i}", maxerr(gws[i], refs[i]), 2e-5)
+    # three and four layers in one launch of the F(4x4) kernel (wino4_wgrad4_kernel): the chip's workgroups shared by work,
+    # half (a third) of the slabs per layer; each layer against its float64 reference, run to run identical
+    for n in (3, 4):
+        ents, outs = [], []
+        for k in range(n):
+            l = layers[k % 2]
+            outs.append(torch.full((l[1].shape[-1], 9, l[2].shape[-1]), float("nan"), device=dev))
+            ents.append((l[0], l[1], l[2], outs[-1].data_ptr(), 0.0, None))
+        assert ops.wgrad_group_supported([e[0] for e in ents])
+        rows = []
+        ops.conv_wgrad_group(ents, rows)
+        assert "wino4_wgrad4_kernel" in ops.lib()._dll.lgm_last_kernel().decode() and len(rows) == n
+        ops.wgrad_reduce_batch(rows, dev)
+        for k in range(n):
+            parity(f"{n} layers in one F(4x4) launch, layer {k}", maxerr(outs[k], refs[k % 2]), 2e-5)
+        again = [torch.empty_like(o) for o in outs]
+        rows = []
+        ops.conv_wgrad_group([(e[0], e[1], e[2], a.data_ptr(), 0.0, None) for e, a in zip(ents, again)], rows)
+        ops.wgrad_reduce_batch(rows, dev)
+        assert all(torch.equal(a, o) for a, o in zip(again, outs))
 
 
 def test_grouped_weight_gradients_of_wide_layers_do_not_share_the_f4x4_launch(dev, parity):
