@@ -597,7 +597,8 @@ int lgm_conv3x3_wino_bwd(const LgmConvGeom* g, const float* gy, int64_t gy_pitch
  * with one prologue and one slab - for the large-map layers whose weights are small and whose input gradient runs apart
  * (lgm_conv3x3_wino4).  Workspace sizes: lgm_conv3x3_wino_wgrad2_workspaces. */
 int64_t lgm_conv3x3_wino_wgrad2_supported(const LgmConvGeom* ga, const LgmConvGeom* gb);
-/* The same for 2 ... 4 layers.  LgmWgradItem = one layer's arguments of lgm_conv_wgrad_deferred. */
+/* The same for 2 ... 4 layers (up to 8 when every layer takes the F(4x4) weight-gradient kernel).  LgmWgradItem = one
+ * layer's arguments of lgm_conv_wgrad_deferred. */
 typedef struct {
   const LgmConvGeom* g;
   const float* y;

@@ -1517,8 +1517,8 @@ int lgm_wino4_wgradn_launch(int n, const LgmConvGeom* const* gs, const float* co
 // kernel and still gets at least two slabs' worth of its 64 x 32-channel blocks out of the 256 workgroups (the 512-channel
 // layers of the 64 x 64 configuration do not fit side by side: they take the F(2x2) grouped launch or go alone)
 static bool wgradn_use4(int n, const LgmConvGeom* const* gs) {
-  static const int nmax = getenv("LGM_W4W_GROUP") ? atoi(getenv("LGM_W4W_GROUP")) : 4;
-  if (n < 2 || n > 4 || n > nmax) return false;
+  static const int nmax = getenv("LGM_W4W_GROUP") ? atoi(getenv("LGM_W4W_GROUP")) : 8;
+  if (n < 2 || n > 8 || n > nmax) return false;
   long need = 0;
   for (int k = 0; k < n; ++k) {
     if (!lgm_wino4_wgrad_use(gs[k])) return false;
@@ -1527,8 +1527,8 @@ static bool wgradn_use4(int n, const LgmConvGeom* const* gs) {
   return need <= 256;
 }
 static void wgrad4_budgets(int n, const LgmConvGeom* const* gs, long* budget) {     // blocks of 64 x 32 channels, shares by work
-  double w[4], tot = 0;
-  long mn[4], left = 256;
+  double w[8], tot = 0;
+  long mn[8], left = 256;
   for (int k = 0; k < n; ++k) {
     w[k] = (double)gs[k]->B * gs[k]->H * gs[k]->W * gs[k]->Nw * gs[k]->Cw;
     tot += w[k];
@@ -1551,7 +1551,12 @@ static void wgrad4_budgets(int n, const LgmConvGeom* const* gs, long* budget) { 
 // class, and each still gets at least two slabs out of its share of the chip
 static bool wgradn_supported(int n, const LgmConvGeom* const* gs) {
   using namespace lgmwino;
-  if (n < 2 || n > 4) return false;
+  if (n < 2 || n > 8) return false;
+  if (n > 4) {                       // five ... eight layers: the F(4x4) kernel only
+    for (int k = 0; k < n; ++k)
+      if (!gs[k]) return false;
+    return wgradn_use4(n, gs);
+  }
   int G0 = 0;
   long need = 0;
   // layers that would each take the F(4x4) kernel but do not fit side by side (wgradn_use4: the 512-channel layers of the
@@ -1610,7 +1615,7 @@ extern "C" int64_t lgm_conv3x3_wino_wgrad2_supported(const LgmConvGeom* ga, cons
 extern "C" int lgm_conv3x3_wino_wgradn_workspaces(int n, const LgmConvGeom* const* geoms, int64_t* out) {
   LGM_REQUIRE(geoms && out && wgradn_supported(n, geoms), "conv3x3_wino_wgradn_workspaces: unsupported group of layers");
   if (wgradn_use4(n, geoms)) {
-    long b4[4];
+    long b4[8];
     wgrad4_budgets(n, geoms, b4);
     for (int k = 0; k < n; ++k) {
       int splits, gps, total;
@@ -1635,8 +1640,8 @@ extern "C" int lgm_conv3x3_wino_wgrad2_workspaces(const LgmConvGeom* ga, const L
 
 extern "C" int lgm_conv3x3_wino_wgradn(int n, const LgmWgradItem* it, void* stream) {
   using namespace lgmwino;
-  LGM_REQUIRE(it && n >= 2 && n <= 4, "conv3x3_wino_wgradn: 2 ... 4 layers expected");
-  const LgmConvGeom* gs[4];
+  LGM_REQUIRE(it && n >= 2 && n <= 8, "conv3x3_wino_wgradn: 2 ... 8 layers expected");
+  const LgmConvGeom* gs[8];
   for (int k = 0; k < n; ++k) gs[k] = it[k].g;
   LGM_REQUIRE(wgradn_supported(n, gs), "conv3x3_wino_wgradn: unsupported group of layers");
   for (int k = 0; k < n; ++k)
@@ -1644,13 +1649,13 @@ extern "C" int lgm_conv3x3_wino_wgradn(int n, const LgmWgradItem* it, void* stre
                 wgrad2_operands_ok(it[k].g, it[k].y, it[k].y_pitch, it[k].x, it[k].x_pitch, it[k].gw, it[k].gbias),
                 "conv3x3_wino_wgradn: layer %d: 16-byte aligned operands with pitch %% 4 == 0 inside 32-bit offsets expected", k);
   if (wgradn_use4(n, gs)) {                       // all layers on the F(4x4) kernel: one launch of that kernel
-    long b4[4];
+    long b4[8];
     wgrad4_budgets(n, gs, b4);
-    const float* ys[4];
-    const float* xs[4];
-    long yps[4], xps[4], slabs[4];
-    float* outs[4];
-    int biases[4], splits[4], gpss[4], totals[4];
+    const float* ys[8];
+    const float* xs[8];
+    long yps[8], xps[8], slabs[8];
+    float* outs[8];
+    int biases[8], splits[8], gpss[8], totals[8];
     for (int k = 0; k < n; ++k) {
       const LgmConvGeom* g = gs[k];
       lgm_wino4_wgrad_plan(g, b4[k], &splits[k], &gpss[k], &totals[k]);

@@ -437,6 +437,20 @@ __global__ __launch_bounds__(512, 2) void wino4_wgrad4_kernel(const WArgs p0, co
   else wino4_wgrad_body(p3, b - e2);
 }
 
+// up to eight layers in one launch (the argument block is 8 x 104 bytes): range ends in e[0 .. 6]
+struct WArgs8 {
+  WArgs p[8];
+  int e[7];
+};
+__global__ __launch_bounds__(512, 2) void wino4_wgrad8_kernel(const WArgs8 a) {
+  const int b = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) k += b >= a.e[i] ? 1 : 0;           // block-uniform
+  const int base = k == 0 ? 0 : a.e[k - 1];
+  wino4_wgrad_body(a.p[k], b - base);
+}
+
 }  // namespace lgmwino4w
 
 // ---- host ------------------------------------------------------------------------------------------------------------
@@ -517,14 +531,30 @@ int lgm_wino4_wgradn_launch(int n, const LgmConvGeom* const* gs, const float* co
                             const float* const* xs, const long* xps, float* const* outs, const int* biases, const long* slabs,
                             const int* splits, const int* gpss, const int* totals, hipStream_t s) {
   using namespace lgmwino4w;
-  WArgs pp[4];
-  unsigned nb[4] = {0, 0, 0, 0};
+  WArgs pp[8];
+  unsigned nb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int k = 0; k < n; ++k) {
     wino4_wgrad_prepare(gs[k], ys[k], yps[k], xs[k], xps[k], outs[k], biases[k], slabs[k], splits[k], gpss[k], totals[k], pp[k]);
     nb[k] = (unsigned)((gs[k]->Nw / 64) * (gs[k]->Cw / 32) * splits[k]);
   }
-  for (int k = n; k < 4; ++k) pp[k] = pp[n - 1];            // never reached: its block range is empty
-  if (n == 2) {
+  for (int k = n; k < 8; ++k) pp[k] = pp[n - 1];            // never reached: its block range is empty
+  if (n > 4) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_wgrad8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kW4Smem);
+      attr = true;
+    }
+    WArgs8 a8;
+    unsigned tot = 0;
+    for (int k = 0; k < 8; ++k) {
+      a8.p[k] = pp[k];
+      tot += nb[k];
+      if (k < 7) a8.e[k] = (int)tot;
+    }
+    lgm_note_kernel(LGM_KNAME("lgmwino4w::wino4_wgrad8_kernel"));
+    hipLaunchKernelGGL(wino4_wgrad8_kernel, dim3(tot), dim3(512), kW4Smem, s, a8);
+  } else if (n == 2) {
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

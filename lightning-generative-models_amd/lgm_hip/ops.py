@@ -609,7 +609,7 @@ _PAIR_OK = {}
 # n = 2 / 3 / 4 (round 4's "groups of 3 and 4 measured the same" came through a dangling geometry array that refused every
 # group above two; with only the F(2x2) kernel grouping, n = 4 was 10.11 vs 10.08).
 WGRAD2 = _os.environ.get("LGM_NO_WGRAD2", "0") != "1"
-WGRAD_GROUP = max(2, min(4, int(_os.environ.get("LGM_WGRAD_GROUP", "4"))))
+WGRAD_GROUP = max(2, min(8, int(_os.environ.get("LGM_WGRAD_GROUP", "4"))))
 _WG2_OK = {}
 _WG2_WS = {}
 

@@ -726,7 +726,7 @@ def test_winograd4_weight_gradients_of_two_layers_in_one_launch(dev, parity):
         parity(f"grouped F(4x4) weight gradient, layer {i}", maxerr(gws[i], refs[i]), 2e-5)
     # three and four layers in one launch of the F(4x4) kernel (wino4_wgrad4_kernel): the chip's workgroups shared by work,
     # half (a third) of the slabs per layer; each layer against its float64 reference, run to run identical
-    for n in (3, 4):
+    for n in (3, 4, 7):
         ents, outs = [], []
         for k in range(n):
             l = layers[k % 2]
@@ -735,7 +735,8 @@ def test_winograd4_weight_gradients_of_two_layers_in_one_launch(dev, parity):
         assert ops.wgrad_group_supported([e[0] for e in ents])
         rows = []
         ops.conv_wgrad_group(ents, rows)
-        assert "wino4_wgrad4_kernel" in ops.lib()._dll.lgm_last_kernel().decode() and len(rows) == n
+        assert ("wino4_wgrad8_kernel" if n > 4 else "wino4_wgrad4_kernel") in ops.lib()._dll.lgm_last_kernel().decode()
+        assert len(rows) == n
         ops.wgrad_reduce_batch(rows, dev)
         for k in range(n):
             parity(f"{n} layers in one F(4x4) launch, layer {k}", maxerr(outs[k], refs[k % 2]), 2e-5)
