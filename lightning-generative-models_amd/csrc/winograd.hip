@@ -1520,10 +1520,19 @@ static bool wgradn_use4(int n, const LgmConvGeom* const* gs) {
   static const int nmax = getenv("LGM_W4W_GROUP") ? atoi(getenv("LGM_W4W_GROUP")) : 8;
   if (n < 2 || n > 8 || n > nmax) return false;
   long need = 0;
+  double phases = 0.0;                 // tile groups x channel blocks of the whole group = phases the chip's workgroups share
   for (int k = 0; k < n; ++k) {
     if (!lgm_wino4_wgrad_use(gs[k])) return false;
-    need += 2L * (gs[k]->Nw / 64) * (gs[k]->Cw / 32);
+    const long blocks = (long)(gs[k]->Nw / 64) * (gs[k]->Cw / 32);
+    need += 2L * blocks;
+    phases += (double)gs[k]->B * gs[k]->H * gs[k]->W / 64.0 * (double)blocks;
   }
+  // More than two layers share a launch only while a workgroup's run stays short: past ~80 phases per workgroup the
+  // prologue / epilogue / slab savings are used up and the longer tail costs more (32 x 32 maps at B = 128: four layers =
+  // 64 phases, 10.03 -> 10.01 ms per step; 64 x 64 maps at B = 64: four layers = 128 phases, 16.78 -> 17.26 ms; eight layers
+  // at 32 x 32 = 128 phases: 10.21 ms).  LGM_W4W_MAX_PHASES: tuning knob.
+  static const double max_phases = getenv("LGM_W4W_MAX_PHASES") ? atof(getenv("LGM_W4W_MAX_PHASES")) : 80.0;
+  if (n > 2 && phases / 256.0 > max_phases) return false;
   return need <= 256;
 }
 static void wgrad4_budgets(int n, const LgmConvGeom* const* gs, long* budget) {     // blocks of 64 x 32 channels, shares by work

@@ -726,10 +726,21 @@ def test_winograd4_weight_gradients_of_two_layers_in_one_launch(dev, parity):
         parity(f"grouped F(4x4) weight gradient, layer {i}", maxerr(gws[i], refs[i]), 2e-5)
     # three and four layers in one launch of the F(4x4) kernel (wino4_wgrad4_kernel): the chip's workgroups shared by work,
     # half (a third) of the slabs per layer; each layer against its float64 reference, run to run identical
-    for n in (3, 4, 7):
-        ents, outs = [], []
+    # (more than two layers share a launch only while a workgroup's run stays under ~80 phases: three mixed layers, four of
+    # the small one, seven of the small one at half the batch)
+    half = (ops.make_geom(64, 32, 32, 64, 64, 3, 3, 1, 1), layers[0][1][:64].contiguous(), layers[0][2][:64].contiguous())
+    w0 = torch.zeros(64, 64, 3, 3, dtype=torch.double, requires_grad=True)
+    acc = torch.zeros(64, 9, 64, dtype=torch.double)
+    for k in range(0, 64, 8):
+        out = F.conv2d(half[2][k:k + 8].cpu().permute(0, 3, 1, 2).double(), w0, None, padding=1)
+        gk, = torch.autograd.grad(out, w0, half[1][k:k + 8].cpu().permute(0, 3, 1, 2).double())
+        acc += gk.permute(0, 2, 3, 1).reshape(64, 9, 64)
+    assert not ops.wgrad_group_supported([layers[1][0]] * 4)        # 4 x 128 -> 64 @ 32 x 32, B = 128: 128 phases per workgroup
+    for n, pick in ((3, lambda k: (layers[k % 2], refs[k % 2])), (4, lambda k: (layers[0], refs[0])), (7, lambda k: (half, acc))):
+        ents, outs, want = [], [], []
         for k in range(n):
-            l = layers[k % 2]
+            l, r = pick(k)
+            want.append(r)
             outs.append(torch.full((l[1].shape[-1], 9, l[2].shape[-1]), float("nan"), device=dev))
             ents.append((l[0], l[1], l[2], outs[-1].data_ptr(), 0.0, None))
         assert ops.wgrad_group_supported([e[0] for e in ents])
@@ -739,7 +750,7 @@ def test_winograd4_weight_gradients_of_two_layers_in_one_launch(dev, parity):
         assert len(rows) == n
         ops.wgrad_reduce_batch(rows, dev)
         for k in range(n):
-            parity(f"{n} layers in one F(4x4) launch, layer {k}", maxerr(outs[k], refs[k % 2]), 2e-5)
+            parity(f"{n} layers in one F(4x4) launch, layer {k}", maxerr(outs[k], want[k]), 2e-5)
         again = [torch.empty_like(o) for o in outs]
         rows = []
         ops.conv_wgrad_group([(e[0], e[1], e[2], a.data_ptr(), 0.0, None) for e, a in zip(ents, again)], rows)
