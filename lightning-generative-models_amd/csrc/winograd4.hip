@@ -648,16 +648,17 @@ static int unit_class(int H, int W) {
 bool lgm_wino4l_supported(const LgmConvGeom* g, int gather_channels, int out_channels);
 long lgm_wino4l_units(const LgmConvGeom* g, int out_channels);
 int lgm_wino4l_stats_parts(const LgmConvGeom* g);
+int lgm_wino4l_class(const LgmConvGeom* g);
 int lgm_wino4l_splits(const LgmConvGeom* g, int gather_channels, int out_channels);
 int lgm_wino4l_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, const float* u, const float* bias,
                       const float* res, long res_pitch, float* out, long out_pitch, void* workspace, long workspace_bytes,
                       hipStream_t s, int64_t* partial, float* stats);
-// LGM_WINO4_LIGHT: 1 = the light workgroups wherever they take the geometry, 0 = the 32-tile workgroups only.  Default: light
-// when this process is one of several ranks (WORLD_SIZE > 1: a resident collective shares the chip - with one foreign
+// LGM_WINO4_LIGHT: 1 = the light workgroups wherever they take the geometry, 0 = the 32-tile workgroups only.  Unset: all
+// light when this process is one of several ranks (WORLD_SIZE > 1: a resident collective shares the chip - with one foreign
 // workgroup resident the step costs +38 % on the 32-tile kernels and +30 % with the light ones, tools/cu_hog_step.py - and the
-// per-rank batches are the ones they win at: 6.89 vs 6.96 ms at B = 64), the 32-tile workgroups on one GPU (B = 128: 10.13 vs
-// 10.22 ms per step; isolated and cache-warm the light kernel is 4-20 % faster at every batch, tools/wino4l_bench.py, but
-// inside the step every launch starts cold and two waves per SIMD hide more of that).
+// per-rank batches are the ones they win at), and on one GPU launch by launch (the rule inside wino4_use_light: B = 128 keeps
+// the 32-tile workgroups, 10.03 vs 10.13 ms all light; isolated and cache-warm the light kernel is 4-20 % faster at every
+// batch, tools/wino4l_bench.py, but inside the step every launch starts cold and two waves per SIMD hide more of that).
 static int lgm_wino4_light_override = -1;         // diagnostic / tests: lgm_wino4_set_light
 extern "C" int lgm_wino4_set_light(int mode) {
   lgm_wino4_light_override = mode;
@@ -667,7 +668,26 @@ static bool wino4_use_light(const LgmConvGeom* g, int gather_channels, int out_c
   static const int env_mode = getenv("LGM_WINO4_LIGHT") ? atoi(getenv("LGM_WINO4_LIGHT"))
                               : (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 ? 1 : 0);
   const int mode = lgm_wino4_light_override >= 0 ? lgm_wino4_light_override : env_mode;
-  return mode != 0 && lgm_wino4l_supported(g, gather_channels, out_channels);
+  if (!lgm_wino4l_supported(g, gather_channels, out_channels)) return false;
+  if (mode != 0) return true;
+  if (getenv("LGM_WINO4_LIGHT") != nullptr || lgm_wino4_light_override >= 0) return false;   // 0 asked for: 32-tile only
+  // One GPU, nothing asked for: the light workgroups for the launches the 32-tile kernel cannot fill the chip with -
+  // fewer 32-tile units than the class's bound (LGM_WINO4_LIGHT_BELOW="a,b,c": W % 32 == 0 maps, 16x16, 8x8; 0 = never).
+  // Measured per step (tools/step_ab.sh): B = 64 6.94 -> 6.73 ms, B = 32 5.37 -> 5.21; at B = 128 (256 / 128 / 64 units)
+  // the 16x16 launches are neutral and the 8x8 ones cost 0.06 ms light, so the bounds sit at or below those counts.
+  static long below[3] = {-1, 0, 0};
+  if (below[0] < 0) {
+    long b0 = 200, b1 = 128, b2 = 64;
+    if (const char* e = getenv("LGM_WINO4_LIGHT_BELOW")) {
+      b1 = b2 = -1;
+      sscanf(e, "%ld,%ld,%ld", &b0, &b1, &b2);
+      if (b1 < 0) b1 = b0;
+      if (b2 < 0) b2 = b1;
+    }
+    below[1] = b1, below[2] = b2, below[0] = b0 < 0 ? 0 : b0;
+  }
+  const int cls = lgm_wino4l_class(g);
+  return cls >= 0 && lgm_wino4l_units(g, out_channels) / 2 < below[cls];
 }
 
 static bool wino4_big_supported(const LgmConvGeom* g, int gather_channels, int out_channels);

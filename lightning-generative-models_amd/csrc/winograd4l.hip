@@ -512,6 +512,9 @@ long lgm_wino4l_units(const LgmConvGeom* g, int out_channels) {
   return cls < 0 ? 0 : unit_count(cls, g->B, g->H, g->W) * (out_channels / 64);
 }
 
+// 0: maps with H % 8 == 0 and W % 32 == 0, 1: 16x16, 2: 8x8 (four images to a unit); -1: not taken
+int lgm_wino4l_class(const LgmConvGeom* g) { return lgmwino4l::unit_class(g->H, g->W); }
+
 // rows of GroupNorm statistics one image contributes per channel (STATS build: one row per wave of a unit)
 int lgm_wino4l_stats_parts(const LgmConvGeom* g) {
   using namespace lgmwino4l;
