@@ -53,6 +53,7 @@ struct WArgs {
   int splits, gps, total_groups;
   int grow;            // groups per group row (W / 16, or W / 8 for square groups)
   int trows;           // group rows per image (H / 4, or H / 8)
+  int xcd_order;       // 1: sharers of a pixel range on one XCD (see the block decode)
   int sq;              // group shape: 0 = four tiles in a row (4 x 16 output pixels), 1 = 2 x 2 tiles (8 x 8: the 8 x 8 maps)
 };
 
@@ -83,9 +84,20 @@ __device__ __forceinline__ void wino4_wgrad_body(const WArgs& p, const int bidx)
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
 
-  int bid = bidx;
-  const int split = bid % p.splits;
-  bid /= p.splits;
+  // Block -> (split, input-channel block, output-channel block).  The tiles_c * tiles_n workgroups of a split read the SAME
+  // pixels (all of them dY's 64-channel slice, pairs of them the same 32 channels of x): they get consecutive logical ids
+  // inside one XCD's share of the range (blocks with equal id & 7 sit on one XCD whatever the range's first block is), so
+  // that one of them fetches and the others hit that XCD's L2.  With the split index fastest (the former order) the
+  // sharers sat on different XCDs and dY came from memory tiles_c times (404 MB fetched per four-layer launch against 268
+  // MB of operands, profiles/r05_pmc_traffic.json).
+  int L = bidx;
+  const int inner = p.tiles_c * (p.Nw >> 6);
+  if (p.xcd_order) {
+    const int nblk = inner * p.splits, v = bidx & 7, r = nblk & 7;
+    L = v * (nblk >> 3) + (v < r ? v : r) + (bidx >> 3);
+  }
+  const int split = p.xcd_order ? L / inner : L % p.splits;
+  const int bid = p.xcd_order ? L % inner : L / p.splits;
   const int tc = bid % p.tiles_c, tn = bid / p.tiles_c;
   const int n0 = tn * 64, c0 = tc * 32;
   const int g_begin = split * p.gps;
@@ -502,6 +514,8 @@ static void wino4_wgrad_prepare(const LgmConvGeom* g, const float* y, long y_pit
   p.tiles_c = g->Cw / 32;
   p.splits = splits; p.gps = gps; p.total_groups = total;
   p.sq = (g->W % 16 != 0) ? 1 : 0;
+  static const int xcd_order = getenv("LGM_W4W_XCD") ? atoi(getenv("LGM_W4W_XCD")) : 1;
+  p.xcd_order = xcd_order;
   p.grow = p.sq ? g->W / 8 : g->W / 16;
   p.trows = p.sq ? g->H / 8 : g->H / 4;
 }

@@ -1,5 +1,5 @@
 """Per-kernel counter summary from separate rocprofv3 --pmc passes over the same command
-(`python3 bench.py --only --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline`):
+(`python3 bench.py --only --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-roofline`):
 
     python tools/pmc_kernels.py <fetch-dir> <write-dir> <mfma-dir> > profiles/rNN_pmc_traffic.json
 
@@ -16,27 +16,39 @@ from collections import defaultdict
 
 
 def load(d):
-    tot, n = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
+    """Counter sums and launch counts per kernel name over the STEADY-STATE steps only: the dispatches between the first and the
+    last `adam_kernel` of the process (a training step ends with the fused Adam launch; what precedes the first one is model
+    construction, parameter initialisation, the first step's one-time buffer fills and copies; what follows the last one is
+    the tail of the run).  Returns (sums, counts, steps)."""
+    rows = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 k = row["Kernel_Name"].replace("(anonymous namespace)::", "")
                 k = re.sub(r"^void ", "", k)
                 k = re.sub(r"\(.*$", "", k).strip()                          # drop the argument list
-                tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
-                n[k][row["Counter_Name"]] += 1
-    return tot, n
+                rows.append((int(row["Dispatch_Id"]), k, row["Counter_Name"], float(row["Counter_Value"])))
+    rows.sort()
+    adam = sorted({r[0] for r in rows if "adam_kernel" in r[1]})
+    lo, hi, steps = (adam[0], adam[-1], len(adam) - 1) if len(adam) >= 2 else (-1, 1 << 62, max(len(adam), 1))
+    tot, n = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
+    for did, k, c, v in rows:
+        if lo < did <= hi:
+            tot[k][c] += v
+            n[k][c] += 1
+    return tot, n, steps
 
 
 def main():
-    ft, fn = load(sys.argv[1])
-    wt, wn = load(sys.argv[2])
-    mt, mn = load(sys.argv[3]) if len(sys.argv) > 3 else ({}, {})
+    ft, fn, steps = load(sys.argv[1])
+    wt, wn, _ = load(sys.argv[2])
+    mt, mn, _ = load(sys.argv[3]) if len(sys.argv) > 3 else ({}, {}, 0)
     out = {"method": "rocprofv3 --pmc in separate passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES "
-                     "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) over `python3 bench.py --only --steps 3 --warmup 1 --no-graph "
-                     "--no-cpu-baseline --no-roofline`; KB -> bytes; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md); means per launch",
+                     "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) over `python3 bench.py --only --steps 4 --warmup 1 --no-graph "
+                     "--no-cpu-baseline --no-roofline`; the dispatches between the first and the last adam_kernel only (steady-state "
+                     "steps: no model construction, no first-step buffer fills); KB -> bytes; FETCH_SIZE x2 on gfx950 "
+                     "(MI355X_MICROARCH.md); means per launch",
            "kernels": {}}
-    steps = max((fn[k]["FETCH_SIZE"] for k in fn if "adam_kernel" in k), default=1)
     tf = tw = 0.0
     for k in sorted(ft, key=lambda k: -ft[k].get("FETCH_SIZE", 0.0)):
         nl = fn[k]["FETCH_SIZE"]

@@ -20,7 +20,7 @@ echo "kernel traces done"
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $c | cut -d' ' -f1)
   rm -rf /tmp/pmc_$tag
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$tag --output-format csv -- python3 bench.py --only --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > $out/pmc_$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$tag --output-format csv -- python3 bench.py --only --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > $out/pmc_$tag.log 2>&1
   echo "pmc $tag done"
 done
 python3 tools/pmc_kernels.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES > $out/${R}_pmc_traffic.json
