@@ -515,6 +515,11 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
         line["config"]["grad_exchange"] = ("bucketed all-reduce overlapped with the backward (RCCL)"
                                            if os.environ.get("LGM_DDP_OVERLAP", "1") != "0"
                                            else "one all-reduce after the backward (LGM_DDP_OVERLAP=0)")
+        from lgm_hip import ops as _ops
+        line["config"]["kernel_selection"] = {
+            "cu_margin": int(_ops.lib().lgm_cu_margin()),
+            "note": "launch plans sized for 256 - cu_margin CUs (a collective's workgroups hold the rest), light F(4x4) "
+                    "workgroups; LGM_CU_MARGIN / LGM_WINO4_LIGHT override"}
         if comm:
             line["config"].update({k: comm[k] for k in ("bucket_bytes", "collectives_per_step", "backend", "rccl_ranks")})
             line["comm_exposed_ms"] = comm["comm_exposed_ms"]
@@ -726,9 +731,11 @@ def main():
         line["secondary"] = sec
         proxy = {}
         # the proxies run what a RANK of an N > 1 job runs: the library picks the light F(4x4) workgroups when WORLD_SIZE > 1
-        # (csrc/winograd4.hip: wino4_use_light), so the proxy legs switch them on the same way (and back off afterwards)
+        # (csrc/winograd4.hip: wino4_use_light) and plans its launches for 240 CUs (csrc/elementwise.hip: lgm_cu_budget), so the
+        # proxy legs switch both on the same way (and back off afterwards)
         from lgm_hip import ops as _ops
         _ops.lib().lgm_wino4_set_light(1)
+        _ops.lib().lgm_set_cu_margin(16)
         try:
             for b in (64, 32, 16):
                 r = leg(f"proxy_b{b}", lambda b=b: run_workload("ddpm32", args, dev, 1, 0, 20, 5, batch=b, roofline=False,
@@ -736,9 +743,11 @@ def main():
                 proxy[f"b{b}"] = r.get("ms_per_step") if isinstance(r, dict) else None
         finally:
             _ops.lib().lgm_wino4_set_light(-1)
+            _ops.lib().lgm_set_cu_margin(-1)
         proxy["note"] = ("ms per step of the headline workload on ONE GPU at the per-rank batch of 2 / 4 / 8 GPUs "
                          "(global batch 128): compute between the gradient exchanges under strong scaling; kernel "
-                         "selection as under WORLD_SIZE > 1 (light F(4x4) workgroups)")
+                         "selection as under WORLD_SIZE > 1 (light F(4x4) workgroups, launch plans sized for 240 of the 256 CUs: "
+                         "lgm_set_cu_margin)")
         line["per_rank_proxy"] = proxy
         if faulted is not None:
             line["device_error_in"] = faulted

@@ -39,10 +39,11 @@
 extern "C" {
 #endif
 
-#define LGM_ABI_VERSION 4   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial;
+#define LGM_ABI_VERSION 5   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial;
                              * 3: lgm_conv3x3_wino4*, lgm_gn_fwd_stats, lgm_conv3x3_wino_wgradn* + LgmWgradItem, a negative
                              *    dst offset in lgm_wino_weights table rows means "skip that copy", lgm_kernel_name*;
-                             * 4: LgmPostOp carries the BatchNorm-backward sums (bn_*), lgm_bn_reduce3_coef_tiles */
+                             * 4: LgmPostOp carries the BatchNorm-backward sums (bn_*), lgm_bn_reduce3_coef_tiles;
+                             * 5: lgm_set_cu_margin / lgm_cu_margin */
 #define LGM_OK 0
 #define LGM_ERR_INVALID (-1)
 #define LGM_ERR_UNSUPPORTED (-2)
@@ -674,6 +675,13 @@ int lgm_conv3x3_wino4(int yx, const LgmConvGeom* g, const float* a, int64_t a_pi
  * environment says (LGM_WINO4_LIGHT; default: light when WORLD_SIZE > 1).  Process-wide; callers that cache plans (split counts, workspace sizes)
  * must not flip it between a size query and the launch it sizes. */
 int lgm_wino4_set_light(int mode);
+
+/* Workgroup slots the launch planners leave to a collective resident beside the step (one process per GPU, RCCL's kernel
+ * holds a CU per channel): split-K / slab / persistent-range plans are sized for 256 - margin CUs.  Default: LGM_CU_MARGIN,
+ * else 16 when WORLD_SIZE > 1, else 0; margin < 0 returns to that default; margin <= 128.  Plans made before the call keep
+ * their grids (captured graphs included).  lgm_cu_margin() reads the value in force. */
+int lgm_set_cu_margin(int margin);
+int lgm_cu_margin(void);
 int64_t lgm_conv3x3_wino4l_supported(const LgmConvGeom* g, int yx);
 int64_t lgm_conv3x3_wino4l_workspace(const LgmConvGeom* g, int yx);   /* split-K partial outputs (bytes) */
 int lgm_conv3x3_wino4l(int yx, const LgmConvGeom* g, const float* a, int64_t a_pitch, const float* u,

@@ -1134,7 +1134,7 @@ int lgm_conv3x3_splits(const LgmConvGeom* g, int gather_channels, int out_channe
   for (long c = 1; c <= smax; ++c) {
     const long pps = (phases + c - 1) / c;
     if ((phases + pps - 1) / pps != c) continue;          // would leave an empty split
-    const double rounds = (double)((base * c + 255) / 256);
+    const double rounds = (double)((base * c + lgm_cu_budget() - 1) / lgm_cu_budget());
     const double cost = rounds * (double)pps / (double)phases + 0.02 * (double)(c - 1);
     if (cost < best - 1e-9) {
       best = cost;
@@ -1176,7 +1176,7 @@ int lgm_conv3x3_launch(int mode, const LgmConvGeom* g, const float* a, long a_pi
   p.pps = lgm_cdiv(p.C / 32, p.splits);
   p.splits = lgm_cdiv(p.C / 32, p.pps);
   p.units = (int)((long)groups * p.tiles_h * p.tiles_w * p.tiles_n * p.splits);
-  p.per = lgm_cdiv(p.units, 256);     // one persistent workgroup per CU walks its unit range
+  p.per = lgm_cdiv(p.units, lgm_cu_budget());     // one persistent workgroup per CU walks its unit range
   const unsigned nblocks = (unsigned)lgm_cdiv(p.units, p.per);
   const size_t smem = ((size_t)2 * 288 * 36 + 4 * LGM_TS_FLOATS) * sizeof(float);
 #define LGM_C3_LAUNCH(M)                                                                               \
@@ -1259,7 +1259,7 @@ extern "C" int lgm_conv3x3_bf16x3(int mode, const LgmConvGeom* g, const float* a
   p.pps = lgm_cdiv(p.C / 32, p.splits);
   p.splits = lgm_cdiv(p.C / 32, p.pps);
   p.units = (int)((long)groups * p.tiles_h * p.tiles_w * p.tiles_n * p.splits);
-  p.per = lgm_cdiv(p.units, 256);
+  p.per = lgm_cdiv(p.units, lgm_cu_budget());
   const unsigned nblocks = (unsigned)lgm_cdiv(p.units, p.per);
   const size_t smem = (size_t)2 * 288 * 208 + 4 * LGM_TS_FLOATS * sizeof(float);
   if (mode == 0) {
@@ -1313,7 +1313,7 @@ void lgm_wgrad3x3_plan(const LgmConvGeom* g, int* splits, int* tps, int* total_t
   const int total = lgm_cdiv(g->B, NI) * (g->H / TH) * (g->W / TW);
   const long tiles = (long)(g->Nw / 64) * (g->Cw / 64);
   // LDS allows ONE resident workgroup per CU: never exceed 256 workgroups (a 257th would run alone)
-  long s = 256 / tiles;
+  long s = lgm_cu_budget() / tiles;
   if (s > total) s = total;
   if (s < 1) s = 1;
   const int t = lgm_cdiv(total, s);

@@ -1690,7 +1690,7 @@ extern "C" int64_t lgm_conv_wgrad_workspace(const LgmConvGeom* g) {
   }
   if (use_3x3() && use_wino() && lgm_wino4_wgrad_use(g)) {
     int sw, gps, total;
-    lgm_wino4_wgrad_plan(g, 256, &sw, &gps, &total);
+    lgm_wino4_wgrad_plan(g, lgm_cu_budget(), &sw, &gps, &total);
     if (sw > splits) splits = sw;
   }
   if (g->KH == 1 && g->KW == 1 && g->Nw % 64 == 0 && g->Cw % 64 == 0) {
@@ -1728,7 +1728,7 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
   const bool fastw4 = fastw && lgm_wino4_wgrad_use(g);          // large maps: F(4x4,3x3)
   int tps3 = 0, total3 = 0, per1 = 0, cpsw = 0, totalw = 0;
   if (fastw4)
-    lgm_wino4_wgrad_plan(g, 256, &a.splits, &cpsw, &totalw);
+    lgm_wino4_wgrad_plan(g, lgm_cu_budget(), &a.splits, &cpsw, &totalw);
   else if (fastw)
     lgm_wino_wgrad_plan(g, &a.splits, &cpsw, &totalw);
   else if (fast3)

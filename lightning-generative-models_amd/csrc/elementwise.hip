@@ -21,6 +21,26 @@ extern "C" const char* lgm_last_kernel(void) { return g_kernel; }
 // the name registry: one pointer per LGM_KNAME site of the whole library (section bounds from the linker)
 extern "C" const char* const __start_lgm_knames[];
 extern "C" const char* const __stop_lgm_knames[];
+// CU margin: LGM_CU_MARGIN, else 16 when this process is one rank of several (WORLD_SIZE > 1: a collective's workgroups hold
+// CUs beside the backward pass), else 0; lgm_set_cu_margin(margin) overrides (-1: back to that default).  Measured with 16
+// foreign 256-thread workgroups resident (tools/cu_hog_step.py, light F(4x4) workgroups, ms per step, margin 0 / 16 / 32):
+// B = 64: 8.15 / 7.48 / 7.49 (alone 6.75 / 6.86 / 6.92); B = 16: 4.90 / 4.70 / 4.69 (alone 4.48 / 4.49 / 4.50).
+static int lgm_cu_margin_override = -1;
+extern "C" int lgm_cu_margin(void) { return 256 - lgm_cu_budget(); }
+extern "C" int lgm_set_cu_margin(int margin) {
+  LGM_REQUIRE(margin <= 128, "lgm_set_cu_margin: margin %d leaves less than half of the chip", margin);
+  lgm_cu_margin_override = margin;
+  return LGM_OK;
+}
+int lgm_cu_budget() {
+  static const int env_margin = getenv("LGM_CU_MARGIN") ? atoi(getenv("LGM_CU_MARGIN"))
+                                : (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 ? 16 : 0);
+  int m = lgm_cu_margin_override >= 0 ? lgm_cu_margin_override : env_margin;
+  if (m < 0) m = 0;
+  if (m > 128) m = 128;
+  return 256 - m;
+}
+
 extern "C" int lgm_kernel_name_count(void) { return (int)(__stop_lgm_knames - __start_lgm_knames); }
 extern "C" const char* lgm_kernel_name(int i) {
   return (i >= 0 && i < lgm_kernel_name_count()) ? __start_lgm_knames[i] : nullptr;

@@ -210,7 +210,7 @@ bool make_plan(long M, int N, int K, Plan* pl) {
   pl->tn = nb / 64;
   pl->n_slices = N / nb;
   pl->total_tiles = (int)(M / 64);
-  int rs = 256 / pl->n_slices;
+  int rs = lgm_cu_budget() / pl->n_slices;
   if (rs < 1) rs = 1;
   if (rs > pl->total_tiles) rs = pl->total_tiles;
   pl->tiles_per_block = lgm_cdiv(pl->total_tiles, rs);

@@ -14,6 +14,10 @@ void lgm_set_error(const char* fmt, ...);
 // name (as rocprofv3 prints it, without the argument list) of the primary kernel the calling thread's last
 // convolution-family entry point launched: lets bench.py attribute its HIP-event timings to profiler rows
 void lgm_note_kernel(const char* name);
+// Workgroup slots the launch planners count on: the chip's 256 CUs minus the margin left to the workgroups of a collective
+// that is resident beside the step (LGM_CU_MARGIN / lgm_set_cu_margin, 16 under WORLD_SIZE > 1; elementwise.hip).  One-workgroup-per-CU kernels sized
+// for all 256 CUs need a second round as soon as ONE CU is taken (tools/cu_hog_step.py).
+int lgm_cu_budget();
 // Every name handed to lgm_note_kernel goes through LGM_KNAME: the literal's address is also placed in the ELF section
 // "lgm_knames" at link time (no code runs), so lgm_kernel_name(i) can list every name the library may ever note and
 // tests/test_cabi.py checks each against the kernel symbols of liblgm_hip.so - a template argument added to a kernel

@@ -246,7 +246,7 @@ void lgm_wgrad1x1_plan(const LgmConvGeom* g, int* splits, int* chunks_per_split)
     return;
   }
   const int units = (g->Nw / tile_of(g->Nw)) * (g->Cw / tile_of(g->Cw));
-  int s = 256 / units;
+  int s = lgm_cu_budget() / units;
   if (s > total) s = total;
   if (s < 1) s = 1;
   const int per = lgm_cdiv(total, s);

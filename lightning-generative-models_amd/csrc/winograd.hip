@@ -800,7 +800,7 @@ int lgm_wino_splits(const LgmConvGeom* g, int gather_channels, int out_channels,
   for (long c = 1; c <= smax; ++c) {
     const long pps = (phases + c - 1) / c;
     if ((phases + pps - 1) / pps != c) continue;
-    const double rounds = (double)((base * c + 255) / 256);
+    const double rounds = (double)((base * c + lgm_cu_budget() - 1) / lgm_cu_budget());
     const double cost = rounds * ((double)pps + k_ovh) + (c > 1 ? (fused ? 0.2 : 2.4) : 0.0) + per_split * (double)(c - 1);
     if (cost < best - 1e-9) {
       best = cost;
@@ -841,7 +841,7 @@ static void wino_prepare(const LgmConvGeom* g, int yx, const float* a, long a_pi
   p.pps = lgm_cdiv(p.C / KC, p.splits);
   p.splits = lgm_cdiv(p.C / KC, p.pps);
   p.units = (int)((long)(g->B / NI) * p.tb_h * p.tb_w * p.tiles_n * p.splits);
-  p.per = lgm_cdiv(p.units, 256);
+  p.per = lgm_cdiv(p.units, lgm_cu_budget());
   p.nbg = g->B / NI;
   // Small maps (a unit = whole images): image-group-fastest order, so that the workgroups one XCD runs together (a
   // contiguous unit range, xcd_swizzle) work on ONE channel block and fetch its transformed weights into that XCD's L2
@@ -1424,7 +1424,7 @@ bool lgm_wino_wgrad_supported(const LgmConvGeom* g) {
 // splits >= 2 always (the kernel only writes slabs); cps = chunks per split; budget = workgroups of one round
 static void wino_wgrad_plan_budget(const LgmConvGeom* g, long budget, int* splits, int* cps, int* total_chunks);
 void lgm_wino_wgrad_plan(const LgmConvGeom* g, int* splits, int* cps, int* total_chunks) {
-  wino_wgrad_plan_budget(g, 256, splits, cps, total_chunks);
+  wino_wgrad_plan_budget(g, lgm_cu_budget(), splits, cps, total_chunks);
 }
 static void wino_wgrad_plan_budget(const LgmConvGeom* g, long budget, int* splits, int* cps, int* total_chunks) {
   using namespace lgmwino;
@@ -1532,19 +1532,19 @@ static bool wgradn_use4(int n, const LgmConvGeom* const* gs) {
   // 64 phases, 10.03 -> 10.01 ms per step; 64 x 64 maps at B = 64: four layers = 128 phases, 16.78 -> 17.26 ms; eight layers
   // at 32 x 32 = 128 phases: 10.21 ms).  LGM_W4W_MAX_PHASES: tuning knob.
   static const double max_phases = getenv("LGM_W4W_MAX_PHASES") ? atof(getenv("LGM_W4W_MAX_PHASES")) : 80.0;
-  if (n > 2 && phases / 256.0 > max_phases) return false;
-  return need <= 256;
+  if (n > 2 && phases / (double)lgm_cu_budget() > max_phases) return false;
+  return need <= lgm_cu_budget();
 }
 static void wgrad4_budgets(int n, const LgmConvGeom* const* gs, long* budget) {     // blocks of 64 x 32 channels, shares by work
   double w[8], tot = 0;
-  long mn[8], left = 256;
+  long mn[8], left = lgm_cu_budget();
   for (int k = 0; k < n; ++k) {
     w[k] = (double)gs[k]->B * gs[k]->H * gs[k]->W * gs[k]->Nw * gs[k]->Cw;
     tot += w[k];
     mn[k] = 2L * (gs[k]->Nw / 64) * (gs[k]->Cw / 32);
   }
   for (int k = 0; k < n; ++k) {
-    long b = (long)(256.0 * w[k] / tot + (n == 2 && k == 0 ? 0.5 : 0.0));
+    long b = (long)((double)lgm_cu_budget() * w[k] / tot + (n == 2 && k == 0 ? 0.5 : 0.0));
     if (b < mn[k]) b = mn[k];
     budget[k] = b;
     left -= b;
@@ -1585,20 +1585,20 @@ static bool wgradn_supported(int n, const LgmConvGeom* const* gs) {
     else if (G != G0) return false;
     need += 2L * (gs[k]->Nw / 64) * (gs[k]->Cw / 64);
   }
-  return need <= 256;
+  return need <= lgm_cu_budget();
 }
 
 // the chip's 256 workgroups are shared in proportion to the layers' MFMA work, at least two slabs' worth each
 static void wgradn_budgets(int n, const LgmConvGeom* const* gs, long* budget) {
   double w[4], tot = 0;
-  long mn[4], left = 256;
+  long mn[4], left = lgm_cu_budget();
   for (int k = 0; k < n; ++k) {
     w[k] = (double)gs[k]->B * gs[k]->H * gs[k]->W * gs[k]->Nw * gs[k]->Cw;
     tot += w[k];
     mn[k] = 2L * (gs[k]->Nw / 64) * (gs[k]->Cw / 64);
   }
   for (int k = 0; k < n; ++k) {
-    long b = (long)(256.0 * w[k] / tot);
+    long b = (long)((double)lgm_cu_budget() * w[k] / tot);
     if (b < mn[k]) b = mn[k];
     budget[k] = b;
     left -= b;
@@ -1805,7 +1805,7 @@ static WinoPairPlan wino_pair_plan_search(const LgmConvGeom* g, bool fused) {
   const double slab_cost = k_slab * 4.0 * ((double)g->Nw * 9 * g->Cw + g->Nw) / 4.5e12 / 2.1e-6;
   // makespan of n1 blocks of t1 followed by n2 blocks of t2 on 256 CUs, one block per CU, dispatched in order
   auto makespan = [](long n1, double t1, long n2, double t2) {
-    const long P = 256;
+    const long P = lgm_cu_budget();
     const long r1 = n1 / P, m1 = n1 % P;
     double ta = (double)r1 * t1;                 // the P - m1 CUs without a block of the last conv round
     double tb = (double)(r1 + (m1 ? 1 : 0)) * t1;

@@ -717,8 +717,9 @@ int lgm_wino4_splits(const LgmConvGeom* g, int gather_channels, int out_channels
   int smax = phases / 2 < 16 ? phases / 2 : 16;
   if (smax < 1) smax = 1;
   if (forced > 0) return forced < smax ? forced : smax;
-  if (base >= 192) return 1;
-  int s = (int)((256 + base - 1) / base);
+  const long slots = lgm_cu_budget();
+  if (base >= slots * 3 / 4) return 1;
+  int s = (int)((slots + base - 1) / base);
   if (s > smax) s = smax;
   static const int min_pps = getenv("LGM_WINO4_MIN_PPS") ? atoi(getenv("LGM_WINO4_MIN_PPS")) : 4;
   while (s > 1 && phases / s < min_pps) --s;        // a split shorter than ~4 phases is mostly prologue and epilogue

@@ -601,7 +601,7 @@ extern "C" int64_t lgm_conv3x3_wino4_wgrad_supported(const LgmConvGeom* g) {
 extern "C" int64_t lgm_conv3x3_wino4_wgrad_workspace(const LgmConvGeom* g) {
   if (!g || !lgm_wino4_wgrad_supported(g)) return 0;
   int splits, gps, total;
-  lgm_wino4_wgrad_plan(g, 256, &splits, &gps, &total);
+  lgm_wino4_wgrad_plan(g, lgm_cu_budget(), &splits, &gps, &total);
   return (int64_t)splits * ((int64_t)g->Nw * 9 * g->Cw + g->Nw) * (int64_t)sizeof(float);
 }
 
@@ -616,7 +616,7 @@ extern "C" int lgm_conv3x3_wino4_wgrad(const LgmConvGeom* g, const float* y, int
               ((long)g->B * g->H * g->W + g->W + 1) * x_pitch < (1L << 29) && (long)g->B * g->H * g->W * y_pitch < (1L << 29),
               "conv3x3_wino4_wgrad: 16-byte aligned operands with pitch %% 4 == 0 inside 32-bit offsets expected");
   int splits, gps, total;
-  lgm_wino4_wgrad_plan(g, 256, &splits, &gps, &total);
+  lgm_wino4_wgrad_plan(g, lgm_cu_budget(), &splits, &gps, &total);
   const long n_w = (long)g->Nw * 9 * g->Cw, slab = n_w + g->Nw;
   LGM_REQUIRE(workspace_bytes >= (int64_t)splits * slab * (int64_t)sizeof(float), "conv3x3_wino4_wgrad: workspace too small");
   if (int rc = lgm_wino4_wgrad_launch(g, y, y_pitch, x, x_pitch, (float*)workspace, gbias ? 1 : 0, slab, splits, gps, total,

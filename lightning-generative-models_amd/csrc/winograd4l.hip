@@ -534,7 +534,8 @@ int lgm_wino4l_splits(const LgmConvGeom* g, int gather_channels, int out_channel
   if (forced > 0) return forced < smax ? forced : smax;
   // 256 = one light workgroup per CU: 6.89 vs 6.99 ms per step at B = 64 and 5.38 vs 5.41 at B = 32 against 512 (two per CU),
   // which only wins at B = 128 (10.22 vs 10.27), where the 32-tile kernel is the default anyway
-  static const int target = getenv("LGM_WINO4L_TARGET") ? atoi(getenv("LGM_WINO4L_TARGET")) : 256;
+  static const int target_env = getenv("LGM_WINO4L_TARGET") ? atoi(getenv("LGM_WINO4L_TARGET")) : 0;
+  const int target = target_env > 0 ? target_env : lgm_cu_budget();
   if (base >= target * 3 / 4) return 1;
   int s = (int)((target + base - 1) / base);
   if (s > smax) s = smax;

@@ -102,7 +102,7 @@ class _Lib:
             fn = getattr(self._dll, name)  # AttributeError if the .so misses a declared symbol
             fn.restype = res
             fn.argtypes = args
-            if res is ctypes.c_int and name not in ("lgm_abi_version", "lgm_kernel_name_count"):
+            if res is ctypes.c_int and name not in ("lgm_abi_version", "lgm_kernel_name_count", "lgm_cu_margin"):
                 setattr(self, name, self._checked(fn, name))
             else:
                 setattr(self, name, fn)

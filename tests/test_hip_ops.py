@@ -99,6 +99,40 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(dev, case):
+    _conv_fwd_dgrad_wgrad(dev, case)
+
+
+def _clear_plan_caches():
+    from lgm_hip import ops
+    for n in ("_WINO4_OK", "_WINO_WS", "_EPI_STATS", "_PAIR_OK", "_WG2_OK", "_WG2_WS", "_WINO_OK"):
+        if hasattr(ops, n):
+            getattr(ops, n).clear()
+
+
+@pytest.mark.parametrize("margin", [16, 40])
+@pytest.mark.parametrize("case", [(40, 32, 32, 64, 64, 3, 1, 1), (24, 16, 16, 128, 128, 3, 1, 1), (11, 4, 4, 256, 256, 3, 1, 1),
+                                  (3, 32, 32, 128, 64, 3, 1, 1), (64, 32, 32, 128, 128, 1, 1, 0), (20, 32, 32, 128, 64, 1, 1, 0),
+                                  (64, 8, 8, 256, 256, 3, 1, 1), (32, 4, 4, 512, 512, 3, 1, 1)])
+def test_conv_with_launch_plans_that_leave_cus_to_a_collective(dev, case, margin):
+    """lgm_set_cu_margin (the default of a rank when WORLD_SIZE > 1 is 16): split-K, slab and persistent-range plans sized for
+    256 - margin CUs give the same forward, input gradient and weight gradient."""
+    from lgm_hip import ops
+    _clear_plan_caches()
+    assert ops.lib().lgm_cu_margin() == 0
+    ops.lib().lgm_set_cu_margin(margin)
+    try:
+        assert ops.lib().lgm_cu_margin() == margin
+        _conv_fwd_dgrad_wgrad(dev, case)
+    finally:
+        ops.lib().lgm_set_cu_margin(-1)
+        _clear_plan_caches()
+    from lgm_hip._lib import LgmArgumentError
+    with pytest.raises(LgmArgumentError):                 # more than half of the chip: refused
+        ops.lib().lgm_set_cu_margin(200)
+    assert ops.lib().lgm_cu_margin() == 0
+
+
+def _conv_fwd_dgrad_wgrad(dev, case):
     from lgm_hip import ops
     B, H, W, Cin, Cout, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))

@@ -94,16 +94,18 @@ def _plan_caches():
 def test_ddpm_at_the_baseline_batch_matches_the_cpu_oracle(dev, parity, B, light):
     """dim 64, 32x32 (BASELINE config 2 as benched): HIP loss and every parameter gradient against
     oracle.diffusion_forward + autograd on the CPU (a few seconds) - at B = 128 with the kernel selection of one GPU, and at
-    the per-rank batches of 2 and 8 GPUs with the selection a RANK gets (light F(4x4) workgroups, csrc/winograd4l.hip: the
-    library switches them on when WORLD_SIZE > 1, here through lgm_wino4_set_light)."""
+    the per-rank batches of 2 and 8 GPUs with the selection a RANK gets (light F(4x4) workgroups, csrc/winograd4l.hip, and launch plans for 240 of the 256 CUs: the
+    library switches both on when WORLD_SIZE > 1, here through lgm_wino4_set_light / lgm_set_cu_margin)."""
     from lgm_hip import ops
     for c in _plan_caches():
         c.clear()                 # plans are cached per geometry: none may survive a change of the kernel selection
     ops.lib().lgm_wino4_set_light(1 if light else -1)
+    ops.lib().lgm_set_cu_margin(16 if light else -1)      # a rank's launch plans leave 16 CUs to the collective
     try:
         _ddpm_vs_oracle(dev, parity, B, light)
     finally:
         ops.lib().lgm_wino4_set_light(-1)
+        ops.lib().lgm_set_cu_margin(-1)
         for c in _plan_caches():
             c.clear()
 
