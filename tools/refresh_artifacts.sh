@@ -10,12 +10,14 @@ out=$PWD/gpurun_out
 python3 bench.py 2> $out/${R}_bench.err | tail -1 > $out/${R}_bench.json
 echo "bench line done"
 GRAPH=1 bash tools/prof_workload.sh ddpm32 ${R}_bench_b128 > /dev/null
-# the per-rank batches run the kernel selection of an N > 1 job (light F(4x4) workgroups), as bench.py's per_rank_proxy does
-for b in 64 32 16; do LGM_WINO4_LIGHT=1 GRAPH=1 bash tools/prof_workload.sh ddpm32 ${R}_bench_b$b --batch $b > /dev/null; done
+# the per-rank batches run the kernel selection of an N > 1 job (light F(4x4) workgroups, launch plans for 240 CUs), as
+# bench.py's per_rank_proxy does
+for b in 64 32 16; do LGM_WINO4_LIGHT=1 LGM_CU_MARGIN=16 GRAPH=1 bash tools/prof_workload.sh ddpm32 ${R}_bench_b$b --batch $b > /dev/null; done
 for w in ddpm64 wgan_gp64 vqvae vqvae_ema; do GRAPH=1 bash tools/prof_workload.sh $w ${R}_bench_$w > /dev/null; done
 bash tools/prof_launches.sh ddpm32 ${R}_b128 > /dev/null
-LGM_WINO4_LIGHT=1 bash tools/prof_launches.sh ddpm32 ${R}_b16 --batch 16 > /dev/null
+LGM_WINO4_LIGHT=1 LGM_CU_MARGIN=16 bash tools/prof_launches.sh ddpm32 ${R}_b16 --batch 16 > /dev/null
 bash tools/prof_launches.sh vqvae ${R}_vqvae > /dev/null
+bash tools/prof_launches.sh wgan_gp64 ${R}_wgan_generator_step > /dev/null
 echo "kernel traces done"
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $c | cut -d' ' -f1)
@@ -26,3 +28,9 @@ done
 python3 tools/pmc_kernels.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES > $out/${R}_pmc_traffic.json
 bash tools/pmc_lds.sh > $out/${R}_pmc_lds.txt 2>&1 || true
 tail -c 300 $out/${R}_pmc_traffic.json
+# what a resident collective costs (1-GPU emulation): 1 / 16 foreign workgroups beside the replayed step, with the kernel
+# selection of one GPU and of a rank (light workgroups; without and with the CU margin)
+hipcc --offload-arch=gfx950 -shared -fPIC -o tools/libcu_hog.so tools/cu_hog.hip
+( for e in "LGM_WINO4_LIGHT=0 LGM_CU_MARGIN=0" "LGM_WINO4_LIGHT=1 LGM_CU_MARGIN=0" "LGM_WINO4_LIGHT=1 LGM_CU_MARGIN=16"; do
+    echo "== $e"; env $e python3 tools/cu_hog_step.py 128 64 32 16 2>&1 | grep -v amdgpu.ids; done ) > $out/${R}_hog_step.txt
+tail -4 $out/${R}_hog_step.txt
