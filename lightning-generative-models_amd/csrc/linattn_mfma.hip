@@ -39,32 +39,14 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
   const float* memv = mem_kv + ((long)(1 * heads + h) * DH) * M;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+  // MODE 0: softmax over the pixels with a RUNNING maximum (one pass over k instead of a maximum pass plus a product pass:
+  // see DESIGN section 3.4.1 for the timings).  Per tile the column maxima of its 128 rows join the running maximum m; the
+  // accumulators and the partial sums so far are rescaled by exp(m_old - m_new) (1 when the maximum did not move); at the
+  // end m is the exact column maximum, which the backward kernels get as before.
+  __shared__ float corr_s[DH];
   if (MODE == 0) {
-    // max over the pixels of every key channel: eight independent 16-byte loads in flight
-    f32x4 m4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int i0 = 0; i0 < n; i0 += 256) {
-      f32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + prow + 32 * u;
-        v[u] = i < n ? *reinterpret_cast<const f32x4*>(base + (long)i * pitch + hidden + c4) : m4;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) m4[k] = fmaxf(m4[k], v[u][k]);
-    }
-    *reinterpret_cast<f32x4*>(&red32[prow][c4]) = m4;
-    __syncthreads();
-    if (tid < DH) {
-      float m = red32[0][tid];
-      for (int k = 1; k < 32; ++k) m = fmaxf(m, red32[k][tid]);
-      for (int j = 0; j < M; ++j) m = fmaxf(m, memk[tid * M + j]);
-      kmax_s[tid] = m;
-    }
-    __syncthreads();
+    if (tid < DH) kmax_s[tid] = -INFINITY;
   }
-
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -99,7 +81,29 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
   };
   fetch(0);
   for (int i0 = 0; i0 < total; i0 += TP) {
-    __syncthreads();
+    if (MODE == 0) {
+      f32x4 m4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + prow + 32 * u < total)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) m4[k] = fmaxf(m4[k], w4[u][k]);
+      *reinterpret_cast<f32x4*>(&red32[prow][c4]) = m4;
+    }
+    __syncthreads();          // (also: the previous tile's operand reads are done)
+    if (MODE == 0) {
+      if (tid < DH) {
+        float m = red32[0][tid];
+        for (int k = 1; k < 32; ++k) m = fmaxf(m, red32[k][tid]);
+        const float mo = kmax_s[tid];
+        const float mn = fmaxf(mo, m);            // every tile has a live row: mn is finite
+        corr_s[tid] = __expf(mo - mn);            // first tile: exp(-inf) = 0 on zero accumulators
+        kmax_s[tid] = mn;
+      }
+      __syncthreads();
+      const f32x4 c4v = *reinterpret_cast<const f32x4*>(&corr_s[c4]);
+      wsum4 *= c4v;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = prow + 32 * u;
@@ -142,6 +146,10 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma(const float* __restrict_
         for (int k = 0; k < 8; ++k) Ws[r * LDW + part * 8 + k] = v[k] * inv;
       }
       __syncthreads();
+    }
+    if (MODE == 0) {          // rows d of the accumulator: (r & 3) + 8 (r >> 2) + 4 lh
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= corr_s[(r & 3) + 8 * (r >> 2) + 4 * lh];
     }
     // MFMA: k = pixel; wave w owns pixels [32 w, 32 w + 32) of the tile.  A[i = d][k], B[k][j = e]
     const float* ap = Ws + (32 * wid + lh) * LDW + lr;
