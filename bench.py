@@ -259,6 +259,11 @@ def setup_wgan(args, dev):
     # what MiniTrainer.fit drives for a WGAN: critic graph / generator graph, schedule + Adam on the host
     fast = m.make_fast_step(m._optimizers, 1, use_graph=not args.no_graph)
     eager = m.make_fast_step(m._optimizers, 1, use_graph=False)
+    if not args.no_graph:
+        # both graphs are captured HERE (capture leaves the training state untouched): the first generator update is step 5,
+        # which `--warmup 5` would put - with its capture - inside the timed region
+        for key in ("d", "g"):
+            fast._capture(key, x)
 
     def step(i):
         ld = fast.step((x, None), i)
