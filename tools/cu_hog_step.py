@@ -18,6 +18,7 @@ def main():
     batches = [int(b) for b in sys.argv[1:]] or [128, 64, 16]
     hog = ctypes.CDLL(os.path.join(ROOT, "tools", "libcu_hog.so"))
     hog.cu_hog.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+    hog.cu_hog_quiet.argtypes = hog.cu_hog.argtypes
     dev = torch.device("cuda", 0)
     sink = torch.zeros(4, device=dev)
     side = torch.cuda.Stream()
@@ -33,7 +34,7 @@ def main():
             torch.cuda.synchronize()
             if k:
                 # ~60 ms of spinning at ~2.1 GHz: covers the 20 timed steps at every batch here
-                hog.cu_hog(k, 256, regs, ctypes.c_longlong(int(0.35 * 2.1e9)), sink.data_ptr(), side.cuda_stream)
+                (hog.cu_hog_quiet if os.environ.get("HOG_QUIET") else hog.cu_hog)(k, 256, regs, ctypes.c_longlong(int(0.35 * 2.1e9)), sink.data_ptr(), side.cuda_stream)
             t0 = time.perf_counter()
             for i in range(n):
                 step(100 + i)
@@ -44,8 +45,9 @@ def main():
         base = timed(0, 32)
         print(f"B={B}: alone {base:.3f} ms/step", flush=True)
         for k in (1, 16):
-            for regs in (96,):
-                print(f"   {k:3d} resident workgroups x 256 threads ({regs} VGPR class): {timed(k, regs):.3f} ms/step", flush=True)
+            quiet = ", quiet" if os.environ.get("HOG_QUIET") else ""
+            for regs in [int(v) for v in os.environ.get("HOG_REGS", "96").split(",")]:
+                print(f"   {k:3d} resident workgroups x 256 threads ({regs} VGPR class{quiet}): {timed(k, regs):.3f} ms/step", flush=True)
         del step, info
         bench._release()
 
