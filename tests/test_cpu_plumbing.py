@@ -550,3 +550,45 @@ def test_workspaces_of_live_flat_buffers_survive_cleanup():
     assert k1 in ops._WGRAD_WS and t1 in ops._WGRAD_TABLES          # the live model keeps its workspaces
     assert k2 not in ops._WGRAD_WS and t2 not in ops._WGRAD_TABLES  # the dead one's are gone
     del ops._WGRAD_WS[k1], ops._WGRAD_TABLES[t1]
+
+
+def test_counter_summary_counts_steady_state_steps_only(tmp_path):
+    """tools/pmc_kernels.py (the source of bench.py's `roofline.traffic` and of the per-step HBM bytes): only the dispatches
+    between the first and the last `adam_kernel` count - model construction and the first step's one-time fills must not be
+    averaged into the step - FETCH_SIZE is doubled (gfx950) and both counters are KB."""
+    import csv
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def write(d, counter, rows):
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "x_counter_collection.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+            for did, name, val in rows:
+                w.writerow([did, name, counter, val])
+
+    def run(conv_kb, fill_kb):
+        rows, did = [], 1
+        for _ in range(50):                                   # set-up: parameter initialisation, fills
+            rows.append((did, "void at::native::fill_kernel(float*)", fill_kb)); did += 1
+        for step in range(4):                                 # a step: two convolution launches, then Adam
+            for _ in range(2):
+                rows.append((did, "void lgmwino4::wino4_conv_kernel<0, false, 0, false>(lgmwino4::Args)", conv_kb)); did += 1
+            rows.append((did, "(anonymous namespace)::adam_kernel(float*, float const*)", 100.0)); did += 1
+        rows.append((did, "void at::native::fill_kernel(float*)", fill_kb))        # the tail of the run
+        return rows
+
+    f, w = str(tmp_path / "fetch"), str(tmp_path / "write")
+    write(f, "FETCH_SIZE", run(1000.0, 5000.0))
+    write(w, "WRITE_SIZE", run(400.0, 7000.0))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_kernels.py"), f, w], capture_output=True, text=True,
+                         check=True).stdout
+    d = json.loads(out)
+    assert d["step_total"]["steps_profiled"] == 3            # four Adam launches bound three whole steps
+    k = d["kernels"]["lgmwino4::wino4_conv_kernel<0, false, 0, false>"]
+    assert k["launches_per_step"] == 2.0
+    assert k["fetch_bytes_per_launch"] == 1000 * 2048 and k["write_bytes_per_launch"] == 400 * 1024
+    assert not any("fill_kernel" in n for n in d["kernels"])
+    assert d["step_total"]["fetch_bytes"] == (2 * 1000 + 100) * 2048 and d["step_total"]["write_bytes"] == (2 * 400 + 100) * 1024
