@@ -665,8 +665,9 @@ extern "C" int lgm_wino4_set_light(int mode) {
   return LGM_OK;
 }
 static bool wino4_use_light(const LgmConvGeom* g, int gather_channels, int out_channels) {
+  // (LGM_WINO4_LIGHT_BELOW given without LGM_WINO4_LIGHT: the launch-by-launch rule with those bounds, also under WORLD_SIZE > 1)
   static const int env_mode = getenv("LGM_WINO4_LIGHT") ? atoi(getenv("LGM_WINO4_LIGHT"))
-                              : (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 ? 1 : 0);
+                              : (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 && !getenv("LGM_WINO4_LIGHT_BELOW") ? 1 : 0);
   const int mode = lgm_wino4_light_override >= 0 ? lgm_wino4_light_override : env_mode;
   if (!lgm_wino4l_supported(g, gather_channels, out_channels)) return false;
   if (mode != 0) return true;
