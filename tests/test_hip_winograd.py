@@ -288,7 +288,9 @@ def test_backward_pair_launch_matches_separate_launches(dev, case, variant, pari
         parity(f"input gradient from {part[0]} planes vs separate launch", maxerr(gx, gx_ref.double().cpu()), 2e-6)
     else:
         parity("input gradient vs separate launch (split counts may differ)", maxerr(gx, gx_ref.double().cpu()), 2e-6)
-    parity("weight gradient vs separate launch", maxerr(gw, gw_ref.double().cpu()), 2e-6)
+    # (the pair's slab count and the separate launch's may differ - they do under a CU margin - so this is a comparison of two
+    # summation orders: 2.2e-6 observed with LGM_CU_MARGIN=16)
+    parity("weight gradient vs separate launch", maxerr(gw, gw_ref.double().cpu()), 4e-6)
     parity("bias gradient vs separate launch", maxerr(gb, gb_ref.double().cpu()), 2e-6)
     w4 = w.cpu().reshape(co, 3, 3, ci).permute(0, 3, 1, 2).double().requires_grad_(True)
     x64 = x.cpu().permute(0, 3, 1, 2).double()
