@@ -286,11 +286,24 @@ __global__ __launch_bounds__(256) void vq_scalars_kernel(const float* __restrict
 
 // backward: gx[row] (+)= gq[row] (straight-through) + g_vq * commitment * 2 (x - q) / (N D)
 //           gcb[k]    = beta*gcb + g_vq * 2 (counts[k] cb[k] - dw[k]) / (N D)
-__global__ __launch_bounds__(256) void vq_bwd_x_kernel(const float* __restrict__ x, long x_pitch,
-                                                       const float* __restrict__ q, long q_pitch,
-                                                       const float* __restrict__ gq, long gq_pitch,
-                                                       const float* __restrict__ gvq, float commitment, int N, int D,
-                                                       float* __restrict__ gx, long gx_pitch) {
+// One launch: blocks [0, nbx) the rows' gradient, blocks [nbx, grid) the codebook's (two independent element-wise maps)
+__global__ __launch_bounds__(256) void vq_bwd_kernel(const float* __restrict__ x, long x_pitch,
+                                                     const float* __restrict__ q, long q_pitch,
+                                                     const float* __restrict__ gq, long gq_pitch,
+                                                     const float* __restrict__ gvq, float commitment, int N, int D,
+                                                     float* __restrict__ gx, long gx_pitch, int nbx,
+                                                     const float* __restrict__ cb, const float* __restrict__ dw,
+                                                     const float* __restrict__ counts, int K, float* __restrict__ gcb,
+                                                     float beta) {
+  if ((int)blockIdx.x >= nbx) {
+    const int i = ((int)blockIdx.x - nbx) * blockDim.x + threadIdx.x;
+    if (i >= K * D) return;
+    const int k = i / D;
+    float g = gvq[0] * 2.f / ((float)N * (float)D) * (counts[k] * cb[i] - dw[i]);
+    if (beta != 0.f) g += beta * gcb[i];
+    gcb[i] = g;
+    return;
+  }
   const int d4n = D / 4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)N * d4n) return;
@@ -303,18 +316,6 @@ __global__ __launch_bounds__(256) void vq_bwd_x_kernel(const float* __restrict__
   if (gq) g += *reinterpret_cast<const f32x4*>(gq + row * gq_pitch + d);
   *reinterpret_cast<f32x4*>(gx + row * gx_pitch + d) = g;
 }
-__global__ __launch_bounds__(256) void vq_bwd_cb_kernel(const float* __restrict__ cb, const float* __restrict__ dw,
-                                                        const float* __restrict__ counts,
-                                                        const float* __restrict__ gvq, int K, int N, int D,
-                                                        float* __restrict__ gcb, float beta) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= K * D) return;
-  const int k = i / D;
-  float g = gvq[0] * 2.f / ((float)N * (float)D) * (counts[k] * cb[i] - dw[i]);
-  if (beta != 0.f) g += beta * gcb[i];
-  gcb[i] = g;
-}
-
 }  // namespace
 
 extern "C" int lgm_vq_assign(const float* x, int64_t x_pitch, const float* codebook, int N, int K, int D,
@@ -395,10 +396,9 @@ extern "C" int lgm_vq_bwd(const float* x, int64_t x_pitch, const float* q, int64
                           int64_t gx_pitch, float* gcodebook, float gcb_beta, void* stream) {
   LGM_REQUIRE(x && q && codebook && dw && counts && g_vq_loss && gx && gcodebook && D % 4 == 0, "vq_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(vq_bwd_x_kernel, dim3(lgm_cdiv((long)N * (D / 4), 256)), dim3(256), 0, s, x, (long)x_pitch, q,
-                     (long)q_pitch, gq, (long)gq_pitch, g_vq_loss, commitment, N, D, gx, (long)gx_pitch);
-  hipLaunchKernelGGL(vq_bwd_cb_kernel, dim3(lgm_cdiv((long)K * D, 256)), dim3(256), 0, s, codebook, dw, counts,
-                     g_vq_loss, K, N, D, gcodebook, gcb_beta);
+  const int nbx = lgm_cdiv((long)N * (D / 4), 256), nbc = lgm_cdiv((long)K * D, 256);
+  hipLaunchKernelGGL(vq_bwd_kernel, dim3(nbx + nbc), dim3(256), 0, s, x, (long)x_pitch, q, (long)q_pitch, gq, (long)gq_pitch,
+                     g_vq_loss, commitment, N, D, gx, (long)gx_pitch, nbx, codebook, dw, counts, K, gcodebook, gcb_beta);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

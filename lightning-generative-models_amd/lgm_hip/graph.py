@@ -326,13 +326,17 @@ class ModuleFastStep:
         self.loss = None
         self._captured_logs = {}
         self._bn_trace = []
+        self._one = None
         self.mode = "eager"
 
     # ---- one step from eager launches ---------------------------------------------------------------------------
     def _fwd_bwd(self, batch, batch_idx):
         loss = self.model.training_step(batch, batch_idx)
         self.flat.zero_grad()                        # host flag: this backward overwrites the gradient buffer
-        loss.backward()
+        one = self._one                              # the backward's seed: made once (autograd would fill a new one per step)
+        if one is None or one.device != loss.device or one.dtype != loss.dtype or one.shape != loss.shape:
+            one = self._one = torch.ones_like(loss)
+        loss.backward(one)
         return loss
 
     def _finish(self, batch, batch_idx):
