@@ -36,7 +36,9 @@ extern "C" int cu_hog(int k, int threads, int regs, long long cycles, float* sin
 
 // the quiet guests: same register classes, eight updates per loop trip
 extern "C" int cu_hog_quiet(int k, int threads, int regs, long long cycles, float* sink, void* stream) {
-  if (regs >= 240) hipLaunchKernelGGL((hog_kernel<240, 8>), dim3(k), dim3(threads), 0, (hipStream_t)stream, cycles, sink);
+  // 280: more than half of a SIMD's 512 registers, like rcclGenericKernel (261 - 280): no 256-register wave fits beside it
+  if (regs >= 280) hipLaunchKernelGGL((hog_kernel<280, 8>), dim3(k), dim3(threads), 0, (hipStream_t)stream, cycles, sink);
+  else if (regs >= 240) hipLaunchKernelGGL((hog_kernel<240, 8>), dim3(k), dim3(threads), 0, (hipStream_t)stream, cycles, sink);
   else hipLaunchKernelGGL((hog_kernel<96, 8>), dim3(k), dim3(threads), 0, (hipStream_t)stream, cycles, sink);
   return (int)hipGetLastError();
 }
