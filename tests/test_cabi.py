@@ -39,6 +39,29 @@ def test_abi_version_and_error_string():
     assert L.lgm_linattn_bwd_fused_slabs(128, 1024, 64) == 256 * 384 * 64 * 4
 
 
+def test_cu_margin_changes_the_launch_plans_without_a_gpu():
+    """lgm_set_cu_margin / lgm_cu_margin (host-only): the margin is read back, a plan query answers for 256 - margin workgroup
+    slots, more than half of the chip is refused and -1 returns to the environment's default."""
+    L = _lib.lib()
+    base = L.lgm_cu_margin()
+    g = _lib.ConvGeom(64, 32, 32, 64, 32, 32, 64, 3, 3, 1, 1)    # 64 -> 64 at 32 x 32, B = 64: the slab count fills the slots
+    try:
+        L.lgm_set_cu_margin(0)
+        w0 = L.lgm_conv_wgrad_workspace(ctypes.byref(g))
+        L.lgm_set_cu_margin(16)
+        w16 = L.lgm_conv_wgrad_workspace(ctypes.byref(g))
+        L.lgm_set_cu_margin(64)
+        assert L.lgm_cu_margin() == 64
+        w64 = L.lgm_conv_wgrad_workspace(ctypes.byref(g))
+        assert w0 > w16 > w64 > 0                                  # fewer weight-gradient slabs fit 240 / 192 slots than 256
+        with pytest.raises(_lib.LgmArgumentError):
+            L.lgm_set_cu_margin(129)
+        assert L.lgm_cu_margin() == 64
+    finally:
+        L.lgm_set_cu_margin(-1)
+    assert L.lgm_cu_margin() == base
+
+
 def test_geometry_validation_rejects_inconsistent_shapes():
     L = _lib.lib()
     g = _lib.ConvGeom(1, 8, 8, 4, 9, 8, 4, 3, 3, 1, 1)   # Ho should be 8
