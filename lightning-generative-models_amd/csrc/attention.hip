@@ -284,6 +284,170 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- the same two passes for SMALL maps (n <= 32 query pixels: the 4 x 4 maps where the UNet uses full attention) -------
+// One thread per query row leaves 16 of 128 threads busy and a 20-step dependent chain per thread (17 / 26 us per launch at
+// every batch).  Here every thread works in every stage: scores for all (query, key) pairs, a four-thread softmax per row,
+// then one 16-byte piece of an output row per work item; the backward builds P and dS once and reads each of gq, gk, gv
+// off them.  Three barriers.  Sums run in index order (fixed).
+constexpr int SA_MAXN = 32, SA_MAXK = SA_MAXN + 16, SA_LS = SA_MAXK + 1;
+
+__device__ __forceinline__ void sa_load_rows(const float* __restrict__ qkv, long pitch, const float* __restrict__ mem_kv,
+                                             int b, int h, int n, int heads, int M, float scale, float* Qs, float* Ks,
+                                             float* Vs) {
+  const int hidden = heads * DH, nk = n + M, tid = threadIdx.x;
+  const float* memk = mem_kv + ((long)(0 * heads + h) * M) * DH;  // [j][d]
+  const float* memv = mem_kv + ((long)(1 * heads + h) * M) * DH;
+  for (int e = tid; e < nk * 8; e += blockDim.x) {                  // a row's head slice = eight 16-byte pieces
+    const int j = e >> 3, d = (e & 7) * 4;
+    f32x4 kv, vv;
+    if (j < M) {
+      kv = *reinterpret_cast<const f32x4*>(memk + j * DH + d);
+      vv = *reinterpret_cast<const f32x4*>(memv + j * DH + d);
+    } else {
+      const float* row = qkv + ((long)b * n + (j - M)) * pitch + h * DH + d;
+      kv = *reinterpret_cast<const f32x4*>(row + hidden);
+      vv = *reinterpret_cast<const f32x4*>(row + 2 * hidden);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      Ks[j * FA_LD + d + k] = kv[k];
+      Vs[j * FA_LD + d + k] = vv[k];
+    }
+  }
+  for (int e = tid; e < n * 8; e += blockDim.x) {
+    const int i = e >> 3, d = (e & 7) * 4;
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(qkv + ((long)b * n + i) * pitch + h * DH + d);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Qs[i * FA_LD + d + k] = qv[k] * scale;
+  }
+}
+
+__global__ __launch_bounds__(128) void attn_small_fwd_kernel(const float* __restrict__ qkv, long pitch,
+                                                             const float* __restrict__ mem_kv, int n, int heads, int M,
+                                                             float scale, float* __restrict__ out, long out_pitch,
+                                                             float* __restrict__ lse) {
+  __shared__ float Qs[SA_MAXN * FA_LD], Ks[SA_MAXK * FA_LD], Vs[SA_MAXK * FA_LD], S[SA_MAXN * SA_LS];
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x, nk = n + M;
+  sa_load_rows(qkv, pitch, mem_kv, b, h, n, heads, M, scale, Qs, Ks, Vs);
+  __syncthreads();
+  for (int e = tid; e < n * nk; e += 128) {                          // scores
+    const int i = e / nk, j = e - i * nk;
+    float sd = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) sd += Qs[i * FA_LD + d] * Ks[j * FA_LD + d];
+    S[i * SA_LS + j] = sd;
+  }
+  __syncthreads();
+  {                                                                  // softmax: four threads per row
+    const int i = tid >> 2, part = tid & 3;
+    float mx = -INFINITY;
+    if (i < n)
+      for (int j = part; j < nk; j += 4) mx = fmaxf(mx, S[i * SA_LS + j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sm = 0.f;
+    if (i < n)
+      for (int j = part; j < nk; j += 4) {
+        const float pv = __expf(S[i * SA_LS + j] - mx);
+        S[i * SA_LS + j] = pv;
+        sm += pv;
+      }
+    sm += __shfl_xor(sm, 1, 64);
+    sm += __shfl_xor(sm, 2, 64);
+    if (i < n) {
+      const float inv = 1.f / sm;
+      for (int j = part; j < nk; j += 4) S[i * SA_LS + j] *= inv;
+      if (part == 0) lse[(long)bh * n + i] = mx + __logf(sm);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < n * 8; e += 128) {                           // out = P V
+    const int i = e >> 3, d = (e & 7) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < nk; ++j) {
+      const float pv = S[i * SA_LS + j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += pv * Vs[j * FA_LD + d + k];
+    }
+    *reinterpret_cast<f32x4*>(out + ((long)b * n + i) * out_pitch + h * DH + d) = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __restrict__ qkv, long pitch,
+                                                             const float* __restrict__ mem_kv,
+                                                             const float* __restrict__ out, long out_pitch,
+                                                             const float* __restrict__ gout, long gout_pitch,
+                                                             const float* __restrict__ lse, int n, int heads, int M,
+                                                             float scale, float* __restrict__ gqkv, long gq_pitch,
+                                                             float* __restrict__ gmem_partial) {
+  __shared__ float Qs[SA_MAXN * FA_LD], Ks[SA_MAXK * FA_LD], Vs[SA_MAXK * FA_LD], Gs[SA_MAXN * FA_LD];
+  __shared__ float P[SA_MAXN * SA_LS], dS[SA_MAXN * SA_LS], Ds[SA_MAXN], Ls[SA_MAXN];
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x, nk = n + M, hidden = heads * DH;
+  sa_load_rows(qkv, pitch, mem_kv, b, h, n, heads, M, scale, Qs, Ks, Vs);
+  {                                                                  // G rows and D_i = gout_i . out_i: eight threads per row
+    const int i = tid >> 3, d = (tid & 7) * 4;
+    float ds = 0.f;
+    if (i < n) {
+      const long row = (long)b * n + i;
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(gout + row * gout_pitch + h * DH + d);
+      const f32x4 ov = *reinterpret_cast<const f32x4*>(out + row * out_pitch + h * DH + d);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        Gs[i * FA_LD + d + k] = gv[k];
+        ds += gv[k] * ov[k];
+      }
+    }
+    ds += __shfl_xor(ds, 1, 64);
+    ds += __shfl_xor(ds, 2, 64);
+    ds += __shfl_xor(ds, 4, 64);
+    if (i < n && (tid & 7) == 0) {
+      Ds[i] = ds;
+      Ls[i] = lse[(long)bh * n + i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < n * nk; e += 256) {                          // P and dS = P (G V^T - D)
+    const int i = e / nk, j = e - i * nk;
+    float sd = 0.f, ga = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      sd += Qs[i * FA_LD + d] * Ks[j * FA_LD + d];
+      ga += Gs[i * FA_LD + d] * Vs[j * FA_LD + d];
+    }
+    const float pv = __expf(sd - Ls[i]);
+    P[i * SA_LS + j] = pv;
+    dS[i * SA_LS + j] = pv * (ga - Ds[i]);
+  }
+  __syncthreads();
+  // 16-byte pieces of: gq rows [0, n), gk rows [n, n + nk), gv rows [n + nk, n + 2 nk)
+  for (int e = tid; e < (n + 2 * nk) * 8; e += 256) {
+    const int r = e >> 3, d = (e & 7) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (r < n) {                                                     // gq_i = scale * sum_j dS_ij K_j
+      for (int j = 0; j < nk; ++j) {
+        const float w = dS[r * SA_LS + j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += w * Ks[j * FA_LD + d + k];
+      }
+      *reinterpret_cast<f32x4*>(gqkv + ((long)b * n + r) * gq_pitch + h * DH + d) = acc * scale;
+      continue;
+    }
+    const int which = r < n + nk ? 0 : 1;                            // 0: gk_j = sum_i dS_ij Qs_i (Qs carries scale), 1: gv_j = sum_i P_ij G_i
+    const int j = r - n - which * nk;
+    const float* W = which ? P : dS;
+    const float* X = which ? Gs : Qs;
+    for (int i = 0; i < n; ++i) {
+      const float w = W[i * SA_LS + j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += w * X[i * FA_LD + d + k];
+    }
+    if (j < M)
+      *reinterpret_cast<f32x4*>(gmem_partial + (long)b * 2 * heads * M * DH + ((long)(which * heads + h) * M + j) * DH + d) = acc;
+    else
+      *reinterpret_cast<f32x4*>(gqkv + ((long)b * n + (j - M)) * gq_pitch + (which + 1) * hidden + h * DH + d) = acc;
+  }
+}
+
 int attn_check(int B, int n, int heads, int dim_head, int M) {
   LGM_REQUIRE(B > 0 && n > 0 && heads > 0 && M >= 0 && M <= 16, "attention: bad sizes B=%d n=%d heads=%d M=%d", B, n, heads, M);
   LGM_REQUIRE(dim_head == DH, "attention: dim_head=%d unsupported (kernels are built for 32)", dim_head);
@@ -479,8 +643,14 @@ extern "C" int lgm_attn_fwd(const float* qkv, int64_t qkv_pitch, const float* me
   LGM_REQUIRE(n <= FA_MAXN, "attn_fwd: n=%d > %d query pixels unsupported", n, FA_MAXN);
   LGM_REQUIRE(qkv && mem_kv && out && lse, "attn_fwd: null pointer");
   const size_t smem = (size_t)2 * (n + M) * FA_LD * sizeof(float);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * heads), dim3(128), smem, (hipStream_t)stream, qkv, (long)qkv_pitch,
-                     mem_kv, n, heads, M, 1.f / sqrtf((float)dim_head), out, (long)out_pitch, lse);
+  static const bool no_small = getenv("LGM_NO_SMALL_ATTN") != nullptr;          // A/B switch
+  if (!no_small && n <= SA_MAXN && M <= 16 && qkv_pitch % 4 == 0 && out_pitch % 4 == 0 && lgm_aligned16(qkv) &&
+      lgm_aligned16(out) && lgm_aligned16(mem_kv))
+    hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B * heads), dim3(128), 0, (hipStream_t)stream, qkv, (long)qkv_pitch,
+                       mem_kv, n, heads, M, 1.f / sqrtf((float)dim_head), out, (long)out_pitch, lse);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * heads), dim3(128), smem, (hipStream_t)stream, qkv, (long)qkv_pitch,
+                       mem_kv, n, heads, M, 1.f / sqrtf((float)dim_head), out, (long)out_pitch, lse);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
@@ -506,9 +676,17 @@ int attn_bwd_impl(const float* qkv, int64_t qkv_pitch, const float* mem_kv, cons
     attr_set = true;
   }
   const long ncols = 2L * heads * M * DH;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(192), smem, (hipStream_t)stream, qkv, (long)qkv_pitch,
-                     mem_kv, out, (long)out_pitch, gout, (long)gout_pitch, lse, n, heads, M,
-                     1.f / sqrtf((float)dim_head), gqkv, (long)gqkv_pitch, part);
+  static const bool no_small = getenv("LGM_NO_SMALL_ATTN") != nullptr;          // A/B switch
+  if (!no_small && n <= SA_MAXN && M <= 16 && qkv_pitch % 4 == 0 && out_pitch % 4 == 0 && gout_pitch % 4 == 0 &&
+      gqkv_pitch % 4 == 0 && lgm_aligned16(qkv) && lgm_aligned16(out) && lgm_aligned16(gout) && lgm_aligned16(gqkv) &&
+      lgm_aligned16(mem_kv) && lgm_aligned16(part))
+    hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, qkv, (long)qkv_pitch,
+                       mem_kv, out, (long)out_pitch, gout, (long)gout_pitch, lse, n, heads, M,
+                       1.f / sqrtf((float)dim_head), gqkv, (long)gqkv_pitch, part);
+  else
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(192), smem, (hipStream_t)stream, qkv, (long)qkv_pitch,
+                       mem_kv, out, (long)out_pitch, gout, (long)gout_pitch, lse, n, heads, M,
+                       1.f / sqrtf((float)dim_head), gqkv, (long)gqkv_pitch, part);
   LGM_LAUNCH_CHECK();
   if (gmem_desc) gmem_desc[6] = 0;
   if (M <= 0) return LGM_OK;
