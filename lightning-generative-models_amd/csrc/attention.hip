@@ -284,12 +284,12 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
-// ---- the same two passes for SMALL maps (n <= 32 query pixels: the 4 x 4 maps where the UNet uses full attention) -------
-// One thread per query row leaves 16 of 128 threads busy and a 20-step dependent chain per thread (17 / 26 us per launch at
-// every batch).  Here every thread works in every stage: scores for all (query, key) pairs, a four-thread softmax per row,
-// then one 16-byte piece of an output row per work item; the backward builds P and dS once and reads each of gq, gk, gv
-// off them.  Three barriers.  Sums run in index order (fixed).
-constexpr int SA_MAXN = 32, SA_MAXK = SA_MAXN + 16, SA_LS = SA_MAXK + 1;
+// ---- the same two passes for SMALL maps (n <= 64 query pixels: the 4 x 4 / 8 x 8 maps where the UNets use full attention) ----
+// One thread per query row leaves 16 (64) of 128 threads busy and a 20 (68)-step dependent chain per thread (17 / 26 us per
+// launch at 4 x 4 at every batch).  Here every thread works in every stage: scores for all (query, key) pairs, a four-thread
+// softmax per row, then one 16-byte piece of an output row per work item; the backward builds P and dS once and reads each
+// of gq, gk, gv off them.  Three barriers.  Sums run in index order (fixed).  256 threads, dynamic LDS sized by (n, M).
+constexpr int SA_MAXN = 64;
 
 __device__ __forceinline__ void sa_load_rows(const float* __restrict__ qkv, long pitch, const float* __restrict__ mem_kv,
                                              int b, int h, int n, int heads, int M, float scale, float* Qs, float* Ks,
@@ -322,50 +322,58 @@ __device__ __forceinline__ void sa_load_rows(const float* __restrict__ qkv, long
   }
 }
 
-__global__ __launch_bounds__(128) void attn_small_fwd_kernel(const float* __restrict__ qkv, long pitch,
+// floats of dynamic LDS
+size_t sa_fwd_floats(int n, int M) { return (size_t)(n + 2 * (n + M)) * FA_LD + (size_t)n * (n + M + 1); }
+size_t sa_bwd_floats(int n, int M) { return (size_t)(2 * n + 2 * (n + M)) * FA_LD + (size_t)2 * n * (n + M + 1) + 2 * n; }
+
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* __restrict__ qkv, long pitch,
                                                              const float* __restrict__ mem_kv, int n, int heads, int M,
                                                              float scale, float* __restrict__ out, long out_pitch,
                                                              float* __restrict__ lse) {
-  __shared__ float Qs[SA_MAXN * FA_LD], Ks[SA_MAXK * FA_LD], Vs[SA_MAXK * FA_LD], S[SA_MAXN * SA_LS];
-  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x, nk = n + M;
+  extern __shared__ float sm[];
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x, nk = n + M, LS = nk + 1;
+  float* Qs = sm;
+  float* Ks = Qs + n * FA_LD;
+  float* Vs = Ks + nk * FA_LD;
+  float* S = Vs + nk * FA_LD;
   sa_load_rows(qkv, pitch, mem_kv, b, h, n, heads, M, scale, Qs, Ks, Vs);
   __syncthreads();
-  for (int e = tid; e < n * nk; e += 128) {                          // scores
+  for (int e = tid; e < n * nk; e += 256) {                          // scores
     const int i = e / nk, j = e - i * nk;
     float sd = 0.f;
 #pragma unroll
     for (int d = 0; d < DH; ++d) sd += Qs[i * FA_LD + d] * Ks[j * FA_LD + d];
-    S[i * SA_LS + j] = sd;
+    S[i * LS + j] = sd;
   }
   __syncthreads();
-  {                                                                  // softmax: four threads per row
-    const int i = tid >> 2, part = tid & 3;
+  for (int r0 = 0; r0 < n; r0 += 64) {                               // softmax: four threads per row, 64 rows per pass
+    const int i = r0 + (tid >> 2), part = tid & 3;
     float mx = -INFINITY;
     if (i < n)
-      for (int j = part; j < nk; j += 4) mx = fmaxf(mx, S[i * SA_LS + j]);
+      for (int j = part; j < nk; j += 4) mx = fmaxf(mx, S[i * LS + j]);
     mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-    float sm = 0.f;
+    float sum = 0.f;
     if (i < n)
       for (int j = part; j < nk; j += 4) {
-        const float pv = __expf(S[i * SA_LS + j] - mx);
-        S[i * SA_LS + j] = pv;
-        sm += pv;
+        const float pv = __expf(S[i * LS + j] - mx);
+        S[i * LS + j] = pv;
+        sum += pv;
       }
-    sm += __shfl_xor(sm, 1, 64);
-    sm += __shfl_xor(sm, 2, 64);
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
     if (i < n) {
-      const float inv = 1.f / sm;
-      for (int j = part; j < nk; j += 4) S[i * SA_LS + j] *= inv;
-      if (part == 0) lse[(long)bh * n + i] = mx + __logf(sm);
+      const float inv = 1.f / sum;
+      for (int j = part; j < nk; j += 4) S[i * LS + j] *= inv;
+      if (part == 0) lse[(long)bh * n + i] = mx + __logf(sum);
     }
   }
   __syncthreads();
-  for (int e = tid; e < n * 8; e += 128) {                           // out = P V
+  for (int e = tid; e < n * 8; e += 256) {                           // out = P V
     const int i = e >> 3, d = (e & 7) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < nk; ++j) {
-      const float pv = S[i * SA_LS + j];
+      const float pv = S[i * LS + j];
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] += pv * Vs[j * FA_LD + d + k];
     }
@@ -380,12 +388,19 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __rest
                                                              const float* __restrict__ lse, int n, int heads, int M,
                                                              float scale, float* __restrict__ gqkv, long gq_pitch,
                                                              float* __restrict__ gmem_partial) {
-  __shared__ float Qs[SA_MAXN * FA_LD], Ks[SA_MAXK * FA_LD], Vs[SA_MAXK * FA_LD], Gs[SA_MAXN * FA_LD];
-  __shared__ float P[SA_MAXN * SA_LS], dS[SA_MAXN * SA_LS], Ds[SA_MAXN], Ls[SA_MAXN];
-  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x, nk = n + M, hidden = heads * DH;
+  extern __shared__ float sm[];
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x, nk = n + M, hidden = heads * DH, LS = nk + 1;
+  float* Qs = sm;
+  float* Ks = Qs + n * FA_LD;
+  float* Vs = Ks + nk * FA_LD;
+  float* Gs = Vs + nk * FA_LD;
+  float* P = Gs + n * FA_LD;
+  float* dS = P + n * LS;
+  float* Ds = dS + n * LS;
+  float* Ls = Ds + n;
   sa_load_rows(qkv, pitch, mem_kv, b, h, n, heads, M, scale, Qs, Ks, Vs);
-  {                                                                  // G rows and D_i = gout_i . out_i: eight threads per row
-    const int i = tid >> 3, d = (tid & 7) * 4;
+  for (int r0 = 0; r0 < n; r0 += 32) {                               // G rows and D_i = gout_i . out_i: eight threads per row
+    const int i = r0 + (tid >> 3), d = (tid & 7) * 4;
     float ds = 0.f;
     if (i < n) {
       const long row = (long)b * n + i;
@@ -415,8 +430,8 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __rest
       ga += Gs[i * FA_LD + d] * Vs[j * FA_LD + d];
     }
     const float pv = __expf(sd - Ls[i]);
-    P[i * SA_LS + j] = pv;
-    dS[i * SA_LS + j] = pv * (ga - Ds[i]);
+    P[i * LS + j] = pv;
+    dS[i * LS + j] = pv * (ga - Ds[i]);
   }
   __syncthreads();
   // 16-byte pieces of: gq rows [0, n), gk rows [n, n + nk), gv rows [n + nk, n + 2 nk)
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __rest
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (r < n) {                                                     // gq_i = scale * sum_j dS_ij K_j
       for (int j = 0; j < nk; ++j) {
-        const float w = dS[r * SA_LS + j];
+        const float w = dS[r * LS + j];
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] += w * Ks[j * FA_LD + d + k];
       }
@@ -437,7 +452,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __rest
     const float* W = which ? P : dS;
     const float* X = which ? Gs : Qs;
     for (int i = 0; i < n; ++i) {
-      const float w = W[i * SA_LS + j];
+      const float w = W[i * LS + j];
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] += w * X[i * FA_LD + d + k];
     }
@@ -646,8 +661,17 @@ extern "C" int lgm_attn_fwd(const float* qkv, int64_t qkv_pitch, const float* me
   static const bool no_small = getenv("LGM_NO_SMALL_ATTN") != nullptr;          // A/B switch
   if (!no_small && n <= SA_MAXN && M <= 16 && qkv_pitch % 4 == 0 && out_pitch % 4 == 0 && lgm_aligned16(qkv) &&
       lgm_aligned16(out) && lgm_aligned16(mem_kv))
-    hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B * heads), dim3(128), 0, (hipStream_t)stream, qkv, (long)qkv_pitch,
-                       mem_kv, n, heads, M, 1.f / sqrtf((float)dim_head), out, (long)out_pitch, lse);
+  {
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_small_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(sa_fwd_floats(SA_MAXN, 16) * sizeof(float)));
+      attr = true;
+    }
+    hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B * heads), dim3(256), sa_fwd_floats(n, M) * sizeof(float),
+                       (hipStream_t)stream, qkv, (long)qkv_pitch, mem_kv, n, heads, M, 1.f / sqrtf((float)dim_head), out,
+                       (long)out_pitch, lse);
+  }
   else
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * heads), dim3(128), smem, (hipStream_t)stream, qkv, (long)qkv_pitch,
                        mem_kv, n, heads, M, 1.f / sqrtf((float)dim_head), out, (long)out_pitch, lse);
@@ -680,9 +704,17 @@ int attn_bwd_impl(const float* qkv, int64_t qkv_pitch, const float* mem_kv, cons
   if (!no_small && n <= SA_MAXN && M <= 16 && qkv_pitch % 4 == 0 && out_pitch % 4 == 0 && gout_pitch % 4 == 0 &&
       gqkv_pitch % 4 == 0 && lgm_aligned16(qkv) && lgm_aligned16(out) && lgm_aligned16(gout) && lgm_aligned16(gqkv) &&
       lgm_aligned16(mem_kv) && lgm_aligned16(part))
-    hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, qkv, (long)qkv_pitch,
-                       mem_kv, out, (long)out_pitch, gout, (long)gout_pitch, lse, n, heads, M,
-                       1.f / sqrtf((float)dim_head), gqkv, (long)gqkv_pitch, part);
+  {
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_small_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(sa_bwd_floats(SA_MAXN, 16) * sizeof(float)));
+      attr = true;
+    }
+    hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * heads), dim3(256), sa_bwd_floats(n, M) * sizeof(float),
+                       (hipStream_t)stream, qkv, (long)qkv_pitch, mem_kv, out, (long)out_pitch, gout, (long)gout_pitch, lse, n,
+                       heads, M, 1.f / sqrtf((float)dim_head), gqkv, (long)gqkv_pitch, part);
+  }
   else
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(192), smem, (hipStream_t)stream, qkv, (long)qkv_pitch,
                        mem_kv, out, (long)out_pitch, gout, (long)gout_pitch, lse, n, heads, M,
