@@ -21,6 +21,7 @@ struct RArgs {
   long x_pitch, res_pitch, out_pitch;
   int M, N, K;
   int wcols;          // weight rows (output columns) staged per group, multiple of 64
+  int ncb;            // output columns per workgroup (blockIdx.y walks the column ranges), multiple of 64
 };
 
 template <int TM>   // BM = 64 * TM rows per workgroup; waves 2 (m) x 2 (n), wave tile (32*TM) x 32
@@ -66,9 +67,13 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const RArgs p) {
   const float* a_base = Xs + (wm * 32 * TM + lr) * LD + lh * 4;
   const float* b_lane = Ws + (wn * 32 + lr) * LD + lh * 4;
 
-  for (int g0 = 0; g0 < p.N; g0 += p.wcols) {
-    const int gcols = min(p.wcols, p.N - g0);
-    if (g0 > 0) __syncthreads();          // previous group's weight rows fully consumed
+  // few row tiles (small maps): the columns are dealt out over blockIdx.y as well, so that the launch still fills the chip -
+  // with one workgroup per 64 rows a 8192-row layer ran on 128 CUs, each working through ALL columns (24.9 us for
+  // 128 -> 384 at 8 x 8, B = 128, of which 11.7 are the MFMAs of one workgroup)
+  const int n_lo = (int)blockIdx.y * p.ncb, n_hi = min(p.N, n_lo + p.ncb);
+  for (int g0 = n_lo; g0 < n_hi; g0 += p.wcols) {
+    const int gcols = min(p.wcols, n_hi - g0);
+    if (g0 > n_lo) __syncthreads();       // previous group's weight rows fully consumed
     stage(Ws, p.w, p.K, g0, gcols, p.N);
     __syncthreads();
     for (int nt = 0; nt < gcols / 64; ++nt) {
@@ -128,6 +133,18 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const RArgs p) {
   }
 }
 
+// column ranges per row tile: enough workgroups for the chip's slots, whole 64-column tiles, the X tile re-read per range
+int col_ranges(long row_tiles, int N) {
+  static const int off = getenv("LGM_GR_NO_COLSPLIT") != nullptr;        // A/B switch
+  if (off) return 1;
+  int r = (int)((lgm_cu_budget() + row_tiles - 1) / row_tiles);
+  const int tiles_n = N / 64;
+  if (r > tiles_n) r = tiles_n;
+  if (r < 1) r = 1;
+  while (tiles_n % r != 0) --r;                                          // equal ranges
+  return r;
+}
+
 // LDS plan: rows per workgroup and weight columns per group
 void plan(int N, int K, int* bm, int* wcols, size_t* smem) {
   const long row = (long)(K + 4) * 4;
@@ -148,7 +165,9 @@ bool lgm_gemm_rows_supported(long M, int N, int K) {
   int bm, wcols;
   size_t smem;
   plan(N, K, &bm, &wcols, &smem);
-  return wcols >= 64 && M % bm == 0 && M / bm >= 96;   // whole row tiles, enough of them to fill the chip
+  static const long min_tiles = getenv("LGM_GR_MIN_TILES") ? atol(getenv("LGM_GR_MIN_TILES")) : 96;   // tuning knob
+  // whole row tiles; enough workgroups to fill the chip once the columns are dealt out as well (col_ranges)
+  return wcols >= 64 && M % bm == 0 && M / bm >= min_tiles;
 }
 
 int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const float* bias, const float* res,
@@ -161,6 +180,9 @@ int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const flo
   size_t smem;
   plan(N, K, &bm, &p.wcols, &smem);
   const unsigned nblocks = (unsigned)lgm_cdiv(M, bm);
+  const int ranges = col_ranges((long)nblocks, N);
+  p.ncb = N / ranges;
+  if (p.wcols > p.ncb) p.wcols = p.ncb;
   if (bm == 128) {
     static size_t attr = 0;
     if (smem > attr) {
@@ -168,7 +190,7 @@ int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const flo
       attr = smem;
     }
     lgm_note_kernel(LGM_KNAME("gemm_rows_kernel<2>"));
-    hipLaunchKernelGGL(gemm_rows_kernel<2>, dim3(nblocks), dim3(256), smem, s, p);
+    hipLaunchKernelGGL(gemm_rows_kernel<2>, dim3(nblocks, ranges), dim3(256), smem, s, p);
   } else {
     static size_t attr = 0;
     if (smem > attr) {
@@ -176,7 +198,7 @@ int lgm_gemm_rows_launch(const float* x, long x_pitch, const float* w, const flo
       attr = smem;
     }
     lgm_note_kernel(LGM_KNAME("gemm_rows_kernel<1>"));
-    hipLaunchKernelGGL(gemm_rows_kernel<1>, dim3(nblocks), dim3(256), smem, s, p);
+    hipLaunchKernelGGL(gemm_rows_kernel<1>, dim3(nblocks, ranges), dim3(256), smem, s, p);
   }
   LGM_LAUNCH_CHECK();
   return LGM_OK;
