@@ -30,11 +30,12 @@ Objects of every workload:
                   Winograd F(2x2,3x3) kernel executes algorithmic / 2.25 FLOPs; algorithmic_tflops is the
                   2 B Ho Wo Cout KH KW Cin count over the same time.  ceiling_img_per_s = the fp32 MFMA roof of the
                   algorithm actually run (Winograd on the 3x3 layers), next to SURVEY.md's direct-convolution ceiling.
-  "cpu_baseline"  the CPU oracle (kind "port"), same workload at a bounded batch, on this host's cores.
+  "cpu_baseline"  the CPU oracle (kind "port"), same workload at its own batch for ~10 s of CPU work, on this host's cores (count + model).
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -110,11 +111,25 @@ def _timed_cpu(one, batch, warmup, min_seconds, max_steps, what):
             times.append(time.perf_counter() - t0)
         i += 1
     total = sum(times)
-    return {"value": round(batch * len(times) / total, 2), "unit": "images/s", "cores": nthreads, "kind": "port",
+    return {"value": round(batch * len(times) / total, 2), "unit": "images/s", "cores": nthreads, "cpu_model": _cpu_model(),
+            "kind": "port",
             "sample": f"{what}: {len(times)} steps = {total:.1f} s of CPU work after {warmup} warm-up"}
 
 
-def cpu_baseline_ddpm(img, dim=64, batch=32, min_seconds=12.0):
+def _cpu_model() -> str:
+    """'report the core count and CPU model with the number'."""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline_ddpm(img, dim=64, batch=128, min_seconds=12.0):
     """The CPU oracle (validated against the reference by tests/golden): whole training steps
     (forward + backward + Adam) until ``min_seconds`` of timed work have accumulated."""
     from oracle import diffusion as OD
@@ -131,10 +146,10 @@ def cpu_baseline_ddpm(img, dim=64, batch=32, min_seconds=12.0):
         opt.zero_grad()
         loss.backward()
         opt.step()
-    return _timed_cpu(one, batch, 1, min_seconds, 200, f"oracle fwd+bwd+Adam, B={batch}, 3x{img}x{img}")
+    return _timed_cpu(one, batch, 1, min_seconds, 200, f"oracle fwd+bwd+Adam at the workload's own batch, B={batch}, 3x{img}x{img}")
 
 
-def cpu_baseline_wgan(batch=32, min_seconds=12.0):
+def cpu_baseline_wgan(batch=128, min_seconds=12.0):
     from oracle import gan as OG
     torch.manual_seed(10)
     G, D = OG.gan_init(64, 3, 100, seed=0)
@@ -163,7 +178,7 @@ def cpu_baseline_wgan(batch=32, min_seconds=12.0):
     return _timed_cpu(one, batch, 1, min_seconds, 300, f"oracle WGAN-GP training_step (5 D : 1 G) + Adam, B={batch}, 3x64x64")
 
 
-def cpu_baseline_vqvae(ema, batch=64, min_seconds=10.0):
+def cpu_baseline_vqvae(ema, batch=256, min_seconds=10.0):
     from oracle import vq as OV
     torch.manual_seed(10)
     P = {k: v.requires_grad_(True) for k, v in OV.vqvae_init(seed=0).items()}
@@ -391,14 +406,15 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
     # much of the communication the backward did NOT hide - and the collectives one step issues, for the line's `config`
     comm = None
     sync = getattr(info.get("fast"), "sync", None)
-    if world > 1 and sync is not None and not isinstance(sync, dict):
+    if sync is not None and not isinstance(sync, dict) and sync.active:
         sync.measure = True
         for i in range(min(5, steps)):
             step(warmup + steps + i)
         ev_ms, host_ms, n_meas = sync.exposed_ms()
         sync.measure = False
         cm = torch.tensor([ev_ms or 0.0, host_ms or 0.0], device=dev, dtype=torch.float64)
-        dist.all_reduce(cm, op=dist.ReduceOp.MAX)
+        if world > 1:
+            dist.all_reduce(cm, op=dist.ReduceOp.MAX)
         comm = {"comm_exposed_ms": round(float(cm[0]), 4), "comm_host_wait_ms": round(float(cm[1]), 4),
                 "comm_measured_steps": n_meas,
                 "bucket_bytes": [4 * int(n) for n in sync.last_buckets], "collectives_per_step": len(sync.last_buckets),
@@ -449,18 +465,31 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
     # figure comes from the committed rocprofv3 --pmc summary of this same command (tools/pmc_kernels.py), if any
     # (newest round first; a file whose rows do not hold this kernel's exact name is skipped, never half-used).  The same
     # file's step totals give the counter-side HBM fraction of the whole step.
-    traffic, traffic_src, step_counter_bytes = None, None, None
-    for cand in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    traffic, traffic_src, step_counter_bytes, traffic_stale = None, None, None, None
+    from lgm_hip._lib import source_fingerprint
+    now = source_fingerprint()
+    for cand in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", cand)
         if traffic is None and os.path.exists(pmc) and wl == "ddpm32" and gb == 128 and world == 1:
             with open(pmc) as fh:
                 doc = json.load(fh)
             t = doc.get("kernels", {}).get(name)
-            if t:
-                traffic, traffic_src = t["traffic_bytes_per_launch"], f"profiles/{cand}"
-                st = doc.get("step_total") or {}
-                if "fetch_bytes" in st and "write_bytes" in st:
-                    step_counter_bytes = st["fetch_bytes"] + st["write_bytes"]
+            if not t:
+                continue
+            # counters measured on other kernel code are not this run's traffic: a file without a fingerprint, or whose
+            # fingerprint differs from the tree in the file that defines this kernel (or in a shared header), is STALE
+            then = doc.get("sources")
+            base = re.sub(r"<.*$", "", name).split("::")[-1]
+            own = [f for f in now if f.endswith(".h") or base in open(os.path.join(
+                ROOT, "lightning-generative-models_amd", "csrc", f)).read()] if then else []
+            if not then or any(then.get(f) != now[f] for f in own):
+                traffic_stale = f"profiles/{cand}: measured on other sources" + (
+                    "" if not then else " (" + ", ".join(f for f in own if then.get(f) != now[f]) + ")")
+                break
+            traffic, traffic_src = t["traffic_bytes_per_launch"], f"profiles/{cand}"
+            st = doc.get("step_total") or {}
+            if "fetch_bytes" in st and "write_bytes" in st and then == now:     # the step total depends on every kernel
+                step_counter_bytes = st["fetch_bytes"] + st["write_bytes"]
     flop_per_img, bytes_per_img, bytes_per_step, detail = info["work"]()
     roof = {"bound": "mfma", "kernel": name, "achieved": round(exe_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(exe_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -468,7 +497,8 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
             "executed_flops_per_launch": round(executed(name, d["flops"]) / d["launches"]),
             "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
             "launches_per_step": round(d["launches"] / n_instr, 2), "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
-            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": bool(traffic_stale),
+            "traffic_stale_why": traffic_stale,
             "algorithmic_bytes_per_launch": round(d.get("bytes", 0) / max(d["launches"], 1)) or None,
             "traffic_over_algorithmic": (round(traffic / (d["bytes"] / d["launches"]), 3)
                                          if traffic and d.get("bytes") else None),
@@ -516,15 +546,18 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 5), "launch": launch,
                        "conv_mode": conv_mode},
             "roofline": roof}
-    if world > 1:
+    if world > 1 or comm:
         line["config"]["grad_exchange"] = ("bucketed all-reduce overlapped with the backward (RCCL)"
                                            if os.environ.get("LGM_DDP_OVERLAP", "1") != "0"
                                            else "one all-reduce after the backward (LGM_DDP_OVERLAP=0)")
         from lgm_hip import ops as _ops
-        line["config"]["kernel_selection"] = {
-            "cu_margin": int(_ops.lib().lgm_cu_margin()),
-            "note": "launch plans sized for 256 - cu_margin CUs (a collective's workgroups hold the rest), light F(4x4) "
-                    "workgroups; LGM_CU_MARGIN / LGM_WINO4_LIGHT override"}
+        # which rule chose the kernels (lgm_hip.lightning.FlatGradSync._select_kernels): margin + light workgroups only
+        # while the exchange really overlaps the backward on RCCL; the environment's LGM_CU_MARGIN / LGM_WINO4_LIGHT win
+        sel = dict(getattr(sync, "selection", None) or {}) if sync is not None and not isinstance(sync, dict) else {}
+        sel.setdefault("cu_margin", int(_ops.lib().lgm_cu_margin()))
+        sel["note"] = ("launch plans sized for 256 - cu_margin CUs (a collective's workgroups hold the rest); "
+                       "LGM_CU_MARGIN / LGM_WINO4_LIGHT override the rule")
+        line["config"]["kernel_selection"] = sel
         if comm:
             line["config"].update({k: comm[k] for k in ("bucket_bytes", "collectives_per_step", "backend", "rccl_ranks")})
             line["comm_exposed_ms"] = comm["comm_exposed_ms"]
@@ -535,7 +568,7 @@ def run_workload(wl, args, dev, world, rank, steps, warmup, batch=None, roofline
         if wl == "ddpm32":
             line["cpu_baseline"] = cpu_baseline_ddpm(32, min_seconds=secs)
         elif wl == "ddpm64":
-            line["cpu_baseline"] = cpu_baseline_ddpm(64, batch=8, min_seconds=secs)
+            line["cpu_baseline"] = cpu_baseline_ddpm(64, batch=64, min_seconds=secs)
         elif wl == "wgan_gp64":
             line["cpu_baseline"] = cpu_baseline_wgan(min_seconds=secs)
         else:
@@ -621,8 +654,8 @@ def _release():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)      # >= 50 timed steps
+    ap.add_argument("--warmup", type=int, default=10)     # ... after >= 10 warm-up steps
     ap.add_argument("--workload", default="ddpm32", choices=["ddpm32", "ddpm64", "wgan_gp64", "vqvae", "vqvae_ema"])
     ap.add_argument("--vq-ema", action="store_true", help="vqvae workload: EMA codebook (= --workload vqvae_ema)")
     ap.add_argument("--only", action="store_true", help="only the named workload: no secondary configs, no per-rank proxy")
@@ -668,7 +701,10 @@ def main():
     if rank == 0:
         print(f"[bench] world={world} backend={backend} HSA_ENABLE_IPC_MODE_LEGACY="
               f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '<unset>')} ({_IPC_ENV_SOURCE})", file=sys.stderr, flush=True)
-    if world > 1:
+    # LGM_DDP_FORCE=1 under a launcher with ONE rank: the process group comes up and FlatGradSync issues its collectives
+    # although world == 1 - the one-rank RCCL rehearsal (tests/test_hip_rccl.py)
+    forced = world == 1 and os.environ.get("LGM_DDP_FORCE", "0") == "1" and launch.launched()
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # a rendezvous or a first collective that cannot complete must END the run with the RCCL error text and a
         # non-zero exit code, not hang it: bounded process-group timeout + asynchronous error handling, and a probe

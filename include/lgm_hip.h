@@ -39,11 +39,12 @@
 extern "C" {
 #endif
 
-#define LGM_ABI_VERSION 5   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial;
+#define LGM_ABI_VERSION 6   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial;
                              * 3: lgm_conv3x3_wino4*, lgm_gn_fwd_stats, lgm_conv3x3_wino_wgradn* + LgmWgradItem, a negative
                              *    dst offset in lgm_wino_weights table rows means "skip that copy", lgm_kernel_name*;
                              * 4: LgmPostOp carries the BatchNorm-backward sums (bn_*), lgm_bn_reduce3_coef_tiles;
-                             * 5: lgm_set_cu_margin / lgm_cu_margin */
+                             * 5: lgm_set_cu_margin / lgm_cu_margin;
+                             * 6: lgm_extract_axpby, lgm_model_predictions (GaussianDiffusion's per-sample-time algebra) */
 #define LGM_OK 0
 #define LGM_ERR_INVALID (-1)
 #define LGM_ERR_UNSUPPORTED (-2)
@@ -380,6 +381,21 @@ int lgm_weighted_mse_fwd(const float* out, const float* target, int64_t pitch, c
 int lgm_weighted_mse_bwd(const float* out, const float* target, int64_t pitch, const int64_t* t,
                          const float* loss_weight, const float* gloss, int B, int C, int HW, int Cpad,
                          float* gout, void* stream);
+
+/* GaussianDiffusion's per-sample-timestep algebra on dense NCHW tensors (`extract(table, t, shape) * ...`):
+ *   out[b][i] = clamp?( (ta[t_b] * x[b][i] + sb * tb[t_b] * y[b][i]) / td[t_b] )     i < per_sample
+ * ta / tb / td = NULL read as 1; products and the sum are rounded separately (no contraction), like the reference's ATen
+ * expression.  One entry point for q_sample ddpm.py:869-876 (sqrt_ac, sqrt_1mac, +1), predict_v :684-688, predict_start_from_v
+ * :690-694, predict_start_from_noise :673-677 (sb = -1), predict_noise_from_start :679-682 (ta = sqrt_recip, tb = NULL,
+ * sb = -1, td = sqrt_recipm1) and q_posterior's mean :697-700.  clip != 0: clamp to [-1, 1] (maybe_clip :711-713). */
+int lgm_extract_axpby(const float* ta, const float* tb, const float* td, const int64_t* t, const float* x,
+                      const float* y, float sb, int clip, float* out, int B, int64_t per_sample, int n_table,
+                      void* stream);
+/* model_predictions ddpm.py:707-734, pred_v branch, in one pass over dense NCHW tensors with a per-sample t:
+ *   x_start = maybe_clip(sqrt_ac[t] * x - sqrt_1mac[t] * v) ;  pred_noise = (sqrt_recip[t] * x - x_start) / sqrt_recipm1[t] */
+int lgm_model_predictions(const float* x, const float* v, const int64_t* t, const float* sqrt_ac,
+                          const float* sqrt_1mac, const float* sqrt_recip, const float* sqrt_recipm1, int clip,
+                          float* pred_noise, float* x_start, int B, int64_t per_sample, int n_table, void* stream);
 
 /* One reverse-diffusion update at a shared timestep (model_predictions ddpm.py:707-734 pred_v branch,
  * p_sample :748-757, ddim_sample loop body :805-829):

@@ -1,5 +1,6 @@
 // Small HBM-bound kernels: column sums, time embedding, activations, resampling copies,
 // NCHW<->NHWC conversion, diffusion q_sample / v-target / weighted-MSE loss.
+#include <atomic>
 #include <stdarg.h>
 
 #include "lgm_common.h"
@@ -21,21 +22,22 @@ extern "C" const char* lgm_last_kernel(void) { return g_kernel; }
 // the name registry: one pointer per LGM_KNAME site of the whole library (section bounds from the linker)
 extern "C" const char* const __start_lgm_knames[];
 extern "C" const char* const __stop_lgm_knames[];
-// CU margin: LGM_CU_MARGIN, else 16 when this process is one rank of several (WORLD_SIZE > 1: a collective's workgroups hold
-// CUs beside the backward pass), else 0; lgm_set_cu_margin(margin) overrides (-1: back to that default).  Measured with 16
+// CU margin: lgm_set_cu_margin(margin) (-1: back to the default), else LGM_CU_MARGIN, else 0.  The library no longer derives
+// it from WORLD_SIZE (round 6): lgm_hip.lightning.FlatGradSync sets 16 for a rank whose exchange overlaps its backward pass
+// on RCCL - the one case in which a collective's workgroups hold CUs beside the launches.  Measured with 16
 // foreign 256-thread workgroups resident (tools/cu_hog_step.py, light F(4x4) workgroups, ms per step, margin 0 / 16 / 32):
 // B = 64: 8.15 / 7.48 / 7.49 (alone 6.75 / 6.86 / 6.92); B = 16: 4.90 / 4.70 / 4.69 (alone 4.48 / 4.49 / 4.50).
-static int lgm_cu_margin_override = -1;
+static std::atomic<int> lgm_cu_margin_override{-1};
 extern "C" int lgm_cu_margin(void) { return 256 - lgm_cu_budget(); }
 extern "C" int lgm_set_cu_margin(int margin) {
   LGM_REQUIRE(margin <= 128, "lgm_set_cu_margin: margin %d leaves less than half of the chip", margin);
-  lgm_cu_margin_override = margin;
+  lgm_cu_margin_override.store(margin, std::memory_order_relaxed);
   return LGM_OK;
 }
 int lgm_cu_budget() {
-  static const int env_margin = getenv("LGM_CU_MARGIN") ? atoi(getenv("LGM_CU_MARGIN"))
-                                : (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 ? 16 : 0);
-  int m = lgm_cu_margin_override >= 0 ? lgm_cu_margin_override : env_margin;
+  static const int env_margin = getenv("LGM_CU_MARGIN") ? atoi(getenv("LGM_CU_MARGIN")) : 0;
+  const int ov = lgm_cu_margin_override.load(std::memory_order_relaxed);
+  int m = ov >= 0 ? ov : env_margin;
   if (m < 0) m = 0;
   if (m > 128) m = 128;
   return 256 - m;
@@ -500,6 +502,52 @@ __global__ __launch_bounds__(256) void sample_step_kernel(const float* __restric
   if (x0_out) x0_out[i] = x0;
 }
 
+// GaussianDiffusion's `extract(table, t, shape) * tensor` algebra with a PER-SAMPLE timestep (ddpm.py:673-705, 869-876) on
+// dense NCHW tensors: one thread per element, the three table values of the sample are wave-uniform loads.  Contraction is
+// off: the reference rounds both products and the sum separately.  A timestep outside the table is clamped to it (the
+// reference's gather raises; a device kernel must not fault).
+__device__ __forceinline__ float extract_axpby_one(float a, float bb, float d, float xv, float yv, int clip) {
+#pragma clang fp contract(off)
+  float o = a * xv + bb * yv;
+  if (d != 1.f) o = o / d;
+  if (clip) o = fminf(fmaxf(o, -1.f), 1.f);
+  return o;
+}
+__global__ __launch_bounds__(256) void extract_axpby_kernel(const float* __restrict__ ta, const float* __restrict__ tb,
+                                                            const float* __restrict__ td, const long* __restrict__ t,
+                                                            const float* __restrict__ x, const float* __restrict__ y,
+                                                            float sb, int clip, float* __restrict__ out, long per,
+                                                            int n_table) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.y;
+  long ti = t[b];
+  ti = ti < 0 ? 0 : (ti >= n_table ? n_table - 1 : ti);
+  const float a = ta ? ta[ti] : 1.f, bb = sb * (tb ? tb[ti] : 1.f), d = td ? td[ti] : 1.f;
+  const long base = (long)b * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x)
+    out[base + i] = extract_axpby_one(a, bb, d, x[base + i], y ? y[base + i] : 0.f, clip);
+}
+__global__ __launch_bounds__(256) void model_predictions_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                                const long* __restrict__ t, const float* __restrict__ sa,
+                                                                const float* __restrict__ s1, const float* __restrict__ r,
+                                                                const float* __restrict__ rm1, int clip,
+                                                                float* __restrict__ pn, float* __restrict__ xs, long per,
+                                                                int n_table) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.y;
+  long ti = t[b];
+  ti = ti < 0 ? 0 : (ti >= n_table ? n_table - 1 : ti);
+  const float A = sa[ti], S = s1[ti], R = r[ti], Rm1 = rm1[ti];
+  const long base = (long)b * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+    const float xv = x[base + i];
+    float x0 = A * xv - S * v[base + i];
+    if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    xs[base + i] = x0;
+    pn[base + i] = (R * xv - x0) / Rm1;
+  }
+}
+
 // Graph-replayed sampling (lgm_hip/sampler.py): the per-step scalars come from a device table indexed by a
 // device-side step counter, so ONE captured graph serves every step of a chain.
 //   sampler_time_kernel : t[b] = ttable[counter]                              (before the UNet forward)
@@ -538,6 +586,30 @@ __global__ void sampler_advance_kernel(int* counter) { counter[0] += 1; }
 
 }  // namespace
 
+extern "C" int lgm_extract_axpby(const float* ta, const float* tb, const float* td, const int64_t* t, const float* x,
+                                 const float* y, float sb, int clip, float* out, int B, int64_t per_sample, int n_table,
+                                 void* stream) {
+  LGM_REQUIRE(t && x && out && B > 0 && B <= 65535 && per_sample > 0 && n_table > 0, "extract_axpby: bad arguments");
+  LGM_REQUIRE(y || !tb, "extract_axpby: a second table without a second tensor");
+  const int gx = (int)(per_sample < 256L * 4096 ? lgm_cdiv(per_sample, 256) : 4096);
+  hipLaunchKernelGGL(extract_axpby_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, ta, tb, td, (const long*)t, x,
+                     y, sb, clip, out, (long)per_sample, n_table);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+extern "C" int lgm_model_predictions(const float* x, const float* v, const int64_t* t, const float* sqrt_ac,
+                                     const float* sqrt_1mac, const float* sqrt_recip, const float* sqrt_recipm1, int clip,
+                                     float* pred_noise, float* x_start, int B, int64_t per_sample, int n_table,
+                                     void* stream) {
+  LGM_REQUIRE(x && v && t && sqrt_ac && sqrt_1mac && sqrt_recip && sqrt_recipm1 && pred_noise && x_start && B > 0 &&
+                  B <= 65535 && per_sample > 0 && n_table > 0,
+              "model_predictions: bad arguments");
+  const int gx = (int)(per_sample < 256L * 4096 ? lgm_cdiv(per_sample, 256) : 4096);
+  hipLaunchKernelGGL(model_predictions_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, v, (const long*)t,
+                     sqrt_ac, sqrt_1mac, sqrt_recip, sqrt_recipm1, clip, pred_noise, x_start, (long)per_sample, n_table);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
 extern "C" int lgm_sampler_time(const int64_t* ttable, const int32_t* counter, int64_t* t, int B, void* stream) {
   LGM_REQUIRE(ttable && counter && t && B > 0, "sampler_time: bad arguments");
   hipLaunchKernelGGL(sampler_time_kernel, dim3(lgm_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream,

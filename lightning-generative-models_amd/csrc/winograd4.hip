@@ -24,6 +24,7 @@
 // of 32 output channels, 147 KB each, XOR-swizzled: conflict-free 16-byte writes and reads); thread = (tile, channel
 // quad, output row pair) applies A^T . A and stores full 128-byte segments with bias / residual fused.  Split-K writes
 // partial OUTPUT planes (the output transform is linear) for the fixed-order reducer or the plane-summing GroupNorm.
+#include <atomic>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -653,25 +654,29 @@ int lgm_wino4l_splits(const LgmConvGeom* g, int gather_channels, int out_channel
 int lgm_wino4l_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, const float* u, const float* bias,
                       const float* res, long res_pitch, float* out, long out_pitch, void* workspace, long workspace_bytes,
                       hipStream_t s, int64_t* partial, float* stats);
-// LGM_WINO4_LIGHT: 1 = the light workgroups wherever they take the geometry, 0 = the 32-tile workgroups only.  Unset: all
-// light when this process is one of several ranks (WORLD_SIZE > 1: a resident collective shares the chip - with one foreign
+// LGM_WINO4_LIGHT: 1 = the light workgroups wherever they take the geometry, 0 = the 32-tile workgroups only.  Unset: launch
+// by launch (below) unless lgm_wino4_set_light(1) was called - which lgm_hip.lightning.FlatGradSync does for a rank whose
+// gradient exchange overlaps its backward pass on RCCL (a resident collective shares the chip: with one foreign
 // workgroup resident the step costs +38 % on the 32-tile kernels and +30 % with the light ones, tools/cu_hog_step.py - and the
-// per-rank batches are the ones they win at), and on one GPU launch by launch (the rule inside wino4_use_light: B = 128 keeps
+// per-rank batches are the ones they win at).  Launch by launch (the rule inside wino4_use_light): B = 128 keeps
 // the 32-tile workgroups, 10.03 vs 10.13 ms all light; isolated and cache-warm the light kernel is 4-20 % faster at every
 // batch, tools/wino4l_bench.py, but inside the step every launch starts cold and two waves per SIMD hide more of that).
-static int lgm_wino4_light_override = -1;         // diagnostic / tests: lgm_wino4_set_light
+static std::atomic<int> lgm_wino4_light_override{-1};   // lgm_wino4_set_light: read by whichever thread issues launches
 extern "C" int lgm_wino4_set_light(int mode) {
-  lgm_wino4_light_override = mode;
+  lgm_wino4_light_override.store(mode, std::memory_order_relaxed);
   return LGM_OK;
 }
 static bool wino4_use_light(const LgmConvGeom* g, int gather_channels, int out_channels) {
-  // (LGM_WINO4_LIGHT_BELOW given without LGM_WINO4_LIGHT: the launch-by-launch rule with those bounds, also under WORLD_SIZE > 1)
-  static const int env_mode = getenv("LGM_WINO4_LIGHT") ? atoi(getenv("LGM_WINO4_LIGHT"))
-                              : (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 && !getenv("LGM_WINO4_LIGHT_BELOW") ? 1 : 0);
-  const int mode = lgm_wino4_light_override >= 0 ? lgm_wino4_light_override : env_mode;
+  // The environment is read ONCE.  No rule reads WORLD_SIZE any more (round 6): being one rank of several does
+  // not by itself mean that a collective is resident beside the launches - lgm_hip.lightning.FlatGradSync switches the
+  // light workgroups (and the CU margin) on when its exchange really overlaps the backward pass on RCCL.
+  static const bool env_given = getenv("LGM_WINO4_LIGHT") != nullptr;
+  static const int env_mode = env_given ? atoi(getenv("LGM_WINO4_LIGHT")) : 0;
+  const int ov = lgm_wino4_light_override.load(std::memory_order_relaxed);
+  const int mode = ov >= 0 ? ov : env_mode;
   if (!lgm_wino4l_supported(g, gather_channels, out_channels)) return false;
   if (mode != 0) return true;
-  if (getenv("LGM_WINO4_LIGHT") != nullptr || lgm_wino4_light_override >= 0) return false;   // 0 asked for: 32-tile only
+  if (env_given || ov >= 0) return false;   // 0 asked for: 32-tile only
   // One GPU, nothing asked for: the light workgroups for the launches the 32-tile kernel cannot fill the chip with -
   // fewer 32-tile units than the class's bound (LGM_WINO4_LIGHT_BELOW="a,b,c": W % 32 == 0 maps, 16x16, 8x8; 0 = never).
   // Measured per step (tools/step_ab.sh): B = 64 6.94 -> 6.73 ms, B = 32 5.37 -> 5.21; at B = 128 (256 / 128 / 64 units)
@@ -930,8 +935,13 @@ extern "C" int lgm_conv3x3_wino4_stats(const LgmConvGeom* g, const float* x, int
   LGM_REQUIRE(g && x && u && y && stats, "conv3x3_wino4_stats: null pointer");
   int per = 0;
   const int64_t need = lgm_conv3x3_wino4_stats_floats(g, &per);
-  LGM_REQUIRE(need > 0 && stats_floats >= need && lgm_aligned16(stats) && g->Nw % 4 == 0,
-              "conv3x3_wino4_stats: geometry not taken or statistics buffer too small (ask lgm_conv3x3_wino4_stats_floats)");
+  // == and not >=: the row count per image depends on the workgroup form (light: 8-row units, 32-tile: 16-row units).  A
+  // caller that sized its buffer - and will tell lgm_gn_fwd_stats its rows per image - under another kernel selection would
+  // otherwise read rows this launch never writes.
+  LGM_REQUIRE(need > 0 && stats_floats == need && lgm_aligned16(stats) && g->Nw % 4 == 0,
+              "conv3x3_wino4_stats: geometry not taken, or the statistics buffer (%ld floats) is not what THIS kernel selection "
+              "writes (%ld: ask lgm_conv3x3_wino4_stats_floats again after lgm_wino4_set_light / lgm_set_cu_margin)",
+              (long)stats_floats, (long)need);
   LGM_REQUIRE(x_pitch % 4 == 0 && x_pitch >= g->Cw && lgm_aligned16(x) && lgm_aligned16(u) && lgm_aligned16(y) &&
               y_pitch % 4 == 0 && y_pitch >= g->Nw && (!bias || lgm_aligned16(bias)),
               "conv3x3_wino4_stats: 16-byte aligned operands with pitch %% 4 == 0 expected");

@@ -257,7 +257,7 @@ class DDPMFastStep:
         from .lightning import FlatGradSync
         self.model, self.opt = model, opt
         self.net = model.ema.online_model.model
-        self.sync = FlatGradSync(self.net._flat) if world > 1 else None
+        self.sync = FlatGradSync(self.net._flat) if FlatGradSync.wanted(world) else None
         inner = getattr(opt, "_opt", opt)            # MiniTrainer wraps optimizers in a step-counting proxy
         if self.sync is not None:
             inner.grad_scale = self.sync.grad_scale  # 1/N folded into Adam (no divide pass)
@@ -412,7 +412,8 @@ class WGANFastStep:
                 inner.grad_scale = 1.0 / world
         if world > 1:
             model._grads_prescaled = True
-        self.sync = {"d": FlatGradSync(model.D._flat), "g": FlatGradSync(model.G._flat)} if world > 1 else None
+        self.sync = ({"d": FlatGradSync(model.D._flat, beside_backward=False),
+                      "g": FlatGradSync(model.G._flat, beside_backward=False)} if world > 1 else None)
         self.use_graph = use_graph
         self.graphs = {}          # "d" / "g" -> (graph, static x, captured logs, BatchNorm trace)
         self.mode = "eager"

@@ -96,11 +96,13 @@ def spawn_ranks(script: str, argv: Sequence[str], nproc: int, *, extra_env: Opti
     if timeout is None and os.environ.get("LGM_LAUNCH_TIMEOUT"):
         timeout = float(os.environ["LGM_LAUNCH_TIMEOUT"])
     print(f"[launch] starting {nproc} ranks: {' '.join(cmd[1:])}", file=sys.stderr, flush=True)
-    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
     # The ranks live in their own session: a SIGTERM / SIGHUP / SIGINT that ends THIS process (``timeout -k``, a
-    # scheduler, a closed terminal) would otherwise leave them running and holding the GPUs.  While the child runs the
-    # signals are turned into an exception, so the ``finally``-like paths below end exactly the group started here.
+    # scheduler, a closed terminal) would otherwise leave them running and holding the GPUs.  The handlers are installed
+    # BEFORE the child is started (a signal that arrived between Popen and signal.signal() killed the parent by
+    # default action and orphaned the rank group); while the child runs the signals are turned into an exception, so the
+    # ``finally``-like paths below end exactly the group started here - or nothing, when the child does not exist yet.
     caught: List[int] = []
+    proc: Optional[subprocess.Popen] = None
 
     def _on_signal(signum, _frame):
         caught.append(signum)
@@ -114,6 +116,7 @@ def spawn_ranks(script: str, argv: Sequence[str], nproc: int, *, extra_env: Opti
             except (ValueError, OSError):
                 pass
     try:
+        proc = subprocess.Popen(cmd, env=env, start_new_session=True)
         return int(proc.wait(timeout=timeout))
     except subprocess.TimeoutExpired:
         print(f"[launch] {nproc}-rank run exceeded {timeout:.0f} s: ending its process group", file=sys.stderr, flush=True)
@@ -123,10 +126,12 @@ def spawn_ranks(script: str, argv: Sequence[str], nproc: int, *, extra_env: Opti
         print(f"[launch] signal {e.signum}: ending the {nproc}-rank process group", file=sys.stderr, flush=True)
         for sig in old:                      # a second signal while the group is being ended must not re-enter
             signal.signal(sig, signal.SIG_IGN)
-        _end_group(proc, first=e.signum if e.signum != signal.SIGHUP else signal.SIGTERM)
+        if proc is not None:                 # the signal may have arrived before the child existed
+            _end_group(proc, first=e.signum if e.signum != signal.SIGHUP else signal.SIGTERM)
         return 128 + int(e.signum)
     except BaseException:
-        _end_group(proc)
+        if proc is not None:
+            _end_group(proc)
         raise
     finally:
         for sig, h in old.items():

@@ -230,10 +230,25 @@ class FlatGradSync:
     (+27 ... 35 % on those launches, tools/cu_hog_step.py), so overlap hides the exchange at a price; which
     side wins depends on the link time and can only be measured on more than one GPU."""
 
-    def __init__(self, flat, group=None, overlap: Optional[bool] = None):
+    @staticmethod
+    def wanted(world: int) -> bool:
+        """An exchange object is needed: more than one rank, or ``LGM_DDP_FORCE=1`` with a process group up - the ONE-rank
+        rehearsal (tests/test_hip_rccl.py: RCCL initialised, collectives issued between the four graphs, captures beside
+        the watchdog thread) that makes sure the first multi-GPU run is not the first time this code meets RCCL."""
+        forced = os.environ.get("LGM_DDP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
+        return world > 1 or forced
+
+    def __init__(self, flat, group=None, overlap: Optional[bool] = None, beside_backward: bool = True):
+        """``beside_backward=False``: the owner issues ``ready`` only after its whole backward pass (WGANFastStep), so the
+        collective never shares the chip with a launch plan, whatever ``overlap`` says."""
         self.flat, self.group = flat, group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.beside_backward = bool(beside_backward)
+        up = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if up else 1
+        self.backend = str(dist.get_backend(group)) if up else None
+        self.active = up and FlatGradSync.wanted(self.world)         # False: ready() / finish() issue nothing
         self.overlap = (os.environ.get("LGM_DDP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        self.selection = self._select_kernels()
         self.handles = []
         self.pending = []
         self.covered = 0
@@ -244,6 +259,35 @@ class FlatGradSync:
         self.last_buckets = []
         self._buckets = []
         self._spans = []
+
+    def _select_kernels(self) -> dict:
+        """The kernel selection of a rank follows from what is TRUE of its exchange, not from WORLD_SIZE: light
+        F(4x4) workgroups and launch plans that leave 16 CUs free pay only while a collective's workgroups are resident
+        beside the backward pass - the overlapped exchange on RCCL (``nccl``).  With ``LGM_DDP_OVERLAP=0`` (one all-reduce
+        after the backward), under gloo (host-side reduction) or on one rank nothing shares the chip with a launch and the
+        one-GPU rules are the faster ones (the rank defaults cost +4.9 % on config 5 alone).  An
+        environment setting of a knob wins over this rule.  Every change clears the host's plan caches
+        (lgm_hip/_lib.py: on_selection_change).  Returns the record the bench line prints."""
+        resident = bool(self.active and self.overlap and self.beside_backward and self.backend == "nccl"
+                        and self.flat.grad.is_cuda)
+        rec = {"rule": ("overlapped exchange on RCCL: a collective is resident beside the backward" if resident else
+                        "no collective resident beside the backward (" +
+                        ("one rank" if not self.active else "LGM_DDP_OVERLAP=0" if not self.overlap
+                         else "exchange after the backward" if not self.beside_backward
+                         else f"backend {self.backend}") + "): one-GPU rules")}
+        if not self.flat.grad.is_cuda:
+            return rec
+        from . import ops
+        env = os.environ
+        if resident:                                 # (not resident: nothing is touched - the library's defaults ARE the one-GPU rules)
+            if "LGM_CU_MARGIN" not in env:
+                ops.set_kernel_selection(cu_margin=16)
+            if "LGM_WINO4_LIGHT" not in env and "LGM_WINO4_LIGHT_BELOW" not in env:
+                ops.set_kernel_selection(light=1)
+        rec["cu_margin"] = int(ops.lib().lgm_cu_margin())
+        rec["light_f4x4_workgroups"] = ("all launches" if resident and "LGM_WINO4_LIGHT" not in env
+                                        and "LGM_WINO4_LIGHT_BELOW" not in env else "environment / launch by launch")
+        return rec
 
     def exposed_ms(self):
         """-> (mean stream-side wait per step in ms, mean host-side wait per step in ms, steps) over the steps finished
@@ -260,7 +304,7 @@ class FlatGradSync:
     def ready(self, lo: int, hi: int):
         """-> the asynchronous work handle (None on one rank, and when the exchange is deferred to ``finish``);
         ``finish()`` waits for whatever is still pending"""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return None
         self.covered += hi - lo
         if not self.overlap:
@@ -305,7 +349,7 @@ class FlatGradSync:
         self.handles = []
         if self._buckets:
             self.last_buckets, self._buckets = self._buckets, []
-        if self.world > 1:
+        if self.active:
             assert self.covered == self.flat.total, \
                 f"gradient buckets covered {self.covered} of {self.flat.total} elements"
         self.covered = 0

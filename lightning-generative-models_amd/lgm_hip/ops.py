@@ -814,6 +814,26 @@ def _pair_slabs(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+def clear_plan_caches():
+    """Forget every per-geometry answer of the library's planners (kernel choice, split counts, workspace sizes, statistics
+    row counts).  Runs by itself after lgm_set_cu_margin / lgm_wino4_set_light (lgm_hip/_lib.py: on_selection_change):
+    those knobs change what the queries return.  Buffers are kept (captured graphs have their addresses baked in); they are
+    looked up by size, so a plan that now needs more gets a new one."""
+    for d in (_CONV_WS_BYTES, _WINO_OK, _WINO_WS, _WINO4_OK, _EPI_STATS, _WINO_FITS, _PAIR_OK, _WG2_OK, _WG2_WS,
+              _GN_PLANES_OK):
+        d.clear()
+
+
+def set_kernel_selection(cu_margin: Optional[int] = None, light: Optional[int] = None):
+    """The kernel selection of a rank whose gradient exchange runs BESIDE its backward pass (FlatGradSync decides):
+    ``cu_margin`` CUs left to the collective's workgroups by every launch plan, ``light`` = 1: light F(4x4) workgroups.
+    None leaves a knob alone, -1 returns it to the library's default (environment, else one-GPU rules)."""
+    if cu_margin is not None:
+        lib().lgm_set_cu_margin(int(cu_margin))
+    if light is not None:
+        lib().lgm_wino4_set_light(int(light))
+
+
 def wgrad_reduce_batch(rows, device):
     """One launch: fixed-order reduction of the partial slabs of every deferred weight gradient in ``rows``."""
     if not rows:
@@ -1293,3 +1313,8 @@ def ema_lerp(shadow, online, w):
 
 def fill(x, val):
     lib().lgm_fill(x.data_ptr(), x.numel(), val, stream())
+
+
+from ._lib import on_selection_change as _on_selection_change  # noqa: E402
+
+_on_selection_change(clear_plan_caches)

@@ -268,15 +268,19 @@ def warm_chain(gd, shape, replays: int = 20) -> bool:
 
 
 @torch.no_grad()
-def p_sample_loop(gd, shape, return_all_timesteps=False, init_noise=None, noises: Optional[List[torch.Tensor]] = None):
+def p_sample_loop(gd, shape, return_all_timesteps=False, init_noise=None, noises: Optional[List[torch.Tensor]] = None,
+                  start: Optional[int] = None, unnormalize: Optional[bool] = None):
+    """``start``: walk the chain from step start - 1 down to 0 (GaussianDiffusion.interpolate :861-865) instead of from
+    T - 1; ``unnormalize``: default = the model's auto_normalize (p_sample_loop :779), False for interpolate."""
     chain = _Chain(gd, shape, init_noise)
     dev = chain.x.device
-    ts = list(reversed(range(gd.num_timesteps)))
-    gc = None if return_all_timesteps else _graph_chain(gd, shape, True)
+    ts = list(reversed(range(gd.num_timesteps if start is None else int(start))))
+    unn = gd.auto_normalize if unnormalize is None else bool(unnormalize)
+    gc = None if return_all_timesteps or not ts else _graph_chain(gd, shape, True)
     if gc is not None:
         x = gc.run(chain.x, ts, [_p_sample_coeffs(gd, t) for t in ts], noises)
         chain.x = x
-        return chain.image(gd.auto_normalize)
+        return chain.image(unn)
     frames = [chain.image(False)] if return_all_timesteps else None
     for i, t in enumerate(ts):
         nz = None
@@ -287,8 +291,8 @@ def p_sample_loop(gd, shape, return_all_timesteps=False, init_noise=None, noises
             frames.append(chain.image(False))
     if return_all_timesteps:
         ret = torch.stack(frames, dim=1)
-        return (ret + 1) * 0.5 if gd.auto_normalize else ret
-    return chain.image(gd.auto_normalize)
+        return (ret + 1) * 0.5 if unn else ret
+    return chain.image(unn)
 
 
 @torch.no_grad()

@@ -12,6 +12,7 @@ Reference line anchors are given per class.
 from __future__ import annotations
 
 import math
+from collections import namedtuple
 from typing import List, Optional, Tuple
 
 import torch
@@ -22,6 +23,9 @@ from lgm_hip.flat import FlatParams, _r4
 from lgm_hip.lightning import LightningModule, multi_rank
 from lgm_hip.nn import Conv2d, GradCtx, GroupNorm, Linear, RMSNorm, param_kind
 from lgm_hip.optim import EMA, FusedAdam
+
+
+ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])     # reference :25
 
 
 def _chan(t: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
@@ -790,12 +794,122 @@ class GaussianDiffusion(nn.Module):
         t = torch.randint(0, self.num_timesteps, (b,), device=img.device).long()
         return self.p_losses(img, t, *args, _normalize=self.auto_normalize, **kwargs)
 
-    # -- sampling: see sampler.py (HIP per-step kernels) --------------------------------------
+    # -- the reference's per-sample-timestep algebra (:673-705, 869-876): one lgm_extract_axpby launch each ---------
+    def normalize(self, img):
+        return img * 2 - 1 if self.auto_normalize else img
+
+    def unnormalize(self, t):
+        return (t + 1) * 0.5 if self.auto_normalize else t
+
+    def _axpby(self, ta, tb, td, t, x, y, sb=1.0, clip=False):
+        """out = clamp?((ta[t] * x + sb * tb[t] * y) / td[t]) on dense NCHW tensors, t per sample ([B] int64)."""
+        x = x.detach().float().contiguous()
+        B = x.shape[0]
+        assert t.shape == (B,), f"expected one timestep per sample, got {tuple(t.shape)}"
+        t = t.to(device=x.device, dtype=torch.long).contiguous()
+        if y is not None:
+            y = y.detach().float().contiguous()
+            assert y.shape == x.shape
+        out = torch.empty_like(x)
+        if x.numel() == 0:
+            return out
+        ptr = lambda a: None if a is None else a.data_ptr()  # noqa: E731
+        ops.lib().lgm_extract_axpby(ptr(ta), ptr(tb), ptr(td), t.data_ptr(), x.data_ptr(), ptr(y), float(sb),
+                                    1 if clip else 0, out.data_ptr(), B, x.numel() // B, self.num_timesteps,
+                                    ops.stream())
+        return out
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        return self._axpby(self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, None, t, x_t, noise, -1.0)
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        return self._axpby(self.sqrt_recip_alphas_cumprod, None, self.sqrt_recipm1_alphas_cumprod, t, x_t, x0, -1.0)
+
+    def predict_v(self, x_start, t, noise):
+        return self._axpby(self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, None, t, noise, x_start, -1.0)
+
+    def predict_start_from_v(self, x_t, t, v):
+        return self._axpby(self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, None, t, x_t, v, -1.0)
+
+    def q_sample(self, x_start, t, noise=None):
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return self._axpby(self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, None, t, x_start, noise, 1.0)
+
+    def _extract(self, a, t, ndim):
+        return a.gather(-1, t).reshape(t.shape[0], *((1,) * (ndim - 1)))
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = self._axpby(self.posterior_mean_coef1, self.posterior_mean_coef2, None, t, x_start, x_t, 1.0)
+        return (mean, self._extract(self.posterior_variance, t, x_t.ndim),
+                self._extract(self.posterior_log_variance_clipped, t, x_t.ndim))
+
+    @torch.no_grad()
+    def model_predictions(self, x, t, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False):
+        """-> ModelPrediction(pred_noise, pred_x_start), reference :707-734 (pred_v branch: ``rederive_pred_noise`` has no
+        effect there, the noise is always derived from the possibly clipped x_start).  UNet forward on the HIP engine, then
+        ONE launch for both results."""
+        assert x_self_cond is None, "the network DDPM constructs is not self-conditioned"
+        v = self.model(x, t, x_self_cond)
+        x = x.detach().float().contiguous()
+        B = x.shape[0]
+        t = t.to(device=x.device, dtype=torch.long).contiguous()
+        pred_noise, x_start = torch.empty_like(x), torch.empty_like(x)
+        ops.lib().lgm_model_predictions(x.data_ptr(), v.data_ptr(), t.data_ptr(), self.sqrt_alphas_cumprod.data_ptr(),
+                                        self.sqrt_one_minus_alphas_cumprod.data_ptr(),
+                                        self.sqrt_recip_alphas_cumprod.data_ptr(),
+                                        self.sqrt_recipm1_alphas_cumprod.data_ptr(), 1 if clip_x_start else 0,
+                                        pred_noise.data_ptr(), x_start.data_ptr(), B, x.numel() // B,
+                                        self.num_timesteps, ops.stream())
+        return ModelPrediction(pred_noise, x_start)
+
+    @torch.no_grad()
+    def p_mean_variance(self, x, t, x_self_cond=None, clip_denoised=True):
+        x_start = self.model_predictions(x, t, x_self_cond, clip_x_start=clip_denoised).pred_x_start
+        mean, var, logvar = self.q_posterior(x_start=x_start, x_t=x, t=t)
+        return mean, var, logvar, x_start
+
+    # -- sampling: lgm_hip/sampler.py (one fused update kernel per step, graph replay for whole chains) -------------
+    @torch.no_grad()
+    def p_sample(self, x, t: int, x_self_cond=None, noise=None):
+        """One ancestral step at the shared timestep ``t`` -> (pred_img, x_start), reference :748-757.  ``noise``
+        (extension, for parity tests): the draw the reference takes from randn_like."""
+        from lgm_hip import sampler
+        assert x_self_cond is None
+        chain = sampler._Chain(self, tuple(x.shape), x)
+        if noise is None and t > 0:
+            noise = torch.randn_like(x)
+        sampler.p_sample_step(chain, int(t), noise)
+        x0 = torch.empty(tuple(x.shape), device=chain.x.device)
+        ops.nhwc_to_nchw(chain.x0, x0)
+        return chain.image(False), x0
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, return_all_timesteps=False):
+        from lgm_hip import sampler
+        return sampler.p_sample_loop(self, tuple(shape), return_all_timesteps)
+
+    @torch.no_grad()
+    def ddim_sample(self, shape, return_all_timesteps=False):
+        from lgm_hip import sampler
+        return sampler.ddim_sample(self, tuple(shape), return_all_timesteps)
+
     @torch.no_grad()
     def sample(self, batch_size=16, return_all_timesteps=False):
-        from lgm_hip.sampler import ddim_sample, p_sample_loop
-        fn = ddim_sample if self.is_ddim_sampling else p_sample_loop
-        return fn(self, (batch_size, self.channels, self.img_size, self.img_size), return_all_timesteps)
+        fn = self.ddim_sample if self.is_ddim_sampling else self.p_sample_loop
+        return fn((batch_size, self.channels, self.img_size, self.img_size), return_all_timesteps=return_all_timesteps)
+
+    @torch.no_grad()
+    def interpolate(self, x1, x2, t=None, lam=0.5):
+        """reference :847-867: noise both images to step t, blend, walk the ancestral chain back to 0 (no unnormalise)."""
+        from lgm_hip import sampler
+        b = x1.shape[0]
+        t = self.num_timesteps - 1 if t is None else int(t)
+        assert x1.shape == x2.shape
+        tb = torch.full((b,), t, device=x1.device, dtype=torch.long)
+        xt1, xt2 = self.q_sample(x1, tb), self.q_sample(x2, tb)
+        img = (1 - lam) * xt1 + lam * xt2
+        return sampler.p_sample_loop(self, tuple(img.shape), init_noise=img, start=t, unnormalize=False)
 
 
 def hip_loss_forward(gd: "GaussianDiffusion", img, t, noise, normalize: bool, save: bool):

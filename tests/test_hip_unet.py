@@ -374,3 +374,139 @@ def test_checkpoint_resume_and_torch_optimizer_interchange(dev, tmp_path):
     d._optimizers[0].step()
     for p, q in zip(params, d.ema.online_model.parameters()):
         assert torch.allclose(p.detach(), q.detach().cpu(), rtol=2e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GaussianDiffusion's public method surface (reference ddpm.py:673-757, 782-876) on the HIP path, and the north_star's
+# headline parity quantity: eps = model_predictions(...).pred_noise within 1e-4
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["small", "full", "full64"])
+def test_model_predictions_match_reference_fixture(dev, golden_dir, tag, parity):
+    """``model_predictions(x_t, t, clip_x_start=True, rederive_pred_noise=True)`` of the PRODUCT class against what the
+    reference's own method returned (fixture keys pred_noise_clip / x_start_clip; per-sample t = (37, 912))."""
+    fx, dim, S, P, img, noise, t = case(golden_dir, tag)
+    net, gd = build(dim, S, P, dev, sampling_timesteps=50)
+    x_t = torch.as_tensor(fx["x_t"]).to(dev)
+    pred = gd.model_predictions(x_t, t.to(dev), clip_x_start=True, rederive_pred_noise=True)
+    assert type(pred).__name__ == "ModelPrediction" and pred._fields == ("pred_noise", "pred_x_start")
+    parity("pred_noise (eps), clipped x_start", rel(pred.pred_noise, fx["pred_noise_clip"]), RTOL)
+    parity("pred_x_start, clipped", rel(pred.pred_x_start, fx["x_start_clip"]), RTOL)
+    pn, xs = pred                                            # unpacks like the reference's namedtuple (:808)
+    assert pn is pred.pred_noise and xs is pred.pred_x_start
+    # q_sample(x0, t, noise) reproduces the fixture's x_t (the reference's own q_sample output)
+    parity("q_sample vs the reference's x_t", rel(gd.q_sample((img * 2 - 1).to(dev), t.to(dev), noise.to(dev)), fx["x_t"]),
+           1e-6)
+
+
+def test_eps_prediction_at_the_benchmark_batch_against_the_oracle(dev, parity):
+    """UNCLIPPED eps and x_start at BASELINE config 2's shape (dim 64, 32x32, B = 128, random per-sample t) against
+    oracle.diffusion.model_predictions; and the raw network output (check both)."""
+    from oracle import diffusion as OD
+    dim, S, B = 64, 32, 128
+    P = OD.unet_init(dim=dim, channels=3, seed=21)
+    bufs = OD.diffusion_buffers(1000)
+    g = torch.Generator().manual_seed(2100)
+    x = torch.randn(B, 3, S, S, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    with torch.no_grad():
+        pn_ref, xs_ref, v_ref = OD.model_predictions(P, bufs, x, t, clip_x_start=False, dim=dim)
+        pn_c_ref, xs_c_ref, _ = OD.model_predictions(P, bufs, x, t, clip_x_start=True, dim=dim)
+    net, gd = build(dim, S, P, dev)
+    pred = gd.model_predictions(x.to(dev), t.to(dev))
+    parity("raw network output v, B=128", rel(net(x.to(dev), t.to(dev)), v_ref), RTOL)
+    parity("pred_noise (eps) unclipped, B=128", rel(pred.pred_noise, pn_ref), RTOL)
+    parity("pred_x_start unclipped, B=128", rel(pred.pred_x_start, xs_ref), RTOL)
+    # worst single sample: small-t samples divide by sqrt_recipm1 -> the per-sample error is the interesting one
+    per = ((pred.pred_noise.cpu().double() - pn_ref.double()).flatten(1).norm(dim=1)
+           / pn_ref.double().flatten(1).norm(dim=1))
+    parity("pred_noise (eps) unclipped, worst of the 128 samples", float(per.max()), RTOL)
+    pc = gd.model_predictions(x.to(dev), t.to(dev), clip_x_start=True, rederive_pred_noise=True)
+    parity("pred_noise (eps) clipped, B=128", rel(pc.pred_noise, pn_c_ref), RTOL)
+    parity("pred_x_start clipped, B=128", rel(pc.pred_x_start, xs_c_ref), RTOL)
+
+
+def test_gaussian_diffusion_algebra_methods_match_the_reference_expressions(dev, parity):
+    """q_sample / predict_v / predict_start_from_v / predict_start_from_noise / predict_noise_from_start / q_posterior
+    (reference :673-705, 869-876) with a per-sample t, against the reference's ATen expressions evaluated on the CPU
+    (oracle buffers).  Elementwise fp32 with separately rounded products: bit-equal is expected, 1e-6 is asserted."""
+    from oracle import diffusion as OD
+    bufs = OD.diffusion_buffers(1000)
+    _, gd = build(16, 16, OD.unet_init(dim=16, channels=3, seed=1), dev)
+    g = torch.Generator().manual_seed(5)
+    B = 7
+    a, b = torch.randn(B, 3, 16, 16, generator=g), torch.randn(B, 3, 16, 16, generator=g)
+    t = torch.tensor([0, 1, 37, 500, 912, 998, 999])
+    e = lambda n: OD._ext(bufs[n], t, 4)  # noqa: E731
+    ad, bd, td = a.to(dev), b.to(dev), t.to(dev)
+    cases = {
+        "q_sample": (gd.q_sample(ad, td, bd), e("sqrt_alphas_cumprod") * a + e("sqrt_one_minus_alphas_cumprod") * b),
+        "predict_v": (gd.predict_v(ad, td, bd), e("sqrt_alphas_cumprod") * b - e("sqrt_one_minus_alphas_cumprod") * a),
+        "predict_start_from_v": (gd.predict_start_from_v(ad, td, bd),
+                                 e("sqrt_alphas_cumprod") * a - e("sqrt_one_minus_alphas_cumprod") * b),
+        "predict_start_from_noise": (gd.predict_start_from_noise(ad, td, bd),
+                                     e("sqrt_recip_alphas_cumprod") * a - e("sqrt_recipm1_alphas_cumprod") * b),
+        "predict_noise_from_start": (gd.predict_noise_from_start(ad, td, bd),
+                                     (e("sqrt_recip_alphas_cumprod") * a - b) / e("sqrt_recipm1_alphas_cumprod")),
+        "q_posterior mean": (gd.q_posterior(ad, bd, td)[0], e("posterior_mean_coef1") * a + e("posterior_mean_coef2") * b),
+    }
+    for name, (got, want) in cases.items():
+        assert got.shape == want.shape and got.device.type == "cuda"
+        parity(name, float((got.cpu() - want).abs().max() / want.abs().max()), 1e-6)
+    _, var, logvar = gd.q_posterior(ad, bd, td)
+    assert var.shape == (B, 1, 1, 1) and torch.equal(var.cpu(), e("posterior_variance"))
+    assert torch.equal(logvar.cpu(), e("posterior_log_variance_clipped"))
+    # q_sample without noise draws it (reference default(noise, randn_like)): right shape, finite, not x itself
+    qs = gd.q_sample(ad, td)
+    assert qs.shape == ad.shape and torch.isfinite(qs).all() and not torch.equal(qs, ad)
+    assert torch.equal(gd.normalize(ad), ad * 2 - 1) and torch.equal(gd.unnormalize(ad), (ad + 1) * 0.5)
+    with pytest.raises(AssertionError):
+        gd.q_sample(ad, td[:3], bd)                          # one timestep per sample
+
+
+def test_p_sample_p_mean_variance_and_loops_through_the_class_methods(dev, golden_dir, parity, monkeypatch):
+    """p_mean_variance / p_sample (reference signatures, :736-757) against the reference's fixture images, and
+    p_sample_loop / ddim_sample / sample / interpolate as METHODS: interpolate against the oracle's p_sample chain on
+    the very draws the method made (replayed from the device generator's seed)."""
+    from oracle import diffusion as OD
+    fx, dim, S, P, img, noise, t = case(golden_dir, "small")
+    net, gd = build(dim, S, P, dev, sampling_timesteps=50)
+    bufs = OD.diffusion_buffers(1000)
+    x_t = torch.as_tensor(fx["x_t"]).to(dev)
+    nz = torch.as_tensor(fx["p_sample_noise"]).to(dev)
+    pred_img, x_start = gd.p_sample(x_t, 500, noise=nz)
+    parity("p_sample(x, 500) image", rel(pred_img, fx["p_sample_500"]), RTOL)
+    pred0, _ = gd.p_sample(x_t, 0)
+    parity("p_sample(x, 0) image", rel(pred0, fx["p_sample_0"]), RTOL)
+    tb = torch.full((x_t.shape[0],), 500, device=dev, dtype=torch.long)
+    mean, var, logvar, xs = gd.p_mean_variance(x_t, tb, clip_denoised=True)
+    with torch.no_grad():
+        _, xs_ref = OD.p_sample(P, bufs, x_t.cpu(), 500, nz.cpu(), dim=dim)
+    parity("p_mean_variance x_start", rel(xs, xs_ref), RTOL)
+    parity("p_sample's x_start == p_mean_variance's", rel(x_start, xs), 1e-6)
+    parity("p_mean_variance mean + sigma * noise == p_sample", rel(mean + (0.5 * logvar).exp() * nz, fx["p_sample_500"]), RTOL)
+    # loops as methods: shapes, range, and the DDIM loop is the same chain lgm_hip.sampler runs
+    shape = tuple(fx["x_t"].shape)
+    assert gd.is_ddim_sampling
+    torch.manual_seed(11)
+    a = gd.sample(batch_size=shape[0])
+    torch.manual_seed(11)
+    b = gd.ddim_sample(shape)
+    assert a.shape == shape and torch.equal(a, b) and 0.0 <= float(a.min()) and float(a.max()) <= 1.0
+    allt = gd.ddim_sample(shape, return_all_timesteps=True)
+    assert allt.shape == (shape[0], 51) + shape[1:]
+    # interpolate (:847-867), eager launches so that the draws are randn(shape) in program order
+    monkeypatch.setenv("LGM_NO_SAMPLER_GRAPH", "1")
+    x1, x2 = (img * 2 - 1).to(dev), (img.flip(0) * 2 - 1).to(dev)
+    T0, lam = 6, 0.3
+    torch.manual_seed(77)
+    out = gd.interpolate(x1, x2, t=T0, lam=lam)
+    torch.manual_seed(77)
+    n1, n2 = torch.randn_like(x1), torch.randn_like(x2)
+    steps = [torch.randn(shape, device=dev) for _ in range(T0 - 1)]          # steps T0-1 .. 1 draw, step 0 does not
+    tb = torch.full((shape[0],), T0, dtype=torch.long)
+    ref = (1 - lam) * OD.q_sample(bufs, x1.cpu(), tb, n1.cpu()) + lam * OD.q_sample(bufs, x2.cpu(), tb, n2.cpu())
+    with torch.no_grad():
+        for k, i in enumerate(reversed(range(T0))):
+            ref, _ = OD.p_sample(P, bufs, ref, i, steps[k].cpu() if i > 0 else None, dim=dim)
+    assert out.shape == shape
+    parity(f"interpolate(x1, x2, t={T0}, lam={lam}) vs the oracle's chain on the same draws", rel(out, ref), RTOL)

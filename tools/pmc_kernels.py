@@ -64,6 +64,11 @@ def main():
                 if c in m:
                     ent[c + "_per_launch"] = int(m[c] / mn[k][c])
         out["kernels"][k] = ent
+    # what kernel code these counters were measured on (bench.py refuses the figures on any other)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "lightning-generative-models_amd"))
+    from lgm_hip._lib import source_fingerprint
+    out["sources"] = source_fingerprint()
     out["step_total"] = {"steps_profiled": steps, "fetch_bytes": int(tf / steps), "write_bytes": int(tw / steps)}
     json.dump(out, sys.stdout, indent=1)
     print()
