@@ -44,7 +44,7 @@ extern "C" {
                              *    dst offset in lgm_wino_weights table rows means "skip that copy", lgm_kernel_name*;
                              * 4: LgmPostOp carries the BatchNorm-backward sums (bn_*), lgm_bn_reduce3_coef_tiles;
                              * 5: lgm_set_cu_margin / lgm_cu_margin;
-                             * 6: lgm_extract_axpby, lgm_model_predictions (GaussianDiffusion's per-sample-time algebra) */
+                             * 6: lgm_extract_axpby, lgm_model_predictions (GaussianDiffusion's per-sample-time algebra), lgm_time_mlp_* */
 #define LGM_OK 0
 #define LGM_ERR_INVALID (-1)
 #define LGM_ERR_UNSUPPORTED (-2)
@@ -381,6 +381,22 @@ int lgm_weighted_mse_fwd(const float* out, const float* target, int64_t pitch, c
 int lgm_weighted_mse_bwd(const float* out, const float* target, int64_t pitch, const int64_t* t,
                          const float* loss_weight, const float* gloss, int B, int C, int HW, int Cpad,
                          float* gout, void* stream);
+
+/* The UNet's time embedding in one launch: SinusoidalPosEmb ddpm.py:119-132 -> time_mlp (Linear, GELU, Linear) :328-333 ->
+ * the SiLU every ResnetBlock.mlp applies first :181-183.  t [B] int64; freqs [dim/2] as lgm_posemb takes them; w1 [time_dim][dim],
+ * w2 [time_dim][time_dim] (torch Linear layout, dense).  Outputs, all dense and all kept for the backward:
+ *   pe [B][dim], a1 = pe w1^T + b1, h = gelu(a1), temb = h w2^T + b2, st = silu(temb)   ([B][time_dim] each).
+ * A row's results do not depend on the batch it is part of (fixed per-row summation order). */
+int64_t lgm_time_mlp_supported(int dim, int time_dim);   /* 1 / 0: query, not a status code */
+int lgm_time_mlp_fwd(const int64_t* t, int B, int dim, const float* freqs, const float* w1, const float* b1,
+                     const float* w2, const float* b2, int time_dim, float* pe, float* a1, float* h, float* temb,
+                     float* st, void* stream);
+/* Its backward from gst = d loss / d st (two launches: the row-local chain, then the batch reductions, rows in order):
+ *   gtemb = gst silu'(temb), ga1 = (gtemb w2) gelu'(a1)   (scratch outputs [B][time_dim]),
+ *   gw2 = beta gw2 + gtemb^T h, gb2 = beta gb2 + colsum(gtemb), gw1 = beta gw1 + ga1^T pe, gb1 = beta gb1 + colsum(ga1). */
+int lgm_time_mlp_bwd(const float* gst, const float* pe, const float* a1, const float* h, const float* temb,
+                     const float* w2, int B, int dim, int time_dim, float* gtemb, float* ga1, float* gw1, float* gb1,
+                     float* gw2, float* gb2, float beta, void* stream);
 
 /* GaussianDiffusion's per-sample-timestep algebra on dense NCHW tensors (`extract(table, t, shape) * ...`):
  *   out[b][i] = clamp?( (ta[t_b] * x[b][i] + sb * tb[t_b] * y[b][i]) / td[t_b] )     i < per_sample

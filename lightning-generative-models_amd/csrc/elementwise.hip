@@ -584,6 +584,268 @@ __global__ __launch_bounds__(256) void sample_step_table_kernel(float* __restric
 }
 __global__ void sampler_advance_kernel(int* counter) { counter[0] += 1; }
 
+// ---------------------------------------------------------------------------------------
+// The UNet's time embedding in ONE launch (reference ddpm.py:119-132 SinusoidalPosEmb, :328-333 time_mlp = Linear ->
+// GELU -> Linear, and the SiLU in front of every ResnetBlock.mlp's Linear :181-183).  It was six launches of 4 - 7 us that
+// no batch size shrinks (posemb, GEMM, GELU, split-K GEMM, reducer, SiLU): ~32 us of every training step and of every
+// sampling step.  A workgroup owns RB rows of the batch for the whole chain; a row's vectors live in LDS / registers; a
+// weight row is read by lpr = min(64, K / 4) lanes together (16 bytes each: one coalesced instruction per row, or per
+// 64 / lpr rows) and summed by a fixed xor-butterfly, so a row's result does not depend on the batch it arrives in
+// (2 ranks x B/2 rows == 1 rank x B rows bit for bit).
+// ---------------------------------------------------------------------------------------
+// One linear layer of the chain for the RB rows a workgroup owns: out[r][n] = bias[n] + sum_k xs[r][k] W[n][k], K <= 256.
+// lpr = K / 4 lanes share a weight row (16 bytes each; k order per lane k = 4 sub + j, then a fixed xor-butterfly); a wave
+// owns the rows n = wave * rpp + grp + u * stride.  EVERY global load of a layer (U weight rows + their bias per lane) is
+// issued by tm_fetch() before anything is computed - for both layers at kernel entry - because a load that misses costs
+// 1 - 2 us here (every launch starts cold): the first version (one weight row per loop trip, bias read in the epilogue) spent
+// 140 us in ~70 dependent round trips, the second (eight rows per trip) 50 us.
+constexpr int TM_RB = 4;
+constexpr int TM_THREADS = 512;    // 8 waves, two per SIMD: 256 registers per lane for the prefetched weight rows
+template <int U>
+struct TmRows {
+  f32x4 w[U];
+  float b[U];
+};
+typedef unsigned tm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tm_rsrc(const float* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// Raw buffer loads: ONE lane offset per operand (row wave * rpp + grp, column 4 sub) and a compile-time scalar offset per u
+// (rows u * stride apart: stride * K = nwaves * 256 floats whatever K is), so the U loads of a wave need no address
+// registers (64-bit flat addresses for 32 rows spilled 340 registers); a row >= N is outside the descriptor's range and
+// reads as zeros.
+template <int U>
+__device__ __forceinline__ void tm_fetch(TmRows<U>& R, const float* __restrict__ W, const float* __restrict__ bias, int K,
+                                         int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = TM_THREADS / 64;
+  const int lpr = K / 4, rpp = 64 / lpr, sub = lane % lpr, grp = lane / lpr;
+  const __amdgpu_buffer_rsrc_t rw = tm_rsrc(W, (unsigned)N * (unsigned)K * 4u);
+  const __amdgpu_buffer_rsrc_t rb = tm_rsrc(bias, (unsigned)N * 4u);
+  const unsigned vw = ((unsigned)(wave * rpp + grp) * (unsigned)K + 4u * (unsigned)sub) * 4u;
+  const unsigned vb = (unsigned)(wave * rpp + grp) * 4u;
+  const unsigned sb = (unsigned)(NW * rpp) * 4u;      // bias: rows are stride apart (wave-uniform, runtime)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    R.w[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vw, (unsigned)u * (NW * 256u * 4u), 0));
+    R.b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, vb, (unsigned)u * sb, 0));
+  }
+}
+template <int U, class Emit>
+__device__ __forceinline__ void tm_rows(const TmRows<U>& R, const float* __restrict__ xs, int K, int N, Emit emit) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int lpr = K / 4, rpp = 64 / lpr, sub = lane % lpr, grp = lane / lpr, stride = nwaves * rpp;
+  float xin[TM_RB][4];
+#pragma unroll
+  for (int r = 0; r < TM_RB; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xin[r][j] = xs[r * K + 4 * sub + j];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int nb = wave * rpp + u * stride;           // wave-uniform: the butterfly below is never divergent
+    if (nb >= N) break;
+    float acc[TM_RB];
+#pragma unroll
+    for (int r = 0; r < TM_RB; ++r) {
+      acc[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[r] = fmaf(xin[r][j], R.w[u][j], acc[r]);
+    }
+    for (int off = lpr >> 1; off > 0; off >>= 1)
+#pragma unroll
+      for (int r = 0; r < TM_RB; ++r) acc[r] += __shfl_xor(acc[r], off, 64);
+    if (sub == 0 && nb + grp < N) emit(nb + grp, R.b[u], acc);
+  }
+}
+
+__global__ __launch_bounds__(TM_THREADS) void time_mlp_fwd_kernel(const long* __restrict__ t, int B, int dim,
+                                                                  const float* __restrict__ freqs,
+                                                                  const float* __restrict__ W1, const float* __restrict__ b1,
+                                                                  const float* __restrict__ W2, const float* __restrict__ b2,
+                                                                  int td, float* __restrict__ pe, float* __restrict__ a1,
+                                                                  float* __restrict__ h, float* __restrict__ temb,
+                                                                  float* __restrict__ st) {
+  extern __shared__ float tm_sm[];
+  float* spe = tm_sm;                    // [RB][dim]
+  float* sh = tm_sm + TM_RB * dim;       // [RB][td]  activations (the next layer's input)
+  float* sa = sh + TM_RB * td;           // [RB][td]  pre-activations
+  const int r0 = blockIdx.x * TM_RB, half = dim / 2;
+  // 8 waves.  Layer 2 (K = td <= 256): at most 32 weight rows per wave (rpp = 1 at td = 256); layer 1: td * dim / 2048 <= 8
+  // (host check: time_dim * dim <= 16384).
+  TmRows<8> R1;
+  TmRows<32> R2;
+  tm_fetch(R1, W1, b1, dim, td);
+  for (int i = threadIdx.x; i < TM_RB * half; i += blockDim.x) {
+    const int r = i / half, j = i % half, b = r0 + r;
+    float sv = 0.f, cv = 0.f;
+    if (b < B) {                         // posemb_kernel's arithmetic
+      const float arg = (float)t[b] * freqs[j];
+      sv = sinf(arg), cv = cosf(arg);
+      pe[(long)b * dim + j] = sv;
+      pe[(long)b * dim + half + j] = cv;
+    }
+    spe[r * dim + j] = sv;
+    spe[r * dim + half + j] = cv;
+  }
+  tm_fetch(R2, W2, b2, td, td);          // in flight while layer 1 is computed
+  __syncthreads();
+  // the activations run in their own elementwise passes: inside the unrolled row loop 32 inlined erff / expf bodies cost
+  // 310 spilled registers
+  tm_rows(R1, spe, dim, td, [&](int n, float bias, const float* acc) {
+#pragma unroll
+    for (int r = 0; r < TM_RB; ++r) sa[r * td + n] = acc[r] + bias;
+  });
+  __syncthreads();
+  for (int i = threadIdx.x; i < TM_RB * td; i += blockDim.x) {
+    const int r = i / td, n = i % td;
+    const float a = sa[i], g = act_fwd(a, ACT_GELU, 0.f);
+    sh[i] = g;
+    if (r0 + r < B) a1[(long)(r0 + r) * td + n] = a, h[(long)(r0 + r) * td + n] = g;
+  }
+  __syncthreads();
+  tm_rows(R2, sh, td, td, [&](int n, float bias, const float* acc) {
+#pragma unroll
+    for (int r = 0; r < TM_RB; ++r) sa[r * td + n] = acc[r] + bias;
+  });
+  __syncthreads();
+  for (int i = threadIdx.x; i < TM_RB * td; i += blockDim.x) {
+    const int r = i / td, n = i % td;
+    if (r0 + r < B) {
+      const float e = sa[i];
+      temb[(long)(r0 + r) * td + n] = e;
+      st[(long)(r0 + r) * td + n] = act_fwd(e, ACT_SILU, 0.f);
+    }
+  }
+}
+
+// backward, row-local half: gtemb = gst * silu'(temb); gh = gtemb W2 (thread = (k, quarter of the n range): coalesced weight
+// rows, eight of them requested per trip, LDS-broadcast gtemb; the four quarters are added in order); ga1 = gh * gelu'(a1)
+__global__ __launch_bounds__(TM_THREADS) void time_mlp_bwd_rows_kernel(const float* __restrict__ gst,
+                                                                       const float* __restrict__ a1,
+                                                                       const float* __restrict__ temb,
+                                                                       const float* __restrict__ W2, int B, int td,
+                                                                       float* __restrict__ gtemb, float* __restrict__ ga1) {
+  extern __shared__ float tm_sm[];       // [td][RB] (one 16-byte broadcast read per n), then [4][td][RB] partial sums
+  float* part = tm_sm + td * TM_RB;
+  const int r0 = blockIdx.x * TM_RB;
+  for (int i = threadIdx.x; i < TM_RB * td; i += blockDim.x) {
+    const int r = i / td, n = i % td, b = r0 + r;
+    float g = 0.f;
+    if (b < B) {
+      g = gst[(long)b * td + n] * act_bwd(temb[(long)b * td + n], ACT_SILU, 0.f);
+      gtemb[(long)b * td + n] = g;
+    }
+    tm_sm[n * TM_RB + r] = g;
+  }
+  __syncthreads();
+  const int kq = blockDim.x / 4;                      // threads along k per quarter (256)
+  const int q = threadIdx.x / kq, kt = threadIdx.x % kq;
+  const int nq = td / 4;                              // n range of a quarter (td % 16 == 0)
+  for (int k = kt; k < td; k += kq) {
+    float acc[TM_RB];
+#pragma unroll
+    for (int r = 0; r < TM_RB; ++r) acc[r] = 0.f;
+    for (int n = q * nq; n < (q + 1) * nq; n += 8) {
+      float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = W2[(long)(n + u) * td + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(tm_sm + (n + u) * TM_RB);
+#pragma unroll
+        for (int r = 0; r < TM_RB; ++r) acc[r] = fmaf(g[r], w[u], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TM_RB; ++r) part[(q * td + k) * TM_RB + r] = acc[r];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TM_RB * td; i += blockDim.x) {
+    const int k = i / TM_RB, r = i % TM_RB;
+    if (r0 + r < B) {
+      const float gh = ((part[(0 * td + k) * TM_RB + r] + part[(1 * td + k) * TM_RB + r]) + part[(2 * td + k) * TM_RB + r]) +
+                       part[(3 * td + k) * TM_RB + r];
+      ga1[(long)(r0 + r) * td + k] = gh * act_bwd(a1[(long)(r0 + r) * td + k], ACT_GELU, 0.f);
+    }
+  }
+}
+
+// backward, batch-reducing half: gW[n][k] = beta gW[n][k] + sum_r gy[r][n] x[r][k], gb[n] = beta gb[n] + sum_r gy[r][n], rows in
+// order (deterministic).  A workgroup owns TN consecutive n; 32 rows of x and gy at a time are staged in LDS by all threads
+// (many loads in flight: the row-by-row version spent its 120 us waiting for one load per trip), thread = (k, n slice).
+// blockIdx.y = 0: the second linear (x = h, K = td), 1: the first (x = pe, K = dim).  K <= 256.
+__global__ __launch_bounds__(256) void time_mlp_bwd_wgrad_kernel(const float* __restrict__ gtemb, const float* __restrict__ h,
+                                                                 const float* __restrict__ ga1, const float* __restrict__ pe,
+                                                                 int B, int dim, int td, float* __restrict__ gw2,
+                                                                 float* __restrict__ gb2, float* __restrict__ gw1,
+                                                                 float* __restrict__ gb1, float beta) {
+  constexpr int TN = 16, RC = 32;
+  const bool first = blockIdx.y == 1;
+  const float* gy = first ? ga1 : gtemb;
+  const float* x = first ? pe : h;
+  const int K = first ? dim : td;
+  float* gw = first ? gw1 : gw2;
+  float* gb = first ? gb1 : gb2;
+  const int n0 = blockIdx.x * TN;
+  __shared__ float sgy[RC][TN];
+  __shared__ float sx[RC * 256];
+  const int kthreads = K;                            // threads along k (K <= 256, a power of two >= 16)
+  const int nsl = 256 / kthreads;                    // n slices
+  const int per = TN / nsl;                          // outputs per thread along n
+  const int kk = threadIdx.x % kthreads, sl = threadIdx.x / kthreads;
+  float acc[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) acc[i] = 0.f;
+  float bsum = 0.f;
+  for (int rb = 0; rb < B; rb += RC) {
+    const int rows = B - rb < RC ? B - rb : RC;
+    __syncthreads();
+    {   // all of a chunk's loads first, then the LDS writes (a load -> store loop is one round trip per trip)
+      float tg[RC * TN / 256], tx[RC];
+#pragma unroll
+      for (int q = 0; q < RC * TN / 256; ++q) {
+        const int i = threadIdx.x + 256 * q, r = i / TN, j = i % TN;
+        tg[q] = r < rows ? gy[(long)(rb + r) * td + n0 + j] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < RC; ++q) {
+        const int i = threadIdx.x + 256 * q;          // rows are dense: one flat copy of rows * K floats
+        tx[q] = i < rows * K ? x[(long)rb * K + i] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < RC * TN / 256; ++q) {
+        const int i = threadIdx.x + 256 * q;
+        sgy[i / TN][i % TN] = tg[q];
+      }
+#pragma unroll
+      for (int q = 0; q < RC; ++q)
+        if (threadIdx.x + 256 * q < RC * K) sx[threadIdx.x + 256 * q] = tx[q];
+    }
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {
+      const float xv = sx[r * K + kk];
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        if (i < per) acc[i] = fmaf(sgy[r][sl * per + i], xv, acc[i]);
+    }
+    if (threadIdx.x < TN)
+      for (int r = 0; r < rows; ++r) bsum += sgy[r][threadIdx.x];
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+    if (i < per) {
+      float* d = gw + (long)(n0 + sl * per + i) * K + kk;
+      *d = beta != 0.f ? beta * *d + acc[i] : acc[i];
+    }
+  if (threadIdx.x < TN) {
+    float* d = gb + n0 + threadIdx.x;
+    *d = beta != 0.f ? beta * *d + bsum : bsum;
+  }
+}
 }  // namespace
 
 extern "C" int lgm_extract_axpby(const float* ta, const float* tb, const float* td, const int64_t* t, const float* x,
@@ -607,6 +869,38 @@ extern "C" int lgm_model_predictions(const float* x, const float* v, const int64
   const int gx = (int)(per_sample < 256L * 4096 ? lgm_cdiv(per_sample, 256) : 4096);
   hipLaunchKernelGGL(model_predictions_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, v, (const long*)t,
                      sqrt_ac, sqrt_1mac, sqrt_recip, sqrt_recipm1, clip, pred_noise, x_start, (long)per_sample, n_table);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+static bool tm_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static bool tm_dims_ok(int dim, int td) {
+  // K / 4 lanes per weight row must be a power of two <= 64, or K a multiple of 256 up to 1024
+  auto ok = [](int K) { return K >= 16 && K <= 256 && K % 4 == 0 && tm_pow2(K / 4); };   // K / 4 lanes share a weight row
+  return ok(dim) && ok(td) && td % 32 == 0 && dim % 2 == 0 && (long)td * dim <= 16384;
+}
+extern "C" int64_t lgm_time_mlp_supported(int dim, int time_dim) { return tm_dims_ok(dim, time_dim) ? 1 : 0; }
+extern "C" int lgm_time_mlp_fwd(const int64_t* t, int B, int dim, const float* freqs, const float* w1, const float* b1,
+                                const float* w2, const float* b2, int time_dim, float* pe, float* a1, float* h,
+                                float* temb, float* st, void* stream) {
+  LGM_REQUIRE(t && freqs && w1 && b1 && w2 && b2 && pe && a1 && h && temb && st && B > 0, "time_mlp_fwd: bad arguments");
+  LGM_REQUIRE(tm_dims_ok(dim, time_dim), "time_mlp_fwd: dim %d / time_dim %d not taken (lgm_time_mlp_supported)", dim, time_dim);
+  LGM_REQUIRE(lgm_aligned16(w1) && lgm_aligned16(w2), "time_mlp_fwd: weights must be 16-byte aligned");
+  const size_t sm = sizeof(float) * TM_RB * (size_t)(dim + 2 * time_dim);
+  hipLaunchKernelGGL(time_mlp_fwd_kernel, dim3(lgm_cdiv(B, TM_RB)), dim3(TM_THREADS), sm, (hipStream_t)stream, (const long*)t, B,
+                     dim, freqs, w1, b1, w2, b2, time_dim, pe, a1, h, temb, st);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+extern "C" int lgm_time_mlp_bwd(const float* gst, const float* pe, const float* a1, const float* h, const float* temb,
+                                const float* w2, int B, int dim, int time_dim, float* gtemb, float* ga1, float* gw1,
+                                float* gb1, float* gw2, float* gb2, float beta, void* stream) {
+  LGM_REQUIRE(gst && pe && a1 && h && temb && w2 && gtemb && ga1 && gw1 && gb1 && gw2 && gb2 && B > 0,
+              "time_mlp_bwd: bad arguments");
+  LGM_REQUIRE(tm_dims_ok(dim, time_dim), "time_mlp_bwd: dim %d / time_dim %d not taken (lgm_time_mlp_supported)", dim, time_dim);
+  hipLaunchKernelGGL(time_mlp_bwd_rows_kernel, dim3(lgm_cdiv(B, TM_RB)), dim3(TM_THREADS), sizeof(float) * TM_RB * time_dim * 5,
+                     (hipStream_t)stream, gst, a1, temb, w2, B, time_dim, gtemb, ga1);
+  hipLaunchKernelGGL(time_mlp_bwd_wgrad_kernel, dim3(time_dim / 16, 2), dim3(256), 0, (hipStream_t)stream, gtemb, h, ga1, pe,
+                     B, dim, time_dim, gw2, gb2, gw1, gb1, beta);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

@@ -1236,6 +1236,36 @@ def posemb(t, dim, theta, out):
                      pitch(out), stream())
 
 
+# The time embedding as ONE forward launch + two backward launches instead of 6 + 6 (lgm_time_mlp_fwd / _bwd): built, parity-
+# tested, and measured SLOWER on the MI355X - opt-in (LGM_TIME_MLP=1).  Per step, graph replay, three versions of the kernels
+# (profiles/r06_negative_results.txt): B = 128 9.86 -> 10.14 / 9.96 / 9.92 ms, B = 16 4.37 -> 4.55 / 4.42 / 4.38.  The chain
+# is 3 dependent stages of 10 MFLOP; each stage of a plain FMA kernel pays a cold global round trip (1 - 2 us) and a 6-level
+# ds_bpermute butterfly per weight row, while the six separate launches it would replace are pipelined MFMA GEMMs of 5 - 6 us
+# each: 32.8 us fused vs 31.8 us for the six forward launches, 89 us vs 29 us backward.
+TIME_MLP = _os.environ.get("LGM_TIME_MLP", "0") == "1"
+_TIME_MLP_OK = {}
+
+
+def time_mlp_ok(dim: int, time_dim: int, l1, l2) -> bool:
+    """The fused time-embedding kernels take these widths (dense, unpadded Linear weights)."""
+    key = (dim, time_dim)
+    v = _TIME_MLP_OK.get(key)
+    if v is None:
+        v = bool(TIME_MLP and dim % 4 == 0 and time_dim % 4 == 0 and lib().lgm_time_mlp_supported(dim, time_dim))
+        _TIME_MLP_OK[key] = v
+    return v and l1.bias is not None and l2.bias is not None
+
+
+def time_mlp_fwd(t, dim, theta, w1, b1, w2, b2, time_dim, pe, a1, h, temb, st):
+    lib().lgm_time_mlp_fwd(t.data_ptr(), t.shape[0], dim, posemb_freqs(dim, theta, t.device).data_ptr(), w1, b1, w2, b2,
+                           time_dim, pe.data_ptr(), a1.data_ptr(), h.data_ptr(), temb.data_ptr(), st.data_ptr(), stream())
+
+
+def time_mlp_bwd(gst, pe, a1, h, temb, w2, dim, time_dim, gtemb, ga1, gw1, gb1, gw2, gb2, beta):
+    lib().lgm_time_mlp_bwd(gst.data_ptr(), pe.data_ptr(), a1.data_ptr(), h.data_ptr(), temb.data_ptr(), w2, pe.shape[0],
+                           dim, time_dim, gtemb.data_ptr(), ga1.data_ptr(), gw1, gb1, gw2, gb2, float(beta), stream())
+
+
 def act_fwd(x, bias_ptr, res, y, act, slope=0.0):
     lib().lgm_act_fwd(x.data_ptr(), pitch(x), bias_ptr, _p(res), pitch(res) if res is not None else 0,
                       y.data_ptr(), pitch(y), rows(x), x.shape[-1], act, slope, stream())

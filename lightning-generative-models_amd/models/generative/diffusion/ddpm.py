@@ -382,15 +382,20 @@ class Unet(nn.Module):
         fp = self._flat
         l1, l2 = self.time_mlp[1], self.time_mlp[3]
         pe = ops.new((B, self.dim), t)
-        ops.posemb(t, self.dim, self.theta, pe)
         a1 = ops.new((B, self.time_dim), t)
-        ops.conv_xy(l1.geom(B), pe, fp.ptr(l1.weight), fp.ptr(l1.bias), None, a1)
         h = ops.new((B, self.time_dim), t)
-        ops.act_fwd(a1, None, None, h, ops.ACT_GELU)
         temb = ops.new((B, self.time_dim), t)
-        ops.conv_xy(l2.geom(B), h, fp.ptr(l2.weight), fp.ptr(l2.bias), None, temb)
         st = ops.new((B, self.time_dim), t)
-        ops.act_fwd(temb, None, None, st, ops.ACT_SILU)
+        if ops.time_mlp_ok(self.dim, self.time_dim, l1, l2):
+            # posemb -> Linear -> GELU -> Linear -> SiLU in ONE launch (was six: csrc/elementwise.hip time_mlp_fwd_kernel)
+            ops.time_mlp_fwd(t, self.dim, self.theta, fp.ptr(l1.weight), fp.ptr(l1.bias), fp.ptr(l2.weight),
+                             fp.ptr(l2.bias), self.time_dim, pe, a1, h, temb, st)
+        else:
+            ops.posemb(t, self.dim, self.theta, pe)
+            ops.conv_xy(l1.geom(B), pe, fp.ptr(l1.weight), fp.ptr(l1.bias), None, a1)
+            ops.act_fwd(a1, None, None, h, ops.ACT_GELU)
+            ops.conv_xy(l2.geom(B), h, fp.ptr(l2.weight), fp.ptr(l2.bias), None, temb)
+            ops.act_fwd(temb, None, None, st, ops.ACT_SILU)
         g = self._mlp_geoms.get(B)
         if g is None:
             g = ops.make_geom(B, 1, 1, self.time_dim, self._ss_total, 1, 1, 1, 0)
@@ -414,6 +419,15 @@ class Unet(nn.Module):
         gst = ops.new(st.shape, st)
         ops.conv_yx(g, gss_all, fp.ptr(rbs[0].mlp[1].weight), None, None, gst)
         gtemb = ops.new(st.shape, st)
+        if ops.time_mlp_ok(self.dim, self.time_dim, l1, l2):
+            # SiLU' -> (weight / bias gradient, input gradient) of the second linear -> GELU' -> weight / bias gradient of the
+            # first: two launches (row-local chain, batch reductions in row order) instead of six
+            bw = gc.beta(l2.weight)
+            assert bw == gc.beta(l2.bias) == gc.beta(l1.weight) == gc.beta(l1.bias)
+            ga1 = ops.new(a1.shape, a1)
+            ops.time_mlp_bwd(gst, pe, a1, h, temb, fp.ptr(l2.weight), self.dim, self.time_dim, gtemb, ga1,
+                             fp.gptr(l1.weight), fp.gptr(l1.bias), fp.gptr(l2.weight), fp.gptr(l2.bias), bw)
+            return
         ops.act_bwd(temb, None, gst, gtemb, False, ops.ACT_SILU)
         gh = ops.new(h.shape, h)
         # weight gradient and input gradient of the second time-MLP linear in one launch (lgm_conv_bwd_pair)

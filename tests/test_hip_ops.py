@@ -738,3 +738,49 @@ def test_vqvae_residual_stack_forward_in_one_launch(dev, B, layers):
     for l in range(layers):
         assert rel(nchw(r[0][l]), ys[l]) < 2e-5, l
         assert rel(nchw(r[1][l]), zs[l]) < 2e-5, l
+
+
+@pytest.mark.parametrize("dim,B", [(16, 2), (32, 5), (64, 128), (64, 16), (64, 1)])
+def test_time_embedding_in_one_launch(dev, dim, B, parity):
+    """lgm_time_mlp_fwd / _bwd (SinusoidalPosEmb -> Linear -> GELU -> Linear -> SiLU, reference ddpm.py:119-132, 328-333,
+    181-183; opt-in, LGM_TIME_MLP=1: measured slower than the six launches it replaces) against the same chain in torch
+    float64 autograd; a row's results are bit-identical whatever batch it is in."""
+    from lgm_hip import ops
+    td = 4 * dim
+    g = torch.Generator().manual_seed(dim + B)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    w1, b1 = torch.randn(td, dim, generator=g) * dim ** -0.5, torch.randn(td, generator=g) * 0.1
+    w2, b2 = torch.randn(td, td, generator=g) * td ** -0.5, torch.randn(td, generator=g) * 0.1
+    gst = torch.randn(B, td, generator=g)
+    assert ops.lib().lgm_time_mlp_supported(dim, td) == 1
+    d = lambda x: x.to(dev).contiguous()  # noqa: E731
+    W1, B1, W2, B2, T, GST = d(w1), d(b1), d(w2), d(b2), d(t), d(gst)
+    outs = [torch.empty(B, n, device=dev) for n in (dim, td, td, td, td)]
+    ops.time_mlp_fwd(T, dim, 10000.0, W1.data_ptr(), B1.data_ptr(), W2.data_ptr(), B2.data_ptr(), td, *outs)
+    pe, a1, h, temb, st = outs
+    # float64 reference with the reference's own frequency table (fp32 exp on the host, as ops.posemb_freqs)
+    fr = ops.posemb_freqs(dim, 10000.0, "cpu").double()
+    arg = (t.float()[:, None] * fr.float()[None, :]).double()          # the product is formed in fp32 (ddpm.py:130)
+    pe_r = torch.cat([arg.sin(), arg.cos()], 1)
+    W1r, W2r = w1.double().requires_grad_(True), w2.double().requires_grad_(True)
+    B1r, B2r = b1.double().requires_grad_(True), b2.double().requires_grad_(True)
+    a1_r = pe_r @ W1r.T + B1r
+    h_r = F.gelu(a1_r)
+    temb_r = h_r @ W2r.T + B2r
+    st_r = F.silu(temb_r)
+    st_r.backward(gst.double())
+    for name, got, want in (("pe", pe, pe_r), ("a1", a1, a1_r), ("h", h, h_r), ("temb", temb, temb_r), ("st", st, st_r)):
+        parity(f"time embedding {name} (dim {dim}, B {B})", rel(got, want.detach()), 1e-5)
+    gtemb, ga1 = torch.empty(B, td, device=dev), torch.empty(B, td, device=dev)
+    for beta in (0.0, 1.0):
+        gw1, gb1 = torch.full((td, dim), 0.5, device=dev), torch.full((td,), 0.5, device=dev)
+        gw2, gb2 = torch.full((td, td), 0.5, device=dev), torch.full((td,), 0.5, device=dev)
+        ops.time_mlp_bwd(GST, pe, a1, h, temb, W2.data_ptr(), dim, td, gtemb, ga1, gw1.data_ptr(), gb1.data_ptr(),
+                         gw2.data_ptr(), gb2.data_ptr(), beta)
+        for name, got, want in (("gw1", gw1, W1r.grad), ("gb1", gb1, B1r.grad), ("gw2", gw2, W2r.grad), ("gb2", gb2, B2r.grad)):
+            parity(f"time embedding {name} (beta {beta})", rel(got.double().cpu() - 0.5 * beta, want), 2e-5)
+    if B >= 5:      # rows 1..3 alone == the same rows inside the batch, bit for bit (2 ranks x B/2 == 1 rank x B)
+        sub = [torch.empty(3, n, device=dev) for n in (dim, td, td, td, td)]
+        ops.time_mlp_fwd(T[1:4].contiguous(), dim, 10000.0, W1.data_ptr(), B1.data_ptr(), W2.data_ptr(), B2.data_ptr(), td, *sub)
+        for a, b in zip(sub, outs):
+            assert torch.equal(a, b[1:4])
