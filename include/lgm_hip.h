@@ -44,7 +44,7 @@ extern "C" {
                              *    dst offset in lgm_wino_weights table rows means "skip that copy", lgm_kernel_name*;
                              * 4: LgmPostOp carries the BatchNorm-backward sums (bn_*), lgm_bn_reduce3_coef_tiles;
                              * 5: lgm_set_cu_margin / lgm_cu_margin;
-                             * 6: lgm_extract_axpby, lgm_model_predictions (GaussianDiffusion's per-sample-time algebra), lgm_time_mlp_* */
+                             * 6: lgm_extract_axpby, lgm_model_predictions (GaussianDiffusion's per-sample-time algebra), lgm_time_mlp_*, lgm_weng_* */
 #define LGM_OK 0
 #define LGM_ERR_INVALID (-1)
 #define LGM_ERR_UNSUPPORTED (-2)
@@ -429,6 +429,31 @@ int lgm_sampler_time(const int64_t* ttable, const int32_t* counter, int64_t* t, 
 int lgm_sample_step_table(float* x, const float* v, const float* noise, float* x0_out, int B, int C, int HW,
                           int Cpad, const float* table, const int32_t* counter, int clip, int advance,
                           void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Non-fused Winograd engine (csrc/winograd_eng.hip): input transform launch -> ONE batched weight-stationary fp32 MFMA GEMM
+ * -> output transform launch, for the layers the fused Winograd kernels' workgroup shapes cannot fill:
+ *   f43      3x3 / stride 1 / pad 1 as F(4x4, 3x3) (Block.proj ddpm.py:160 on the 4 x 4 maps: one tile per image);
+ *   f42 xy   4x4 / stride 2 / pad 1 Conv2d forward (Discriminator dcgan.py:150-158) as F(4x4, 2x2) on the four pixel phases of
+ *            the input, the phases summed inside the GEMM (k = (2p + q) * C + c): 100 products per 16 outputs instead of 256;
+ *   f42 yx   the same layer's input gradient = ConvTranspose2d forward (Generator dcgan.py:79-87): four per-phase problems.
+ * Tensors: V[xi][T][K], U[xi][N][K] (prepared by the caller: lgm_hip/weng.py), M[xi][T][N], all dense fp32; T = tiles.
+ * ------------------------------------------------------------------------------------- */
+/* C[b][m][n] = sum_k A[b][m][k] * Bm[b][n][k], b < batch (strides in floats).  K, lda, ldb, batch strides % 4 == 0. */
+int lgm_weng_gemm(const float* A, const float* Bm, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
+                  int64_t a_batch, int64_t b_batch, int64_t c_batch, void* stream);
+/* x [B][H][W][C] (pitch) -> V[36][T][C], T = B (H/4) (W/4);  M[36][T][N] -> y [B][H][W][N] (pitch) + bias */
+int lgm_weng_f43_in(const float* x, int64_t x_pitch, int B, int H, int W, int C, float* V, void* stream);
+int lgm_weng_f43_out(const float* M, int B, int H, int W, int N, const float* bias, float* y, int64_t y_pitch,
+                     void* stream);
+/* x [B][H][W][C] -> V[25][T][4C], T = B (H/8) (W/8);  M[25][T][N] -> y [B][H/2][W/2][N] + bias */
+int lgm_weng_f42_in_xy(const float* x, int64_t x_pitch, int B, int H, int W, int C, float* V, void* stream);
+int lgm_weng_f42_out_xy(const float* M, int B, int Ho, int Wo, int N, const float* bias, float* y, int64_t y_pitch,
+                        void* stream);
+/* dy [B][Ho][Wo][Ny] -> V[4][25][T][Ny], T = B (Ho/4) (Wo/4);  M[4][25][T][C] -> dx [B][2 Ho][2 Wo][C] + bias */
+int lgm_weng_f42_in_yx(const float* dy, int64_t pitch, int B, int Ho, int Wo, int Ny, float* V, void* stream);
+int lgm_weng_f42_out_yx(const float* M, int B, int Ho, int Wo, int C, const float* bias, float* dx, int64_t pitch,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Vector quantiser (VQ-VAE) — models/modules/vector_quantizer.py.
