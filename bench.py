@@ -61,6 +61,8 @@ WINO4_FACTOR = 4.0              # ... per Winograd F(4x4,3x3) multiply (144 / 36
 
 def mfma_factor(kernel_name: str) -> float:
     """algorithmic (direct-convolution) FLOPs per FLOP the MFMA pipe executes, by kernel family"""
+    if "weng" in kernel_name:        # F(4x4,2x2) on pixel phases: 100 products per 16 outputs instead of 256
+        return 2.56
     if "wino4" in kernel_name:
         return WINO4_FACTOR
     if "wino_" in kernel_name:

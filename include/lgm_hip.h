@@ -454,6 +454,15 @@ int lgm_weng_f42_out_xy(const float* M, int B, int Ho, int Wo, int N, const floa
 int lgm_weng_f42_in_yx(const float* dy, int64_t pitch, int B, int Ho, int Wo, int Ny, float* V, void* stream);
 int lgm_weng_f42_out_yx(const float* M, int B, int Ho, int Wo, int C, const float* bias, float* dx, int64_t pitch,
                         void* stream);
+/* The output transforms with LgmPostOp's elementwise part in them: out = act(v + bias) (act 0 / 3 ReLU / 4 LeakyReLU), then
+ * * (mask > 0 ? 1 : mask_slope) with mask = a saved activation of the output's shape (NULL: none). */
+int lgm_weng_f42_out_xy_post(const float* M, int B, int Ho, int Wo, int N, const float* bias, float* y, int64_t y_pitch,
+                             int act, float slope, const float* mask, int64_t mask_pitch, float mask_slope, void* stream);
+int lgm_weng_f42_out_yx_post(const float* M, int B, int Ho, int Wo, int C, const float* bias, float* dx, int64_t pitch,
+                             int act, float slope, const float* mask, int64_t mask_pitch, float mask_slope, void* stream);
+/* U of a 4x4 / stride-2 layer for both directions from its weights w [Nw][16][Cw] (float64 arithmetic, rounded once):
+ * Uxy [25][Nw][4 Cw], Uyx [4][25][Cw][Nw]; either may be NULL. */
+int lgm_weng_f42_weights(const float* w, int Nw, int Cw, float* Uxy, float* Uyx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Vector quantiser (VQ-VAE) — models/modules/vector_quantizer.py.

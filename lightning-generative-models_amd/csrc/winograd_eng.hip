@@ -322,9 +322,36 @@ __global__ __launch_bounds__(256) void f42_in_xy_kernel(const float* __restrict_
         *reinterpret_cast<f32x4*>(V + ((long)(r * 5 + s) * T + t) * K + (long)pq * C + 4 * c4) = v;
       });
 }
+// What the implicit-GEMM kernels' LgmPostOp does in their epilogue, here in the output transform (the tensor is being written
+// anyway): out = act(v + bias) then * (mask > 0 ? 1 : mask_slope) - an activation behind a forward convolution, or the
+// derivative of the activation in front of the layer applied to an input gradient (mask = that activation's saved output).
+struct Epi {
+  int act;                 // 0, 3 = ReLU, 4 = LeakyReLU (elementwise.hip's codes)
+  float slope;
+  const float* mask;       // same pixel layout as the output; NULL = none
+  long mask_pitch;
+  float mask_slope;
+};
+__device__ __forceinline__ f32x4 epi_apply(f32x4 v, const Epi& e, long pix, int c) {
+  if (e.act == 3) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+  } else if (e.act == 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * e.slope;
+  }
+  if (e.mask) {
+    const f32x4 m = *reinterpret_cast<const f32x4*>(e.mask + pix * e.mask_pitch + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : v[j] * e.mask_slope;
+  }
+  return v;
+}
+
 // f42 xy output: M[25][T][N] -> y [B][Ho][Wo][N] + bias
 __global__ __launch_bounds__(256) void f42_out_xy_kernel(const float* __restrict__ M, int B, int Ho, int Wo, int N,
-                                                         const float* __restrict__ bias, float* __restrict__ y, long pitch) {
+                                                         const float* __restrict__ bias, float* __restrict__ y, long pitch,
+                                                         Epi epi) {
   const int N4 = N / 4, TY = Ho / 4, TX = Wo / 4;
   const long T = (long)B * TY * TX;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,7 +362,8 @@ __global__ __launch_bounds__(256) void f42_out_xy_kernel(const float* __restrict
   const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * n4) : f32x4{0.f, 0.f, 0.f, 0.f};
   tile_out<5>([&](int r, int s) { return *reinterpret_cast<const f32x4*>(M + ((long)(r * 5 + s) * T + t) * N + 4 * n4); },
               [&](int r, int s, f32x4 v) {
-                *reinterpret_cast<f32x4*>(y + (((long)b * Ho + 4 * ty + r) * Wo + 4 * tx + s) * pitch + 4 * n4) = v + bv;
+                const long pix = ((long)b * Ho + 4 * ty + r) * Wo + 4 * tx + s;
+                *reinterpret_cast<f32x4*>(y + pix * pitch + 4 * n4) = epi_apply(v + bv, epi, pix, 4 * n4);
               });
 }
 // f42 yx input: dy [B][Ho][Wo][Ny] -> V[4][25][T][Ny], T = B * (Ho/4) * (Wo/4); phase (p, q) reads the 5 x 5 window whose first
@@ -363,7 +391,8 @@ __global__ __launch_bounds__(256) void f42_in_yx_kernel(const float* __restrict_
 }
 // f42 yx output: M[4][25][T][C] -> dx [B][2 Ho][2 Wo][C]: phase (p, q), tile output (u, v) -> pixel (8 ty + 2 u + 1 - p, 8 tx + 2 v + 1 - q)
 __global__ __launch_bounds__(256) void f42_out_yx_kernel(const float* __restrict__ M, int B, int Ho, int Wo, int C,
-                                                         const float* __restrict__ bias, float* __restrict__ dx, long pitch) {
+                                                         const float* __restrict__ bias, float* __restrict__ dx, long pitch,
+                                                         Epi epi) {
   const int C4 = C / 4, TY = Ho / 4, TX = Wo / 4;
   const long T = (long)B * TY * TX;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -378,8 +407,76 @@ __global__ __launch_bounds__(256) void f42_out_yx_kernel(const float* __restrict
       [&](int r, int s) { return *reinterpret_cast<const f32x4*>(M + (((long)pq * 25 + r * 5 + s) * T + t) * C + 4 * c4); },
       [&](int u, int s, f32x4 v) {
         const int h = 8 * ty + 2 * u + 1 - pp, w = 8 * tx + 2 * s + 1 - qq;
-        *reinterpret_cast<f32x4*>(dx + (((long)b * H + h) * W + w) * pitch + 4 * c4) = v + bv;
+        const long pix = ((long)b * H + h) * W + w;
+        *reinterpret_cast<f32x4*>(dx + pix * pitch + 4 * c4) = epi_apply(v + bv, epi, pix, 4 * c4);
       });
+}
+
+// U of one 4x4 / stride-2 layer for both directions from its weights w [Nw][16][Cw] (tap = 4 kh + kw), float64 arithmetic,
+// rounded once:  xy: U[xi][n][(2p + q) Cw + c] = (G g_pq G^T)[xi], g_pq[a][b] = w[2a + p][2b + q]
+//                yx: U[2p + q][xi][c][n]       = (G f_pq G^T)[xi], f_pq[a][b] = w[2 (1 - a) + p][2 (1 - b) + q]
+// G = [[1/2, 0], [-1/2, -1/2], [-1/6, 1/6], [1/6, 1/3], [0, 1]].  One instantiation per direction: xy (thread = (n, 4 channels):
+// 16-byte loads and stores along c), yx (thread = (4 channels, n), n fastest: the stores run along n).
+__device__ __forceinline__ void g42(const double (&g)[2][2], double (&u)[5][5]) {
+  double t[5][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    t[0][b] = 0.5 * g[0][b];
+    t[1][b] = -0.5 * (g[0][b] + g[1][b]);
+    t[2][b] = (g[1][b] - g[0][b]) / 6.0;
+    t[3][b] = g[0][b] / 6.0 + g[1][b] / 3.0;
+    t[4][b] = g[1][b];
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    u[i][0] = 0.5 * t[i][0];
+    u[i][1] = -0.5 * (t[i][0] + t[i][1]);
+    u[i][2] = (t[i][1] - t[i][0]) / 6.0;
+    u[i][3] = t[i][0] / 6.0 + t[i][1] / 3.0;
+    u[i][4] = t[i][1];
+  }
+}
+template <bool yx>
+__global__ __launch_bounds__(256) void f42_weights_kernel(const float* __restrict__ w, int Nw, int Cw,
+                                                          float* __restrict__ Uxy, float* __restrict__ Uyx) {
+  const int C4 = Cw / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)Nw * C4) return;
+  const int n = yx ? (int)(i % Nw) : (int)(i / C4);
+  const int c4 = yx ? (int)(i / Nw) : (int)(i % C4);
+  f32x4 tap[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tap[k] = *reinterpret_cast<const f32x4*>(w + ((long)n * 16 + k) * Cw + 4 * c4);
+#pragma unroll
+  for (int pq = 0; pq < 4; ++pq) {
+    const int pp = pq >> 1, qq = pq & 1;
+    double u[4][5][5];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double g[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int aa = yx ? 1 - a : a, bb = yx ? 1 - b : b;
+          g[a][b] = (double)tap[(2 * aa + pp) * 4 + 2 * bb + qq][j];
+        }
+      g42(g, u[j]);
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < 5; ++s2) {
+        const int xi = r * 5 + s2;
+        if (!yx) {
+          const f32x4 v = {(float)u[0][r][s2], (float)u[1][r][s2], (float)u[2][r][s2], (float)u[3][r][s2]};
+          *reinterpret_cast<f32x4*>(Uxy + ((long)xi * Nw + n) * (4L * Cw) + (long)pq * Cw + 4 * c4) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Uyx[(((long)pq * 25 + xi) * Cw + 4 * c4 + j) * Nw + n] = (float)u[j][r][s2];
+        }
+      }
+  }
 }
 
 }  // namespace lgmweng
@@ -418,10 +515,10 @@ extern "C" int lgm_weng_gemm(const float* A, const float* Bm, float* C, int M, i
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(kern, grid, dim3(256), sm, (hipStream_t)stream, p);
   };
-  if (bm == 128 && bn == 128) launch(weng_gemm_kernel<128, 128>);
-  else if (bm == 64 && bn == 128) launch(weng_gemm_kernel<64, 128>);
-  else if (bm == 128 && bn == 64) launch(weng_gemm_kernel<128, 64>);
-  else launch(weng_gemm_kernel<64, 64>);
+  if (bm == 128 && bn == 128) launch(weng_gemm_kernel<128, 128>), lgm_note_kernel(LGM_KNAME("lgmweng::weng_gemm_kernel<128, 128>"));
+  else if (bm == 64 && bn == 128) launch(weng_gemm_kernel<64, 128>), lgm_note_kernel(LGM_KNAME("lgmweng::weng_gemm_kernel<64, 128>"));
+  else if (bm == 128 && bn == 64) launch(weng_gemm_kernel<128, 64>), lgm_note_kernel(LGM_KNAME("lgmweng::weng_gemm_kernel<128, 64>"));
+  else launch(weng_gemm_kernel<64, 64>), lgm_note_kernel(LGM_KNAME("lgmweng::weng_gemm_kernel<64, 64>"));
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
@@ -461,7 +558,26 @@ extern "C" int lgm_weng_f42_out_xy(const float* M, int B, int Ho, int Wo, int N,
   if (int rc = weng_check(y, y_pitch, N, "weng_f42_out_xy")) return rc;
   LGM_REQUIRE(M && lgm_aligned16(M) && B > 0 && Ho % 4 == 0 && Wo % 4 == 0 && (!bias || lgm_aligned16(bias)), "weng_f42_out_xy: bad arguments");
   const long n = (long)B * (Ho / 4) * (Wo / 4) * (N / 4);
-  hipLaunchKernelGGL(f42_out_xy_kernel, dim3(lgm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, M, B, Ho, Wo, N, bias, y, (long)y_pitch);
+  hipLaunchKernelGGL(f42_out_xy_kernel, dim3(lgm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, M, B, Ho, Wo, N, bias, y, (long)y_pitch,
+                     Epi{0, 0.f, nullptr, 0, 0.f});
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+static int weng_epi(Epi& e, int act, float slope, const float* mask, int64_t mask_pitch, float mask_slope, int C, const char* who) {
+  LGM_REQUIRE(act == 0 || act == 3 || act == 4, "%s: activation %d not taken (0, 3 = ReLU, 4 = LeakyReLU)", who, act);
+  LGM_REQUIRE(!mask || (lgm_aligned16(mask) && mask_pitch % 4 == 0 && mask_pitch >= C), "%s: mask must be 16-byte aligned, pitch %% 4", who);
+  e = Epi{act, slope, mask, (long)mask_pitch, mask_slope};
+  return LGM_OK;
+}
+extern "C" int lgm_weng_f42_out_xy_post(const float* M, int B, int Ho, int Wo, int N, const float* bias, float* y,
+                                        int64_t y_pitch, int act, float slope, const float* mask, int64_t mask_pitch,
+                                        float mask_slope, void* stream) {
+  if (int rc = weng_check(y, y_pitch, N, "weng_f42_out_xy_post")) return rc;
+  LGM_REQUIRE(M && lgm_aligned16(M) && B > 0 && Ho % 4 == 0 && Wo % 4 == 0 && (!bias || lgm_aligned16(bias)), "weng_f42_out_xy_post: bad arguments");
+  Epi e;
+  if (int rc = weng_epi(e, act, slope, mask, mask_pitch, mask_slope, N, "weng_f42_out_xy_post")) return rc;
+  const long n = (long)B * (Ho / 4) * (Wo / 4) * (N / 4);
+  hipLaunchKernelGGL(f42_out_xy_kernel, dim3(lgm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, M, B, Ho, Wo, N, bias, y, (long)y_pitch, e);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
@@ -478,7 +594,30 @@ extern "C" int lgm_weng_f42_out_yx(const float* M, int B, int Ho, int Wo, int C,
   if (int rc = weng_check(dx, pitch, C, "weng_f42_out_yx")) return rc;
   LGM_REQUIRE(M && lgm_aligned16(M) && B > 0 && Ho % 4 == 0 && Wo % 4 == 0 && (!bias || lgm_aligned16(bias)), "weng_f42_out_yx: bad arguments");
   const long n = (long)B * (Ho / 4) * (Wo / 4) * C;
-  hipLaunchKernelGGL(f42_out_yx_kernel, dim3(lgm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, M, B, Ho, Wo, C, bias, dx, (long)pitch);
+  hipLaunchKernelGGL(f42_out_yx_kernel, dim3(lgm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, M, B, Ho, Wo, C, bias, dx, (long)pitch,
+                     Epi{0, 0.f, nullptr, 0, 0.f});
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+extern "C" int lgm_weng_f42_out_yx_post(const float* M, int B, int Ho, int Wo, int C, const float* bias, float* dx,
+                                        int64_t pitch, int act, float slope, const float* mask, int64_t mask_pitch,
+                                        float mask_slope, void* stream) {
+  if (int rc = weng_check(dx, pitch, C, "weng_f42_out_yx_post")) return rc;
+  LGM_REQUIRE(M && lgm_aligned16(M) && B > 0 && Ho % 4 == 0 && Wo % 4 == 0 && (!bias || lgm_aligned16(bias)), "weng_f42_out_yx_post: bad arguments");
+  Epi e;
+  if (int rc = weng_epi(e, act, slope, mask, mask_pitch, mask_slope, C, "weng_f42_out_yx_post")) return rc;
+  const long n = (long)B * (Ho / 4) * (Wo / 4) * C;
+  hipLaunchKernelGGL(f42_out_yx_kernel, dim3(lgm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, M, B, Ho, Wo, C, bias, dx, (long)pitch, e);
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+/* U of both directions from the layer's weights (either output may be NULL) */
+extern "C" int lgm_weng_f42_weights(const float* w, int Nw, int Cw, float* Uxy, float* Uyx, void* stream) {
+  LGM_REQUIRE(w && lgm_aligned16(w) && Nw > 0 && Cw > 0 && Cw % 4 == 0 && (Uxy || Uyx) && (!Uxy || lgm_aligned16(Uxy)),
+              "weng_f42_weights: bad arguments (Cw %% 4 == 0, 16-byte aligned)");
+  const long n = (long)Nw * (Cw / 4);
+  if (Uxy) hipLaunchKernelGGL(f42_weights_kernel<false>, dim3(lgm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, Nw, Cw, Uxy, Uyx);
+  if (Uyx) hipLaunchKernelGGL(f42_weights_kernel<true>, dim3(lgm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, Nw, Cw, Uxy, Uyx);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

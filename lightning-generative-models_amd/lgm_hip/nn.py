@@ -181,6 +181,13 @@ class Conv2d(nn.Module):
                 gx = ops.new(x.shape, x)
                 accumulate = False
             assert not (accumulate and res is not None)
+            if ops._weng_take(g, fp.ptr(self.weight), gx if accumulate else res, False) is not None:
+                # 4x4 / stride-2 layer registered with the non-fused Winograd engine: its input gradient runs there, the
+                # weight gradient keeps the implicit-GEMM kernel (the one-launch pair would bypass the engine)
+                ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=dfr)
+                ops.conv_yx(g, gy, fp.ptr(self.weight), None, None, gx, fp.tptr(self.weight),
+                            post=ops.make_post(0, 0.0, mask, mask_slope, bn=bn_sums), post_mask=mask)
+                return gx
             ops.conv_bwd_generic(g, gy, x, fp.ptr(self.weight), fp.tptr(self.weight), fp.gptr(self.weight), bw, gb, dfr,
                                  gx if accumulate else res, gx, post=ops.make_post(0, 0.0, mask, mask_slope, bn=bn_sums),
                                  post_mask=mask)

@@ -441,6 +441,76 @@ def _apply_post_separately(post: PostOp, out, mask):
         act_bwd(mask, None, out, out, False, ACT_LRELU if post.mask_slope != 0.0 else ACT_RELU, post.mask_slope)
 
 
+# ----------------------------------------------------------------------------------------
+# Non-fused Winograd engine for the 4x4 / stride-2 / pad-1 layers (csrc/winograd_eng.hip; DCGAN generator / critic,
+# reference dcgan.py:79-87, 150-158): F(4x4, 2x2) on the four pixel phases - input transform launch, ONE batched GEMM, output
+# transform launch (bias, activation and backward mask in it) - for the forward AND the input-gradient direction of a
+# registered layer.  LGM_WENG=1 switches it on, LGM_WENG_MIN_GFLOP (default 4) is the smallest layer it takes.  A layer takes
+# part once its module registered the weight slot (weng_register) and keeps its transformed weights current (weng_refresh
+# after every change of the weights, BEFORE the first convolution that uses them: models/generative/gan/dcgan.py).
+# ----------------------------------------------------------------------------------------
+WENG = _os.environ.get("LGM_WENG", "0") == "1"
+WENG_MIN_FLOP = float(_os.environ.get("LGM_WENG_MIN_GFLOP", "4")) * 1e9
+_WENG_U = {}       # weight address -> (Nw, Cw, Uxy tensor [25][Nw][4 Cw], Uyx tensor [4][25][Cw][Nw])
+
+
+def weng_register(w_ptr: int, Nw: int, Cw: int, device):
+    """Allocate the transformed-weight tensors of the 4x4 / stride-2 layer whose physical weight [Nw][16][Cw] starts at
+    ``w_ptr`` (idempotent; the tensors never move, so captured graphs stay valid)."""
+    if not WENG or Cw % 4 or Nw % 4 or Cw < 32 or Nw < 32:
+        return False
+    ent = _WENG_U.get(w_ptr)
+    if ent is None or ent[0] != Nw or ent[1] != Cw or ent[2].device != torch.device(device):
+        _WENG_U[w_ptr] = (Nw, Cw, torch.zeros(25 * Nw * 4 * Cw, dtype=torch.float32, device=device),
+                          torch.zeros(100 * Cw * Nw, dtype=torch.float32, device=device))
+    return True
+
+
+def weng_refresh(w_ptrs, xy: bool = True, yx: bool = True):
+    """U = G g G^T of the current weights for the given registered layers (one launch per direction and layer)."""
+    for wp in w_ptrs:
+        ent = _WENG_U.get(wp)
+        if ent is not None:
+            lib().lgm_weng_f42_weights(wp, ent[0], ent[1], ent[2].data_ptr() if xy else None,
+                                       ent[3].data_ptr() if yx else None, stream())
+
+
+def _weng_take(g: ConvGeom, w_ptr, res, partial: bool):
+    if not WENG or partial or res is not None or w_ptr is None:
+        return None
+    if not (g.KH == 4 and g.KW == 4 and g.stride == 2 and g.pad == 1 and g.H % 8 == 0 and g.W % 8 == 0):
+        return None
+    ent = _WENG_U.get(w_ptr)
+    if ent is None or ent[0] != g.Nw or ent[1] != g.Cw or _conv_flops(g) < WENG_MIN_FLOP:
+        return None
+    return ent
+
+
+def _weng_conv(yx: int, g: ConvGeom, a, ent, bias_ptr, out, post: Optional[PostOp]):
+    """The three launches; ``a`` / ``out``: the Y side / X side tensors for yx = 1, X side / Y side for yx = 0."""
+    L, st = lib(), stream()
+    Nw, Cw, uxy, uyx = ent
+    T = g.B * (g.Ho // 4) * (g.Wo // 4)
+    act, slope, mask, mpitch, mslope = 0, 0.0, None, 0, 0.0
+    if post is not None:
+        act, slope, mask, mpitch, mslope = post.act, post.slope, post.mask, post.mask_pitch, post.mask_slope
+    if yx == 0:
+        K = 4 * Cw
+        ws = workspace(4 * 25 * T * (K + Nw), a.device)
+        V, M = ws.data_ptr(), ws.data_ptr() + 4 * 25 * T * K
+        L.lgm_weng_f42_in_xy(a.data_ptr(), pitch(a), g.B, g.H, g.W, Cw, V, st)
+        L.lgm_weng_gemm(V, uxy.data_ptr(), M, T, Nw, K, K, K, Nw, 25, T * K, Nw * K, T * Nw, st)
+        L.lgm_weng_f42_out_xy_post(M, g.B, g.Ho, g.Wo, Nw, bias_ptr, out.data_ptr(), pitch(out), act, slope, mask, mpitch,
+                                   mslope, st)
+    else:
+        ws = workspace(4 * 100 * T * (Nw + Cw), a.device)
+        V, M = ws.data_ptr(), ws.data_ptr() + 4 * 100 * T * Nw
+        L.lgm_weng_f42_in_yx(a.data_ptr(), pitch(a), g.B, g.Ho, g.Wo, Nw, V, st)
+        L.lgm_weng_gemm(V, uyx.data_ptr(), M, T, Cw, Nw, Nw, Nw, Cw, 100, T * Nw, Cw * Nw, T * Cw, st)
+        L.lgm_weng_f42_out_yx_post(M, g.B, g.Ho, g.Wo, Cw, bias_ptr, out.data_ptr(), pitch(out), act, slope, mask, mpitch,
+                                   mslope, st)
+
+
 def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y, partial: bool = False, post: Optional[PostOp] = None,
             post_mask=None):
     """``partial=True`` (the consumer is a GroupNorm that can sum split-K planes, see gn_fwd): returns
@@ -449,6 +519,12 @@ def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y, partial
     ``post`` (make_post): activation / backward mask applied by the convolution's epilogue (lgm_conv_xy_post)."""
     if TIMER is not None:
         TIMER.begin("igemm_xy", _conv_flops(g), _conv_bytes(g))
+    ent = _weng_take(g, w_ptr, res, partial)
+    if ent is not None:          # (a BatchNorm-sums request in ``post`` is not served here: its tile count stays 0)
+        _weng_conv(0, g, x, ent, bias_ptr, y, post)
+        if TIMER is not None:
+            TIMER.end()
+        return None
     if post is not None:
         ws = _conv_ws(g, 0, x.device)
         if POSTOPS:
@@ -501,6 +577,12 @@ def conv_stats(yx: int, g: ConvGeom, a, w_ptr: int, out, wt_ptr: Optional[int] =
     L = lib()
     if TIMER is not None:
         TIMER.begin("igemm_yx" if yx else "igemm_xy", _conv_flops(g), _conv_bytes(g))
+    ent = _weng_take(g, w_ptr, None, False)
+    if ent is not None:          # the engine's output transform leaves no statistics: tiles = 0, the BatchNorm reduces itself
+        _weng_conv(yx, g, a, ent, None, out, None)
+        if TIMER is not None:
+            TIMER.end()
+        return None, 0
     ws = _conv_ws(g, yx, a.device)
     oc = g.Cw if yx else g.Nw
     stats = torch.empty(L.lgm_conv_stats_floats(ctypes.byref(g), yx), dtype=torch.float32, device=a.device)
@@ -523,6 +605,12 @@ def conv_yx(g: ConvGeom, y, w_ptr: int, bias_ptr: Optional[int], res, x, wt_ptr:
     """``partial`` / ``post``: as conv_xy."""
     if TIMER is not None:
         TIMER.begin("igemm_yx", _conv_flops(g), _conv_bytes(g))
+    ent = _weng_take(g, w_ptr, res, partial)
+    if ent is not None:
+        _weng_conv(1, g, y, ent, bias_ptr, x, post)
+        if TIMER is not None:
+            TIMER.end()
+        return None
     if post is not None:
         ws = _conv_ws(g, 1, y.device)
         if POSTOPS:

@@ -46,7 +46,38 @@ class _Net(nn.Module):
         if self._flat is not None and self._flat.device == device and self._flat.still_bound():
             return self._flat
         self._flat = FlatParams([(n, p, param_kind(n, p)) for n, p in self.named_parameters()], device)
+        # the 4x4 / stride-2 layers register with the non-fused Winograd engine (opt-in: LGM_WENG=1, lgm_hip/ops.py)
+        self._weng_ptrs = []
+        for m in self.modules():
+            if isinstance(m, (Conv2d, ConvTranspose2d)) and m.k == 4 and m.stride == 2 and m.padding == 1:
+                nw, cw = (m.cin, m.cout) if isinstance(m, ConvTranspose2d) else (m.cout, m.cin)   # Y side / X side channels
+                wp = self._flat.ptr(m.weight)
+                if ops.weng_register(wp, _r4(nw), _r4(cw), device):
+                    self._weng_ptrs.append(wp)
+        self._weng_hold = False
         return self._flat
+
+    def weng_refresh(self, xy: bool = True, yx: bool = True):
+        """The engine's transformed weights from the CURRENT weights (no-op unless layers registered).  Called at the start
+        of every forward pass - the weights may have changed since the last one - unless a caller holds them fresh."""
+        if getattr(self, "_weng_ptrs", None) and not self._weng_hold:
+            ops.weng_refresh(self._weng_ptrs, xy, yx)
+
+    def weng_fresh(self):
+        """Context: refresh once, then skip the per-forward refreshes inside (several forward passes on unchanged weights:
+        the critic's real / fake / interpolate passes of one loss)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def hold():
+            self.prepare_hip(self.device)
+            self.weng_refresh()
+            prev, self._weng_hold = self._weng_hold, True
+            try:
+                yield
+            finally:
+                self._weng_hold = prev
+        return hold()
 
     def _anchor(self, device):
         self.prepare_hip(device)
@@ -88,6 +119,7 @@ class Generator(_Net):
 
     # ---- engine -----------------------------------------------------------------------------
     def fwd(self, z4, save: bool):
+        self.weng_refresh(xy=False, yx=True)         # a ConvTranspose2d forward is the Y -> X direction
         tape = []
         h = z4
         n = len(self.model)
@@ -107,6 +139,7 @@ class Generator(_Net):
         return h, (tape if save else None)
 
     def bwd(self, tape, gout):
+        self.weng_refresh(xy=True, yx=False)         # its input gradient the X -> Y direction (weights unchanged since fwd)
         gc = GradCtx(self._flat)
         n = len(self.model)
         g = gout
@@ -175,6 +208,7 @@ class Discriminator(_Net):
     # ---- engine: first-order ------------------------------------------------------------------
     def fwd(self, x4, save: bool = True):
         """x4: [B,H,W,r4(C)] -> scores [B,1,1,4] (column 0).  tape[k] = (h_in, a, bn_saved, h_out)."""
+        self.weng_refresh()
         tape = []
         h = x4
         for blk, (ci, co, k, s, p, bn, final) in zip(self.model, self.spec):

@@ -78,6 +78,7 @@ class WGAN(DCGAN):
         launch over the critic's flat parameter buffer (its padding lanes are zero and stay zero)."""
         self.D.prepare_hip(next(self.D.parameters()).device)
         ops.clamp_(self.D._flat.data, -float(self.hparams.clip_value), float(self.hparams.clip_value))
+        self.D.weng_refresh()        # the backward pass that follows reads the CLIPPED weights (reference :101-102)
 
     def _calculate_g_loss(self, x_hat):
         """reference :112-115: g_loss = -D(x_hat).mean()"""
@@ -100,18 +101,19 @@ class _CriticLossFn(torch.autograd.Function):
         st = ops.stream()
         B = x.shape[0]
         x4, xh4 = _to_nhwc(x), _to_nhwc(x_hat)
-        s_real, t_real = D.fwd(x4, True)
-        s_fake, t_fake = D.fwd(xh4, True)
-        vals = torch.zeros(4, device=x.device)
-        L.lgm_mean_col(s_real.data_ptr(), 4, B, 1.0, vals[0:1].data_ptr(), st)
-        L.lgm_mean_col(s_fake.data_ptr(), 4, B, 1.0, vals[1:2].data_ptr(), st)
-        gp_state = None
-        if with_gp:
-            xi = ops.new(x4.shape, x4)
-            a = alpha.detach().float().reshape(B).contiguous()
-            L.lgm_lerp_rows(x4.data_ptr(), xh4.data_ptr(), a.data_ptr(), xi.data_ptr(), B, x4[0].numel(), st)
-            pen, gp_state = D.gradient_penalty(xi, lam)
-            vals[2:3].copy_(pen)
+        with D.weng_fresh():         # three forward passes on the same weights: the engine's weight transform runs once
+            s_real, t_real = D.fwd(x4, True)
+            s_fake, t_fake = D.fwd(xh4, True)
+            vals = torch.zeros(4, device=x.device)
+            L.lgm_mean_col(s_real.data_ptr(), 4, B, 1.0, vals[0:1].data_ptr(), st)
+            L.lgm_mean_col(s_fake.data_ptr(), 4, B, 1.0, vals[1:2].data_ptr(), st)
+            gp_state = None
+            if with_gp:
+                xi = ops.new(x4.shape, x4)
+                a = alpha.detach().float().reshape(B).contiguous()
+                L.lgm_lerp_rows(x4.data_ptr(), xh4.data_ptr(), a.data_ptr(), xi.data_ptr(), B, x4[0].numel(), st)
+                pen, gp_state = D.gradient_penalty(xi, lam)
+                vals[2:3].copy_(pen)
         L.lgm_wgan_dloss(vals.data_ptr(), st)
         ctx.stuff = (D, t_real, t_fake, gp_state, B)
         outs = (vals[3].clone(), vals[0].clone(), vals[1].clone(), vals[2].clone())
