@@ -531,6 +531,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, const int bidx) {
     __syncthreads();
     float* Ts = smem + wid * LGM_TS_FLOATS;
     float* const Bst = smem + 4 * LGM_TS_FLOATS;       // BatchNorm sums: [2 sums][wm][wn][TN][32 columns] behind the four wave tiles
+    // the epilogue's staging (four wave tiles + the sums) reuses the main loop's operand buffers: it must fit them
+    static_assert(2 * (A_TILE + B_TILE) >= 4 * LGM_TS_FLOATS + 2 * 2 * 2 * TN * 32,
+                  "igemm epilogue staging (wave tiles + BatchNorm sums) exceeds the operand buffers");
     const bool bnred = p.bn_part != nullptr;           // kernel argument: wave-uniform
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
