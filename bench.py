@@ -773,9 +773,9 @@ def main():
         sec["ddpm64_sampling_1000"] = leg("ddpm64_sampling_1000", lambda: run_sampling_ancestral(dev))
         line["secondary"] = sec
         proxy = {}
-        # the proxies run what a RANK of an N > 1 job runs: the library picks the light F(4x4) workgroups when WORLD_SIZE > 1
-        # (csrc/winograd4.hip: wino4_use_light) and plans its launches for 240 CUs (csrc/elementwise.hip: lgm_cu_budget), so the
-        # proxy legs switch both on the same way (and back off afterwards)
+        # the proxies run what a RANK of an N > 1 job runs when its exchange overlaps the backward on RCCL: light F(4x4)
+        # workgroups (csrc/winograd4.hip: wino4_use_light) and launch plans for 240 CUs (csrc/elementwise.hip: lgm_cu_budget) -
+        # FlatGradSync sets both for such a rank (lgm_hip/lightning.py); the proxy legs set them the same way (and back)
         from lgm_hip import ops as _ops
         _ops.lib().lgm_wino4_set_light(1)
         _ops.lib().lgm_set_cu_margin(16)
@@ -789,8 +789,8 @@ def main():
             _ops.lib().lgm_set_cu_margin(-1)
         proxy["note"] = ("ms per step of the headline workload on ONE GPU at the per-rank batch of 2 / 4 / 8 GPUs "
                          "(global batch 128): compute between the gradient exchanges under strong scaling; kernel "
-                         "selection as under WORLD_SIZE > 1 (light F(4x4) workgroups, launch plans sized for 240 of the 256 CUs: "
-                         "lgm_set_cu_margin)")
+                         "selection of a rank whose exchange overlaps its backward on RCCL (light F(4x4) workgroups, launch plans "
+                         "sized for 240 of the 256 CUs: lgm_set_cu_margin)")
         line["per_rank_proxy"] = proxy
         if faulted is not None:
             line["device_error_in"] = faulted
