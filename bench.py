@@ -61,8 +61,9 @@ WINO4_FACTOR = 4.0              # ... per Winograd F(4x4,3x3) multiply (144 / 36
 
 def mfma_factor(kernel_name: str) -> float:
     """algorithmic (direct-convolution) FLOPs per FLOP the MFMA pipe executes, by kernel family"""
-    if "weng" in kernel_name:        # F(4x4,2x2) on pixel phases: 100 products per 16 outputs instead of 256
-        return 2.56
+    if "weng" in kernel_name:        # the engine's GEMM: a plain 1x1 GEMM by default (factor 1); with LGM_WENG=1 it also runs the
+        # 4x4 / stride-2 layers as F(4x4,2x2) on pixel phases (100 products per 16 outputs instead of 256)
+        return 2.56 if os.environ.get("LGM_WENG", "0") == "1" else 1.0
     if "wino4" in kernel_name:
         return WINO4_FACTOR
     if "wino_" in kernel_name:

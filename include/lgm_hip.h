@@ -442,6 +442,10 @@ int lgm_sample_step_table(float* x, const float* v, const float* noise, float* x
 /* C[b][m][n] = sum_k A[b][m][k] * Bm[b][n][k], b < batch (strides in floats).  K, lda, ldb, batch strides % 4 == 0. */
 int lgm_weng_gemm(const float* A, const float* Bm, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
                   int64_t a_batch, int64_t b_batch, int64_t c_batch, void* stream);
+/* The same kernel as ONE un-split GEMM with a bias / residual epilogue: C[m][n] = bias[n] + res[m][ldr ...] + sum_k A[m][k] Bm[n][k]
+ * (a 1x1 Conv2d / Linear: ddpm.py:96-103, 187, 213-215, 252-253; weights [N][K] as the library stores them; res may alias C). */
+int lgm_weng_gemm_epi(const float* A, const float* Bm, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      const float* bias, const float* res, int ldr, void* stream);
 /* x [B][H][W][C] (pitch) -> V[36][T][C], T = B (H/4) (W/4);  M[36][T][N] -> y [B][H][W][N] (pitch) + bias */
 int lgm_weng_f43_in(const float* x, int64_t x_pitch, int B, int H, int W, int C, float* V, void* stream);
 int lgm_weng_f43_out(const float* M, int B, int H, int W, int N, const float* bias, float* y, int64_t y_pitch,

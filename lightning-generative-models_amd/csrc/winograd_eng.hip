@@ -52,6 +52,9 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc;
   long a_batch, b_batch, c_batch;      // strides in floats between consecutive batch entries
   int tiles_m, tiles_n;
+  const float* bias;                   // [N] added per column, or NULL   (batch == 1 callers: the 1x1 convolutions)
+  const float* res;                    // [M][ldr] added elementwise, or NULL (may alias C)
+  int ldr;
 };
 
 constexpr int BK = 32, LD = 36;
@@ -178,10 +181,15 @@ __global__ __launch_bounds__(256, 2) void weng_gemm_kernel(GemmArgs p) {
     for (int j = 0; j < CT; ++j) {
       const int col = tn * BN + wn * (CT * 32) + j * 32 + lr;
       const int row0 = tm * BM + wm * (RT * 32) + i * 32;
+      const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < p.M && col < p.N) C[(long)row * p.ldc + col] = acc[i][j][r];
+        if (row < p.M && col < p.N) {
+          float v = acc[i][j][r] + bv;
+          if (p.res) v += p.res[(long)row * p.ldr + col];
+          C[(long)row * p.ldc + col] = v;
+        }
       }
     }
 }
@@ -483,6 +491,9 @@ __global__ __launch_bounds__(256) void f42_weights_kernel(const float* __restric
 
 using namespace lgmweng;
 
+static int weng_gemm_launch(const float* A, const float* Bm, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                            int batch, int64_t a_batch, int64_t b_batch, int64_t c_batch, const float* bias,
+                            const float* res, int ldr, void* stream);
 extern "C" int lgm_weng_gemm(const float* A, const float* Bm, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                              int batch, int64_t a_batch, int64_t b_batch, int64_t c_batch, void* stream) {
   LGM_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "weng_gemm: bad arguments");
@@ -490,7 +501,23 @@ extern "C" int lgm_weng_gemm(const float* A, const float* Bm, float* C, int M, i
                   lgm_aligned16(Bm) && a_batch % 4 == 0 && b_batch % 4 == 0,
               "weng_gemm: K, lda, ldb and the batch strides must be multiples of 4 floats, operands 16-byte aligned");
   LGM_REQUIRE(((long)M * lda + K) * 4 < (1L << 31) && ((long)N * ldb + K) * 4 < (1L << 31), "weng_gemm: operand block too large");
-  GemmArgs p{A, Bm, C, M, N, K, lda, ldb, ldc, (long)a_batch, (long)b_batch, (long)c_batch, 0, 0};
+  return weng_gemm_launch(A, Bm, C, M, N, K, lda, ldb, ldc, batch, a_batch, b_batch, c_batch, nullptr, nullptr, 0, stream);
+}
+/* y[m][n] = bias[n] + res[m][n] + sum_k x[m][k] w[n][k]: a 1x1 convolution / linear layer (Conv2d ddpm.py:96-103, 187, 213-215,
+ * 252-253) as ONE un-split GEMM launch - no split-K planes, no reducer launch */
+extern "C" int lgm_weng_gemm_epi(const float* A, const float* Bm, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                 const float* bias, const float* res, int ldr, void* stream) {
+  LGM_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0, "weng_gemm_epi: bad arguments");
+  LGM_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && lgm_aligned16(A) &&
+                  lgm_aligned16(Bm) && (!res || ldr >= N),
+              "weng_gemm_epi: K, lda, ldb must be multiples of 4 floats, operands 16-byte aligned");
+  LGM_REQUIRE(((long)M * lda + K) * 4 < (1L << 31) && ((long)N * ldb + K) * 4 < (1L << 31), "weng_gemm_epi: operand block too large");
+  return weng_gemm_launch(A, Bm, C, M, N, K, lda, ldb, ldc, 1, 0, 0, 0, bias, res, ldr, stream);
+}
+static int weng_gemm_launch(const float* A, const float* Bm, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                            int batch, int64_t a_batch, int64_t b_batch, int64_t c_batch, const float* bias,
+                            const float* res, int ldr, void* stream) {
+  GemmArgs p{A, Bm, C, M, N, K, lda, ldb, ldc, (long)a_batch, (long)b_batch, (long)c_batch, 0, 0, bias, res, ldr};
   // Tile choice, measured (tools/weng_gemm_bench.py, fraction of the 157.3 TFLOP/s fp32 MFMA peak, warm): the 128 x 128 tile
   // reaches 0.83 on a 4096^3 product (64 x 64: 0.80), but every shape the engine meets (M = tiles of a batch: 128 ... 2048,
   // batch 25 ... 100) is a few hundred to a few thousand workgroups of 8 ... 64 K-chunks, where start / drain and the

@@ -449,6 +449,25 @@ def _apply_post_separately(post: PostOp, out, mask):
 # part once its module registered the weight slot (weng_register) and keeps its transformed weights current (weng_refresh
 # after every change of the weights, BEFORE the first convolution that uses them: models/generative/gan/dcgan.py).
 # ----------------------------------------------------------------------------------------
+# The 1x1 convolutions' forward through the engine's GEMM kernel used as a plain NT GEMM (lgm_weng_gemm_epi: ONE un-split
+# launch, bias + residual in the epilogue).  Layer by layer and cold (tools/gemm1x1_bench.py) it is 1.1 - 1.5x faster than
+# lgm_conv_xy's dispatcher for 1024 <= rows <= 32768 with >= 128 reduction and output channels (those launches split K and run a
+# reducer) - and INSIDE the step it gains nothing: 9.81 / 9.81 vs 9.81 / 9.80 ms at B = 128, 6.61 vs 6.67 at B = 64, 4.38 vs
+# 4.40 at B = 16 (profiles/r06_negative_results.txt).  Opt-in: LGM_GEMM1X1=1.
+GEMM1X1 = _os.environ.get("LGM_GEMM1X1", "0") == "1"
+
+
+def _gemm1x1_take(g: ConvGeom, x, y, res, w_ptr, bias_ptr) -> bool:
+    if not (g.KH == 1 and g.KW == 1 and g.stride == 1 and g.pad == 0) or w_ptr is None:
+        return False
+    M = g.B * g.H * g.W
+    if not (1024 <= M <= 32768 and g.Cw >= 128 and g.Nw >= 128):
+        return False
+    if x.data_ptr() % 16 or pitch(x) % 4 or w_ptr % 16 or g.Cw % 4:
+        return False
+    return M * max(pitch(x), g.Cw) * 4 < (1 << 31)
+
+
 WENG = _os.environ.get("LGM_WENG", "0") == "1"
 WENG_MIN_FLOP = float(_os.environ.get("LGM_WENG_MIN_GFLOP", "4")) * 1e9
 _WENG_U = {}       # weight address -> (Nw, Cw, Uxy tensor [25][Nw][4 Cw], Uyx tensor [4][25][Cw][Nw])
@@ -519,6 +538,14 @@ def conv_xy(g: ConvGeom, x, w_ptr: int, bias_ptr: Optional[int], res, y, partial
     ``post`` (make_post): activation / backward mask applied by the convolution's epilogue (lgm_conv_xy_post)."""
     if TIMER is not None:
         TIMER.begin("igemm_xy", _conv_flops(g), _conv_bytes(g))
+    if GEMM1X1 and post is None and not partial and _gemm1x1_take(g, x, y, res, w_ptr, bias_ptr):
+        # mid-sized 1x1 convolutions as ONE un-split GEMM launch of the engine's kernel (no split-K planes, no reducer)
+        M = g.B * g.H * g.W
+        lib().lgm_weng_gemm_epi(x.data_ptr(), w_ptr, y.data_ptr(), M, g.Nw, g.Cw, pitch(x), g.Cw, pitch(y), bias_ptr,
+                                _p(res), pitch(res) if res is not None else 0, stream())
+        if TIMER is not None:
+            TIMER.end()
+        return None
     ent = _weng_take(g, w_ptr, res, partial)
     if ent is not None:          # (a BatchNorm-sums request in ``post`` is not served here: its tile count stays 0)
         _weng_conv(0, g, x, ent, bias_ptr, y, post)

@@ -65,3 +65,25 @@ def test_f42_stride2_both_directions(dev, B, C, N, H, parity):
     dx = weng.conv4x4s2_yx(nhwc(dy), weng.f42_weights_yx(w), bc)
     refx = F.conv_transpose2d(dy.double(), w.double(), bc.double(), stride=2, padding=1)
     parity(f"F(4x4,2x2)-phase engine, Y->X {N}->{C} @{H // 2}->{H}, B={B}", rel(dx, nhwc(refx)), 2e-5)
+
+
+@pytest.mark.parametrize("M,K,N,xp,yp,rp", [(2048, 512, 384, 512, 384, 0), (8192, 256, 384, 256, 384, 0),
+                                            (2048, 768, 512, 768, 1024, 1024), (32768, 192, 128, 192, 256, 128),
+                                            (1000, 132, 130, 136, 132, 140)])
+def test_gemm_with_bias_and_residual_epilogue(dev, M, K, N, xp, yp, rp, parity):
+    """lgm_weng_gemm_epi = a 1x1 convolution (y = x W^T + b + res) with pitched operands: a channel slice of a concat buffer in,
+    a channel slice out, the residual from a third pitch; rp == 0: no residual."""
+    from lgm_hip import ops
+    g = torch.Generator().manual_seed(M + K)
+    xb = torch.randn(M, xp, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    yb = torch.full((M, yp), float("nan"), device=dev)
+    rb = torch.randn(M, rp, generator=g).to(dev) if rp else None
+    ops.lib().lgm_weng_gemm_epi(xb.data_ptr(), w.data_ptr(), yb.data_ptr(), M, N, K, xp, K, yp, b.data_ptr(),
+                                None if rb is None else rb.data_ptr(), rp, ops.stream())
+    ref = xb[:, :K].double() @ w.double().T + b.double()
+    if rb is not None:
+        ref = ref + rb[:, :N].double()
+    parity(f"1x1 GEMM with epilogue M={M} K={K} N={N}", rel(yb[:, :N], ref), 2e-6)
+    assert torch.isnan(yb[:, N:]).all()                        # nothing written past the N columns of a wider row
