@@ -510,3 +510,31 @@ def test_p_sample_p_mean_variance_and_loops_through_the_class_methods(dev, golde
             ref, _ = OD.p_sample(P, bufs, ref, i, steps[k].cpu() if i > 0 else None, dim=dim)
     assert out.shape == shape
     parity(f"interpolate(x1, x2, t={T0}, lam={lam}) vs the oracle's chain on the same draws", rel(out, ref), RTOL)
+
+
+@pytest.mark.parametrize("graph", [True, False], ids=["graph_replay", "eager"])
+def test_stochastic_ddim_chain_matches_the_oracle(dev, golden_dir, parity, monkeypatch, graph):
+    """DDIM with eta > 0 (reference ddpm.py:820-827: sigma = eta sqrt((1 - a/a_next)(1 - a_next)/(1 - a)), c = sqrt(1 - a_next -
+    sigma^2), + sigma * noise): a 20-pair chain with eta = 0.7 and injected noise against oracle.ddim_sample_loop - the fixture
+    loops only cover eta = 0, where the noise term is multiplied by zero."""
+    from lgm_hip import sampler
+    from models.generative.diffusion.ddpm import GaussianDiffusion
+    from oracle import diffusion as OD
+    if not graph:
+        monkeypatch.setenv("LGM_NO_SAMPLER_GRAPH", "1")
+    fx, dim, S, P, img, noise, t = case(golden_dir, "small")
+    shape = tuple(fx["x_t"].shape)
+    net, _ = build(dim, S, P, dev)
+    gd = GaussianDiffusion(net, img_size=S, timesteps=1000, sampling_timesteps=20, ddim_sampling_eta=0.7).to(dev)
+    bufs = OD.diffusion_buffers(1000)
+    init, nz = OD.draw_loop_noise(31337, shape, 20)
+    with torch.no_grad():
+        ref = OD.ddim_sample_loop(P, bufs, init, nz, 20, eta=0.7, dim=dim)
+    out = sampler.ddim_sample(gd, shape, init_noise=init.to(dev), noises=[n.to(dev) for n in nz])
+    parity(f"20-pair DDIM chain, eta = 0.7 ({'graph replay' if graph else 'eager launches'})", rel(out, ref), RTOL)
+    # the method itself draws its own noise: right shape and range, and a different draw gives a different image
+    torch.manual_seed(1)
+    a = gd.ddim_sample(shape)
+    torch.manual_seed(2)
+    b = gd.ddim_sample(shape)
+    assert a.shape == shape and not torch.equal(a, b) and 0.0 <= float(a.min()) and float(a.max()) <= 1.0
