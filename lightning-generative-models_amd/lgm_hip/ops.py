@@ -450,9 +450,9 @@ def _apply_post_separately(post: PostOp, out, mask):
 # after every change of the weights, BEFORE the first convolution that uses them: models/generative/gan/dcgan.py).
 # ----------------------------------------------------------------------------------------
 # The 1x1 convolutions' forward through the engine's GEMM kernel used as a plain NT GEMM (lgm_weng_gemm_epi: ONE un-split
-# launch, bias + residual in the epilogue).  Layer by layer and cold (tools/gemm1x1_bench.py) it is 1.1 - 1.5x faster than
-# lgm_conv_xy's dispatcher for 1024 <= rows <= 32768 with >= 128 reduction and output channels (those launches split K and run a
-# reducer) - and INSIDE the step it gains nothing: 9.81 / 9.81 vs 9.81 / 9.80 ms at B = 128, 6.61 vs 6.67 at B = 64, 4.38 vs
+# launch, bias + residual in the epilogue).  Layer by layer and cold (tools/gemm1x1_bench.py) it is within +-10 % of
+# lgm_conv_xy's dispatcher for 1024 <= rows <= 32768 with >= 128 reduction and output channels (two layers 1.3x faster; those
+# launches split K and run a reducer), 0.6 - 0.7x on the 32 x 32 maps - and INSIDE the step it gains nothing: 9.81 / 9.81 vs 9.81 / 9.80 ms at B = 128, 6.61 vs 6.67 at B = 64, 4.38 vs
 # 4.40 at B = 16 (profiles/r06_negative_results.txt).  Opt-in: LGM_GEMM1X1=1.
 GEMM1X1 = _os.environ.get("LGM_GEMM1X1", "0") == "1"
 
