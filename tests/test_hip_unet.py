@@ -538,3 +538,38 @@ def test_stochastic_ddim_chain_matches_the_oracle(dev, golden_dir, parity, monke
     torch.manual_seed(2)
     b = gd.ddim_sample(shape)
     assert a.shape == shape and not torch.equal(a, b) and 0.0 <= float(a.min()) and float(a.max()) <= 1.0
+
+
+def test_opt_in_kernel_routes_match_the_oracle(dev, parity, monkeypatch):
+    """The round-6 opt-in routes - the time embedding as one launch (LGM_TIME_MLP=1) and the mid-sized 1x1 convolutions through the
+    engine's un-split GEMM (LGM_GEMM1X1=1) - through the whole network: dim 64, 32x32, B = 8 (2048 pixel rows at 16x16, so the 1x1
+    rule takes layers), loss and ALL parameter gradients against the oracle's autograd."""
+    from lgm_hip import ops
+    from oracle import diffusion as OD
+    monkeypatch.setattr(ops, "TIME_MLP", True)
+    monkeypatch.setattr(ops, "GEMM1X1", True)
+    ops._TIME_MLP_OK.clear()
+    taken = []
+    real = ops.lib().lgm_weng_gemm_epi
+    monkeypatch.setattr(ops.lib(), "lgm_weng_gemm_epi", lambda *a: (taken.append(a[3:6]), real(*a))[1])
+    try:
+        dim, S, B = 64, 32, 8
+        P = OD.unet_init(dim=dim, channels=3, seed=13)
+        bufs = OD.diffusion_buffers(1000)
+        g = torch.Generator().manual_seed(1300)
+        img = torch.rand(B, 3, S, S, generator=g)
+        noise = torch.randn(B, 3, S, S, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        loss_ref = OD.diffusion_forward(Pr, bufs, img, t, noise, dim=dim)
+        loss_ref.backward()
+        net, gd = build(dim, S, P, dev)
+        loss = gd.p_losses(img.to(dev), t.to(dev), noise.to(dev), _normalize=True)
+        parity("loss with the opt-in routes", abs(loss.item() - loss_ref.item()) / loss_ref.item(), RTOL)
+        loss.backward()
+        errs = {n: rel(p.grad, Pr[n].grad) for n, p in net.named_parameters()}
+        wn = max(errs, key=errs.get)
+        parity(f"worst of ALL {len(errs)} parameter gradients with the opt-in routes ({wn})", errs[wn], RTOL)
+        assert len(taken) >= 2, taken                      # the 1x1 rule really routed layers through the engine's GEMM (16x16 maps)
+    finally:
+        ops._TIME_MLP_OK.clear()
