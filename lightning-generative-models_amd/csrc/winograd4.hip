@@ -39,9 +39,13 @@ int lgm_splitk_reduce_launch(const float* ws, long ws_stride, int splits, const 
 // [31] s_memrealtime at exit.  Never set on the product path.
 static void* lgm_wino4_debug_buffer = nullptr;
 static int lgm_wino4_debug_exp = 0;
+static int lgm_wino4_debug_slots = 0;      // exp bits 16+: > 0 = every stamped launch takes the next slot of 4096 x 32 entries
+static int lgm_wino4_debug_next = 0;       // (tools/wino4_step_stamps.py: the kernel's launches INSIDE a training step)
 extern "C" int lgm_wino4_set_debug_buffer(void* buf, int exp) {
   lgm_wino4_debug_buffer = buf;
-  lgm_wino4_debug_exp = exp;
+  lgm_wino4_debug_exp = exp & 0xffff;
+  lgm_wino4_debug_slots = exp >> 16;
+  lgm_wino4_debug_next = 0;
   return LGM_OK;
 }
 
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
     }
   };
   stamp();
+  const long long rt_entry = DBG ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   constexpr int NI = GE::NI, PH = GE::PH, PW = GE::PW, RS = GE::RS, IMG = GE::IMG, PLANE = GE::PLANE;
   constexpr int RBUF = 8 * PLANE;
   constexpr int NPIX = NI * PH * PW;
@@ -527,6 +532,12 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const Args p) {
     if (DBG && threadIdx.x == 0) {
       p.dbg[blockIdx.x * 32] = nstamp;
       p.dbg[blockIdx.x * 32 + 31] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (nstamp <= 29) p.dbg[blockIdx.x * 32 + 30] = rt_entry;       // 100 MHz, one clock for the chip
+      if (blockIdx.x == 0) {                            // the launch's shape, in the slot's last row (never a workgroup's)
+        long long* m = p.dbg + 4095 * 32;
+        m[0] = p.C; m[1] = p.N; m[2] = p.H; m[3] = p.W; m[4] = p.B; m[5] = p.splits; m[6] = CLS; m[7] = gridDim.x;
+        m[8] = p.res != nullptr; m[9] = p.tn_slowest;
+      }
     }
   };
   if (half == 0) body(std::integral_constant<int, 0>{});
@@ -774,6 +785,10 @@ int lgm_wino4_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch,
   }
   const size_t smem = (size_t)MBUF * sizeof(float);
   p.dbg = (long long*)lgm_wino4_debug_buffer;
+  if (p.dbg && lgm_wino4_debug_slots > 0) {
+    if (lgm_wino4_debug_next >= lgm_wino4_debug_slots || p.units > 4095) p.dbg = nullptr;     // out of slots: the plain build
+    else p.dbg += (long)(lgm_wino4_debug_next++) * 4096 * 32;
+  }
 #define LGM_W4LAUNCH(CC, DD, EE)                                                                                \
   do {                                                                                                          \
     auto kern = wino4_conv_kernel<CC, DD, EE>;                                                                        \

@@ -27,15 +27,19 @@ def main():
     for _ in range(200):                      # clocks up
         wino4(0, g, x, uf, bias, None, y)
     torch.cuda.synchronize()
+    cold = len(sys.argv) >= 7 and sys.argv[6] == "cold"      # every stamped launch behind a 512 MB fill, as inside the step
+    big = torch.empty(128 << 20, device=dev) if cold else None
     for exp in exps:
-        one(exp, g, x, uf, bias, y, dev)
+        one(exp, g, x, uf, bias, y, dev, big)
 
 
-def one(exp, g, x, uf, bias, y, dev):
+def one(exp, g, x, uf, bias, y, dev, big=None):
     nwg = 4096
     dbg = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
     ops.lib().lgm_wino4_set_debug_buffer(dbg.data_ptr(), exp)
     for _ in range(3):
+        if big is not None:
+            big.fill_(1.0)
         wino4(0, g, x, uf, bias, None, y)
     torch.cuda.synchronize()
     ops.lib().lgm_wino4_set_debug_buffer(None, 0)
