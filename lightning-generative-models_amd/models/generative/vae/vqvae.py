@@ -9,10 +9,9 @@ Forward and backward are explicit kernel sequences; autograd only sees one Funct
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional
 
 import torch
-import torch.distributed as dist
 from torch import nn
 
 from lgm_hip import ops
@@ -20,55 +19,8 @@ from lgm_hip.flat import FlatParams, _r4
 from lgm_hip.lightning import LightningModule, multi_rank
 from lgm_hip.nn import Conv2d, ConvTranspose2d, GradCtx, param_kind
 from lgm_hip.optim import FusedAdam
-
-
-class ResidualBlock(nn.Module):
-    """reference residual.py:5-21 — note the in-place first ReLU: the block returns
-    relu(x) + conv1x1(relu(conv3x3(relu(x))))."""
-
-    def __init__(self, in_channels, hidden_dim, num_residual_hiddens):
-        super().__init__()
-        self.block = nn.Sequential(nn.Identity(), Conv2d(in_channels, num_residual_hiddens, 3, padding=1, bias=False),
-                                   nn.Identity(), Conv2d(num_residual_hiddens, hidden_dim, 1, bias=False))
-
-
-class ResidualStack(nn.Module):
-    def __init__(self, in_channels, hidden_dim, num_residual_layers, num_residual_hiddens):
-        super().__init__()
-        self.layers = nn.ModuleList([ResidualBlock(in_channels, hidden_dim, num_residual_hiddens)
-                                     for _ in range(num_residual_layers)])
-
-    def fwd(self, cur, save):
-        """``cur`` arrives with the first block's (in-place) ReLU already applied by the epilogue of the convolution
-        that produced it; every ReLU in here rides in a convolution epilogue too (lgm_conv_xy_post):
-        y = relu(conv3x3(cur)), cur' = relu(conv1x1(y) + cur) - the next block's in-place ReLU, or the stack's final one."""
-        tape = []
-        c3 = self.layers[0].block[1]
-        if c3.weight.shape[1] == cur.shape[-1] and c3.weight.shape[1] == self.layers[0].block[3].weight.shape[0]:
-            fp = c3.weight._lgm_flat
-            r = ops.resstack_fwd(cur, [fp.ptr(b.block[1].weight) for b in self.layers],
-                                 [fp.ptr(b.block[3].weight) for b in self.layers], c3.weight.shape[0])
-            if r is not None:                     # the whole stack in one launch (4 x 4 maps of the 32 x 32 configuration)
-                for y, z in zip(*r):
-                    tape.append((cur, y))
-                    cur = z
-                return cur, (tape, cur)
-        for blk in self.layers:
-            y = blk.block[1].fwd(cur, act=ops.ACT_RELU)
-            z = blk.block[3].fwd(y, res=cur, act=ops.ACT_RELU)
-            tape.append((cur, y))
-            cur = z
-        return cur, (tape, cur)
-
-    def bwd(self, gc, saved, g):
-        """``g`` arrives already multiplied by the final ReLU's mask (the consumer's input gradient applied it in its
-        epilogue, mask = the stack's output); returns the gradient w.r.t. the stack's (ReLU'd) input, again with that
-        ReLU's mask applied - every activation backward is an epilogue mask of the input gradient before it."""
-        tape, out = saved
-        for blk, (r, y) in zip(reversed(self.layers), reversed(tape)):
-            gy = blk.block[3].bwd(gc, y, g, mask=y)
-            blk.block[1].bwd(gc, r, gy, g, True, mask=r)                # g = (g + dgrad(gy)) * relu'(r)
-        return g
+from models.modules.residual import ResidualBlock, ResidualStack  # noqa: F401  (reference layout: modules/residual.py)
+from models.modules.vector_quantizer import VectorQuantizer, VectorQuantizerEMA  # noqa: F401
 
 
 class Encoder(nn.Module):
@@ -138,84 +90,6 @@ class Decoder(nn.Module):
         g = L[2].bwd(gc, s, g, mask=s)
         g = L[1].bwd(gc, st, g)
         return L[0].bwd(gc, q, g)
-
-
-class _Embedding(nn.Module):
-    def __init__(self, num_embeddings, embedding_dim):
-        super().__init__()
-        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim).uniform_(
-            -1 / num_embeddings, 1 / num_embeddings))          # vector_quantizer.py:39-43
-
-
-def _world_size() -> int:
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-
-
-class VectorQuantizer(nn.Module):
-    """reference vector_quantizer.py:8-93 (state: ``embedding.weight``)."""
-
-    use_ema = False
-
-    def __init__(self, num_embeddings, embedding_dim, commitment_cost=0.25):
-        super().__init__()
-        self.num_embeddings, self.embedding_dim, self.commitment_cost = num_embeddings, embedding_dim, commitment_cost
-        self.embedding = _Embedding(num_embeddings, embedding_dim)
-
-    def fwd(self, lat, training: bool):
-        """lat: [B,H,W,D] dense NHWC.  Returns (q, scalars[3] = vq_loss, perplexity, mse, saved)."""
-        B, H, W, D = lat.shape
-        N, K = B * H * W, self.num_embeddings
-        L = ops.lib()
-        st = ops.stream()
-        fp = self.embedding.weight._lgm_flat
-        cb = fp.ptr(self.embedding.weight)
-        idx = torch.empty(N, dtype=torch.long, device=lat.device)
-        L.lgm_vq_assign(lat.data_ptr(), D, cb, N, K, D, idx.data_ptr(), None, st)
-        dw = ops.new((K, D), lat)
-        counts = ops.new((K,), lat)
-        L.lgm_vq_segment_sum(lat.data_ptr(), D, idx.data_ptr(), N, K, D, dw.data_ptr(), counts.data_ptr(), st)
-        if self.use_ema and training:      # codebook is replaced BEFORE the lookup (:168-177)
-            cnt_u, dw_u = counts, dw
-            if _world_size() > 1:
-                # Deliberate deviation (SURVEY.md §8e): upstream updates the codebook Parameter from per-rank
-                # statistics while DDP only re-broadcasts the EMA buffers, so ranks drift.  Here the batch
-                # statistics (count[K], dw[K,D]: 133 KB) are summed over ranks first; every rank then applies
-                # the identical update.  Single-GPU arithmetic is unchanged.
-                stat = torch.cat([counts.reshape(-1), dw.reshape(-1)])
-                dist.all_reduce(stat)
-                cnt_u, dw_u = stat[:K], stat[K:].view(K, D)
-            L.lgm_vq_ema_update(self._ema_cluster_size.data_ptr(), self._ema_embedding.data_ptr(), cb,
-                                cnt_u.data_ptr(), dw_u.data_ptr(), K, D, self.decay, self.epsilon, st)
-        q = ops.new(lat.shape, lat)
-        out3 = ops.new((3,), lat)
-        ws = ops.workspace(L.lgm_vq_gather_workspace(N, D), lat.device)
-        L.lgm_vq_gather_loss(lat.data_ptr(), D, cb, idx.data_ptr(), counts.data_ptr(), N, K, D,
-                             self.commitment_cost, q.data_ptr(), D, out3.data_ptr(), ws.data_ptr(), st)
-        return q, out3, (lat, q, idx, dw, counts)
-
-    def bwd(self, gc: GradCtx, saved, gq, g_vq):
-        lat, q, idx, dw, counts = saved
-        B, H, W, D = lat.shape
-        N, K = B * H * W, self.num_embeddings
-        fp = gc.flat
-        w = self.embedding.weight
-        glat = ops.new(lat.shape, lat)
-        ops.lib().lgm_vq_bwd(lat.data_ptr(), D, q.data_ptr(), D, gq.data_ptr(), D, fp.ptr(w), dw.data_ptr(),
-                             counts.data_ptr(), g_vq.data_ptr(), self.commitment_cost, N, K, D, glat.data_ptr(), D,
-                             fp.gptr(w), gc.beta(w), ops.stream())
-        return glat
-
-
-class VectorQuantizerEMA(VectorQuantizer):
-    """reference vector_quantizer.py:96-179 (buffers ``_ema_cluster_size``, ``_ema_embedding``)."""
-
-    use_ema = True
-
-    def __init__(self, num_embeddings, embedding_dim, commitment_cost=0.25, decay=0.99, epsilon=1e-5):
-        super().__init__(num_embeddings, embedding_dim, commitment_cost)
-        self.register_buffer("_ema_cluster_size", torch.zeros(num_embeddings))
-        self.register_buffer("_ema_embedding", self.embedding.weight.data.clone())
-        self.decay, self.epsilon = decay, epsilon
 
 
 class VQVAE(LightningModule):
