@@ -30,11 +30,14 @@ def _r4(n: int) -> int:
 
 
 class ParamSlot:
-    __slots__ = ("param", "name", "kind", "offset", "numel", "phys_shape")
+    __slots__ = ("param", "name", "kind", "offset", "numel", "phys_shape", "ref_shape")
 
     def __init__(self, param, name, kind, offset, numel, phys_shape):
         self.param, self.name, self.kind = param, name, kind
         self.offset, self.numel, self.phys_shape = offset, numel, phys_shape
+        # shape under which checkpoints exchange this parameter when it differs from the parameter's own (a layer held in
+        # the form its kernel wants whose row-major flattening is the reference's tensor: ddpm._DownConv); None: the same
+        self.ref_shape = None
 
 
 def phys_numel(p: torch.Tensor, kind: str) -> Tuple[int, Tuple[int, ...]]:

@@ -99,6 +99,8 @@ class FusedAdam(torch.optim.Optimizer):
                     for mine, theirs in self._STATE_KEYS:
                         ent[theirs] = logical_view(st[mine][sl.offset:sl.offset + sl.numel], p.shape, sl.kind,
                                                    sl.phys_shape).detach().clone().contiguous()
+                        if sl.ref_shape is not None:          # the reference's shape (same row-major order)
+                            ent[theirs] = ent[theirs].reshape(sl.ref_shape)
                     state[idx] = ent
                 ids.append(idx)
                 idx += 1
@@ -128,7 +130,7 @@ class FusedAdam(torch.optim.Optimizer):
                 sl = fp.slot(p)
                 for mine, theirs in self._STATE_KEYS:
                     logical_view(st[mine][sl.offset:sl.offset + sl.numel], p.shape, sl.kind, sl.phys_shape).copy_(
-                        ent[theirs].to(fp.device, torch.float32))
+                        ent[theirs].to(fp.device, torch.float32).reshape(p.shape))
                 st["step"] = int(float(ent["step"]))
 
 

@@ -191,25 +191,51 @@ class Attention(nn.Module):
         return gx
 
 
+class _DownConv(Conv2d):
+    """The convolution of ``Downsample`` (:100-104: ``Rearrange('b c (h p1) (w p2) -> b (c p1 p2) h w')`` + ``Conv2d(4 C, N, 1)``)
+    as what the two are together: a 2 x 2 / stride-2 convolution of the un-shuffled tensor (the index shuffle lives
+    in the convolution's gather, nothing is materialised).  The parameter is held as ``[N, C, 2, 2]``; its row-major
+    flattening IS the reference's ``[N, 4 C, 1, 1]`` weight (input channel ``c p1 p2`` = ``4 c + 2 p1 + p2``), same fan-in, same
+    initialisation stream.  ``state_dict()`` / ``load_state_dict()`` and the optimizer's checkpoint state exchange the
+    reference's shape (``ParamSlot.ref_shape``)."""
+
+    def __init__(self, dim, dim_out):
+        super().__init__(dim, dim_out, 2, stride=2, padding=0)
+
+    @property
+    def ref_shape(self):
+        return (self.cout, 4 * self.cin, 1, 1)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        k = prefix + "weight"
+        destination[k] = destination[k].reshape(self.ref_shape)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        k = prefix + "weight"
+        w = state_dict.get(k)
+        if w is not None and tuple(w.shape) == self.ref_shape:
+            state_dict = {kk: v for kk, v in state_dict.items() if kk.startswith(prefix)}
+            state_dict[k] = w.reshape(self.weight.shape)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+
 class _Down(nn.Module):
-    """Downsample (:100-104): pixel-unshuffle + 1x1 conv; keys ``<idx>.1.weight``."""
+    """Downsample (:100-104): pixel-unshuffle + 1x1 conv = one 2x2 / stride-2 convolution (``_DownConv``); keys
+    ``<idx>.1.weight`` / ``<idx>.1.bias``."""
 
     def __init__(self, dim, dim_out):
         super().__init__()
         self.add_module("0", nn.Identity())
-        self.add_module("1", Conv2d(dim * 4, dim_out, 1))
+        self.add_module("1", _DownConv(dim, dim_out))
 
     def fwd(self, x, out, save):
-        B, H, W, C = x.shape
-        lo = ops.new((B, H // 2, W // 2, 4 * C), x)
-        ops.pixel_unshuffle(x, lo, inverse=False)
-        self._modules["1"].fwd(lo, out=out)
-        return (x.shape, lo) if save else None
+        self._modules["1"].fwd(x, out=out)
+        return (x,) if save else None
 
     def bwd(self, gc, saved, gy, gx, accumulate):
-        xshape, lo = saved
-        glo = self._modules["1"].bwd(gc, lo, gy)
-        ops.pixel_unshuffle(gx, glo, inverse=True, accumulate=accumulate)
+        (x,) = saved
+        self._modules["1"].bwd(gc, x, gy, gx, accumulate)
         return gx
 
 
@@ -346,6 +372,9 @@ class Unet(nn.Module):
         taken = {id(p) for _, p, _ in first}
         rest = [(n, p, param_kind(n, p)) for n, p in named.items() if id(p) not in taken]
         self._flat = FlatParams(first + rest, device)
+        for m in self.modules():
+            if isinstance(m, _DownConv):       # checkpoints exchange this weight as the reference's [N, 4 C, 1, 1]
+                self._flat.slot(m.weight).ref_shape = m.ref_shape
         if ops.B3:                     # opt-in split-precision 3x3 convolutions (LGM_CONV_MODE=bf16x3)
             self._flat.enable_b3()
         elif ops.WINO:                 # Winograd F(2x2,3x3) in exact fp32 arithmetic for the 3x3 layers
