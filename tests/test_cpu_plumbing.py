@@ -193,6 +193,46 @@ dist.destroy_process_group()
 '''
 
 
+def test_downsample_weight_is_exchanged_in_the_reference_shape():
+    """ddpm._DownConv holds Downsample's weight (reference ddpm.py:100-104) as [N, C, 2, 2]; its row-major flattening is the
+    reference's [N, 4 C, 1, 1] tensor (input channel 'c p1 p2').  state_dict / load_state_dict use the reference's shape, on
+    plain parameters and on parameters bound to flat storage; the arithmetic is the reference's (Rearrange + 1x1)."""
+    import torch.nn.functional as F
+    from models.generative.diffusion.ddpm import Unet, _Down
+    torch.manual_seed(0)
+    d = _Down(6, 10)
+    conv = d._modules["1"]
+    assert conv.weight.shape == (10, 6, 2, 2) and conv.ref_shape == (10, 24, 1, 1)
+    sd = d.state_dict()
+    assert sd["1.weight"].shape == (10, 24, 1, 1) and sd["1.bias"].shape == (10,)
+    assert torch.equal(sd["1.weight"].reshape(10, 6, 2, 2), conv.weight)
+    x = torch.randn(2, 6, 8, 8)
+    b, c, hh, ww = x.shape                                      # the reference's Rearrange 'b c (h p1) (w p2) -> b (c p1 p2) h w'
+    lo = x.view(b, c, hh // 2, 2, ww // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(b, 4 * c, hh // 2, ww // 2)
+    want = F.conv2d(lo, sd["1.weight"], sd["1.bias"])
+    got = F.conv2d(x, conv.weight, conv.bias, stride=2)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+    w_new = torch.randn(10, 24, 1, 1)
+    d.load_state_dict({"1.weight": w_new, "1.bias": sd["1.bias"]}, strict=True)
+    assert torch.equal(conv.weight, w_new.reshape(10, 6, 2, 2))
+    d.load_state_dict({"1.weight": w_new.reshape(10, 6, 2, 2) * 2, "1.bias": sd["1.bias"]}, strict=True)   # its own shape too
+    assert torch.equal(conv.weight, w_new.reshape(10, 6, 2, 2) * 2)
+    # a whole network: reference-keyed, reference-shaped dictionary in and out, also once the parameters are flat-bound
+    from oracle import diffusion as OD
+    P = OD.unet_init(dim=8, channels=3, seed=3)
+    net = Unet(dim=8, channels=3)
+    net.load_state_dict(P, strict=True)
+    fp = net.prepare_hip("cpu")
+    out = net.state_dict()
+    assert set(out) == set(P) and all(out[k].shape == P[k].shape and torch.equal(out[k], P[k]) for k in P)
+    changed = [n for n, q in net.named_parameters() if q.shape != P[n].shape]
+    assert changed == ["downs.0.3.1.weight", "downs.1.3.1.weight", "downs.2.3.1.weight"]
+    for n in changed:
+        assert fp.slot(dict(net.named_parameters())[n]).ref_shape == tuple(P[n].shape)
+    net.load_state_dict({k: v * 3 for k, v in P.items()}, strict=True)
+    assert fp.still_bound() and torch.equal(net.state_dict()[changed[0]], P[changed[0]] * 3)
+
+
 def test_data_parallel_gloo_world2(tmp_path):
     """N-rank averaged gradients == 1-rank gradients on the concatenated batch (gloo, 2 ranks)."""
     script = tmp_path / "worker.py"

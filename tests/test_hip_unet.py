@@ -44,6 +44,51 @@ def case(golden_dir, tag):
     return fx, dim, S, P, img, noise, torch.as_tensor(fx["t"])
 
 
+@pytest.mark.parametrize("C,N,S,B", [(64, 64, 32, 4), (64, 128, 16, 3), (128, 256, 8, 8), (16, 16, 16, 2)])
+def test_downsample_is_one_strided_convolution(dev, C, N, S, B, parity):
+    """Downsample (reference ddpm.py:100-104, Rearrange 'b c (h p1) (w p2) -> b (c p1 p2) h w' + Conv2d(4C, N, 1))
+    runs as ONE 2x2 / stride-2 convolution of the un-shuffled tensor.  Forward, input gradient (overwrite and accumulate),
+    weight and bias gradient against the reference's two operations in float64, with the weight in the reference's shape."""
+    import torch.nn.functional as F
+    from lgm_hip import ops
+    from lgm_hip.flat import FlatParams
+    from lgm_hip.nn import GradCtx, param_kind
+    from models.generative.diffusion.ddpm import _Down
+    torch.manual_seed(C + N + S)
+    d = _Down(C, N)
+    w_ref = d.state_dict()["1.weight"].double().requires_grad_(True)          # [N, 4C, 1, 1]
+    b_ref = d.state_dict()["1.bias"].double().requires_grad_(True)
+    fp = FlatParams([(n, p, param_kind(n, p)) for n, p in d.named_parameters()], dev)
+    x = torch.randn(B, C, S, S)
+    gy = torch.randn(B, N, S // 2, S // 2)
+    xr = x.double().requires_grad_(True)
+    lo = xr.view(B, C, S // 2, 2, S // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, 4 * C, S // 2, S // 2)
+    want = F.conv2d(lo, w_ref, b_ref)
+    want.backward(gy.double())
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = torch.empty(B, S // 2, S // 2, N, device=dev)
+    saved = d.fwd(xh, out, True)
+    parity("forward", rel(out.permute(0, 3, 1, 2), want), RTOL)
+    gc = GradCtx(fp)
+    gyh = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    gx = torch.full((B, S, S, C), 7.0, device=dev)
+    d.bwd(gc, saved, gyh, gx, False)
+    gc.flush()
+    parity("input gradient", rel(gx.permute(0, 3, 1, 2), xr.grad), RTOL)
+    fp.bind_grad_views()
+    conv = d._modules["1"]
+    parity("weight gradient", rel(conv.weight.grad, w_ref.grad), RTOL)
+    parity("bias gradient", rel(conv.bias.grad, b_ref.grad), RTOL)
+    base = torch.randn(B, S, S, C, device=dev)
+    gx2 = base.clone()
+    gc2 = GradCtx(fp)
+    d.bwd(gc2, saved, gyh, gx2, True)
+    gc2.flush()
+    parity("accumulated input gradient", rel((gx2 - base).permute(0, 3, 1, 2), xr.grad), 10 * RTOL)
+    parity("accumulated weight gradient (beta = 1)", rel(conv.weight.grad, 2 * w_ref.grad), RTOL)
+    assert ops.lib() is not None
+
+
 @pytest.mark.parametrize("tag", ["small", "full", "full64"])
 def test_unet_matches_reference_fixture(dev, golden_dir, tag, parity):
     """small: dim 16 @16^2; full: dim 64 @32^2 (BASELINE config 2's network); full64: dim 64 @64^2 (config 5's).
