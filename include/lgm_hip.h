@@ -39,12 +39,13 @@
 extern "C" {
 #endif
 
-#define LGM_ABI_VERSION 6   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial;
+#define LGM_ABI_VERSION 7   /* 2: lgm_posemb takes a frequency table, BatchNorm entry points, *_planes / *_partial;
                              * 3: lgm_conv3x3_wino4*, lgm_gn_fwd_stats, lgm_conv3x3_wino_wgradn* + LgmWgradItem, a negative
                              *    dst offset in lgm_wino_weights table rows means "skip that copy", lgm_kernel_name*;
                              * 4: LgmPostOp carries the BatchNorm-backward sums (bn_*), lgm_bn_reduce3_coef_tiles;
                              * 5: lgm_set_cu_margin / lgm_cu_margin;
-                             * 6: lgm_extract_axpby, lgm_model_predictions (GaussianDiffusion's per-sample-time algebra), lgm_time_mlp_*, lgm_weng_* */
+                             * 6: lgm_extract_axpby, lgm_model_predictions (GaussianDiffusion's per-sample-time algebra), lgm_time_mlp_*, lgm_weng_*;
+                             * 7: lgm_gn_bwd_add */
 #define LGM_OK 0
 #define LGM_ERR_INVALID (-1)
 #define LGM_ERR_UNSUPPORTED (-2)
@@ -235,6 +236,17 @@ int lgm_gn_bwd_planes(const float* x, int64_t x_pitch, const float* gy_planes, i
                       const float* coefB, float* gx, int64_t gx_pitch, int accumulate_gx, float* ggamma,
                       float* gbeta, float affine_beta, float* gss, int64_t gss_pitch, float gss_beta,
                       float* workspace, float* rows, int64_t* desc, void* stream);
+/* ABI 7.  lgm_gn_bwd (rows = desc = NULL) / lgm_gn_bwd_deferred (both given) that ALSO adds gy to a second tensor,
+ * add_out[b, p, c] += gy[b, p, c] (add_pitch % 4 == 0, >= C; not gx, not gy): the gradient of ResnetBlock's identity
+ * residual - reference ddpm.py:187,200, `return h + self.res_conv(x)` with res_conv = nn.Identity - when the block's input
+ * gradient is accumulated into a tensor that already holds another branch's gradient (the skip connections of the UNet's
+ * down path, ddpm.py:440-447).  Replaces the separate `gx += gy` pass: block2's GroupNorm backward reads gy anyway. */
+int lgm_gn_bwd_add(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
+                   int C, int G, const float* gamma, const float* beta, const float* ss,
+                   int64_t ss_pitch, int act, const float* mean, const float* rstd, const float* coefA,
+                   const float* coefB, float* gx, int64_t gx_pitch, int accumulate_gx, float* ggamma,
+                   float* gbeta, float affine_beta, float* gss, int64_t gss_pitch, float gss_beta,
+                   float* workspace, float* rows, int64_t* desc, float* add_out, int64_t add_pitch, void* stream);
 /* Deferred form: when the one-pass kernel applies, the per-image rows [sc*S2 | sc*S1] (B x 2C floats) are left in
  * `rows` and `desc` is filled in the format of lgm_conv_wgrad_deferred (images play the role of splits), so that
  * lgm_wgrad_reduce_batch produces ggamma / gbeta of many layers in one launch; otherwise the gradients are

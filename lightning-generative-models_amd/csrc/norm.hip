@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ S1, const float* __restrict__ S2,
                                                            const float* __restrict__ ss, long ss_pitch, int B,
                                                            float* __restrict__ ggamma, float* __restrict__ gbeta,
-                                                           float affine_beta) {
+                                                           float affine_beta, float* add_out, long add_pitch) {
   const int affine_blocks = (int)gridDim.x - apply_blocks;
   if ((int)blockIdx.x < affine_blocks) {   // leading blocks: gamma/beta gradients, concurrent with the apply pass
     gn_bwd_affine_body((int)blockIdx.x, S1, S2, ss, ss_pitch, B, C, ggamma, gbeta, affine_beta);
@@ -545,6 +545,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   const long bc_off = (pix / HW) * C + c;
   const f32x4 xv = *reinterpret_cast<const f32x4*>(x + pix * x_pitch + c);
   f32x4 g = *reinterpret_cast<const f32x4*>(gy + pix * gy_pitch + c);
+  if (add_out) {                       // add_out += gy (see gn_fused_bwd_kernel)
+    float* ap = add_out + pix * add_pitch + c;
+    *reinterpret_cast<f32x4*>(ap) = *reinterpret_cast<const f32x4*>(ap) + g;
+  }
   if (act) {
     const f32x4 z = xv * *reinterpret_cast<const f32x4*>(A + bc_off) + *reinterpret_cast<const f32x4*>(Bc + bc_off);
 #pragma unroll
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
                                                            float* __restrict__ S1, float* __restrict__ S2,
                                                            float* __restrict__ gx, long gx_pitch, int accumulate,
                                                            float* __restrict__ T, const float* __restrict__ planes,
-                                                           long pstride, int splits) {
+                                                           long pstride, int splits, float* add_out, long add_pitch) {
   __shared__ float sh[NT * 8];
   __shared__ float wa1[256], wa2[256];
   __shared__ __align__(16) float cP[256], cQ[256], cR[256];
@@ -619,6 +623,21 @@ __global__ __launch_bounds__(NT) void gn_fused_bwd_kernel(const float* __restric
   } else {
 #pragma unroll
     for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const f32x4*>(gb + (long)(pl + k * ppb) * gy_pitch);
+  }
+  if (add_out) {
+    // add_out += gy: the gradient of an identity residual that leaves the block beside this norm (ResnetBlock with
+    // res_conv = Identity, reference ddpm.py:187,200) - gy is in registers here anyway, its own axpby launch is not needed.
+    // Rounds of four rows (NV more quads at once would spill at NV = 8).
+    float* ab = add_out + (long)b * HW * add_pitch + c;
+    constexpr int RN = NV < 4 ? NV : 4;
+#pragma unroll
+    for (int k0 = 0; k0 < NV; k0 += RN) {
+      f32x4 t[RN];
+#pragma unroll
+      for (int k = 0; k < RN; ++k) t[k] = *reinterpret_cast<const f32x4*>(ab + (long)(pl + (k0 + k) * ppb) * add_pitch);
+#pragma unroll
+      for (int k = 0; k < RN; ++k) *reinterpret_cast<f32x4*>(ab + (long)(pl + (k0 + k) * ppb) * add_pitch) = t[k] + g[k0 + k];
+    }
   }
   const f32x4 a = *reinterpret_cast<const f32x4*>(A + (long)b * C + c);
   const f32x4 bc = *reinterpret_cast<const f32x4*>(Bc + (long)b * C + c);
@@ -1019,7 +1038,8 @@ static int gn_bwd_impl(const float* x, int64_t x_pitch, const float* gy, int64_t
                        const float* coefA, const float* coefB, float* gx, int64_t gx_pitch,
                        int accumulate_gx, float* ggamma, float* gbeta, float affine_beta, float* gss,
                        int64_t gss_pitch, float gss_beta, float* workspace, float* rows, int64_t* desc,
-                       void* stream, const float* planes = nullptr, long pstride = 0, int splits = 0) {
+                       void* stream, const float* planes = nullptr, long pstride = 0, int splits = 0,
+                       float* add_out = nullptr, long add_pitch = 0) {
   if (desc) desc[6] = 0;      // nothing deferred unless the one-pass kernel below takes it
   if (int rc = gn_check(B, HW, C, G)) return rc;
   LGM_REQUIRE(x && (gy || planes) && gamma && beta && mean && rstd && coefA && coefB && gx && ggamma && gbeta && workspace,
@@ -1041,7 +1061,8 @@ static int gn_bwd_impl(const float* x, int64_t x_pitch, const float* gy, int64_t
 #define GN_FUSED(NTV, NVV)                                                                                             \
   hipLaunchKernelGGL((gn_fused_bwd_kernel<NTV, NVV>), dim3(B * (C / cb)), dim3(NTV), 0, s, x, (long)x_pitch, gy,        \
                      (long)gy_pitch, coefA, coefB, mean, rstd, HW, C, G, cb, act, gamma, beta, ss, (long)ss_pitch, gss, \
-                     (long)gss_pitch, gss_beta, S1, S2, gx, (long)gx_pitch, accumulate_gx, rows, planes, pstride, splits)
+                     (long)gss_pitch, gss_beta, S1, S2, gx, (long)gx_pitch, accumulate_gx, rows, planes, pstride, splits, \
+                     add_out, add_pitch)
 #define GN_FUSED_NV(NTV)                                                                       \
   do {                                                                                         \
     if (nv == 1) GN_FUSED(NTV, 1); else if (nv == 2) GN_FUSED(NTV, 2); else if (nv == 4) GN_FUSED(NTV, 4); \
@@ -1081,7 +1102,7 @@ static int gn_bwd_impl(const float* x, int64_t x_pitch, const float* gy, int64_t
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(apply_blocks + lgm_cdiv(C, 16)), dim3(256), 0, s, x, (long)x_pitch, gy,
                      (long)gy_pitch, coefA, coefB, P, Qc, Rc, gx, (long)gx_pitch, npix, HW, C, act, accumulate_gx,
                      apply_blocks, (const float*)S1, (const float*)S2, ss, (long)ss_pitch, B, ggamma, gbeta,
-                     affine_beta);
+                     affine_beta, add_out, add_pitch);
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }
@@ -1109,6 +1130,27 @@ extern "C" int lgm_gn_bwd_deferred(const float* x, int64_t x_pitch, const float*
   return gn_bwd_impl(x, x_pitch, gy, gy_pitch, B, HW, C, G, gamma, beta, ss, ss_pitch, act, mean, rstd, coefA, coefB, gx,
                      gx_pitch, accumulate_gx, ggamma, gbeta, affine_beta, gss, gss_pitch, gss_beta, workspace, rows, desc,
                      stream);
+}
+
+/* lgm_gn_bwd / lgm_gn_bwd_deferred (rows and desc both NULL or both given) that ALSO adds gy to a second tensor:
+ * add_out[b, p, c] += gy[b, p, c].  The backward of ResnetBlock's identity residual (reference ddpm.py:187,200:
+ * `return h + self.res_conv(x)` with res_conv = nn.Identity) when the block's input gradient is accumulated into a tensor
+ * that already holds another branch's gradient: gy is being read here anyway. */
+extern "C" int lgm_gn_bwd_add(const float* x, int64_t x_pitch, const float* gy, int64_t gy_pitch, int B, int HW,
+                              int C, int G, const float* gamma, const float* beta, const float* ss,
+                              int64_t ss_pitch, int act, const float* mean, const float* rstd,
+                              const float* coefA, const float* coefB, float* gx, int64_t gx_pitch,
+                              int accumulate_gx, float* ggamma, float* gbeta, float affine_beta, float* gss,
+                              int64_t gss_pitch, float gss_beta, float* workspace, float* rows, int64_t* desc,
+                              float* add_out, int64_t add_pitch, void* stream) {
+  LGM_REQUIRE((!rows && !desc) || (rows && desc && lgm_aligned16(rows) && lgm_aligned16(ggamma) && lgm_aligned16(gbeta)),
+              "gn_bwd_add: rows / descriptor must come together, gradients 16-byte aligned");
+  LGM_REQUIRE(gy && add_out && lgm_aligned16(add_out) && add_pitch % 4 == 0 && add_pitch >= C && add_out != gx &&
+                  (const float*)add_out != gy,
+              "gn_bwd_add: the second output must be a 16-byte aligned tensor of its own (pitch %% 4 == 0, >= C)");
+  return gn_bwd_impl(x, x_pitch, gy, gy_pitch, B, HW, C, G, gamma, beta, ss, ss_pitch, act, mean, rstd, coefA, coefB, gx,
+                     gx_pitch, accumulate_gx, ggamma, gbeta, affine_beta, gss, gss_pitch, gss_beta, workspace, rows, desc,
+                     stream, nullptr, 0, 0, add_out, (long)add_pitch);
 }
 
 /* gy given as the split-K partial planes of the producing input-gradient convolution (see lgm_gn_fwd_planes);

@@ -356,7 +356,8 @@ class GroupNorm(nn.Module):
         sv = ops.gn_fwd(x, self.groups, self.eps, fp.ptr(self.weight), fp.ptr(self.bias), ss, act, res, y, planes=planes)
         return y, sv
 
-    def bwd(self, gc: GradCtx, x, gy, ss, act, sv, gss, gx=None, accumulate=False, gy_planes=None):
+    def bwd(self, gc: GradCtx, x, gy, ss, act, sv, gss, gx=None, accumulate=False, gy_planes=None, add_gy_to=None):
+        """``add_gy_to``: a tensor that also receives ``+= gy`` in this launch (ops.gn_bwd)."""
         fp = gc.flat
         if gx is None:
             gx = ops.new(x.shape, x)
@@ -364,7 +365,7 @@ class GroupNorm(nn.Module):
         dfr = gc.defer_for(self.weight)
         ops.gn_bwd(x, gy, self.groups, fp.ptr(self.weight), fp.ptr(self.bias), ss, act, sv, gx, accumulate,
                    fp.gptr(self.weight), fp.gptr(self.bias), gc.beta(self.weight), gss, 0.0, defer=dfr,
-                   gy_planes=gy_planes)
+                   gy_planes=gy_planes, add_gy_to=add_gy_to)
         gc.beta(self.bias)
         return gx
 

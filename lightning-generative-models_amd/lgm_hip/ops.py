@@ -1087,10 +1087,32 @@ def gn_fwd(x, G, eps, gamma_ptr, beta_ptr, ss, act: bool, res, y, planes=None) -
 
 
 def gn_bwd(x, gy, G, gamma_ptr, beta_ptr, ss, act: bool, sv: GNSaved, gx, accumulate: bool,
-           ggamma_ptr, gbeta_ptr, affine_beta: float, gss, gss_beta: float, defer=None, gy_planes=None):
-    """``gy_planes`` = (address, stride, count, _) from conv_yx(partial=True): gy is summed from them (``gy`` unused)."""
+           ggamma_ptr, gbeta_ptr, affine_beta: float, gss, gss_beta: float, defer=None, gy_planes=None, add_gy_to=None):
+    """``gy_planes`` = (address, stride, count, _) from conv_yx(partial=True): gy is summed from them (``gy`` unused).
+    ``add_gy_to``: a second tensor that receives ``+= gy`` in the same launch (lgm_gn_bwd_add: an identity residual's
+    gradient beside this norm)."""
     B, H, W, C = x.shape
     ws = _gn_scratch(5 * B * C, x.device)
+    if add_gy_to is not None:
+        assert gy_planes is None and add_gy_to.shape == gy.shape
+        rws, desc = None, None
+        if defer is not None and ggamma_ptr % 16 == 0 and gbeta_ptr % 16 == 0:
+            key = (ggamma_ptr, B * 2 * C)
+            rws = _WGRAD_WS.get(key)
+            if rws is None:
+                rws = torch.empty(B * 2 * C + 4, dtype=torch.float32, device=x.device)
+                _WGRAD_WS[key] = rws
+            desc = (ctypes.c_int64 * 8)()
+        lib().lgm_gn_bwd_add(x.data_ptr(), pitch(x), gy.data_ptr(), pitch(gy), B, H * W, C, G, gamma_ptr, beta_ptr,
+                             _p(ss), pitch(ss) if ss is not None else 0, 1 if act else 0, sv.mean.data_ptr(),
+                             sv.rstd.data_ptr(), sv.A.data_ptr(), sv.Bc.data_ptr(), gx.data_ptr(), pitch(gx),
+                             1 if accumulate else 0, ggamma_ptr, gbeta_ptr, affine_beta, _p(gss),
+                             pitch(gss) if gss is not None else 0, gss_beta, ws.data_ptr(),
+                             None if rws is None else rws.data_ptr(), None if desc is None else ctypes.addressof(desc),
+                             add_gy_to.data_ptr(), pitch(add_gy_to), stream())
+        if desc is not None and desc[6] > 0:
+            defer.append(tuple(desc))
+        return
     if gy_planes is not None:
         rws, desc = None, None
         if defer is not None and ggamma_ptr % 16 == 0 and gbeta_ptr % 16 == 0:

@@ -12,6 +12,7 @@ Reference line anchors are given per class.
 from __future__ import annotations
 
 import math
+import os
 from collections import namedtuple
 from typing import List, Optional, Tuple
 
@@ -26,6 +27,9 @@ from lgm_hip.optim import EMA, FusedAdam
 
 
 ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])     # reference :25
+
+
+_NO_RES_FOLD = os.environ.get("LGM_NO_RES_FOLD") is not None       # A/B switch: the identity residual's gradient as its own axpby launch
 
 
 def _chan(t: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
@@ -69,7 +73,10 @@ class ResnetBlock(nn.Module):
 
     def bwd(self, gc: GradCtx, saved, gy, gss, gx, accumulate: bool):
         x, ss, u1, sv1, h1, u2, sv2 = saved
-        gu2 = self.block2.norm.bwd(gc, u2, gy, None, True, sv2, None)
+        # identity residual whose gradient joins a tensor that already holds another branch's (the skip connections of the
+        # down path): gx += gy rides in block2's GroupNorm backward, which reads gy anyway (lgm_gn_bwd_add; was an axpby launch)
+        fold_res = accumulate and not isinstance(self.res_conv, Conv2d) and not _NO_RES_FOLD
+        gu2 = self.block2.norm.bwd(gc, u2, gy, None, True, sv2, None, add_gy_to=gx if fold_res else None)
         gh1, pg = self.block2.proj.bwd(gc, h1, gu2, planes_for_groups=self.block1.norm.groups)
         del gu2
         gu1 = self.block1.norm.bwd(gc, u1, gh1, ss, True, sv1, gss, gy_planes=pg)
@@ -78,7 +85,8 @@ class ResnetBlock(nn.Module):
             self.block1.proj.bwd(gc, x, gu1, gx, accumulate)
             self.res_conv.bwd(gc, x, gy, gx, True)
         elif accumulate:
-            ops.axpby(gx, 1.0, gy, 1.0, gx)
+            if not fold_res:
+                ops.axpby(gx, 1.0, gy, 1.0, gx)
             self.block1.proj.bwd(gc, x, gu1, gx, True)
         else:
             self.block1.proj.bwd(gc, x, gu1, gx, False, res=gy)

@@ -26,7 +26,7 @@ def test_header_parses_and_library_exports_all_symbols():
 
 def test_abi_version_and_error_string():
     L = _lib.lib()
-    assert L.lgm_abi_version() == _lib.ABI_VERSION == 6        # the loader refuses a library built for another ABI
+    assert L.lgm_abi_version() == _lib.ABI_VERSION == 7        # the loader refuses a library built for another ABI
     # invalid-argument path works without a GPU: null geometry is rejected before any launch
     with pytest.raises(_lib.LgmError) as e:
         L.lgm_conv_xy(None, None, 0, None, None, None, 0, None, 0, None, 0, None)

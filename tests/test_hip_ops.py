@@ -267,6 +267,23 @@ def test_groupnorm_film_silu(dev, shape, film):
                gg2.data_ptr(), gb2.data_ptr(), 0.0, None, 0.0, defer=rows)
     ops.wgrad_reduce_batch(rows, dev)
     assert rel(nchw(gx2), x.grad) < RTOL and rel(gg2, gamma.grad) < RTOL and rel(gb2, beta.grad) < RTOL
+    # lgm_gn_bwd_add: the same results, and a second tensor (a channel slice of a wider one) receives += gy in the launch -
+    # bit for bit what a separate addition gives; immediate and deferred forms
+    for deferred in (False, True):
+        rows = []
+        wide = torch.randn(B, H, W, C + 8, device=dev)
+        tgt = wide[..., 4:4 + C]
+        want = tgt + gyd
+        keep = wide.clone()
+        gx3 = torch.zeros(B, H, W, C, device=dev)
+        gg3, gb3 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        ops.gn_bwd(xd, gyd, G, gd.data_ptr(), bd.data_ptr(), ssd if film else None, True, sv, gx3, False,
+                   gg3.data_ptr(), gb3.data_ptr(), 0.0, None, 0.0, defer=rows if deferred else None, add_gy_to=tgt)
+        if deferred:
+            ops.wgrad_reduce_batch(rows, dev)
+        assert torch.equal(gx3, gx2) and rel(gg3, gamma.grad) < RTOL and rel(gb3, beta.grad) < RTOL
+        assert torch.equal(tgt, want)
+        assert torch.equal(wide[..., :4], keep[..., :4]) and torch.equal(wide[..., 4 + C:], keep[..., 4 + C:])
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 128, 8, 8), (2, 512, 4, 4), (2, 16, 8, 8), (130, 256, 4, 4)])
