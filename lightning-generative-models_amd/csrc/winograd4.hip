@@ -723,6 +723,32 @@ static bool wino4_big_supported(const LgmConvGeom* g, int gather_channels, int o
   return g->B % (cls == 1 ? 2 : cls == 2 ? 8 : 1) == 0;
 }
 
+// Split count of an F(4x4) launch with `base` workgroups per split on `slots` workgroup slots.  A workgroup has the CU to
+// itself, so a grid a little above the slot count costs a whole second round: ceil(slots / base) - the former rule - gave
+// 256 -> 384 @ 8 x 8 (96 units) three splits = 288 workgroups = two rounds of 11 phases, 80 us, where two splits = 192
+// workgroups run ONE round of 16 phases, 52 us.  Cost in phase units (2.45 us): rounds x (fixed part of a workgroup +
+// its phases) + what the reducer (or the plane-summing GroupNorm) pays per plane - consulted only when the former rule's
+// grid does not fit one round, so the measured plans of DESIGN section 3.5 (128 units -> 2 splits, 64 -> 4) stand.
+int lgm_wino4_pick_splits(long base, long slots, int phases, int smax, int min_pps) {
+  int s0 = (int)((slots + base - 1) / base);        // the former rule: fill the slots
+  if (s0 > smax) s0 = smax;
+  while (s0 > 1 && phases / s0 < min_pps) --s0;     // a split shorter than ~4 phases is mostly prologue and epilogue
+  if (base * s0 <= slots) return s0;                // one round: the measured plans stand
+  int best = s0;
+  double best_cost = 1e30;
+  for (int s = 1; s <= smax; ++s) {
+    if (s > 1 && phases / s < min_pps) break;
+    const long rounds = (base * s + slots - 1) / slots;
+    const double pps = (double)((phases + s - 1) / s);
+    const double cost = (double)rounds * (5.5 + pps) + (s > 1 ? 2.0 + 0.5 * s : 0.0);
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = s;
+    }
+  }
+  return best;
+}
+
 int lgm_wino4_splits(const LgmConvGeom* g, int gather_channels, int out_channels) {
   using namespace lgmwino4;
   if (wino4_use_light(g, gather_channels, out_channels)) return lgm_wino4l_splits(g, gather_channels, out_channels);
@@ -736,11 +762,15 @@ int lgm_wino4_splits(const LgmConvGeom* g, int gather_channels, int out_channels
   if (forced > 0) return forced < smax ? forced : smax;
   const long slots = lgm_cu_budget();
   if (base >= slots * 3 / 4) return 1;
-  int s = (int)((slots + base - 1) / base);
-  if (s > smax) s = smax;
   static const int min_pps = getenv("LGM_WINO4_MIN_PPS") ? atoi(getenv("LGM_WINO4_MIN_PPS")) : 4;
-  while (s > 1 && phases / s < min_pps) --s;        // a split shorter than ~4 phases is mostly prologue and epilogue
-  return s;
+  static const bool old_rule = getenv("LGM_WINO4_SPLITS_CEIL") != nullptr;      // A/B switch: the former rule
+  if (old_rule) {
+    int s = (int)((slots + base - 1) / base);
+    if (s > smax) s = smax;
+    while (s > 1 && phases / s < min_pps) --s;      // a split shorter than ~4 phases is mostly prologue and epilogue
+    return s;
+  }
+  return lgm_wino4_pick_splits(base, slots, phases, smax, min_pps);
 }
 
 // partial (optional, int64 x 2): as lgm_wino_launch - the caller's consumer sums the split-K planes itself
