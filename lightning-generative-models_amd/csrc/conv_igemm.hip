@@ -1387,14 +1387,16 @@ struct WgradArgs {
 // and masks and every load is a raw buffer load (zero fill = an offset at the descriptor's range) - ~12 VALU
 // instructions per gathered row instead of ~60 (two integer divisions each), which beside fp32 MFMAs is the
 // difference between a VALU-bound and an MFMA-bound loop (DESIGN finding 11).
+// `lds`: 2 * WBK * (BM + BN) floats of workgroup memory, 16-byte aligned (the caller's: the stand-alone kernel's own
+// array, or - gemm_bwd_pair_kernel - the dynamic allocation the input-gradient body uses in ITS blocks)
 template <int BM, int BN, int TM, int TN, bool FAST>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bidx) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bidx, float* const lds) {
   static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 wave grid");
   constexpr int A_TPR = BM / 4, A_RPP = 256 / A_TPR, A_PER = WBK / A_RPP > 0 ? WBK / A_RPP : 1;
   constexpr int B_TPR = BN / 4, B_RPP = 256 / B_TPR, B_PER = WBK / B_RPP > 0 ? WBK / B_RPP : 1;
   static_assert(A_RPP <= WBK && B_RPP <= WBK, "tile too narrow for 256 threads");
-  __shared__ __align__(16) float As[2][WBK * BM];
-  __shared__ __align__(16) float Bs[2][WBK * BN];
+  float (*As)[WBK * BM] = reinterpret_cast<float (*)[WBK * BM]>(lds);
+  float (*Bs)[WBK * BN] = reinterpret_cast<float (*)[WBK * BN]>(lds + 2 * WBK * BM);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -1606,16 +1608,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bidx) {
 
 template <int BM, int BN, int TM, int TN, bool FAST>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
-  wgrad_body<BM, BN, TM, TN, FAST>(p, p.swz ? lgm_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);
+  __shared__ __align__(16) float wlds[2 * WBK * (BM + BN)];
+  wgrad_body<BM, BN, TM, TN, FAST>(p, p.swz ? lgm_xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x, wlds);
 }
 
 // Input gradient (blocks [0, n_ig): the 64 x 64 uniform-tap implicit GEMM) and weight gradient (the rest: the generic
 // 64 x 64 kernel) of ONE layer in ONE launch - the 1x1 convolutions and linears of the UNet (to_qkv / to_out
 // ddpm.py:214-223, res_conv :184, Downsample :100-104).  Same bodies as the separate kernels: bit-identical results.
 // At the per-GPU batches of a strong-scaled run each of the two is a ~9 us launch on a quarter of the chip.
+// ONE dynamic allocation serves whichever body a block runs (max of the two: 64 KB, two workgroups per CU).  With the
+// weight-gradient body's operands in a static array of their own the kernel asked for 64 + 34 KB = 98 KB, ONE workgroup
+// per CU - and its 288 ... 384-block grids ran a second, nearly empty round (profiles/r06_negative_results.txt, item 9).
 __global__ __launch_bounds__(256) void gemm_bwd_pair_kernel(const IgemmArgs pi, const WgradArgs pw, const int n_ig) {
+  extern __shared__ __align__(16) float smem[];
   if ((int)blockIdx.x < n_ig) igemm_body<MODE_YX, 64, 64, 1, 1, true>(pi, (int)blockIdx.x);
-  else wgrad_body<64, 64, 1, 1, true>(pw, (int)blockIdx.x - n_ig);
+  else wgrad_body<64, 64, 1, 1, true>(pw, (int)blockIdx.x - n_ig, smem);
 }
 
 // Deterministic split-K reduction: out[i] = beta*out[i] + sum_s ws[s*slab + i] (fixed order:
@@ -1941,13 +1948,15 @@ static int conv_bwd_pair_impl(const LgmConvGeom* g, const float* gy, int64_t gy_
   const bool together = c.rec_i && c.rec_w && c.ig_blocks + c.wg_blocks <= pair_max;
   if (together) {
     static size_t attr = 0;
-    if (c.ig_smem > attr) {
+    constexpr size_t wg_smem = (size_t)2 * WBK * (64 + 64) * sizeof(float);      // wgrad_body<64, 64>: 64 KB
+    const size_t pair_smem = c.ig_smem > wg_smem ? c.ig_smem : wg_smem;
+    if (pair_smem > attr) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bwd_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)c.ig_smem);
-      attr = c.ig_smem;
+                          (int)pair_smem);
+      attr = pair_smem;
     }
     lgm_note_kernel(LGM_KNAME("gemm_bwd_pair_kernel"));
-    hipLaunchKernelGGL(gemm_bwd_pair_kernel, dim3(c.ig_blocks + c.wg_blocks), dim3(256), c.ig_smem, s, c.ig, wa,
+    hipLaunchKernelGGL(gemm_bwd_pair_kernel, dim3(c.ig_blocks + c.wg_blocks), dim3(256), pair_smem, s, c.ig, wa,
                        (int)c.ig_blocks);
   } else {
     if (c.rec_w) {
