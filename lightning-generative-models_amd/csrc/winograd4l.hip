@@ -523,8 +523,6 @@ int lgm_wino4l_stats_parts(const LgmConvGeom* g) {
 
 // Split-K plan.  Light workgroups come two to a CU (512 slots, two waves per SIMD - what hides a cold launch's memory
 // latency): a launch is split until it fills them, while every split keeps >= min_pps phases.
-int lgm_wino4_pick_splits(long base, long slots, int phases, int smax, int min_pps);
-
 int lgm_wino4l_splits(const LgmConvGeom* g, int gather_channels, int out_channels) {
   using namespace lgmwino4l;
   const long base = lgm_wino4l_units(g, out_channels);
@@ -540,14 +538,12 @@ int lgm_wino4l_splits(const LgmConvGeom* g, int gather_channels, int out_channel
   const int target = target_env > 0 ? target_env : lgm_cu_budget();
   if (base >= target * 3 / 4) return 1;
   static const int min_pps = getenv("LGM_WINO4L_MIN_PPS") ? atoi(getenv("LGM_WINO4L_MIN_PPS")) : 4;
-  static const bool old_rule = getenv("LGM_WINO4_SPLITS_CEIL") != nullptr;      // A/B switch: the former rule
-  if (old_rule) {
-    int s = (int)((target + base - 1) / base);
-    if (s > smax) s = smax;
-    while (s > 1 && phases / s < min_pps) --s;
-    return s;
-  }
-  return lgm_wino4_pick_splits(base, target, phases, smax, min_pps);     // (winograd4.hip: no grid a little above the slots)
+  // (two light workgroups fit a CU: a grid a little above `target` does not run a second round, so the 32-tile kernel's
+  // lgm_wino4_pick_splits does not apply - with it B = 64 on a rank's plans went 6.74 -> 6.84 ms)
+  int s = (int)((target + base - 1) / base);
+  if (s > smax) s = smax;
+  while (s > 1 && phases / s < min_pps) --s;
+  return s;
 }
 
 int lgm_wino4l_launch(const LgmConvGeom* g, int yx, const float* a, long a_pitch, const float* u, const float* bias,
