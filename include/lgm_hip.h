@@ -45,7 +45,7 @@ extern "C" {
                              * 4: LgmPostOp carries the BatchNorm-backward sums (bn_*), lgm_bn_reduce3_coef_tiles;
                              * 5: lgm_set_cu_margin / lgm_cu_margin;
                              * 6: lgm_extract_axpby, lgm_model_predictions (GaussianDiffusion's per-sample-time algebra), lgm_time_mlp_*, lgm_weng_*;
-                             * 7: lgm_gn_bwd_add */
+                             * 7: lgm_gn_bwd_add, lgm_wgrad1x1_group* */
 #define LGM_OK 0
 #define LGM_ERR_INVALID (-1)
 #define LGM_ERR_UNSUPPORTED (-2)
@@ -695,6 +695,14 @@ typedef struct {
   int64_t ws_bytes;
   int64_t* desc;
 } LgmWgradItem;
+/* ABI 7.  The same for the weight / bias gradients of 2 ... 4 1x1 convolutions (reference: autograd's backward of res_conv
+ * ddpm.py:187, to_out :215,253, to_qkv :213,252): ONE launch of the streaming 1x1 weight-gradient kernel, every layer on its
+ * share of the chip.  All layers must take that kernel on their own (channel counts in whole 64-blocks, whole 64-pixel
+ * chunks) and use the same block tile (Nw % 128 and Cw % 128 agree).  Descriptors as lgm_conv_wgrad_deferred (desc[6] = 1:
+ * that layer's gradient is complete on return). */
+int64_t lgm_wgrad1x1_group_supported(int n, const LgmConvGeom* const* geoms);
+int lgm_wgrad1x1_group_workspaces(int n, const LgmConvGeom* const* geoms, int64_t* out);     /* bytes per layer */
+int lgm_wgrad1x1_group(int n, const LgmWgradItem* items, void* stream);
 int64_t lgm_conv3x3_wino_wgradn_supported(int n, const LgmConvGeom* const* geoms);
 int lgm_conv3x3_wino_wgradn_workspaces(int n, const LgmConvGeom* const* geoms, int64_t* out);
 int lgm_conv3x3_wino_wgradn(int n, const LgmWgradItem* items, void* stream);

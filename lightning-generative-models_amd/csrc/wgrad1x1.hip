@@ -29,8 +29,10 @@ struct PArgs {
   int tiles_n, tiles_k, splits, chunks_per_split, total_chunks;
 };
 
+// The kernel body as a device function of (arguments, logical block id): its own launch (wgrad1x1_kernel) or one block
+// range of wgrad1x1_group_kernel (several layers' weight gradients in ONE launch).
 template <int TN, int TK>   // wave tile (32 TN) x (32 TK); waves 2 (n) x 2 (k); block tile NB x KB
-__global__ __launch_bounds__(256) void wgrad1x1_kernel(const PArgs p) {
+__device__ __forceinline__ void wgrad1x1_body(const PArgs& p, const int bidx) {
   constexpr int NB = 64 * TN, KB = 64 * TK;
   constexpr int R = 64;                         // pixel rows per chunk
   constexpr int NLY = NB / 16, NLX = KB / 16;   // 16-byte loads per thread and chunk
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const PArgs p) {
   const int wn = wid >> 1, wk = wid & 1;
   const int lr = lane & 31, lh = lane >> 5;
 
-  int bid = blockIdx.x;
+  int bid = bidx;
   const int split = bid % p.splits;
   bid /= p.splits;
   const int tk = bid % p.tiles_k, tn = bid / p.tiles_k;
@@ -219,6 +221,26 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const PArgs p) {
   }
 }
 
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad1x1_kernel(const PArgs p) {
+  wgrad1x1_body<TN, TK>(p, (int)blockIdx.x);
+}
+
+// Two ... four layers with the same block tile in one grid: blocks [0, e0) run layer a, [e0, e1) layer b, [e1, e2) layer c,
+// the rest layer d.  A stand-alone launch of this kernel is ~13 us of prologue, epilogue and ramp around a K loop that runs
+// at the MFMA rate (tools/step listing: 27 us for 14 us of MFMAs at 128 -> 64 @ 32 x 32, B = 128); the weight gradient has no
+// reader before the optimizer, so up to four layers wait for each other (GradCtx.queue_wgrad1x1) and share ONE of them -
+// each on its share of the chip with a proportionally longer pixel range per workgroup (fewer slabs as well).
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad1x1_group_kernel(const PArgs a, const PArgs b, const PArgs c, const PArgs d,
+                                                             const int e0, const int e1, const int e2) {
+  const int bid = (int)blockIdx.x;
+  if (bid < e0) wgrad1x1_body<TN, TK>(a, bid);
+  else if (bid < e1) wgrad1x1_body<TN, TK>(b, bid - e0);
+  else if (bid < e2) wgrad1x1_body<TN, TK>(c, bid - e1);
+  else wgrad1x1_body<TN, TK>(d, bid - e2);
+}
+
 inline int tile_of(int dim) { return dim % 128 == 0 ? 128 : 64; }
 
 }  // namespace
@@ -281,6 +303,121 @@ int lgm_wgrad1x1_launch(const LgmConvGeom* g, const float* y, long y_pitch, cons
   else if (KB == 128) LGM_W1_LAUNCH(1, 2);
   else LGM_W1_LAUNCH(1, 1);
 #undef LGM_W1_LAUNCH
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+// ---- several layers in one launch --------------------------------------------------------------------------------------
+// Plan: the chip's workgroup slots are dealt out in proportion to the layers' work (64-row chunks x weight blocks); a layer's
+// share / its weight blocks = its split count.  false: not a group this kernel takes (2 ... 4 layers, each supported on its
+// own, one block tile for all, every split at least four chunks long).
+static bool wgrad1x1_group_plan(int n, const LgmConvGeom* const* gs, int* splits, int* per) {
+  if (n < 2 || n > 4) return false;
+  double work[4], tot = 0.0;
+  int units[4], total[4];
+  const int nb0 = tile_of(gs[0]->Nw), kb0 = tile_of(gs[0]->Cw);
+  for (int k = 0; k < n; ++k) {
+    const LgmConvGeom* g = gs[k];
+    if (!g || !lgm_wgrad1x1_supported(g, g->Nw, g->Cw)) return false;
+    if (tile_of(g->Nw) != nb0 || tile_of(g->Cw) != kb0) return false;
+    units[k] = (g->Nw / nb0) * (g->Cw / kb0);
+    total[k] = (int)(((long)g->B * g->H * g->W) / 64);
+    work[k] = (double)total[k] * units[k];
+    tot += work[k];
+  }
+  const int budget = lgm_cu_budget();
+  long used = 0;
+  for (int k = 0; k < n; ++k) {
+    int s = (int)((double)budget * work[k] / tot) / units[k];
+    if (s < 1) s = 1;
+    if (s > total[k]) s = total[k];
+    per[k] = lgm_cdiv(total[k], s);
+    if (per[k] < 4) return false;
+    splits[k] = lgm_cdiv(total[k], per[k]);
+    used += (long)splits[k] * units[k];
+  }
+  return used <= budget;
+}
+
+extern "C" int64_t lgm_wgrad1x1_group_supported(int n, const LgmConvGeom* const* geoms) {
+  if (!geoms || n < 2 || n > 4) return 0;
+  int splits[4], per[4];
+  return wgrad1x1_group_plan(n, geoms, splits, per) ? 1 : 0;
+}
+
+extern "C" int lgm_wgrad1x1_group_workspaces(int n, const LgmConvGeom* const* geoms, int64_t* out) {
+  LGM_REQUIRE(geoms && out && n >= 2 && n <= 4, "wgrad1x1_group_workspaces: 2 ... 4 layers expected");
+  int splits[4], per[4];
+  LGM_REQUIRE(wgrad1x1_group_plan(n, geoms, splits, per), "wgrad1x1_group_workspaces: unsupported group of layers");
+  for (int k = 0; k < n; ++k) {
+    const int64_t slab = (int64_t)geoms[k]->Nw * geoms[k]->Cw + geoms[k]->Nw;
+    out[k] = splits[k] > 1 ? (int64_t)splits[k] * slab * (int64_t)sizeof(float) : 16;
+  }
+  return LGM_OK;
+}
+
+extern "C" int lgm_wgrad1x1_group(int n, const LgmWgradItem* it, void* stream) {
+  LGM_REQUIRE(it && n >= 2 && n <= 4, "wgrad1x1_group: 2 ... 4 layers expected");
+  const LgmConvGeom* gs[4];
+  for (int k = 0; k < n; ++k) gs[k] = it[k].g;
+  int splits[4], per[4];
+  LGM_REQUIRE(wgrad1x1_group_plan(n, gs, splits, per), "wgrad1x1_group: unsupported group of layers");
+  PArgs pp[4];
+  int nb[4] = {0, 0, 0, 0};
+  const int NB = tile_of(gs[0]->Nw), KB = tile_of(gs[0]->Cw);
+  for (int k = 0; k < n; ++k) {
+    const LgmConvGeom* g = gs[k];
+    LGM_REQUIRE(it[k].desc && it[k].y && it[k].x && it[k].gw && it[k].y_pitch % 4 == 0 && it[k].x_pitch % 4 == 0 &&
+                    it[k].y_pitch >= g->Nw && it[k].x_pitch >= g->Cw && lgm_aligned16(it[k].y) && lgm_aligned16(it[k].x) &&
+                    lgm_aligned16(it[k].gw) && (!it[k].gbias || lgm_aligned16(it[k].gbias)) &&
+                    lgm_wgrad1x1_supported(g, it[k].y_pitch, it[k].x_pitch),
+                "wgrad1x1_group: layer %d: 16-byte aligned operands with pitch %% 4 == 0 inside 32-bit offsets expected", k);
+    const long n_w = (long)g->Nw * g->Cw, slab = n_w + g->Nw;
+    PArgs& p = pp[k];
+    p = PArgs{};
+    p.y = it[k].y; p.x = it[k].x; p.beta = it[k].beta; p.slab = slab;
+    p.y_pitch = it[k].y_pitch; p.x_pitch = it[k].x_pitch;
+    p.P = g->B * g->H * g->W; p.Nw = g->Nw; p.Cw = g->Cw;
+    p.tiles_n = g->Nw / NB; p.tiles_k = g->Cw / KB;
+    p.splits = splits[k]; p.chunks_per_split = per[k]; p.total_chunks = p.P / 64;
+    if (splits[k] > 1) {
+      LGM_REQUIRE(it[k].ws && lgm_aligned16(it[k].ws) && it[k].ws_bytes >= (int64_t)splits[k] * slab * (int64_t)sizeof(float),
+                  "wgrad1x1_group: workspace %d too small", k);
+      p.out = (float*)it[k].ws;
+      p.bias_out = it[k].gbias ? (float*)it[k].ws + n_w : nullptr;
+    } else {
+      p.out = it[k].gw;
+      p.bias_out = it[k].gbias;
+    }
+    nb[k] = p.tiles_n * p.tiles_k * splits[k];
+    union { float f; int64_t i; } bbits;
+    bbits.i = 0;
+    bbits.f = it[k].beta;
+    int64_t* d = it[k].desc;
+    d[0] = (int64_t)(uintptr_t)it[k].ws; d[1] = slab; d[2] = (int64_t)(uintptr_t)it[k].gw; d[3] = n_w;
+    d[4] = (int64_t)(uintptr_t)it[k].gbias; d[5] = it[k].gbias ? g->Nw : 0; d[6] = splits[k]; d[7] = bbits.i;
+  }
+  for (int k = n; k < 4; ++k) pp[k] = pp[n - 1];           // never reached: its block range is empty
+  const int e0 = nb[0], e1 = e0 + nb[1], e2 = e1 + nb[2];
+  const unsigned nblocks = (unsigned)(e2 + nb[3]);
+  const size_t smem = (size_t)2 * 64 * (NB + KB) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define LGM_W1G_LAUNCH(TNV, TKV)                                                                                       \
+  do {                                                                                                                 \
+    auto kern = wgrad1x1_group_kernel<TNV, TKV>;                                                                       \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    lgm_note_kernel(LGM_KNAME("wgrad1x1_group_kernel<" #TNV ", " #TKV ">"));                                            \
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, s, pp[0], pp[1], pp[2], pp[3], e0, e1, e2);               \
+  } while (0)
+  if (NB == 128 && KB == 128) LGM_W1G_LAUNCH(2, 2);
+  else if (NB == 128) LGM_W1G_LAUNCH(2, 1);
+  else if (KB == 128) LGM_W1G_LAUNCH(1, 2);
+  else LGM_W1G_LAUNCH(1, 1);
+#undef LGM_W1G_LAUNCH
   LGM_LAUNCH_CHECK();
   return LGM_OK;
 }

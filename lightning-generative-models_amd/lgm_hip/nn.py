@@ -34,6 +34,7 @@ class GradCtx:
         # one launch per layer; the owner of the context MUST call flush() before the gradients are read
         self.deferred = [] if defer else None
         self._pending = []
+        self._pending1 = []
         if transposed:
             flat.refresh_transposed()      # one launch per backward pass
 
@@ -60,6 +61,32 @@ class GradCtx:
             ops.conv_wgrad(e[0], e[1], e[2], e[3], e[4], e[5], defer=self.deferred)
         elif pend:
             ops.conv_wgrad_group(pend, self.deferred)
+        self.finish_pending1x1()
+
+    # -- 1x1 weight gradients on the streaming kernel wait for partners too: up to four share ONE launch ----------------
+    def queue_wgrad1x1(self, g, gy, x, gw_ptr: int, beta: float, gb_ptr):
+        """Deferred passes only; same rules as queue_wgrad (ops.conv_wgrad1x1_group)."""
+        new = (g, gy, x, gw_ptr, beta, gb_ptr)
+        # one queue per block tile (a launch runs one instantiation of the kernel): a layer joins the queue whose group
+        # takes it, and a queue is issued when it is full or at the end of the bucket - layers of another tile in between
+        # do not break it up (they did at first: 14 launches became 11 instead of 5)
+        for q in self._pending1:
+            if ops.wgrad1x1_group_supported([e[0] for e in q] + [g]):
+                q.append(new)
+                if len(q) == 4:
+                    self._pending1.remove(q)
+                    ops.conv_wgrad1x1_group(q, self.deferred)
+                return
+        self._pending1.append([new])
+
+    def finish_pending1x1(self):
+        queues, self._pending1 = self._pending1, []
+        for pend in queues:
+            if len(pend) == 1:
+                e = pend[0]
+                ops.conv_wgrad(e[0], e[1], e[2], e[3], e[4], e[5], defer=self.deferred)
+            else:
+                ops.conv_wgrad1x1_group(pend, self.deferred)
 
     def defer_for(self, p: nn.Parameter):
         """The deferred-reduction list for the FIRST gradient contribution of ``p`` in this pass, else None: the
@@ -173,6 +200,17 @@ class Conv2d(nn.Module):
             r = ops.conv_bwd_pair(g, gy, x, fp.ptr(self.weight), fp.gptr(self.weight), bw, gb, dfr, pres, gx, partial=ok_pl)
             if r is not False:
                 return (gx, r) if planes_for_groups else gx
+        if (need_gx and self.k == 1 and mask is None and bn_sums is None and not planes_for_groups and dfr is not None
+                and ops.wgrad1x1_queueable(g, gy, x)):
+            # a 1x1 layer whose weight gradient runs the streaming kernel on a launch of its own: it waits for up to three
+            # partners (GradCtx.queue_wgrad1x1: one launch for four); the input gradient as before
+            gc.queue_wgrad1x1(g, gy, x, fp.gptr(self.weight), bw, gb)
+            if gx is None:
+                gx = ops.new(x.shape, x)
+                accumulate = False
+            assert not (accumulate and res is not None)
+            ops.conv_yx(g, gy, fp.ptr(self.weight), None, gx if accumulate else res, gx, fp.tptr(self.weight))
+            return gx
         if need_gx and (self.k != 3 or mask is not None or bn_sums is not None) and not planes_for_groups and not ops.B3:
             # the other layers (1x1, 4x4 / stride 2, 7x7; a 3x3 layer the pair above did not take keeps its Winograd /
             # direct input gradient below): both gradients through lgm_conv_bwd_pair - one launch when the kernels can

@@ -817,6 +817,75 @@ def conv_wgrad2(a, b, defer):
     conv_wgrad_group([a, b], defer)
 
 
+# Up to four 1x1 layers' weight gradients in one launch of the streaming 1x1 kernel (lgm_wgrad1x1_group): a stand-alone
+# launch is ~13 us of prologue / epilogue / ramp around a K loop at the MFMA rate, and nothing reads a weight gradient
+# before the optimizer.  LGM_NO_WGRAD1X1_GROUP=1 issues them singly (A/B switch).
+WGRAD1X1_GROUP = _os.environ.get("LGM_NO_WGRAD1X1_GROUP", "0") != "1"
+_W1G_OK = {}
+_W1G_WS = {}
+
+
+def wgrad1x1_group_supported(geoms) -> bool:
+    key = tuple(_gkey(g) for g in geoms)
+    v = _W1G_OK.get(key)
+    if v is None:
+        arr = _geom_array(geoms)        # bound to a local: the C side reads it during the call
+        v = bool(lib().lgm_wgrad1x1_group_supported(len(geoms), ctypes.addressof(arr)))
+        del arr
+        _W1G_OK[key] = v
+    return v
+
+
+def wgrad1x1_queueable(g: ConvGeom, gy, x) -> bool:
+    """1x1 layers whose weight gradient takes the streaming kernel on its own launch today (never the one-launch
+    gemm_bwd_pair): it can wait for partners."""
+    if not WGRAD1X1_GROUP or B3 or g.KH != 1 or g.KW != 1 or g.stride != 1 or g.pad != 0:
+        return False
+    if gy.data_ptr() % 16 or x.data_ptr() % 16 or pitch(gy) % 4 or pitch(x) % 4:
+        return False
+    return wgrad1x1_group_supported([g, g])
+
+
+def conv_wgrad1x1_group(entries, defer):
+    """entries = 2 ... 4 of (geometry, gy, x, gw address, beta, gbias address), 1x1 layers: all weight gradients in ONE
+    launch; slab descriptors of the layers that split join ``defer``."""
+    L = lib()
+    n = len(entries)
+    geoms = [e[0] for e in entries]
+    wkey = tuple(_gkey(g) for g in geoms)
+    need = _W1G_WS.get(wkey)
+    if need is None:
+        out = (ctypes.c_int64 * n)()
+        arr = _geom_array(geoms)
+        L.lgm_wgrad1x1_group_workspaces(n, ctypes.addressof(arr), ctypes.addressof(out))
+        del arr
+        need = tuple(max(int(out[k]), int(L.lgm_conv_wgrad_workspace(ctypes.byref(g)))) for k, g in enumerate(geoms))
+        _W1G_WS[wkey] = need
+    items = (WgradItem * n)()
+    descs = []
+    flops = nbytes_alg = 0.0
+    for k, (g, gy, x, gw_ptr, beta, gb_ptr) in enumerate(entries):
+        key = (gw_ptr, need[k])
+        ws = _WGRAD_WS.get(key)
+        if ws is None:
+            ws = torch.empty(max(need[k] // 4 + 4, 16), dtype=torch.float32, device=gy.device)
+            _WGRAD_WS[key] = ws
+        desc = (ctypes.c_int64 * 8)()
+        descs.append(desc)
+        items[k] = WgradItem(ctypes.addressof(g), gy.data_ptr(), pitch(gy), x.data_ptr(), pitch(x), gw_ptr, gb_ptr, beta,
+                             ws.data_ptr(), ws.numel() * 4, ctypes.addressof(desc))
+        flops += _conv_flops(g)
+        nbytes_alg += _conv_bytes(g)
+    if TIMER is not None:
+        TIMER.begin("wgrad", flops, nbytes_alg)
+    L.lgm_wgrad1x1_group(n, ctypes.addressof(items), stream())
+    if TIMER is not None:
+        TIMER.end()
+    for desc in descs:
+        if desc[6] > 1:
+            defer.append(tuple(desc))
+
+
 def conv_bwd_pair(g: ConvGeom, gy, x, w_ptr: int, gw_ptr: int, beta: float, gbias_ptr: Optional[int], defer, res, gx,
                   partial: bool = False):
     """Input gradient AND weight gradient of a 3x3 layer in ONE launch (lgm_conv3x3_wino_bwd): at small per-GPU batches
@@ -935,7 +1004,7 @@ def clear_plan_caches():
     those knobs change what the queries return.  Buffers are kept (captured graphs have their addresses baked in); they are
     looked up by size, so a plan that now needs more gets a new one."""
     for d in (_CONV_WS_BYTES, _WINO_OK, _WINO_WS, _WINO4_OK, _EPI_STATS, _WINO_FITS, _PAIR_OK, _WG2_OK, _WG2_WS,
-              _GN_PLANES_OK):
+              _W1G_OK, _W1G_WS, _GN_PLANES_OK):
         d.clear()
 
 

@@ -218,6 +218,50 @@ def test_conv_transpose(dev, case):
     assert rel(gw, phys_weight(w.grad, dev)) < RTOL
 
 
+@pytest.mark.parametrize("layers", [
+    [(64, 32, 128, 64, True), (64, 32, 128, 64, False), (128, 32, 128, 64, True)],             # tile 64 x 128, three layers
+    [(128, 16, 128, 256, True), (128, 16, 256, 256, True)],                                    # tile 128 x 128, a pair
+    [(64, 32, 64, 64, True), (64, 32, 64, 64, True), (128, 32, 64, 64, False), (96, 32, 64, 64, True)]])   # tile 64 x 64, four
+def test_grouped_1x1_weight_gradients(dev, layers):
+    """lgm_wgrad1x1_group: the weight / bias gradients of 2 ... 4 1x1 convolutions in ONE launch (block ranges of one grid,
+    every layer on its share of the chip) against float64, overwrite and accumulate, through the batched slab reducer."""
+    from lgm_hip import ops
+    g = torch.Generator().manual_seed(len(layers))
+    ents, refs, keep = [], [], []
+    for (B, S, C, N, bias) in layers:
+        x = torch.randn(B, C, S, S, generator=g)
+        gy = torch.randn(B, N, S, S, generator=g)
+        xd, gyd = nhwc(x, dev, extra=4), nhwc(gy, dev)
+        geom = ops.make_geom(B, S, S, C, N, 1, 1, 1, 0)
+        gw = torch.full((N, 1, C), 3.0, device=dev)
+        gb = torch.full((N,), -1.0, device=dev) if bias else None
+        ents.append((geom, gyd, xd, gw.data_ptr(), 0.0, gb.data_ptr() if bias else None))
+        refs.append((torch.einsum("bnhw,bchw->nc", gy.double(), x.double()), gy.double().sum((0, 2, 3))))
+        keep.append((gw, gb, xd, gyd, geom))
+    assert ops.wgrad1x1_group_supported([e[0] for e in ents])
+    rows = []
+    ops.conv_wgrad1x1_group(ents, rows)
+    assert ops.lib()._dll.lgm_last_kernel().decode().startswith("wgrad1x1_group_kernel")
+    ops.wgrad_reduce_batch(rows, dev)
+    for (gw, gb, _, _, _), (rw, rb) in zip(keep, refs):
+        assert rel(gw[:, 0, :], rw) < RTOL
+        if gb is not None:
+            assert rel(gb, rb) < RTOL
+    # beta = 1: accumulates
+    rows = []
+    ops.conv_wgrad1x1_group([(e[0], e[1], e[2], e[3], 1.0, e[5]) for e in ents], rows)
+    ops.wgrad_reduce_batch(rows, dev)
+    for (gw, gb, _, _, _), (rw, rb) in zip(keep, refs):
+        assert rel(gw[:, 0, :], 2 * rw) < RTOL
+        if gb is not None:
+            assert rel(gb, 2 * rb) < RTOL
+    # the same layers one by one give the same numbers to rounding
+    for (geom, gyd, xd, _, _, gbp), (gw, gb, _, _, _) in zip(ents, keep):
+        gw1 = torch.zeros_like(gw)
+        ops.conv_wgrad(geom, gyd, xd, gw1.data_ptr(), 0.0, None)
+        assert rel(gw, 2 * gw1) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(3, 64, 16, 16, 8), (2, 128, 8, 8, 8), (2, 512, 4, 4, 8), (2, 16, 8, 8, 8), (5, 256, 4, 4, 8),
                                    (2, 64, 32, 32, 8),     # one-pass kernels, 1024-thread blocks
                                    (1, 64, 64, 64, 8)])    # slice too large for the registers: two-pass kernels
