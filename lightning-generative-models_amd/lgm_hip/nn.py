@@ -49,18 +49,22 @@ class GradCtx:
         full, when a layer arrives that cannot join it, or at the end of the bucket (finish_pending)."""
         new = (g, gy, x, gw_ptr, beta, gb_ptr)
         if self._pending and not ops.wgrad_group_supported([e[0] for e in self._pending] + [g]):
-            self.finish_pending()
+            self._finish_pending3x3()
         self._pending.append(new)
         if len(self._pending) == ops.WGRAD_GROUP:
-            self.finish_pending()
+            self._finish_pending3x3()
 
-    def finish_pending(self):
+    def _finish_pending3x3(self):
         pend, self._pending = self._pending, []
         if len(pend) == 1:
             e = pend[0]
             ops.conv_wgrad(e[0], e[1], e[2], e[3], e[4], e[5], defer=self.deferred)
         elif pend:
             ops.conv_wgrad_group(pend, self.deferred)
+
+    def finish_pending(self):
+        """End of a bucket (or of the pass): every weight gradient still waiting for partners is issued."""
+        self._finish_pending3x3()
         self.finish_pending1x1()
 
     # -- 1x1 weight gradients on the streaming kernel wait for partners too: up to four share ONE launch ----------------
