@@ -45,7 +45,7 @@ extern "C" {
                              * 4: LgmPostOp carries the BatchNorm-backward sums (bn_*), lgm_bn_reduce3_coef_tiles;
                              * 5: lgm_set_cu_margin / lgm_cu_margin;
                              * 6: lgm_extract_axpby, lgm_model_predictions (GaussianDiffusion's per-sample-time algebra), lgm_time_mlp_*, lgm_weng_*;
-                             * 7: lgm_gn_bwd_add, lgm_wgrad1x1_group* */
+                             * 7: lgm_gn_bwd_add, lgm_wgrad1x1_group*, lgm_wgrad_queue_* */
 #define LGM_OK 0
 #define LGM_ERR_INVALID (-1)
 #define LGM_ERR_UNSUPPORTED (-2)
@@ -701,6 +701,15 @@ typedef struct {
  * chunks) and use the same block tile (Nw % 128 and Cw % 128 agree).  Descriptors as lgm_conv_wgrad_deferred (desc[6] = 1:
  * that layer's gradient is complete on return). */
 int64_t lgm_wgrad1x1_group_supported(int n, const LgmConvGeom* const* geoms);
+/* ABI 7.  Stand-alone launches of the generic weight-gradient kernel may wait for each other (per calling thread): while
+ * the queue is ON, lgm_conv_wgrad_deferred / lgm_conv_bwd_pair[_post] with a descriptor do not launch that kernel but queue
+ * it; four queued layers - or lgm_wgrad_queue_flush - issue ONE launch with the layers' grids one after the other (each
+ * layer's own plan: results are bit-identical to separate launches).  The caller keeps the operands (y, x, workspaces)
+ * alive until the flush and flushes before lgm_wgrad_reduce_batch / any reader of the gradients.  lgm_wgrad_queue_enable
+ * returns the previous state; the queue is OFF by default.  (Reference: autograd's weight gradients of the 1x1 / 7x7 /
+ * 2x2 convolutions and linears, ddpm.py:103,180,304,330-332,422 - none is read before the optimizer step.) */
+int lgm_wgrad_queue_enable(int on);
+int lgm_wgrad_queue_flush(void);
 int lgm_wgrad1x1_group_workspaces(int n, const LgmConvGeom* const* geoms, int64_t* out);     /* bytes per layer */
 int lgm_wgrad1x1_group(int n, const LgmWgradItem* items, void* stream);
 int64_t lgm_conv3x3_wino_wgradn_supported(int n, const LgmConvGeom* const* geoms);

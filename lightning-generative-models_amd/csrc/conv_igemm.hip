@@ -1625,6 +1625,64 @@ __global__ __launch_bounds__(256) void gemm_bwd_pair_kernel(const IgemmArgs pi, 
   else wgrad_body<64, 64, 1, 1, true>(pw, (int)blockIdx.x - n_ig, smem);
 }
 
+// The stand-alone weight gradients of two ... four layers in ONE launch: their grids one after the other, every layer with
+// the plan (splits, slabs) it has on its own - same blocks, same sums, bit-identical results.  Nothing reads a weight
+// gradient before the optimizer, so a deferred backward pass lets these launches wait for each other (the queue below):
+// 13 launches of 5 ... 17 us in the B = 128 DDPM step become 5.
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs a, const WgradArgs b, const WgradArgs c,
+                                                          const WgradArgs d, const int e0, const int e1, const int e2) {
+  __shared__ __align__(16) float wlds[2 * WBK * (64 + 64)];
+  const int bid = (int)blockIdx.x;
+  if (bid < e0) wgrad_body<64, 64, 1, 1, true>(a, a.swz ? lgm_xcd_swizzle(bid, e0) : bid, wlds);
+  else if (bid < e1) wgrad_body<64, 64, 1, 1, true>(b, b.swz ? lgm_xcd_swizzle(bid - e0, e1 - e0) : bid - e0, wlds);
+  else if (bid < e2) wgrad_body<64, 64, 1, 1, true>(c, c.swz ? lgm_xcd_swizzle(bid - e1, e2 - e1) : bid - e1, wlds);
+  else wgrad_body<64, 64, 1, 1, true>(d, d.swz ? lgm_xcd_swizzle(bid - e2, (int)gridDim.x - e2) : bid - e2, wlds);
+}
+
+// Per-thread queue of such launches.  Off unless the caller switches it on around a call (lgm_wgrad_queue_enable): only a
+// caller that will call lgm_wgrad_queue_flush before anything reads the gradients - and keeps the operands alive until
+// then - may let a launch wait (lgm_hip.nn.GradCtx does, for its deferred passes).
+struct WgradQueue {
+  WgradArgs a[4];
+  unsigned nb[4];
+  int n;
+  bool on;
+  hipStream_t s;
+};
+static thread_local WgradQueue t_wq = {};
+
+static int wq_launch() {
+  WgradQueue& q = t_wq;
+  if (q.n == 0) return LGM_OK;
+  if (q.n == 1) {
+    lgm_note_kernel(LGM_KNAME("wgrad_kernel<64, 64, 1, 1, true>"));
+    hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1, true>), dim3(q.nb[0]), dim3(256), 0, q.s, q.a[0]);
+  } else {
+    for (int k = q.n; k < 4; ++k) {
+      q.a[k] = q.a[q.n - 1];          // never reached: empty block range
+      q.nb[k] = 0;
+    }
+    const int e0 = (int)q.nb[0], e1 = e0 + (int)q.nb[1], e2 = e1 + (int)q.nb[2];
+    lgm_note_kernel(LGM_KNAME("wgrad_group_kernel"));
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)(e2 + (int)q.nb[3])), dim3(256), 0, q.s, q.a[0], q.a[1], q.a[2], q.a[3],
+                       e0, e1, e2);
+  }
+  q.n = 0;
+  LGM_LAUNCH_CHECK();
+  return LGM_OK;
+}
+
+static int wq_push(const WgradArgs& a, unsigned blocks, hipStream_t s) {
+  WgradQueue& q = t_wq;
+  if (q.n > 0 && q.s != s)
+    if (int rc = wq_launch()) return rc;
+  q.s = s;
+  q.a[q.n] = a;
+  q.nb[q.n] = blocks;
+  if (++q.n == 4) return wq_launch();
+  return LGM_OK;
+}
+
 // Deterministic split-K reduction: out[i] = beta*out[i] + sum_s ws[s*slab + i] (fixed order:
 // 4 split lanes summed in LDS in lane order).  i < n_w -> gw, n_w <= i < n_w + n_b -> gbias.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, long slab,
@@ -1799,6 +1857,8 @@ static int conv_wgrad_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch
     } else if (big) {
       a.tiles_m = a.Nw / 128;
       hipLaunchKernelGGL((wgrad_kernel<128, 64, 2, 1, true>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
+    } else if (fast && t_wq.on && desc) {            // deferred pass: the launch waits for up to three partners
+      if (int rc = wq_push(a, (unsigned)(a.tiles_m * a.tiles_n * a.splits), s)) return rc;
     } else if (fast)
       hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1, true>), dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), 0, s, a);
     else
@@ -1959,7 +2019,9 @@ static int conv_bwd_pair_impl(const LgmConvGeom* g, const float* gy, int64_t gy_
     hipLaunchKernelGGL(gemm_bwd_pair_kernel, dim3(c.ig_blocks + c.wg_blocks), dim3(256), pair_smem, s, c.ig, wa,
                        (int)c.ig_blocks);
   } else {
-    if (c.rec_w) {
+    if (c.rec_w && t_wq.on && desc) {
+      if (int r2 = wq_push(wa, c.wg_blocks, s)) return r2;
+    } else if (c.rec_w) {
       lgm_note_kernel(LGM_KNAME("wgrad_kernel<64, 64, 1, 1, true>"));
       hipLaunchKernelGGL((wgrad_kernel<64, 64, 1, 1, true>), dim3(c.wg_blocks), dim3(256), 0, s, wa);
     }
@@ -2018,6 +2080,14 @@ extern "C" int lgm_conv_bwd_pair_post(const LgmConvGeom* g, const float* gy, int
   return conv_bwd_pair_impl(g, gy, gy_pitch, x, x_pitch, w, w_t, res, res_pitch, gx, gx_pitch, dgrad_ws, dgrad_ws_bytes, gw,
                             gbias, beta, wgrad_ws, wgrad_ws_bytes, desc, post, stream);
 }
+
+extern "C" int lgm_wgrad_queue_enable(int on) {
+  const int was = t_wq.on ? 1 : 0;
+  t_wq.on = on != 0;
+  return was;
+}
+
+extern "C" int lgm_wgrad_queue_flush(void) { return wq_launch(); }
 
 extern "C" int lgm_conv_wgrad(const LgmConvGeom* g, const float* y, int64_t y_pitch, const float* x,
                               int64_t x_pitch, float* gw, float* gbias, float beta, void* workspace,

@@ -130,7 +130,8 @@ class _Lib:
             fn = getattr(self._dll, name)  # AttributeError if the .so misses a declared symbol
             fn.restype = res
             fn.argtypes = args
-            if res is ctypes.c_int and name not in ("lgm_abi_version", "lgm_kernel_name_count", "lgm_cu_margin"):
+            if res is ctypes.c_int and name not in ("lgm_abi_version", "lgm_kernel_name_count", "lgm_cu_margin",
+                                                    "lgm_wgrad_queue_enable"):      # (returns the previous state)
                 call = self._checked(fn, name)
                 if name in _SELECTION_KNOBS:
                     call = self._with_selection_hooks(call, name)

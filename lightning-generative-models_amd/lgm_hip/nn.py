@@ -35,6 +35,7 @@ class GradCtx:
         self.deferred = [] if defer else None
         self._pending = []
         self._pending1 = []
+        self._keep = []            # operands of generic weight-gradient launches waiting in the library's queue
         if transposed:
             flat.refresh_transposed()      # one launch per backward pass
 
@@ -66,6 +67,9 @@ class GradCtx:
         """End of a bucket (or of the pass): every weight gradient still waiting for partners is issued."""
         self._finish_pending3x3()
         self.finish_pending1x1()
+        if self._keep:
+            ops.wgrad_queue_flush()
+            self._keep.clear()
 
     # -- 1x1 weight gradients on the streaming kernel wait for partners too: up to four share ONE launch ----------------
     def queue_wgrad1x1(self, g, gy, x, gw_ptr: int, beta: float, gb_ptr):
@@ -230,14 +234,18 @@ class Conv2d(nn.Module):
                 ops.conv_yx(g, gy, fp.ptr(self.weight), None, None, gx, fp.tptr(self.weight),
                             post=ops.make_post(0, 0.0, mask, mask_slope, bn=bn_sums), post_mask=mask)
                 return gx
+            if dfr is not None:
+                gc._keep.append((gy, x))       # a stand-alone weight-gradient launch may wait in the library's queue
             ops.conv_bwd_generic(g, gy, x, fp.ptr(self.weight), fp.tptr(self.weight), fp.gptr(self.weight), bw, gb, dfr,
                                  gx if accumulate else res, gx, post=ops.make_post(0, 0.0, mask, mask_slope, bn=bn_sums),
-                                 post_mask=mask)
+                                 post_mask=mask, queue=dfr is not None)
             return gx
         if dfr is not None and self.k == 3 and ops.wgrad_queueable(g, gy, x):
             gc.queue_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb)      # issued with the next such layer's (one launch for two)
         else:
-            ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=dfr)
+            if dfr is not None:
+                gc._keep.append((gy, x))
+            ops.conv_wgrad(g, gy, x, fp.gptr(self.weight), bw, gb, defer=dfr, queue=dfr is not None)
         if not need_gx:
             return None
         if gx is None:

@@ -689,10 +689,21 @@ _WGRAD_WS = {}        # deferred mode: one persistent slab workspace per weight 
 _WGRAD_TABLES = {}    # tuple of descriptor rows -> (device table, blocks)
 
 
-def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[int] = None, defer=None):
+WGRAD_QUEUE = _os.environ.get("LGM_NO_WGRAD_QUEUE", "0") != "1"       # A/B switch: generic weight gradients launch at once
+
+
+def wgrad_queue_flush():
+    """Issue the generic weight-gradient launches still waiting for partners (lgm_wgrad_queue_*)."""
+    lib().lgm_wgrad_queue_flush()
+
+
+def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[int] = None, defer=None, queue: bool = False):
     """``defer``: a list collecting slab descriptors; the caller must call ``wgrad_reduce_batch(defer)`` before
-    the gradients are used (one reduce launch for many layers instead of one per layer)."""
+    the gradients are used (one reduce launch for many layers instead of one per layer).
+    ``queue`` (with ``defer``): a stand-alone launch of the generic kernel may wait for partners - the caller keeps ``y`` /
+    ``x`` alive and calls ``wgrad_queue_flush()`` before the reduction (GradCtx does)."""
     L = lib()
+    queue = queue and defer is not None and WGRAD_QUEUE
     nbytes = L.lgm_conv_wgrad_workspace(ctypes.byref(g))
     if TIMER is not None:
         TIMER.begin("wgrad", _conv_flops(g), _conv_bytes(g))
@@ -707,8 +718,14 @@ def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[
             ws = torch.empty(max(nbytes // 4 + 4, 16), dtype=torch.float32, device=y.device)
             _WGRAD_WS[key] = ws
         desc = (ctypes.c_int64 * 8)()
-        L.lgm_conv_wgrad_deferred(ctypes.byref(g), y.data_ptr(), pitch(y), x.data_ptr(), pitch(x), gw_ptr, gbias_ptr,
-                                  beta, ws.data_ptr(), ws.numel() * 4, ctypes.addressof(desc), stream())
+        if queue:
+            L.lgm_wgrad_queue_enable(1)
+        try:
+            L.lgm_conv_wgrad_deferred(ctypes.byref(g), y.data_ptr(), pitch(y), x.data_ptr(), pitch(x), gw_ptr, gbias_ptr,
+                                      beta, ws.data_ptr(), ws.numel() * 4, ctypes.addressof(desc), stream())
+        finally:
+            if queue:
+                L.lgm_wgrad_queue_enable(0)
         if desc[6] > 1:
             defer.append(tuple(desc))
     if TIMER is not None:
@@ -950,7 +967,7 @@ def conv_bwd_pair(g: ConvGeom, gy, x, w_ptr: int, gw_ptr: int, beta: float, gbia
 
 
 def conv_bwd_generic(g: ConvGeom, gy, x, w_ptr: int, wt_ptr: Optional[int], gw_ptr: int, beta: float,
-                     gbias_ptr: Optional[int], defer, res, gx, post=None, post_mask=None):
+                     gbias_ptr: Optional[int], defer, res, gx, post=None, post_mask=None, queue: bool = False):
     """Weight / bias gradient and input gradient of any layer through lgm_conv_bwd_pair: ONE launch when the dispatchers
     pick the two kernels that can share a grid (the 1x1 convolutions and linears at small row counts), else exactly
     conv_wgrad + conv_yx."""
@@ -972,12 +989,19 @@ def conv_bwd_generic(g: ConvGeom, gy, x, w_ptr: int, wt_ptr: Optional[int], gw_p
             pitch(res) if res is not None else 0, gx.data_ptr(), pitch(gx),
             None if dws is None else dws.data_ptr(), 0 if dws is None else dws.numel() * 4, gw_ptr, gbias_ptr,
             beta, wws.data_ptr(), wws.numel() * 4, None if desc is None else ctypes.addressof(desc))
-    if post is None or not POSTOPS:
-        L.lgm_conv_bwd_pair(*args, stream())
-        if post is not None:
-            _apply_post_separately(post, gx, post_mask)
-    else:                # ``post_mask`` only keeps the mask tensor alive for the duration of the call
-        L.lgm_conv_bwd_pair_post(*args, ctypes.byref(post), stream())
+    queue = queue and desc is not None and WGRAD_QUEUE      # (see conv_wgrad: a stand-alone weight-gradient launch may wait)
+    if queue:
+        L.lgm_wgrad_queue_enable(1)
+    try:
+        if post is None or not POSTOPS:
+            L.lgm_conv_bwd_pair(*args, stream())
+            if post is not None:
+                _apply_post_separately(post, gx, post_mask)
+        else:                # ``post_mask`` only keeps the mask tensor alive for the duration of the call
+            L.lgm_conv_bwd_pair_post(*args, ctypes.byref(post), stream())
+    finally:
+        if queue:
+            L.lgm_wgrad_queue_enable(0)
     if TIMER is not None:
         TIMER.end()
     if desc is not None and desc[6] > 1:
