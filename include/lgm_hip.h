@@ -706,7 +706,8 @@ int64_t lgm_wgrad1x1_group_supported(int n, const LgmConvGeom* const* geoms);
  * it; four queued layers - or lgm_wgrad_queue_flush - issue ONE launch with the layers' grids one after the other (each
  * layer's own plan: results are bit-identical to separate launches).  The caller keeps the operands (y, x, workspaces)
  * alive until the flush and flushes before lgm_wgrad_reduce_batch / any reader of the gradients.  lgm_wgrad_queue_enable
- * returns the previous state; the queue is OFF by default.  (Reference: autograd's weight gradients of the 1x1 / 7x7 /
+ * returns the previous state (on < 0: switch off AND discard what is queued - the start of a pass, in case an earlier one
+ * was abandoned half-way); the queue is OFF by default.  (Reference: autograd's weight gradients of the 1x1 / 7x7 /
  * 2x2 convolutions and linears, ddpm.py:103,180,304,330-332,422 - none is read before the optimizer step.) */
 int lgm_wgrad_queue_enable(int on);
 int lgm_wgrad_queue_flush(void);

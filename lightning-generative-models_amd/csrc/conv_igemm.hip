@@ -2083,7 +2083,8 @@ extern "C" int lgm_conv_bwd_pair_post(const LgmConvGeom* g, const float* gy, int
 
 extern "C" int lgm_wgrad_queue_enable(int on) {
   const int was = t_wq.on ? 1 : 0;
-  t_wq.on = on != 0;
+  if (on < 0) t_wq.n = 0;      // discard: entries an abandoned pass left behind must never be launched (their operands are gone)
+  t_wq.on = on > 0;
   return was;
 }
 

@@ -36,6 +36,8 @@ class GradCtx:
         self._pending = []
         self._pending1 = []
         self._keep = []            # operands of generic weight-gradient launches waiting in the library's queue
+        if defer:
+            ops.lib().lgm_wgrad_queue_enable(-1)     # nothing an abandoned pass left queued may ever be launched
         if transposed:
             flat.refresh_transposed()      # one launch per backward pass
 

@@ -694,7 +694,11 @@ WGRAD_QUEUE = _os.environ.get("LGM_NO_WGRAD_QUEUE", "0") != "1"       # A/B swit
 
 def wgrad_queue_flush():
     """Issue the generic weight-gradient launches still waiting for partners (lgm_wgrad_queue_*)."""
+    if TIMER is not None:            # (their FLOPs were counted where they were queued)
+        TIMER.begin("wgrad", 0.0, 0.0)
     lib().lgm_wgrad_queue_flush()
+    if TIMER is not None:
+        TIMER.end()
 
 
 def conv_wgrad(g: ConvGeom, y, x, gw_ptr: int, beta: float, gbias_ptr: Optional[int] = None, defer=None, queue: bool = False):
