@@ -922,6 +922,91 @@ extern "C" int64_t lgm_conv_workspace(const LgmConvGeom* g, int yx) {
   return s > 1 ? (int64_t)s * g->B * g->H * g->W * oc * (int64_t)sizeof(float) : 0;
 }
 
+namespace {
+// 1x1 convolution between 64 channels and <= 4 (the UNet's final_conv 64 -> 3, reference ddpm.py:422, and its input gradient).
+// As a GEMM it has N = 4 and idles 15/16 of a 64-wide MFMA tile (igemm_kernel<0, 128, 64>: 25 us for 33.5 MB at B = 128); it
+// is a streaming dot product: the 16 lanes of a DPP row own one pixel (lane = four channels, one 16-byte load), the four
+// weight rows sit in registers, the row sums are four rotate-and-add steps on the DPP path (no LDS, no shuffle through the
+// crossbar - DESIGN finding 19), lane 0 of the row stores the pixel's four outputs.
+template <int CTRL>
+__device__ __forceinline__ float lgm_dpp_row(float a) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lgm_row16_sum(float v) {
+  v += lgm_dpp_row<0x128>(v);      // row_ror:8
+  v += lgm_dpp_row<0x124>(v);      // row_ror:4
+  v += lgm_dpp_row<0x122>(v);      // row_ror:2
+  v += lgm_dpp_row<0x121>(v);      // row_ror:1
+  return v;
+}
+
+__global__ __launch_bounds__(256) void narrow1x1_fwd_kernel(const float* __restrict__ x, long x_pitch,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, long y_pitch, long P) {
+  const int cl = threadIdx.x & 15, slot = threadIdx.x >> 4;          // 16 pixels per block and trip
+  f32x4 wr[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) wr[n] = *reinterpret_cast<const f32x4*>(w + n * 64 + cl * 4);
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
+  const long stride = (long)gridDim.x * 64;                          // four trips' pixels in flight per thread
+  for (long p0 = (long)blockIdx.x * 64 + slot; p0 < P; p0 += stride) {
+    f32x4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long pix = p0 + 16 * u;
+      xv[u] = pix < P ? *reinterpret_cast<const f32x4*>(x + pix * x_pitch + cl * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long pix = p0 + 16 * u;
+      f32x4 o;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const f32x4 t = xv[u] * wr[n];
+        o[n] = lgm_row16_sum((t[0] + t[1]) + (t[2] + t[3]));
+      }
+      if (cl == 0 && pix < P) *reinterpret_cast<f32x4*>(y + pix * y_pitch) = o + bv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void narrow1x1_dgrad_kernel(const float* __restrict__ gy, long gy_pitch,
+                                                              const float* __restrict__ w, float* __restrict__ gx,
+                                                              long gx_pitch, long P) {
+  const int cl = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  f32x4 wr[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) wr[n] = *reinterpret_cast<const f32x4*>(w + n * 64 + cl * 4);
+  const long stride = (long)gridDim.x * 64;
+  for (long p0 = (long)blockIdx.x * 64 + slot; p0 < P; p0 += stride) {
+    f32x4 g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long pix = p0 + 16 * u;
+      g[u] = pix < P ? *reinterpret_cast<const f32x4*>(gy + pix * gy_pitch) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long pix = p0 + 16 * u;
+      if (pix < P)
+        *reinterpret_cast<f32x4*>(gx + pix * gx_pitch + cl * 4) =
+            (wr[0] * g[u][0] + wr[1] * g[u][1]) + (wr[2] * g[u][2] + wr[3] * g[u][3]);
+    }
+  }
+}
+
+// the layers these two kernels take: 1x1 / stride 1 / unpadded, 64 channels on the wide side, 4 (padded) on the narrow one
+bool narrow1x1_geom(const LgmConvGeom* g) {
+  static const bool off = getenv("LGM_NO_NARROW1X1") != nullptr;        // A/B switch
+  return !off && g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 && g->Nw == 4 && g->Cw == 64;
+}
+unsigned narrow1x1_blocks(long P) {
+  const long want = (P + 63) / 64;
+  return (unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+}
+}  // namespace
+
 static int conv_xy_impl(const LgmConvGeom* g, const float* x, int64_t x_pitch, const float* w,
                         const float* bias, const float* res, int64_t res_pitch, float* y,
                         int64_t y_pitch, void* workspace, int64_t workspace_bytes, float* stats, int* stats_tiles,
@@ -933,6 +1018,14 @@ static int conv_xy_impl(const LgmConvGeom* g, const float* x, int64_t x_pitch, c
   LGM_REQUIRE(x_pitch % 4 == 0 && x_pitch >= g->Cw && lgm_aligned16(x) && lgm_aligned16(w),
               "conv_xy: x/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(y_pitch >= g->Nw && (!res || res_pitch >= g->Nw), "conv_xy: output pitch < Nw");
+  if (use_3x3() && narrow1x1_geom(g) && !res && !stats && !t_post.post && wide_ok(y, y_pitch, nullptr, 0, bias)) {
+    const long P = (long)g->B * g->H * g->W;
+    lgm_note_kernel(LGM_KNAME("narrow1x1_fwd_kernel"));
+    hipLaunchKernelGGL(narrow1x1_fwd_kernel, dim3(narrow1x1_blocks(P)), dim3(256), 0, (hipStream_t)stream, x, (long)x_pitch, w,
+                       bias, y, (long)y_pitch, P);
+    LGM_LAUNCH_CHECK();
+    return LGM_OK;
+  }
   static const bool post_3x3 = getenv("LGM_POST_VIA_3X3") != nullptr;   // A/B switch: direct 3x3 kernel + elementwise post-op
   if (use_3x3() && (!t_post.post || post_3x3) && wide_ok(y, y_pitch, res, res_pitch, bias) && lgm_conv3x3_supported(g, g->Cw, g->Nw) &&
       ((long)g->B * g->H * g->W + g->W + 1) * x_pitch < (1L << 29))   // buffer offsets (bytes) below 2^31
@@ -1274,6 +1367,14 @@ static int conv_yx_impl(const LgmConvGeom* g, const float* y, int64_t y_pitch, c
   LGM_REQUIRE(y_pitch % 4 == 0 && y_pitch >= g->Nw && lgm_aligned16(y) && lgm_aligned16(w),
               "conv_yx: y/w must be 16B aligned with pitch %% 4 == 0");
   LGM_REQUIRE(x_pitch >= g->Cw && (!res || res_pitch >= g->Cw), "conv_yx: output pitch < Cw");
+  if (use_3x3() && narrow1x1_geom(g) && !res && !bias && !stats && !t_post.post && wide_ok(x, x_pitch, nullptr, 0, nullptr)) {
+    const long P = (long)g->B * g->H * g->W;
+    lgm_note_kernel(LGM_KNAME("narrow1x1_dgrad_kernel"));
+    hipLaunchKernelGGL(narrow1x1_dgrad_kernel, dim3(narrow1x1_blocks(P)), dim3(256), 0, (hipStream_t)stream, y, (long)y_pitch, w,
+                       x, (long)x_pitch, P);
+    LGM_LAUNCH_CHECK();
+    return LGM_OK;
+  }
   static const bool post_3x3 = getenv("LGM_POST_VIA_3X3") != nullptr;   // A/B switch (see conv_xy_impl)
   if (use_3x3() && (!t_post.post || post_3x3) && wide_ok(x, x_pitch, res, res_pitch, bias) && lgm_conv3x3_supported(g, g->Nw, g->Cw) &&
       ((long)g->B * g->H * g->W + g->W + 1) * y_pitch < (1L << 29))

@@ -218,6 +218,33 @@ def test_conv_transpose(dev, case):
     assert rel(gw, phys_weight(w.grad, dev)) < RTOL
 
 
+@pytest.mark.parametrize("B,S", [(3, 16), (5, 32), (1, 8), (7, 5)])
+def test_narrow_1x1_convolution(dev, B, S):
+    """final_conv (reference ddpm.py:422: Conv2d(64, 3, 1)) forward and input gradient on the streaming dot-product kernels
+    (narrow1x1_*: 16 lanes of a DPP row per pixel) instead of an MFMA tile that idles 15/16 of its columns; ragged pixel
+    counts included.  Against float64 and against the implicit-GEMM path (LGM_NO_NARROW1X1 is read once: compared by value)."""
+    from lgm_hip import ops
+    g = torch.Generator().manual_seed(B * 100 + S)
+    x = torch.randn(B, 64, S, S, generator=g)
+    w = torch.randn(3, 64, 1, 1, generator=g) * 0.2
+    b = torch.randn(3, generator=g)
+    gy = torch.randn(B, 3, S, S, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = F.conv2d(xr, w.double(), b.double())
+    yr.backward(gy.double())
+    xd, gyd = nhwc(x, dev, extra=4), nhwc(gy, dev)
+    wd, bd = phys_weight(w, dev), vec(b, dev)
+    geom = ops.make_geom(B, S, S, 64, 4, 1, 1, 1, 0)
+    yd = torch.full((B, S, S, 4), 9.0, device=dev)
+    ops.conv_xy(geom, xd, wd.data_ptr(), bd.data_ptr(), None, yd)
+    assert ops.lib()._dll.lgm_last_kernel().decode().startswith("narrow1x1_fwd_kernel")
+    assert rel(nchw(yd, 3), yr) < RTOL and float(yd[..., 3].abs().max()) == 0.0        # the pad lane stays zero
+    gxd = torch.full((B, S, S, 64), 9.0, device=dev)
+    ops.conv_yx(geom, gyd, wd.data_ptr(), None, None, gxd)
+    assert ops.lib()._dll.lgm_last_kernel().decode().startswith("narrow1x1_dgrad_kernel")
+    assert rel(nchw(gxd), xr.grad) < RTOL
+
+
 @pytest.mark.parametrize("layers", [
     [(64, 32, 128, 64, True), (64, 32, 128, 64, False), (128, 32, 128, 64, True)],             # tile 64 x 128, three layers
     [(128, 16, 128, 256, True), (128, 16, 256, 256, True)],                                    # tile 128 x 128, a pair
